@@ -1,0 +1,37 @@
+// Shared host-side helpers of the dspnet_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#define DSPN_OK_ 0
+#define DSPN_ERR_ARG_ (-1)
+#define DSPN_ERR_WORKSPACE_ (-2)
+#define DSPN_ERR_LAUNCH_ (-3)
+
+namespace dspn {
+
+char *last_error_buf();   // thread-local, 512 bytes (defined in capi.hip)
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DSPN_ERR_LAUNCH_, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace dspn
+
+#define DSPN_REQUIRE(cond, ...) \
+  do { if (!(cond)) return dspn::fail(DSPN_ERR_ARG_, __VA_ARGS__); } while (0)

@@ -1,0 +1,833 @@
+// SSD multibox operators for MI355X (gfx950): MultiBoxPrior / MultiBoxTarget /
+// MultiBoxDetection.  C ABI in include/dspn_multibox.h.
+//
+// These are HBM/latency-bound integer+float bookkeeping ops: no
+// MFMA.  The design points are
+//   * IoU is recomputed on the fly from the (A,4) anchor table (L2 resident)
+//     and the <=L valid ground-truth boxes held in LDS, instead of the
+//     reference's (11,B,A,L) float scratch (operator/multibox_target-inl.h:114-161);
+//   * every data-dependent choice (bipartite match, hard-negative ranking, score
+//     sort, NMS) is made with a TOTAL order identical to the CPU reference's
+//     scan order / std::stable_sort, so indices are bit-exact and run-to-run
+//     deterministic (the reference's CUDA path is neither);
+//   * float arithmetic is kept bit-identical to the CPU reference: no FMA
+//     contraction, IEEE divide/sqrt, and expf evaluated with glibc's own
+//     algorithm (see expf_cr).
+#include "dspn_common.h"
+#include "../../include/dspn_multibox.h"
+#include <cstdint>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxAttr = 32;     // max sizes / ratios per prior layer
+constexpr int kMaxLabels = 1024; // max padded label rows per sample
+constexpr int kTB = 1024;        // threads of the per-sample kernels
+
+// expf with the bits of glibc's expf (sysdeps/ieee754/flt-32/e_expf.c: the
+// table-of-32 2^(i/32) * cubic algorithm evaluated in double, FMA-contracted as
+// the x86-64 FMA ifunc variant is).  glibc's expf is NOT correctly rounded
+// (0.502 ulp; ~6e-4 of inputs differ from a rounded double exp), and the
+// ranking of hard negatives / the NMS decisions depend on its exact bits, so
+// the algorithm is replicated instead of approximated: on 2e8 random inputs the
+// host model of this function matched glibc 2.35 bit for bit.
+__constant__ unsigned long long kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float expf_cr(float x) {
+  const double kInvLn2N = 0x1.71547652b82fep+0 * 32;
+  const double kShift = 0x1.8p+52;
+  const double c0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, c1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
+               c2 = 0x1.62e42ff0c52d6p-1 / 32;
+  if (!(fabsf(x) < 88.0f)) {
+    if (x != x) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();
+    if (x < -0x1.9fe368p6f) return 0.0f;
+  }
+  double z = kInvLn2N * (double)x;
+  double kd = z + kShift;
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= kShift;
+  const double r = z - kd;
+  const unsigned long long t = kExp2fTab[ki & 31u] + (ki << 47);
+  const double s = __longlong_as_double((long long)t);
+  z = fma(c0, r, c1);
+  const double r2 = r * r;
+  double y = fma(c2, r, 1.0);
+  y = fma(z, r2, y);
+  y = y * s;
+  return (float)y;
+}
+// glibc's logf is 0.818 ulp (table-driven, not reproducible without its table);
+// it only feeds loc_target VALUES, never an index, so a correctly rounded log is
+// used and the tests allow 1 ulp on those two columns.
+__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float fmaxr(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float fminr(float a, float b) { return a < b ? a : b; }
+
+// ---------------------------------------------------------------------------
+// MultiBoxPrior: one thread per (location, anchor slot)
+// ---------------------------------------------------------------------------
+struct PriorAttr {
+  float sizes[kMaxAttr];
+  float ratios[kMaxAttr];
+};
+
+__global__ void prior_kernel(PriorAttr attr, int num_sizes, int num_ratios, int H, int W,
+                             float step_y, float step_x, float off_y, float off_x, int clip,
+                             float4 *__restrict__ out) {
+  const int per = num_sizes + num_ratios - 1;
+  const int total = H * W * per;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int loc = idx / per, slot = idx - loc * per;
+  const int r = loc / W, c = loc - r * W;
+  const float cy = (r + off_y) * step_y;
+  const float cx = (c + off_x) * step_x;
+  float w, h;
+  if (slot < num_sizes) {
+    const float size = attr.sizes[slot];
+    w = size * H / W / 2;
+    h = size / 2;
+  } else {
+    const float size = attr.sizes[0];
+    const float ratio = sqrtf(attr.ratios[slot - num_sizes + 1]);
+    w = size * H / W * ratio / 2;
+    h = size / ratio / 2;
+  }
+  float4 o = make_float4(cx - w, cy - h, cx + w, cy + h);
+  if (clip) {
+    o.x = o.x < 0.f ? 0.f : (o.x > 1.f ? 1.f : o.x);
+    o.y = o.y < 0.f ? 0.f : (o.y > 1.f ? 1.f : o.y);
+    o.z = o.z < 0.f ? 0.f : (o.z > 1.f ? 1.f : o.z);
+    o.w = o.w < 0.f ? 0.f : (o.w > 1.f ? 1.f : o.w);
+  }
+  out[idx] = o;
+}
+
+// ---------------------------------------------------------------------------
+// MultiBoxTarget
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float target_iou(const float4 a, const float gl, const float gt,
+                                            const float gr, const float gb) {
+  const float iw = fmaxr(0.f, fminr(a.z, gr) - fmaxr(a.x, gl));
+  const float ih = fmaxr(0.f, fminr(a.w, gb) - fmaxr(a.y, gt));
+  const float inter = iw * ih;
+  const float uni = (a.z - a.x) * (a.w - a.y) + (gr - gl) * (gb - gt) - inter;
+  return uni == 0.f ? 0.f : inter / uni;
+}
+
+struct TargetWs {
+  int *err;            // [B]
+  int *ngt;            // [B]
+  float *row_iou;      // [B*A] best IoU of each anchor over the valid GTs
+  int *row_gt;         // [B*A] arg of it (later: matched GT of positives)
+  unsigned *bgkey;     // [B*A] float bits of softmax P(background)
+  signed char *flag;   // [B*A] -1 ignore, 0 negative, 1 positive
+};
+
+// number of valid GT rows = index of the first row whose class is -1
+__device__ int count_valid_gt(const float *lab, int L, int lw, int *s_G) {
+  if (threadIdx.x == 0) *s_G = L;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x)
+    if (lab[i * lw] == -1.0f) atomicMin(s_G, i);
+  __syncthreads();
+  return *s_G;
+}
+
+// K1: per anchor, best GT by IoU and softmax background probability.
+__global__ __launch_bounds__(256) void target_rows_kernel(
+    const float4 *__restrict__ anchors, const float *__restrict__ labels,
+    const float *__restrict__ cls_preds, int A, int L, int lw, int C, TargetWs ws) {
+  __shared__ float s_gt[kMaxLabels * 4];
+  __shared__ int s_G;
+  const int b = blockIdx.y;
+  const float *lab = labels + (size_t)b * L * lw;
+  const int G = count_valid_gt(lab, L, lw, &s_G);
+  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) {
+    const int k = i >> 2, q = i & 3;
+    s_gt[i] = lab[k * lw + 1 + q];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A) return;
+  const size_t o = (size_t)b * A + j;
+  if (G == 0) {  // nothing downstream reads the workspace of an empty sample
+    ws.row_iou[o] = -1.f; ws.row_gt[o] = -1; ws.bgkey[o] = 0u;
+    return;
+  }
+  const float4 a = anchors[j];
+  float best = -1.0f; int bk = -1;
+  for (int k = 0; k < G; ++k) {
+    const float iou = target_iou(a, s_gt[4 * k], s_gt[4 * k + 1], s_gt[4 * k + 2], s_gt[4 * k + 3]);
+    if (iou > best) { best = iou; bk = k; }
+  }
+  ws.row_iou[o] = best;
+  ws.row_gt[o] = bk;
+  // softmax P(background), float, sequential sum (multibox_target.cc:218-232)
+  const float *p = cls_preds + (size_t)b * C * A + j;
+  const float p0 = p[0];
+  float mx = p0;
+  for (int k = 1; k < C; ++k) { const float t = p[(size_t)k * A]; if (t > mx) mx = t; }
+  float sum = 0.f;
+  for (int k = 0; k < C; ++k) sum += expf_cr(p[(size_t)k * A] - mx);
+  const float prob = expf_cr(p0 - mx) / sum;
+  ws.bgkey[o] = __float_as_uint(prob);
+}
+
+struct Best { float iou; int a; int k; };
+// order of the reference's scan (anchor-major, gt-minor, strict '>'):
+// larger IoU first, then lower anchor, then lower gt.
+__device__ __forceinline__ bool better(const Best &x, const Best &y) {
+  if (x.iou != y.iou) return x.iou > y.iou;
+  if (x.a != y.a) return x.a < y.a;
+  return x.k < y.k;
+}
+__device__ __forceinline__ Best wave_best(Best v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    Best o;
+    o.iou = __shfl_xor(v.iou, m, 64);
+    o.a = __shfl_xor(v.a, m, 64);
+    o.k = __shfl_xor(v.k, m, 64);
+    if (better(o, v)) v = o;
+  }
+  return v;
+}
+
+// exclusive scan of a predicate over the 1024-thread block; returns this
+// thread's offset, sets total.  s_w: int[16].  Two barriers.
+__device__ __forceinline__ int block_scan_pred(bool f, int *s_w, int &total) {
+  const unsigned long long bal = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wprefix = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_w[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kTB / 64; ++w) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+  __syncthreads();
+  total = tot;
+  return off + wprefix;
+}
+
+// K2: one workgroup per sample: bipartite stage, threshold stage, mining.
+__global__ __launch_bounds__(kTB) void target_match_kernel(
+    const float4 *__restrict__ anchors, const float *__restrict__ labels, int A, int L, int lw,
+    float overlap_threshold, float neg_ratio, float neg_thresh, TargetWs ws) {
+  __shared__ float s_gt[kMaxLabels * 4];
+  __shared__ float s_ciou[kMaxLabels];
+  __shared__ int s_ca[kMaxLabels];
+  __shared__ int s_gflag[kMaxLabels];
+  __shared__ Best s_wb[kTB / 64];
+  __shared__ Best s_best;
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_w[kTB / 64];
+  __shared__ int s_G, s_cnt, s_bin, s_kk;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *lab = labels + (size_t)b * L * lw;
+  const int G = count_valid_gt(lab, L, lw, &s_G);
+  if (tid == 0) {
+    int err = 0;
+    if (G < L) {  // CHECK_EQ x4 on the terminating row (multibox_target.cc:98-101)
+      const float *row = lab + G * lw;
+      if (row[1] != -1.0f || row[2] != -1.0f || row[3] != -1.0f || row[4] != -1.0f) err = 2;
+    }
+    ws.err[b] = err;
+    ws.ngt[b] = G;
+  }
+  if (G == 0) return;
+  float *row_iou = ws.row_iou + (size_t)b * A;
+  int *row_gt = ws.row_gt + (size_t)b * A;
+  unsigned *bgkey = ws.bgkey + (size_t)b * A;
+  signed char *flag = ws.flag + (size_t)b * A;
+
+  for (int i = tid; i < G * 4; i += kTB) s_gt[i] = lab[(i >> 2) * lw + 1 + (i & 3)];
+  for (int j = tid; j < A; j += kTB) flag[j] = -1;
+  __syncthreads();
+
+  // column maxima: best unmatched anchor of every GT, one wave per GT
+  for (int k = wave; k < G; k += kTB / 64) {
+    const float gl = s_gt[4 * k], gt = s_gt[4 * k + 1], gr = s_gt[4 * k + 2], gb = s_gt[4 * k + 3];
+    Best v{-1.0f, 0x7fffffff, k};
+    for (int j = lane; j < A; j += 64) {
+      const float iou = target_iou(anchors[j], gl, gt, gr, gb);
+      if (iou > v.iou) { v.iou = iou; v.a = j; }
+    }
+    v = wave_best(v);
+    if (lane == 0) { s_ciou[k] = v.iou; s_ca[k] = v.a; s_gflag[k] = 0; }
+  }
+  __syncthreads();
+
+  // greedy bipartite matching (multibox_target.cc:113-149)
+  int npos = 0;
+  for (;;) {
+    if (wave == 0) {
+      Best v{-2.0f, 0x7fffffff, -1};
+      for (int k = lane; k < G; k += 64) {
+        if (s_gflag[k]) continue;
+        Best c{s_ciou[k], s_ca[k], k};
+        if (better(c, v)) v = c;
+      }
+      v = wave_best(v);
+      if (lane == 0) s_best = v;
+    }
+    __syncthreads();
+    const Best bb = s_best;
+    if (bb.k < 0 || !(bb.iou > 1e-6f)) break;
+    if (tid == 0) { flag[bb.a] = 1; row_gt[bb.a] = bb.k; s_gflag[bb.k] = 1; }
+    ++npos;
+    __syncthreads();
+    // GTs whose best anchor was just consumed need a new column maximum
+    for (int k = 0; k < G; ++k) {
+      if (s_gflag[k] || s_ca[k] != bb.a) continue;   // block-uniform
+      const float gl = s_gt[4 * k], gt = s_gt[4 * k + 1], gr = s_gt[4 * k + 2], gb = s_gt[4 * k + 3];
+      Best v{-1.0f, 0x7fffffff, k};
+      for (int j = tid; j < A; j += kTB) {
+        if (flag[j] == 1) continue;
+        const float iou = target_iou(anchors[j], gl, gt, gr, gb);
+        if (iou > v.iou) { v.iou = iou; v.a = j; }
+      }
+      v = wave_best(v);
+      if (lane == 0) s_wb[wave] = v;
+      __syncthreads();
+      if (wave == 0) {
+        Best u = lane < kTB / 64 ? s_wb[lane] : Best{-1.0f, 0x7fffffff, k};
+        u = wave_best(u);
+        if (lane == 0) { s_ciou[k] = u.iou; s_ca[k] = u.a; }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // threshold stage (multibox_target.cc:151-180) + candidate census
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  {
+    int add = 0;
+    if (overlap_threshold > 0) {
+      for (int j = tid; j < A; j += kTB) {
+        if (flag[j] == 1) continue;
+        if (row_iou[j] > overlap_threshold) { flag[j] = 1; ++add; }
+      }
+    }
+    for (int m = 32; m >= 1; m >>= 1) add += __shfl_xor(add, m, 64);
+    if (lane == 0 && add) atomicAdd(&s_cnt, add);
+  }
+  __syncthreads();
+  npos += s_cnt;
+  __syncthreads();
+
+  if (!(neg_ratio > 0)) {  // use all negatives (multibox_target.cc:242-249)
+    for (int j = tid; j < A; j += kTB) if (flag[j] != 1) flag[j] = 0;
+    return;
+  }
+  int num_negative = (int)((float)npos * neg_ratio);
+  if (num_negative > A - npos) num_negative = A - npos;
+  if (num_negative <= 0) return;
+
+  // candidates: not positive and best IoU below the mining threshold
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  {
+    int c = 0;
+    for (int j = tid; j < A; j += kTB) c += (flag[j] != 1 && row_iou[j] < neg_thresh) ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if (lane == 0 && c) atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  const int ncand = s_cnt;
+  if (ncand < num_negative) {  // CHECK_GE(temp.size(), num_negative), multibox_target.cc:236
+    if (tid == 0) ws.err[b] = 3;
+    num_negative = ncand;
+  }
+  if (num_negative == ncand) {
+    for (int j = tid; j < A; j += kTB)
+      if (flag[j] != 1 && row_iou[j] < neg_thresh) flag[j] = 0;
+    return;
+  }
+
+  // radix-select the num_negative-th smallest P(background); ties go to the
+  // lower anchor index ( == std::stable_sort on -prob, multibox_target.cc:58-70,237 )
+  unsigned prefix = 0;
+  int kk = num_negative;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += kTB) s_hist[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < A; j += kTB) {
+      if (flag[j] == 1 || !(row_iou[j] < neg_thresh)) continue;
+      const unsigned key = bgkey[j];
+      const bool match = (shift == 24) ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, bin = 0;
+      for (; bin < 256; ++bin) {
+        const int h = (int)s_hist[bin];
+        if (cum + h >= kk) break;
+        cum += h;
+      }
+      s_bin = bin; s_kk = kk - cum;
+    }
+    __syncthreads();
+    prefix |= (unsigned)s_bin << shift;
+    kk = s_kk;
+    __syncthreads();
+  }
+  const unsigned T = prefix;
+  int taken_ties = 0;
+  for (int base = 0; base < A; base += kTB) {
+    const int j = base + tid;
+    bool cand = false; unsigned key = 0;
+    if (j < A) { cand = (flag[j] != 1 && row_iou[j] < neg_thresh); key = bgkey[j]; }
+    const bool tie = cand && key == T;
+    int total;
+    const int off = block_scan_pred(tie, s_w, total);
+    if (cand && (key < T || (tie && taken_ties + off < kk))) flag[j] = 0;
+    taken_ties += total;
+  }
+}
+
+// K3: expand flags into the three outputs (multibox_target.cc:251-281; init
+// values of multibox_target-inl.h:121-123 for untouched anchors).
+__global__ __launch_bounds__(256) void target_write_kernel(
+    const float4 *__restrict__ anchors, const float *__restrict__ labels, int A, int L, int lw,
+    float ignore_label, float vx, float vy, float vw, float vh, TargetWs ws,
+    float *__restrict__ loc_target, float *__restrict__ loc_mask, float *__restrict__ cls_target) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A) return;
+  const size_t o = (size_t)b * A + j;
+  const int G = ws.ngt[b];
+  const int f = G > 0 ? (int)ws.flag[o] : -1;
+  float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float m = 0.f, c = ignore_label;
+  if (f == 1) {
+    const float *g = labels + ((size_t)b * L + ws.row_gt[o]) * lw;
+    c = g[0] + 1;
+    m = 1.f;
+    const float4 a = anchors[j];
+    const float aw = a.z - a.x, ah = a.w - a.y;
+    const float ax = (float)((a.x + a.z) * 0.5), ay = (float)((a.y + a.w) * 0.5);
+    const float gl = g[1], gt = g[2], gr = g[3], gb = g[4], gz = g[5];
+    const float gw = gr - gl, gh = gb - gt;
+    const float gx = (float)((gl + gr) * 0.5), gy = (float)((gt + gb) * 0.5);
+    t[0] = (gx - ax) / aw / vx;
+    t[1] = (gy - ay) / ah / vy;
+    t[2] = logf_cr(gw / aw) / vw;
+    t[3] = logf_cr(gh / ah) / vh;
+    t[4] = (float)((double)gz / 0.1);
+  } else if (f == 0) {
+    c = 0.f;
+  }
+  cls_target[o] = c;
+  float *lt = loc_target + o * 5, *lm = loc_mask + o * 5;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { lt[q] = t[q]; lm[q] = m; }
+}
+
+// ---------------------------------------------------------------------------
+// MultiBoxDetection
+// ---------------------------------------------------------------------------
+struct DetWs {
+  int *nms_count;              // [B] rows that take part in sort+NMS (0 = none)
+  float *temp;                 // [B*A*7] pre-sort copy of the compacted rows
+  unsigned long long *keys;    // [B*n2] sort keys when they do not fit LDS
+  unsigned long long *mask;    // [B*A*nwords] suppression bit matrix
+};
+
+__device__ __forceinline__ unsigned ordered_bits(float s) {
+  if (s == 0.f) s = 0.f;  // -0 -> +0
+  const unsigned u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float clip01(float v) { return fmaxr(0.f, fminr(1.f, v)); }
+
+template <bool kLdsKeys>
+__global__ __launch_bounds__(kTB) void det_decode_sort_kernel(
+    const float *__restrict__ cls_prob, const float *__restrict__ loc_pred,
+    const float4 *__restrict__ anchors, int A, int C, float threshold, int clip,
+    float vx, float vy, float vw, float vh, int nms_enabled, int nms_topk, int n2cap,
+    DetWs ws, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_w[kTB / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  unsigned long long *keys = kLdsKeys ? reinterpret_cast<unsigned long long *>(smem)
+                                      : ws.keys + (size_t)b * n2cap;
+  const float *prob = cls_prob + (size_t)b * C * A;
+  const float *loc = loc_pred + (size_t)b * A * 5;
+  float *po = out + (size_t)b * A * 7;
+  float *pt = ws.temp + (size_t)b * A * 7;
+
+  int V = 0;
+  for (int base = 0; base < A; base += kTB) {
+    const int i = base + tid;
+    float score = -1.f; int id = 0;
+    if (i < A) {
+      for (int j = 1; j < C; ++j) {
+        const float t = prob[(size_t)j * A + i];
+        if (t > score) { score = t; id = j; }
+      }
+      if (id > 0 && score < threshold) id = 0;
+    }
+    int total;
+    const int pos = V + block_scan_pred(id > 0, s_w, total);
+    if (id > 0) {
+      const float4 a = anchors[i];
+      const float *p = loc + (size_t)i * 5;
+      const float aw = a.z - a.x, ah = a.w - a.y;
+      const float ax = (a.x + a.z) / 2.f, ay = (a.y + a.w) / 2.f;
+      const float ox = p[0] * vx * aw + ax;
+      const float oy = p[1] * vy * ah + ay;
+      const float ow = expf_cr(p[2] * vw) * aw / 2;
+      const float oh = expf_cr(p[3] * vh) * ah / 2;
+      const float oz = (float)((double)p[4] * 0.1);
+      float r[7];
+      r[0] = (float)(id - 1);
+      r[1] = score;
+      r[2] = clip ? clip01(ox - ow) : ox - ow;
+      r[3] = clip ? clip01(oy - oh) : oy - oh;
+      r[4] = clip ? clip01(ox + ow) : ox + ow;
+      r[5] = clip ? clip01(oy + oh) : oy + oh;
+      r[6] = clip ? clip01(oz) : oz;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { po[(size_t)pos * 7 + q] = r[q]; pt[(size_t)pos * 7 + q] = r[q]; }
+      if (nms_enabled)
+        keys[pos] = ((unsigned long long)(~ordered_bits(score)) << 32) | (unsigned)pos;
+    }
+    V += total;
+  }
+  for (size_t r = (size_t)V * 7 + tid; r < (size_t)A * 7; r += kTB) po[r] = -1.f;
+  const bool do_nms = nms_enabled && V >= 1;
+  if (tid == 0) ws.nms_count[b] = do_nms ? V : 0;
+  if (!do_nms) return;
+
+  // stable sort by score, descending: keys are unique (score, position) pairs
+  int n2 = 1;
+  while (n2 < V) n2 <<= 1;
+  for (int i = V + tid; i < n2; i += kTB) keys[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += kTB) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool asc = (i & k) == 0;
+          if ((x > y) == asc) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int nkeep = V;
+  if (nms_topk > 0 && nms_topk < nkeep) nkeep = nms_topk;
+  for (int e = tid; e < nkeep * 7; e += kTB) {
+    const int i = e / 7, q = e - i * 7;
+    const unsigned src = (unsigned)(keys[i] & 0xffffffffull);
+    po[e] = pt[(size_t)src * 7 + q];
+  }
+}
+
+__device__ __forceinline__ float nms_iou(const float *a, const float *b) {
+  const float w = fmaxr(0.f, fminr(a[2], b[2]) - fmaxr(a[0], b[0]));
+  const float h = fmaxr(0.f, fminr(a[3], b[3]) - fmaxr(a[1], b[1]));
+  const float i = w * h;
+  const float u = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - i;
+  return u <= 0.f ? 0.f : i / u;
+}
+
+// 64x64 tiles of the upper-triangular suppression matrix:
+// bit (i,j), j>i: row i would suppress row j (multibox_detection.cc:153-167).
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ out, int A,
+                                                      int nwords, float nms_threshold,
+                                                      int force, DetWs ws) {
+  const int ct = blockIdx.x, rt = blockIdx.y, b = blockIdx.z;
+  if (ct < rt) return;
+  const int V = ws.nms_count[b];
+  if (rt * 64 >= V || ct * 64 >= V) return;
+  __shared__ float s_box[64][5];
+  const float *po = out + (size_t)b * A * 7;
+  const int lane = threadIdx.x;
+  const int jc = ct * 64 + lane;
+  if (jc < V) {
+    const float *r = po + (size_t)jc * 7;
+    s_box[lane][0] = r[2]; s_box[lane][1] = r[3]; s_box[lane][2] = r[4]; s_box[lane][3] = r[5];
+    s_box[lane][4] = r[0];
+  }
+  __syncthreads();
+  const int i = rt * 64 + lane;
+  if (i >= V) return;
+  const float *ri = po + (size_t)i * 7;
+  const float bi[4] = {ri[2], ri[3], ri[4], ri[5]};
+  const float idi = ri[0];
+  unsigned long long bits = 0;
+  const int jmax = min(64, V - ct * 64);
+  for (int t = 0; t < jmax; ++t) {
+    const int j = ct * 64 + t;
+    if (j <= i) continue;
+    if (force || idi == s_box[t][4]) {
+      if (nms_iou(bi, s_box[t]) >= nms_threshold) bits |= 1ull << t;
+    }
+  }
+  ws.mask[((size_t)b * A + i) * nwords + ct] = bits;
+}
+
+// One wave per sample walks the rows in order and ORs the masks of surviving rows.
+__global__ __launch_bounds__(64) void nms_scan_kernel(float *__restrict__ out, int A, int nwords,
+                                                      DetWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long *removed = reinterpret_cast<unsigned long long *>(smem);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int V = ws.nms_count[b];
+  if (V == 0) return;
+  const int nw = (V + 63) >> 6;
+  const unsigned long long *mask = ws.mask + (size_t)b * A * nwords;
+  for (int w = lane; w < nw; w += 64) removed[w] = 0;
+  __syncthreads();
+  for (int w0 = 0; w0 < nw; ++w0) {
+    const int row = w0 * 64 + lane;
+    const unsigned long long diag = row < V ? mask[(size_t)row * nwords + w0] : 0ull;
+    unsigned long long cur = removed[w0];
+    for (int t = 0; t < 64; ++t) {
+      const unsigned long long d = __shfl(diag, t, 64);
+      if (!((cur >> t) & 1ull)) cur |= d;
+    }
+    const int rows_here = min(64, V - w0 * 64);
+    const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+    const unsigned long long alive = ~cur & valid;
+    __syncthreads();
+    if (lane == 0) removed[w0] = cur;
+    for (int w = w0 + 1 + lane; w < nw; w += 64) {
+      unsigned long long acc = removed[w];
+      unsigned long long rem = alive;
+      const unsigned long long *base = mask + (size_t)(w0 * 64) * nwords + w;
+      while (rem) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (rem) {
+            const int t = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            v[u] = base[(size_t)t * nwords];
+          } else {
+            v[u] = 0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc |= v[u];
+      }
+      removed[w] = acc;
+    }
+    __syncthreads();
+  }
+  float *po = out + (size_t)b * A * 7;
+  for (int i = lane; i < V; i += 64)
+    if ((removed[i >> 6] >> (i & 63)) & 1ull) po[(size_t)i * 7] = -1.f;
+}
+
+struct TargetLayout { size_t err, ngt, row_iou, row_gt, bgkey, flag, total; };
+TargetLayout target_layout(int B, int A) {
+  TargetLayout l;
+  size_t o = 0;
+  l.err = o; o = dspn::align_up(o + sizeof(int) * B, 256);
+  l.ngt = o; o = dspn::align_up(o + sizeof(int) * B, 256);
+  l.row_iou = o; o = dspn::align_up(o + sizeof(float) * (size_t)B * A, 256);
+  l.row_gt = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
+  l.bgkey = o; o = dspn::align_up(o + sizeof(unsigned) * (size_t)B * A, 256);
+  l.flag = o; o = dspn::align_up(o + (size_t)B * A, 256);
+  l.total = o;
+  return l;
+}
+
+constexpr int kLdsKeyCap = 16384;  // 128 KiB of 64-bit keys
+int next_pow2(int v) { int n = 1; while (n < v) n <<= 1; return n; }
+struct DetLayout { size_t cnt, temp, keys, mask, total; int n2cap, nwords; bool lds_keys; };
+DetLayout det_layout(int B, int A) {
+  DetLayout l;
+  l.n2cap = next_pow2(A);
+  l.lds_keys = l.n2cap <= kLdsKeyCap;
+  l.nwords = (A + 63) / 64;
+  size_t o = 0;
+  l.cnt = o; o = dspn::align_up(o + sizeof(int) * B, 256);
+  l.temp = o; o = dspn::align_up(o + sizeof(float) * (size_t)B * A * 7, 256);
+  l.keys = o; if (!l.lds_keys) o = dspn::align_up(o + 8 * (size_t)B * l.n2cap, 256);
+  l.mask = o; o = dspn::align_up(o + 8 * (size_t)B * A * l.nwords, 256);
+  l.total = o;
+  return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspn_multibox_prior_f32(const float *sizes, int num_sizes, const float *ratios, int num_ratios,
+                            int in_height, int in_width, float step_y, float step_x,
+                            float offset_y, float offset_x, int clip, float *out_dev,
+                            void *stream) {
+  // attribute checks of MultiBoxPriorOp's constructor (multibox_prior-inl.h:88-96)
+  DSPN_REQUIRE(sizes && num_sizes > 0, "MultiBoxPrior: sizes must not be empty");
+  DSPN_REQUIRE(ratios && num_ratios > 0, "MultiBoxPrior: ratios must not be empty");
+  DSPN_REQUIRE(num_sizes <= kMaxAttr && num_ratios <= kMaxAttr,
+               "MultiBoxPrior: at most %d sizes / ratios", kMaxAttr);
+  DSPN_REQUIRE(in_height > 0, "Input height should > 0");
+  DSPN_REQUIRE(in_width > 0, "Input width should > 0");
+  DSPN_REQUIRE(offset_y >= 0.f && offset_y <= 1.f && offset_x >= 0.f && offset_x <= 1.f,
+               "MultiBoxPrior: offsets must be in [0,1]");
+  DSPN_REQUIRE(step_y * step_x >= 0, "Must specify both step_y and step_x");
+  DSPN_REQUIRE(out_dev, "MultiBoxPrior: null output");
+  if (step_y <= 0 || step_x <= 0) { step_y = 1.f / in_height; step_x = 1.f / in_width; }
+  PriorAttr attr;
+  memset(&attr, 0, sizeof(attr));
+  memcpy(attr.sizes, sizes, sizeof(float) * num_sizes);
+  memcpy(attr.ratios, ratios, sizeof(float) * num_ratios);
+  const int total = in_height * in_width * (num_sizes + num_ratios - 1);
+  hipLaunchKernelGGL(prior_kernel, dim3(dspn::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     attr, num_sizes, num_ratios, in_height, in_width, step_y, step_x, offset_y,
+                     offset_x, clip, reinterpret_cast<float4 *>(out_dev));
+  return dspn::check_launch("multibox_prior");
+}
+
+size_t dspn_multibox_target_workspace_bytes(int batch, int num_anchors, int num_labels) {
+  (void)num_labels;
+  if (batch <= 0 || num_anchors <= 0) return 0;
+  return target_layout(batch, num_anchors).total;
+}
+
+int dspn_multibox_target_f32(const float *anchors_dev, const float *labels_dev,
+                             const float *cls_preds_dev, int batch, int num_anchors,
+                             int num_labels, int label_width, int num_classes,
+                             float overlap_threshold, float ignore_label,
+                             float negative_mining_ratio, float negative_mining_thresh,
+                             int minimum_negative_samples, const float variances[4],
+                             float *loc_target_dev, float *loc_mask_dev, float *cls_target_dev,
+                             void *workspace_dev, size_t workspace_bytes, void *stream) {
+  (void)minimum_negative_samples;  // CPU reference ignores it (multibox_target.cc:186-189)
+  // shape rules of MultiBoxTargetProp::InferShape (multibox_target-inl.h:213-238)
+  DSPN_REQUIRE(batch > 0, "MultiBoxTarget: batch must be > 0");
+  DSPN_REQUIRE(num_anchors > 0, "Number boxes should > 0");
+  DSPN_REQUIRE(num_labels > 0, "Padded label should > 0");
+  DSPN_REQUIRE(label_width == 6, "Label width should be 6: [cls-xmin-ymin-xmax-ymax-dist]");
+  DSPN_REQUIRE(num_classes > 0, "Prediction: [nbatch-num_classes-num_anchors]");
+  DSPN_REQUIRE(num_labels <= kMaxLabels, "MultiBoxTarget: at most %d label rows", kMaxLabels);
+  DSPN_REQUIRE(variances, "MultiBoxTarget: variances must have 4 values");
+  if (negative_mining_ratio > 0)
+    DSPN_REQUIRE(negative_mining_thresh > 0, "negative_mining_thresh must be > 0");
+  DSPN_REQUIRE(anchors_dev && labels_dev && cls_preds_dev && loc_target_dev && loc_mask_dev &&
+                   cls_target_dev && workspace_dev, "MultiBoxTarget: null pointer");
+  const TargetLayout l = target_layout(batch, num_anchors);
+  if (workspace_bytes < l.total)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "MultiBoxTarget: workspace %zu < %zu bytes",
+                      workspace_bytes, l.total);
+  char *w = static_cast<char *>(workspace_dev);
+  TargetWs ws;
+  ws.err = reinterpret_cast<int *>(w + l.err);
+  ws.ngt = reinterpret_cast<int *>(w + l.ngt);
+  ws.row_iou = reinterpret_cast<float *>(w + l.row_iou);
+  ws.row_gt = reinterpret_cast<int *>(w + l.row_gt);
+  ws.bgkey = reinterpret_cast<unsigned *>(w + l.bgkey);
+  ws.flag = reinterpret_cast<signed char *>(w + l.flag);
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *an = reinterpret_cast<const float4 *>(anchors_dev);
+  const dim3 grid(dspn::cdiv(num_anchors, 256), batch);
+  hipLaunchKernelGGL(target_rows_kernel, grid, dim3(256), 0, s, an, labels_dev, cls_preds_dev,
+                     num_anchors, num_labels, label_width, num_classes, ws);
+  hipLaunchKernelGGL(target_match_kernel, dim3(batch), dim3(kTB), 0, s, an, labels_dev,
+                     num_anchors, num_labels, label_width, overlap_threshold,
+                     negative_mining_ratio, negative_mining_thresh, ws);
+  hipLaunchKernelGGL(target_write_kernel, grid, dim3(256), 0, s, an, labels_dev, num_anchors,
+                     num_labels, label_width, ignore_label, variances[0], variances[1],
+                     variances[2], variances[3], ws, loc_target_dev, loc_mask_dev, cls_target_dev);
+  return dspn::check_launch("multibox_target");
+}
+
+int dspn_multibox_target_errors(const void *workspace_dev, int batch, int *host_codes,
+                                void *stream) {
+  DSPN_REQUIRE(workspace_dev && host_codes && batch > 0, "multibox_target_errors: bad argument");
+  hipError_t e = hipMemcpyAsync(host_codes, workspace_dev, sizeof(int) * batch,
+                                hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess)
+    return dspn::fail(DSPN_ERR_LAUNCH_, "multibox_target_errors: %s", hipGetErrorString(e));
+  for (int i = 0; i < batch; ++i)
+    if (host_codes[i] != 0) {
+      dspn::fail(-host_codes[i], host_codes[i] == 2
+                     ? "MultiBoxTarget: sample %d: padded label row is not all -1"
+                     : "MultiBoxTarget: sample %d: fewer mining candidates than negatives", i);
+      return -host_codes[i];
+    }
+  return 0;
+}
+
+size_t dspn_multibox_detection_workspace_bytes(int batch, int num_anchors) {
+  if (batch <= 0 || num_anchors <= 0) return 0;
+  return det_layout(batch, num_anchors).total;
+}
+
+int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred_dev,
+                                const float *anchors_dev, int batch, int num_anchors,
+                                int num_classes, float threshold, int clip,
+                                const float variances[4], float nms_threshold,
+                                int force_suppress, int nms_topk, float *out_dev,
+                                void *workspace_dev, size_t workspace_bytes, void *stream) {
+  // shape rules of MultiBoxDetectionProp::InferShape (multibox_detection-inl.h:149-171)
+  DSPN_REQUIRE(batch > 0, "MultiBoxDetection: batch must be > 0");
+  DSPN_REQUIRE(num_anchors > 0, "Number of anchors must > 0");
+  DSPN_REQUIRE(num_classes > 0, "MultiBoxDetection: num_classes must be > 0");
+  DSPN_REQUIRE(variances, "Variance size must be 4");
+  DSPN_REQUIRE(cls_prob_dev && loc_pred_dev && anchors_dev && out_dev && workspace_dev,
+               "MultiBoxDetection: null pointer");
+  const DetLayout l = det_layout(batch, num_anchors);
+  if (workspace_bytes < l.total)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "MultiBoxDetection: workspace %zu < %zu bytes",
+                      workspace_bytes, l.total);
+  char *w = static_cast<char *>(workspace_dev);
+  DetWs ws;
+  ws.nms_count = reinterpret_cast<int *>(w + l.cnt);
+  ws.temp = reinterpret_cast<float *>(w + l.temp);
+  ws.keys = reinterpret_cast<unsigned long long *>(w + l.keys);
+  ws.mask = reinterpret_cast<unsigned long long *>(w + l.mask);
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *an = reinterpret_cast<const float4 *>(anchors_dev);
+  const int nms_enabled = !(nms_threshold <= 0 || nms_threshold > 1);
+  if (l.lds_keys) {
+    const size_t lds = 8 * (size_t)l.n2cap;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_decode_sort_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kLdsKeyCap);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(det_decode_sort_kernel<true>, dim3(batch), dim3(kTB), lds, s, cls_prob_dev,
+                       loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, l.n2cap,
+                       ws, out_dev);
+  } else {
+    hipLaunchKernelGGL(det_decode_sort_kernel<false>, dim3(batch), dim3(kTB), 0, s, cls_prob_dev,
+                       loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, l.n2cap,
+                       ws, out_dev);
+  }
+  if (nms_enabled) {
+    const int nt = l.nwords;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, nt, batch), dim3(64), 0, s, out_dev, num_anchors,
+                       l.nwords, nms_threshold, force_suppress, ws);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 8 * (size_t)l.nwords, s, out_dev,
+                       num_anchors, l.nwords, ws);
+  }
+  return dspn::check_launch("multibox_detection");
+}
+
+}  // extern "C"

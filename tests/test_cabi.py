@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/*.h
+declares (no compute calls here)."""
+import glob
+import os
+import re
+
+import pytest
+
+from dspnet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(dspn_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exists_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    lib = _lib.lib()
+    assert lib.dspn_abi_version() >= 1
+    assert lib.dspn_last_error() is not None
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 8
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in dspnet_amd/_lib.py"
+    for name in _lib.SIGNATURES:
+        assert name in decl, f"{name} bound in _lib.py but not declared in include/*.h"
+
+
+def test_workspace_queries_are_pure():
+    lib = _lib.lib()
+    assert lib.dspn_multibox_target_workspace_bytes(32, 6132, 200) > 32 * 6132 * 13
+    assert lib.dspn_multibox_detection_workspace_bytes(2, 6132) > 2 * 6132 * 7 * 4
+    assert lib.dspn_multibox_target_workspace_bytes(0, 10, 10) == 0
+
+
+def test_argument_validation_without_gpu():
+    """shape/attribute checks happen before any HIP call and carry the reference's texts"""
+    import ctypes
+    lib = _lib.lib()
+    rc = lib.dspn_multibox_prior_f32(_lib.floats([0.1]), 1, _lib.floats([1.0]), 1, 0, 4,
+                                     -1.0, -1.0, 0.5, 0.5, 0, ctypes.c_void_p(16), None)
+    assert rc == -1 and b"Input height should > 0" in lib.dspn_last_error()
+    rc = lib.dspn_multibox_target_f32(16, 16, 16, 1, 4, 3, 5, 3, 0.5, -1.0, 3.0, 0.5, 0,
+                                      _lib.floats([.1, .1, .2, .2]), 16, 16, 16, 16, 1 << 20, None)
+    assert rc == -1 and b"Label width should be 6" in lib.dspn_last_error()
+
+
+def test_operator_front_end_rejects_cpu_tensors():
+    import torch
+    from dspnet_amd import operator as op
+    with pytest.raises(_lib.DspnError):
+        op.MultiBoxTarget(torch.zeros(1, 4, 4), torch.zeros(1, 2, 6), torch.zeros(1, 3, 4))
+    with pytest.raises(_lib.DspnError, match="Label width should be 6"):
+        op.MultiBoxTarget(torch.zeros(1, 4, 4), torch.zeros(1, 2, 5), torch.zeros(1, 3, 4))
+    with pytest.raises(_lib.DspnError, match="anchors mismatch"):
+        op.MultiBoxDetection(torch.zeros(1, 3, 4), torch.zeros(1, 19), torch.zeros(1, 4, 4))

@@ -1,0 +1,171 @@
+"""CPU tests of oracle/multibox_oracle.c: the reference-produced probe values recorded in
+SURVEY.md 8(c), agreement with an independent numpy reading, structural properties,
+and the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import mbx_cases as mc
+import ref_numpy as rn
+from oracle import multibox as om
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- the only numbers the reference itself produced ----------
+def test_probe_prior_first_boxes():
+    a = om.multibox_prior(2, 2, [.1, .141], [1, 2, .5])
+    np.testing.assert_allclose(a[0, 0], [0.2, 0.2, 0.3, 0.3], atol=1e-7)
+    np.testing.assert_allclose(a[0, 1], [0.1795, 0.1795, 0.3205, 0.3205], atol=1e-7)
+
+
+def test_probe_target_one_gt_four_anchor_grid():
+    anc = om.multibox_prior(2, 2, [.5], [1])
+    lab = -np.ones((1, 3, 6), np.float32)
+    lab[0, 0] = [1, .1, .1, .4, .4, .2]
+    lt, lm, ct = om.multibox_target(anc, lab, np.zeros((1, 3, 4), np.float32),
+                                    negative_mining_ratio=3)
+    assert ct.tolist() == [[2, 0, 0, 0]]
+    np.testing.assert_allclose(lt[0, :5], [0, 0, -2.554128, -2.554128, 2.0], rtol=1e-6, atol=1e-7)
+    assert lm[0, :5].tolist() == [1] * 5 and lm[0, 5:].sum() == 0
+
+
+def test_probe_detection_second_row_suppressed():
+    cls = np.array([[[0.1, 0.2, 0.3], [0.9, 0.8, 0.1]]], np.float32)
+    anc = np.array([[[0.1, 0.1, 0.5, 0.5], [0.12, 0.12, 0.5, 0.5], [0.6, 0.6, 0.9, 0.9]]], np.float32)
+    loc = np.zeros((1, 15), np.float32)
+    loc[0, 4] = 3.0
+    out = om.multibox_detection(cls, loc, anc)
+    assert out[0, 1, 0] == -1 and out[0, 0, 0] == 0 and out[0, 2, 0] == 0
+    assert abs(out[0, 0, 6] - 0.3) < 1e-6
+
+
+# ---- shapes recorded by the reference (utils.py:38, internal_out_shapes_512) ---------
+def test_anchor_counts_match_recorded_shapes():
+    per_map = [h * w * (len(s) + len(r) - 1) for (h, w), s, r in
+               zip(mc.r50_maps(512, 1024), mc.R50_SIZES, mc.R50_RATIOS)]
+    assert per_map == [8192, 3072, 768, 192, 32, 8]
+    assert mc.r50_anchors(512, 1024).shape == (1, 12264, 4)
+    assert mc.r50_anchors(512, 512).shape == (1, 6132, 4)
+
+
+# ---- prior properties ---------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 7), (32, 64)])
+def test_prior_geometry(h, w):
+    sizes, ratios = [.2, .272], [1, 2, .5, 3, 1. / 3]
+    a = om.multibox_prior(h, w, sizes, ratios)[0].reshape(h, w, -1, 4)
+    cx, cy = (a[..., 0] + a[..., 2]) / 2, (a[..., 1] + a[..., 3]) / 2
+    np.testing.assert_allclose(cx, np.broadcast_to(((np.arange(w) + .5) / w)[None, :, None], cx.shape), atol=1e-6)
+    np.testing.assert_allclose(cy, np.broadcast_to(((np.arange(h) + .5) / h)[:, None, None], cy.shape), atol=1e-6)
+    np.testing.assert_allclose(a[..., 0, 3] - a[..., 0, 1], sizes[0], atol=1e-6)
+    c = om.multibox_prior(h, w, sizes, ratios, clip=True)
+    assert c.min() >= 0 and c.max() <= 1
+    np.testing.assert_array_equal(c, np.clip(om.multibox_prior(h, w, sizes, ratios), 0, 1))
+
+
+# ---- oracle vs the independent numpy reading ------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("ratio,thr", [(3.0, 0.5), (-1.0, 0.5), (3.0, 0.0), (1.5, 0.3)])
+def test_target_matches_numpy_reading(seed, ratio, thr):
+    anc = mc.small_anchors(6, 7)
+    lab, pred = mc.target_inputs(anc, batch=3, num_labels=12, num_classes=4, max_gt=8, seed=seed)
+    got = om.multibox_target(anc, lab, pred, overlap_threshold=thr, negative_mining_ratio=ratio,
+                             negative_mining_thresh=0.5)
+    exp = rn.target(anc, lab, pred, overlap_threshold=thr, negative_mining_ratio=ratio,
+                    negative_mining_thresh=0.5)
+    mc.assert_target_equal(got, exp)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("topk,force,clip", [(-1, False, True), (5, False, True), (400, True, False)])
+def test_detection_matches_numpy_reading(seed, topk, force, clip):
+    anc = mc.small_anchors(6, 7)
+    prob, loc = mc.detection_inputs(anc, batch=2, num_classes=4, seed=seed, peaky=False)
+    got = om.multibox_detection(prob, loc, anc, nms_topk=topk, force_suppress=force, clip=clip,
+                                nms_threshold=0.45)
+    exp = rn.detection(prob, loc, anc, nms_topk=topk, force_suppress=force, clip=clip,
+                       nms_threshold=0.45)
+    np.testing.assert_array_equal(got, exp)
+
+
+# ---- behaviours the reference code implies -------------------------------------------
+def test_target_empty_and_terminated_labels():
+    anc = mc.small_anchors()
+    A = anc.shape[1]
+    lab = -np.ones((2, 5, 6), np.float32)
+    lab[1, 0] = [-1, -1, -1, -1, -1, -1]
+    lab[1, 1] = [2, .1, .1, .6, .6, .5]          # after a -1 row: must be ignored
+    pred = np.zeros((2, 3, A), np.float32)
+    lt, lm, ct = om.multibox_target(anc, lab, pred, negative_mining_ratio=3)
+    assert (ct == -1).all() and (lt == 0).all() and (lm == 0).all()
+
+
+def test_target_bad_padding_row_is_reported():
+    anc = mc.small_anchors()
+    lab = -np.ones((1, 4, 6), np.float32)
+    lab[0, 0] = [0, .1, .1, .5, .5, .3]
+    lab[0, 1] = [-1, .2, -1, -1, -1, -1]
+    _, rc = om.multibox_target(anc, lab, np.zeros((1, 3, anc.shape[1]), np.float32),
+                               negative_mining_ratio=3, return_code=True)
+    assert rc == -2
+
+
+def test_target_negative_count_and_tie_order():
+    anc = mc.small_anchors(8, 8)
+    A = anc.shape[1]
+    lab = -np.ones((1, 6, 6), np.float32)
+    lab[0, 0] = [3, .30, .30, .55, .55, .9]
+    pred = np.zeros((1, 5, A), np.float32)        # all-equal scores: ties resolved by index
+    lt, lm, ct = om.multibox_target(anc, lab, pred, negative_mining_ratio=3)
+    npos = int((ct > 0).sum())
+    assert npos >= 1 and int((ct == 0).sum()) == 3 * npos
+    cand = np.nonzero(ct[0] <= 0)[0]
+    negs = np.nonzero(ct[0] == 0)[0]
+    ious = rn.iou_matrix(anc[0], lab[0, :1, 1:5])[:, 0]
+    eligible = [j for j in cand if ious[j] < 0.5]
+    assert negs.tolist() == eligible[:3 * npos]
+    assert (ct[0][ct[0] > 0] == 4).all()
+    pos = np.nonzero(ct[0] > 0)[0]
+    np.testing.assert_allclose(lt.reshape(1, A, 5)[0, pos, 4], np.float32(np.float64(np.float32(.9)) / 0.1))
+
+
+def test_detection_topk_leaves_stale_rows():
+    """rows >= nms_topk keep their pre-sort (anchor-order) content (multibox_detection.cc:143-151)"""
+    anc = mc.small_anchors(6, 7)
+    prob, loc = mc.detection_inputs(anc, batch=1, num_classes=4, seed=5, peaky=False)
+    full = om.multibox_detection(prob, loc, anc, nms_threshold=1.0, nms_topk=-1, threshold=0.0)
+    unsorted = om.multibox_detection(prob, loc, anc, nms_threshold=-1.0, threshold=0.0)
+    top3 = om.multibox_detection(prob, loc, anc, nms_threshold=1.0, nms_topk=3, threshold=0.0)
+    V = int((unsorted[0, :, 1] >= 0).sum())
+    assert V > 10
+    np.testing.assert_array_equal(top3[0, :3, 1:], full[0, :3, 1:])
+    np.testing.assert_array_equal(top3[0, 3:V, 1:], unsorted[0, 3:V, 1:])
+    assert (np.diff(full[0, :V, 1]) <= 0).all()
+
+
+def test_detection_idempotent_under_row_permutation_of_scores():
+    anc = mc.small_anchors(5, 5)
+    prob, loc = mc.detection_inputs(anc, batch=1, num_classes=3, seed=9, peaky=False)
+    out = om.multibox_detection(prob, loc, anc, nms_threshold=0.5)
+    kept = out[0][out[0, :, 0] >= 0]
+    for i in range(len(kept)):
+        for j in range(i + 1, len(kept)):
+            if kept[i, 0] == kept[j, 0]:
+                a, b = kept[i, 2:6], kept[j, 2:6]
+                w = max(0, min(a[2], b[2]) - max(a[0], b[0])); h = max(0, min(a[3], b[3]) - max(a[1], b[1]))
+                u = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - w * h
+                assert u <= 0 or w * h / u < 0.5 + 1e-6
+
+
+# ---- golden fixtures (regression pin of the oracle; consumed again by the GPU tests) ----
+def test_golden_fixtures_reproduce():
+    path = os.path.join(GOLDEN, "multibox_small.npz")
+    g = np.load(path)
+    anc = g["anchors"]
+    got = om.multibox_target(anc, g["label"], g["cls_pred"], negative_mining_ratio=3,
+                             negative_mining_thresh=.5, overlap_threshold=.5)
+    for k, v in zip(("loc_target", "loc_mask", "cls_target"), got):
+        np.testing.assert_array_equal(v, g[k])
+    det = om.multibox_detection(g["cls_prob"], g["loc_pred"], anc, nms_threshold=.45, nms_topk=20)
+    np.testing.assert_array_equal(det, g["det"])
