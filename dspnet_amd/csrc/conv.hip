@@ -1,0 +1,533 @@
+// NHWC fp32 convolution family for MI355X (gfx950) on v_mfma_f32_32x32x2_f32.
+//
+// One implicit-GEMM "NT" kernel serves forward, data-gradient and transposed
+// convolution: the GEMM-M dimension enumerates a grid of output pixels, the
+// K dimension enumerates (tap, channel) of a GATHERED tensor, and a small
+// geometry record says how a grid point + tap maps to a gathered pixel, to a
+// weight tap and to an output address.  Stride-2 data gradients / 4x4 s2
+// transposed convs run as 4 parity classes (no MFMA work on structurally-zero
+// taps).  A second "TN" kernel computes weight gradients with split-K over
+// pixels into slabs that a reduce kernel sums in a fixed order (bitwise
+// reproducible; no float atomics).
+//
+// Tiling (wave64, 4 waves / 256 threads per workgroup): block tile
+// (WAVES_M*TM*32) x (WAVES_N*TN*32), BK = 32 floats.  Tiles are staged
+// global -> registers -> LDS (16 B per lane, coalesced along C of NHWC) and
+// double buffered: the loads of k-step t+1 are issued before the MFMAs of step
+// t and written to the other LDS buffer after them (one barrier per k-step).
+// LDS rows are padded to 36 floats: 16 B aligned for ds_write_b128 and at most
+// 2-way conflicts for the ds_read_b64 fragment reads.  Each ds_read_b64 feeds
+// two MFMAs: within a group of 4 k values lanes 0-31 take k={0,1} and lanes
+// 32-63 take k={2,3} for BOTH operands (the k order inside a sum is free).
+//
+// fp32 MFMA is an exact fmaf chain (no reduced precision); peak 157 TFLOP/s.
+#include "dspn_common.h"
+#include "../../include/dspn_nn.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;        // floats per k-step
+constexpr int kLdsRow = 36;    // padded LDS row (floats)
+constexpr int kThreads = 256;
+
+struct ConvGeom {
+  int N, Hin, Win, Cin;            // gathered tensor (Cin % 4 == 0)
+  int Hg, Wg;                      // grid of output points per image
+  int ish, isw, ioh, iow, idh, idw;  // ih = i*ish + ioh + tr*idh
+  int TR, TS;                      // taps enumerated
+  int WTAPS, WS, wr0, wrs, ws0, wss;  // weight tap = (wr0+tr*wrs)*WS + ws0+ts*wss
+  int Cout;
+  long long obs;                   // output batch stride (floats)
+  int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
+  int flags;                       // 1 bias, 2 relu, 4 accumulate
+  int dense;                       // output address = m*ldc (no decomposition needed)
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD a
+  // contiguous run of logical tiles so neighbouring tiles share its L2.
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + (bid >> 3);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
+    const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per k-step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sA = smem;                          // [2][BM][kLdsRow]
+  float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+  const int mt = tile / n_tiles, nt = tile - mt * n_tiles;   // n fastest: A tile reuse in L2
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int M = g.N * g.Hg * g.Wg;
+  const int CQ = g.Cin >> 2;
+  const int total_q = g.TR * g.TS * CQ;
+  const int nk = (total_q + 7) >> 3;
+
+  const int chunk = tid & 7, row0 = tid >> 3;
+
+  // per-thread gather state of its A rows
+  int a_ih0[A_LD], a_iw0[A_LD];
+  long long a_base[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    if (m < M) {
+      const int hw = g.Hg * g.Wg;
+      const int n = m / hw, rem = m - n * hw;
+      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+      a_ih0[i] = oi * g.ish + g.ioh;
+      a_iw0[i] = oj * g.isw + g.iow;
+      a_base[i] = (long long)n * g.Hin * g.Win * g.Cin;
+    } else {
+      a_ih0[i] = -0x40000000; a_iw0[i] = 0; a_base[i] = 0;
+    }
+  }
+
+  float4 ra[A_LD], rb[B_LD];
+  auto load_tiles = [&](int kt) {
+    const int q = kt * 8 + chunk;
+    const bool qv = q < total_q;
+    const int tap = q / CQ, cq = q - tap * CQ;
+    const int tr = tap / g.TS, ts = tap - tr * g.TS;
+    const int dh = tr * g.idh, dw = ts * g.idw;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
+      const bool v = qv && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      ra[i] = v ? *reinterpret_cast<const float4 *>(
+                      in + a_base[i] + ((long long)ih * g.Win + iw) * g.Cin + cq * 4)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int k = n0 + row0 + 32 * i;
+      const bool v = qv && k < g.Cout;
+      rb[i] = v ? *reinterpret_cast<const float4 *>(
+                      wgt + ((long long)k * g.WTAPS + wtap) * g.Cin + cq * 4)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
+  const int frow = lane & 31, fk = (lane >> 5) * 2;
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
+    const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
+#pragma unroll
+    for (int gq = 0; gq < kBK / 4; ++gq) {
+      float2 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + gq * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow + gq * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    const bool cv = co < g.Cout;
+    const float bv = (has_bias && cv) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (!cv || m >= M) continue;
+        long long off;
+        if (g.dense) {
+          off = (long long)m * g.ldc + co;
+        } else {
+          const int hw = g.Hg * g.Wg;
+          const int n = m / hw, rem = m - n * hw;
+          const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+          off = (long long)n * g.obs +
+                ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+        }
+        float v = acc[i][j][r] + bv;
+        if (accum) v += out[off];
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[off] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dW[k][tap][c] = sum_pix dY[pix][k] * X[pix@tap][c]
+// ---------------------------------------------------------------------------
+struct WgradGeom {
+  int N, Hin, Win, Cin;      // X (gathered), Cin % 4 == 0
+  int Ho, Wo, Cout;          // dY grid and channels (Cout % 4 == 0 physical row = ldy)
+  int ldy;                   // dY pixel stride (floats)
+  int sh, sw, ph, pw, dh, dw;  // ih = ho*sh - ph + r*dh
+  int R, S;
+  int pix_per_split;         // multiple of kBK
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slab,
+    const WgradGeom g, const int k_tiles, const int j_tiles) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;   // BM over cout, BN over (tap,c)
+  constexpr int A_LD = BM * kBK / 4 / kThreads, B_LD = BN * kBK / 4 / kThreads;
+  constexpr int A_CH = BM / 4, B_CH = BN / 4;                      // 16-B chunks per tile row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sA = smem;                      // [2][kBK][BM]
+  float *sB = smem + 2 * kBK * BM;       // [2][kBK][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int kt_i = tile / j_tiles, jt_i = tile - kt_i * j_tiles;
+  const int k0 = kt_i * BM, j0 = jt_i * BN;
+  const int split = blockIdx.y;
+  const int P = g.N * g.Ho * g.Wo;
+  const int J = g.R * g.S * g.Cin;
+  const int p_begin = split * g.pix_per_split;
+  const int p_end = min(P, p_begin + g.pix_per_split);
+  const int nk = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+
+  // fixed per-thread column chunk of the B (x) tile -> fixed tap and channel
+  const int b_chunk = tid % B_CH, b_row0 = tid / B_CH;   // rows step by kThreads / B_CH
+  constexpr int B_RSTEP = kThreads / B_CH;
+  const int jq = (j0 >> 2) + b_chunk;
+  const int CQ = g.Cin >> 2;
+  const bool jv = jq * 4 < J;
+  const int tap = jq / CQ, cq = jq - tap * CQ;
+  const int tr = tap / g.S, ts = tap - tr * g.S;
+  const int tdh = tr * g.dh - g.ph, tdw = ts * g.dw - g.pw;
+  const int a_chunk = tid % A_CH, a_row0 = tid / A_CH;
+  constexpr int A_RSTEP = kThreads / A_CH;
+  const bool kv = k0 + a_chunk * 4 < g.Cout;
+
+  float4 ra[A_LD], rb[B_LD];
+  auto load_tiles = [&](int kt) {
+    const int pb = p_begin + kt * kBK;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int p = pb + a_row0 + i * A_RSTEP;
+      ra[i] = (kv && p < p_end)
+                  ? *reinterpret_cast<const float4 *>(dy + (long long)p * g.ldy + k0 + a_chunk * 4)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int p = pb + b_row0 + i * B_RSTEP;
+      bool v = jv && p < p_end;
+      long long off = 0;
+      if (v) {
+        const int hw = g.Ho * g.Wo;
+        const int n = p / hw, rem = p - n * hw;
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        const int ih = ho * g.sh + tdh, iw = wo * g.sw + tdw;
+        v = (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+        off = (((long long)n * g.Hin + ih) * g.Win + iw) * g.Cin + cq * 4;
+      }
+      rb[i] = v ? *reinterpret_cast<const float4 *>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float *a = sA + buf * kBK * BM, *b = sB + buf * kBK * BN;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<float4 *>(a + (a_row0 + i * A_RSTEP) * BM + a_chunk * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      *reinterpret_cast<float4 *>(b + (b_row0 + i * B_RSTEP) * BN + b_chunk * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
+  if (nk > 0) { load_tiles(0); store_tiles(0); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float *a = sA + buf * kBK * BM + (lane >> 5) * BM + wm + (lane & 31);
+    const float *b = sB + buf * kBK * BN + (lane >> 5) * BN + wn + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < kBK / 2; ++ks) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = a[ks * 2 * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = b[ks * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+  // slab[split][k][J]
+  float *o = slab + (long long)split * g.Cout * J;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jj = j0 + wn + j * 32 + (lane & 31);
+    if (jj >= J) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (k < g.Cout) o[(long long)k * J + jj] = acc[i][j][r];
+      }
+  }
+}
+
+// dw[i] (+)= sum_s slab[s][i], fixed order
+__global__ void slab_reduce_kernel(const float4 *__restrict__ slab, float4 *__restrict__ dw,
+                                   long long n4, int splits, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 s = slab[i];
+    for (int k = 1; k < splits; ++k) {
+      const float4 v = slab[(long long)k * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) { const float4 v = dw[i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    dw[i] = s;
+  }
+}
+
+// W[k][t][c] -> Wt[c][t][k]   (data-gradient operand)
+__global__ void weight_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt,
+                                        int K, int T, int C, int Kp) {
+  // wt has row length Kp >= K (Kp % 4 == 0), zero padded
+  const long long total = (long long)C * T * Kp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const long long ct = i / Kp;
+    const int t = (int)(ct % T), c = (int)(ct / T);
+    wt[i] = k < K ? w[((long long)k * T + t) * C + c] : 0.f;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
+              hipStream_t s) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  const long long M = (long long)g.N * g.Hg * g.Wg;
+  if (M <= 0) return 0;
+  const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * kLdsRow;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt);
+  return dspn::check_launch("conv_nt");
+}
+
+int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
+                hipStream_t s) {
+  const long long M = (long long)g.N * g.Hg * g.Wg;
+  if (g.Cout <= 32) return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s);   // 256 x 32
+  if (g.Cout <= 64) return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s);   // 128 x 64
+  // 128x128 unless that leaves most of the chip idle
+  const long long tiles128 = ((M + 127) / 128) * ((g.Cout + 127) / 128);
+  if (tiles128 < 256) return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s);
+  return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s);                     // 128 x 128
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
+                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                            int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
+                            int relu, int accumulate, void *stream) {
+  DSPN_REQUIRE(x && w && y, "conv2d_forward: null pointer");
+  DSPN_REQUIRE(Cin % 4 == 0, "conv2d_forward: Cin must be a multiple of 4 (pad channels), got %d", Cin);
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0,
+               "conv2d_forward: bad geometry");
+  DSPN_REQUIRE(Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 &&
+                   Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1,
+               "conv2d_forward: output size mismatch");
+  ConvGeom g;
+  memset(&g, 0, sizeof(g));
+  g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Hg = Ho; g.Wg = Wo;
+  g.ish = stride; g.isw = stride; g.ioh = -pad; g.iow = -pad; g.idh = dil; g.idw = dil;
+  g.TR = R; g.TS = S; g.WTAPS = R * S; g.WS = S; g.wr0 = 0; g.wrs = 1; g.ws0 = 0; g.wss = 1;
+  g.Cout = Cout;
+  g.ldc = y_ldc > 0 ? y_ldc : Cout;
+  g.obs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * g.ldc;
+  g.OW = Wo; g.osh = 1; g.osw = 1; g.ooh = 0; g.oow = 0;
+  g.dense = (g.obs == (long long)Ho * Wo * g.ldc);
+  g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0);
+  return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream);
+}
+
+int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
+                                     int Cout_pad, void *stream) {
+  DSPN_REQUIRE(w && wt && Cout > 0 && taps > 0 && Cin > 0 && Cout_pad >= Cout && Cout_pad % 4 == 0,
+               "weight_transpose: bad argument");
+  const long long total = (long long)Cin * taps * Cout_pad;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     wt, Cout, taps, Cin, Cout_pad);
+  return dspn::check_launch("weight_transpose");
+}
+
+// dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
+// Also the forward of a transposed convolution (x := dy).
+int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+                          int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Wo, int dx_ldc, int accumulate, void *stream) {
+  DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
+  DSPN_REQUIRE(ldy % 4 == 0, "conv2d_dgrad: dy channel stride must be a multiple of 4");
+  DSPN_REQUIRE(stride == 1 || (stride == 2 && dil == 1), "conv2d_dgrad: stride 1, or stride 2 with dilation 1");
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && R > 0 && S > 0, "conv2d_dgrad: bad geometry");
+  ConvGeom g;
+  memset(&g, 0, sizeof(g));
+  g.N = N; g.Hin = Ho; g.Win = Wo; g.Cin = ldy; g.Cout = Cin;
+  g.WTAPS = R * S; g.WS = S;
+  g.ldc = dx_ldc > 0 ? dx_ldc : Cin;
+  g.obs = (long long)H * W * g.ldc;
+  g.OW = W;
+  g.flags = accumulate ? 4 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (stride == 1) {
+    g.Hg = H; g.Wg = W; g.ish = 1; g.isw = 1; g.ioh = pad; g.iow = pad; g.idh = -dil; g.idw = -dil;
+    g.TR = R; g.TS = S; g.wr0 = 0; g.wrs = 1; g.ws0 = 0; g.wss = 1;
+    g.osh = 1; g.osw = 1; g.dense = 1;
+    return dispatch_nt(dy, wt, nullptr, dx, g, s);
+  }
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      ConvGeom c = g;
+      c.Hg = (H - ph + 1) / 2; c.Wg = (W - pw + 1) / 2;
+      if (c.Hg <= 0 || c.Wg <= 0) continue;
+      const int r0 = (ph + pad) & 1, s0 = (pw + pad) & 1;
+      c.TR = r0 < R ? (R - r0 + 1) / 2 : 0;
+      c.TS = s0 < S ? (S - s0 + 1) / 2 : 0;
+      if (c.TR == 0 || c.TS == 0) {
+        c.TR = 0; c.TS = 1;
+        if (accumulate) continue;   // nothing to add
+      }
+      c.ish = 1; c.isw = 1; c.ioh = (ph + pad - r0) / 2; c.iow = (pw + pad - s0) / 2;
+      c.idh = -1; c.idw = -1;
+      c.wr0 = r0; c.wrs = 2; c.ws0 = s0; c.wss = 2;
+      c.osh = 2; c.osw = 2; c.ooh = ph; c.oow = pw; c.dense = 0;
+      const int rc = dispatch_nt(dy, wt, nullptr, dx, c, s);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S) {
+  // upper bound on splits is 64
+  return sizeof(float) * (size_t)64 * Cout * R * S * Cin;
+}
+
+int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
+                          int Cout, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Wo, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  DSPN_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
+  DSPN_REQUIRE(Cin % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: channel strides must be multiples of 4");
+  WgradGeom g;
+  g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
+  g.sh = stride; g.sw = stride; g.ph = pad; g.pw = pad; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
+  const long long P = (long long)N * Ho * Wo;
+  const int J = R * S * Cin;
+  const bool narrow = Cout <= 64;
+  const int BM = narrow ? 64 : 128, BN = 128;
+  const int kt = (Cout + BM - 1) / BM, jt = (J + BN - 1) / BN;
+  // enough workgroups for ~3 waves of the chip, at least 256 pixels per split, at most 64 splits
+  long long want = (768 + (long long)kt * jt - 1) / ((long long)kt * jt);
+  long long max_by_pix = (P + 255) / 256;
+  long long splits = std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_pix), 64));
+  long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
+  splits = (P + pps - 1) / pps;
+  g.pix_per_split = (int)pps;
+  const size_t need = sizeof(float) * (size_t)splits * Cout * J;
+  if (workspace_bytes < need)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  float *slab = static_cast<float *>(workspace);
+  const size_t lds = sizeof(float) * 2 * kBK * (BM + BN);
+  if (narrow) {
+    auto kern = conv_wgrad_kernel<2, 2, 1, 2>;   // 64 x 128
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt);
+  } else {
+    auto kern = conv_wgrad_kernel<2, 2, 2, 2>;   // 128 x 128
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt);
+  }
+  int rc = dspn::check_launch("conv_wgrad");
+  if (rc) return rc;
+  const long long n4 = (long long)Cout * J / 4;
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s,
+                     reinterpret_cast<const float4 *>(slab), reinterpret_cast<float4 *>(dw), n4,
+                     (int)splits, accumulate);
+  return dspn::check_launch("conv_wgrad_reduce");
+}
+
+}  // extern "C"

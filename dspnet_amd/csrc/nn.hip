@@ -1,0 +1,819 @@
+// HBM-bound kernels of the DSPNet multi-task step on MI355X (gfx950): batch-stat
+// BatchNorm (+ReLU) forward/backward, pooling, bilinear sampler, losses, SGD and
+// layout helpers.  C ABI in include/dspn_nn.h.
+//
+// All tensors are NHWC fp32 with a physical channel count that is a multiple of
+// 4, so every streaming access is a 16-byte-per-lane float4 with consecutive
+// lanes on consecutive addresses.  Reductions are two-stage (per-slab partials
+// in a caller workspace, then a fixed-order finalize in double), never float
+// atomics, so every result is bitwise reproducible run to run.
+#include "dspn_common.h"
+#include "../../include/dspn_nn.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kSlabRows = 512;
+
+inline int grid_for(long long n, int per_block = kT, int cap = 8192) {
+  long long b = (n + per_block - 1) / per_block;
+  return (int)std::max<long long>(1, std::min<long long>(b, cap));
+}
+
+// ------------------------------------------------------------------ BN statistics
+// partial[slab][0][c] = sum (x - K[c]), partial[slab][1][c] = sum (x - K[c])^2, K = row 0
+__global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__restrict__ x,
+                                                              long long rows, int C4, int CL,
+                                                              float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm4[];
+  const int RL = kT / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c4 = blockIdx.y * CL + cl;
+  const long long r0 = (long long)blockIdx.x * kSlabRows;
+  const long long r1 = min(rows, r0 + kSlabRows);
+  float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+  const bool act = rl < RL && c4 < C4;
+  if (act) {
+    const float4 K = x[c4];
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const float4 v = x[r * C4 + c4];
+      const float a = v.x - K.x, b = v.y - K.y, c = v.z - K.z, d = v.w - K.w;
+      s.x += a; s.y += b; s.z += c; s.w += d;
+      ss.x += a * a; ss.y += b * b; ss.z += c * c; ss.w += d * d;
+    }
+  }
+  float4 *s_s = sm4, *s_ss = sm4 + kT;
+  s_s[threadIdx.x] = s; s_ss[threadIdx.x] = ss;
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    for (int k = 1; k < RL; ++k) {
+      const float4 a = s_s[k * CL + cl], b = s_ss[k * CL + cl];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      ss.x += b.x; ss.y += b.y; ss.z += b.z; ss.w += b.w;
+    }
+    float4 *p = reinterpret_cast<float4 *>(partial) + (long long)blockIdx.x * 2 * C4;
+    p[c4] = s; p[C4 + c4] = ss;
+  }
+}
+
+__global__ void bn_stats_final_kernel(const float *__restrict__ x, const float *__restrict__ partial,
+                                      int nslabs, long long rows, int C, float eps,
+                                      float *__restrict__ mean, float *__restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S = 0, SS = 0;
+  for (int k = 0; k < nslabs; ++k) {
+    S += partial[(long long)k * 2 * C + c];
+    SS += partial[(long long)k * 2 * C + C + c];
+  }
+  const double n = (double)rows;
+  const double m = S / n;
+  double var = SS / n - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)((double)x[c] + m);
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void bn_apply_kernel(const float4 *__restrict__ x, const float *__restrict__ mean,
+                                const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, float4 *__restrict__ y,
+                                long long n4, int C4, int relu) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 v = x[i];
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float g = gamma ? gamma[c + q] : 1.f;
+      const float sc = g * rstd[c + q];
+      float t = (o[q] - mean[c + q]) * sc + beta[c + q];
+      if (relu) t = t > 0.f ? t : 0.f;
+      o[q] = t;
+    }
+    y[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// partial[slab][0][c] = sum dy', partial[slab][1][c] = sum dy' * xhat ; dy' = relu ? dy*(y>0) : dy
+__global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
+    const float4 *__restrict__ x, const float4 *__restrict__ y, const float4 *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ rstd, long long rows, int C4, int CL,
+    int relu, float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm4[];
+  const int RL = kT / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c4 = blockIdx.y * CL + cl;
+  const long long r0 = (long long)blockIdx.x * kSlabRows;
+  const long long r1 = min(rows, r0 + kSlabRows);
+  float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+  if (rl < RL && c4 < C4) {
+    const float4 m = reinterpret_cast<const float4 *>(mean)[c4];
+    const float4 rs = reinterpret_cast<const float4 *>(rstd)[c4];
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const float4 xv = x[r * C4 + c4];
+      float4 g = dy[r * C4 + c4];
+      if (relu) {
+        const float4 yv = y[r * C4 + c4];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+      ss.x += g.x * ((xv.x - m.x) * rs.x); ss.y += g.y * ((xv.y - m.y) * rs.y);
+      ss.z += g.z * ((xv.z - m.z) * rs.z); ss.w += g.w * ((xv.w - m.w) * rs.w);
+    }
+  }
+  float4 *s_s = sm4, *s_ss = sm4 + kT;
+  s_s[threadIdx.x] = s; s_ss[threadIdx.x] = ss;
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    for (int k = 1; k < RL; ++k) {
+      const float4 a = s_s[k * CL + cl], b = s_ss[k * CL + cl];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      ss.x += b.x; ss.y += b.y; ss.z += b.z; ss.w += b.w;
+    }
+    float4 *p = reinterpret_cast<float4 *>(partial) + (long long)blockIdx.x * 2 * C4;
+    p[c4] = s; p[C4 + c4] = ss;
+  }
+}
+
+// sums[0][c] = sum dy', sums[1][c] = sum dy' xhat (kept after the partials in the workspace)
+__global__ void bn_bwd_final_kernel(const float *__restrict__ partial, int nslabs, int C,
+                                    float *__restrict__ sums, float *__restrict__ dgamma,
+                                    float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S = 0, SS = 0;
+  for (int k = 0; k < nslabs; ++k) {
+    S += partial[(long long)k * 2 * C + c];
+    SS += partial[(long long)k * 2 * C + C + c];
+  }
+  sums[c] = (float)S; sums[C + c] = (float)SS;
+  if (dbeta) dbeta[c] = (float)S;
+  if (dgamma) dgamma[c] = (float)SS;
+}
+
+__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ y,
+                                    const float4 *__restrict__ dy, const float *__restrict__ mean,
+                                    const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                    const float *__restrict__ sums, float4 *__restrict__ dx,
+                                    long long n4, int C4, float inv_rows, int relu, int accumulate) {
+  const int C = C4 * 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 xv = x[i];
+    const float4 gv = dy[i];
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (relu) {
+      const float4 yv = y[i];
+      g[0] = yv.x > 0.f ? g[0] : 0.f; g[1] = yv.y > 0.f ? g[1] : 0.f;
+      g[2] = yv.z > 0.f ? g[2] : 0.f; g[3] = yv.w > 0.f ? g[3] : 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float rs = rstd[c + q];
+      const float xh = (xs[q] - mean[c + q]) * rs;
+      const float ga = gamma ? gamma[c + q] : 1.f;
+      o[q] = ga * rs * (g[q] - sums[c + q] * inv_rows - xh * (sums[C + c + q] * inv_rows));
+    }
+    if (accumulate) { const float4 d = dx[i]; o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
+    dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------ element-wise
+__global__ void add_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                           float4 *__restrict__ o, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float4 x = a[i], y = b[i];
+    o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+__global__ void add_tail_kernel(const float *a, const float *b, float *o, long long start, long long n) {
+  const long long i = start + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+__global__ void relu_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
+                                float *__restrict__ dx, long long n, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v = y[i] > 0.f ? dy[i] : 0.f;
+    if (accumulate) v += dx[i];
+    dx[i] = v;
+  }
+}
+__global__ void fill_kernel(float *p, float v, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// column sums, two stage
+__global__ __launch_bounds__(kT) void colsum_partial_kernel(const float *__restrict__ a,
+                                                            long long rows, int C, int ld,
+                                                            float *__restrict__ partial) {
+  __shared__ float sm[kT];
+  const int CL = min(C, kT), RL = kT / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const long long r0 = (long long)blockIdx.x * kSlabRows, r1 = min(rows, r0 + kSlabRows);
+  for (int cb = 0; cb < C; cb += CL) {
+    const int c = cb + cl;
+    float s = 0.f;
+    if (rl < RL && c < C)
+      for (long long r = r0 + rl; r < r1; r += RL) s += a[r * ld + c];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      for (int k = 1; k < RL; ++k) s += sm[k * CL + cl];
+      partial[(long long)blockIdx.x * C + c] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void colsum_final_kernel(const float *partial, int nslabs, int C, float *out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int k = 0; k < nslabs; ++k) s += partial[(long long)k * C + c];
+  out[c] = (float)s;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                    int C, long long HW, long long total_pix, int Cp) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total_pix;
+       p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / HW, hw = p - n * HW;
+    for (int c = 0; c < Cp; ++c)
+      dst[p * Cp + c] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                    int C, long long HW, long long total, int Cp) {
+  // thread per dst element, hw fastest
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long hw = i % HW, nc = i / HW;
+    const long long n = nc / C; const int c = (int)(nc - n * C);
+    dst[i] = src[(n * HW + hw) * Cp + c];
+  }
+}
+__global__ void copy_block_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                  long long rows_per_sample, int C, long long sss, int lds, int soff,
+                                  long long dss, int ldd, int doff, long long total, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const long long s = r / rows_per_sample, rr = r - s * rows_per_sample;
+    const float v = src[s * sss + rr * lds + soff + c];
+    float *d = dst + s * dss + rr * ldd + doff + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+__global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                     int N, int C, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N);
+    const long long bc = i / N;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    dst[i] = src[(b * N + n) * C + c];
+  }
+}
+
+// ------------------------------------------------------------------ pooling
+__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W,
+                                   int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = 0; r < k; ++r) {
+      const int h = ho * stride - pad + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int w = wo * stride - pad + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const float4 v = x[((n * H + h) * W + w) * C4 + c4];
+        m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+        m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+      }
+    }
+    y[i] = m;
+  }
+}
+
+// gather form: for every input pixel, visit the windows covering it in a fixed order and take
+// dy where this pixel is the FIRST maximum of the window in (h, w) scan order.
+__global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                   const float *__restrict__ dy, float *__restrict__ dx, int H, int W,
+                                   int C, int k, int stride, int pad, int Ho, int Wo, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    const float xv = x[i];
+    float g = 0.f;
+    int ho_lo = (h + pad - k + stride) / stride; if (h + pad - k + 1 <= 0) ho_lo = 0;
+    int wo_lo = (w + pad - k + stride) / stride; if (w + pad - k + 1 <= 0) wo_lo = 0;
+    const int ho_hi = min(Ho - 1, (h + pad) / stride), wo_hi = min(Wo - 1, (w + pad) / stride);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const long long oi = ((n * Ho + ho) * Wo + wo) * C + c;
+        if (y[oi] != xv) continue;
+        // is there an earlier position in this window with the same (max) value?
+        bool first = true;
+        const int h0 = ho * stride - pad, w0 = wo * stride - pad;
+        for (int r = 0; r < k && first; ++r) {
+          const int hh = h0 + r;
+          if ((unsigned)hh >= (unsigned)H) continue;
+          for (int s = 0; s < k; ++s) {
+            const int ww = w0 + s;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            if (hh == h && ww == w) { r = k; break; }   // reached ourselves: no earlier max
+            if (x[((n * H + hh) * W + ww) * C + c] == xv) { first = false; break; }
+          }
+        }
+        if (first) g += dy[oi];
+      }
+    dx[i] = g;
+  }
+}
+
+__global__ void avgpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W,
+                                   int C4, int k, int Ho, int Wo, long long total) {
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < k; ++r)
+      for (int q = 0; q < k; ++q) {
+        const float4 v = x[((n * H + ho * k + r) * W + wo * k + q) * C4 + c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    y[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+__global__ void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W,
+                                   int C4, int k, int Ho, int Wo, long long total, int accumulate) {
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    const int ho = h / k, wo = w / k;
+    float4 g = make_float4(0, 0, 0, 0);
+    if (ho < Ho && wo < Wo) {
+      const float4 v = dy[((n * Ho + ho) * Wo + wo) * C4 + c4];
+      g = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+    if (accumulate) { const float4 d = dx[i]; g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w; }
+    dx[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ bilinear sampler
+// GridGenerator(affine identity, target (Ho,Wo)) + BilinearSampler: normalised target coordinate
+// g = -1 + o*2/(O-1); source coordinate s = (g+1)*(I-1)/2; corners outside [0,I-1] contribute 0.
+__device__ __forceinline__ float src_coord(int o, int O, int I) {
+  const float g = O > 1 ? -1.f + (float)o * (2.f / (float)(O - 1)) : 0.f;
+  return (g + 1.f) * (float)(I - 1) / 2.f;
+}
+__global__ void bilinear_fwd_kernel(const float4 *__restrict__ x, float *__restrict__ y, int Hin,
+                                    int Win, int C4, int Ho, int Wo, int ldo, int coff, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const float ys = src_coord(ho, Ho, Hin), xs = src_coord(wo, Wo, Win);
+    const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+    const float wy0 = 1.f - (ys - (float)y0), wx0 = 1.f - (xs - (float)x0);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        const int yy = y0 + dyy, xx = x0 + dxx;
+        if ((unsigned)yy >= (unsigned)Hin || (unsigned)xx >= (unsigned)Win) continue;
+        const float wgt = (dyy ? 1.f - wy0 : wy0) * (dxx ? 1.f - wx0 : wx0);
+        const float4 v = x[((n * Hin + yy) * Win + xx) * C4 + c4];
+        acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+      }
+    *reinterpret_cast<float4 *>(y + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4) = acc;
+  }
+}
+// gather form of the backward: every source pixel collects from the target pixels that touch it
+__global__ void bilinear_bwd_kernel(const float *__restrict__ dy, float4 *__restrict__ dx, int Hin,
+                                    int Win, int C4, int Ho, int Wo, int ldo, int coff, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int w = (int)(t % Win); t /= Win;
+    const int h = (int)(t % Hin);
+    const long long n = t / Hin;
+    // candidate target range: |s(o) - h| < 1  (s is monotone in o); widen by one and test exactly
+    const float sy = Hin > 1 ? (float)(Ho - 1) / (float)(Hin - 1) : 0.f;
+    const float sx = Win > 1 ? (float)(Wo - 1) / (float)(Win - 1) : 0.f;
+    int ho_lo = Hin > 1 ? (int)floorf((float)(h - 1) * sy) - 1 : 0;
+    int ho_hi = Hin > 1 ? (int)ceilf((float)(h + 1) * sy) + 1 : Ho - 1;
+    int wo_lo = Win > 1 ? (int)floorf((float)(w - 1) * sx) - 1 : 0;
+    int wo_hi = Win > 1 ? (int)ceilf((float)(w + 1) * sx) + 1 : Wo - 1;
+    ho_lo = max(ho_lo, 0); wo_lo = max(wo_lo, 0); ho_hi = min(ho_hi, Ho - 1); wo_hi = min(wo_hi, Wo - 1);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const float ys = src_coord(ho, Ho, Hin);
+      const int y0 = (int)floorf(ys);
+      float wy;
+      if (y0 == h) wy = 1.f - (ys - (float)y0);
+      else if (y0 + 1 == h) wy = ys - (float)y0;
+      else continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const float xs = src_coord(wo, Wo, Win);
+        const int x0 = (int)floorf(xs);
+        float wx;
+        if (x0 == w) wx = 1.f - (xs - (float)x0);
+        else if (x0 + 1 == w) wx = xs - (float)x0;
+        else continue;
+        const float wgt = wy * wx;
+        const float4 v = *reinterpret_cast<const float4 *>(
+            dy + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4);
+        acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ losses
+constexpr int kMaxSoftmaxC = 64;
+__global__ void softmax_output_kernel(const float *__restrict__ logits, const float *__restrict__ label,
+                                      float *__restrict__ prob, float *__restrict__ grad, long long rows,
+                                      int C, int ld, float ignore_label, float grad_scale,
+                                      const float *__restrict__ valid_count) {
+  float scale = grad_scale;
+  if (valid_count) scale = grad_scale / fmaxf(1.f, *valid_count);
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
+       r += (long long)gridDim.x * blockDim.x) {
+    const float *p = logits + r * ld;
+    float v[kMaxSoftmaxC];
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) { v[c] = p[c]; mx = v[c] > mx ? v[c] : mx; }
+    float sum = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.f / sum;
+    const float lab = label ? label[r] : 0.f;
+    const bool ign = label ? (lab == ignore_label) : true;
+    const int li = (int)lab;
+    for (int c = 0; c < ld; ++c) {
+      const float pr = c < C ? v[c] * inv : 0.f;
+      prob[r * ld + c] = pr;
+      if (grad) grad[r * ld + c] = (ign || c >= C) ? 0.f : (pr - (c == li ? 1.f : 0.f)) * scale;
+    }
+  }
+}
+__global__ void count_kernel(const float *__restrict__ a, long long n, int mode, float ref, float *out) {
+  float c = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    c += (mode == 0 ? (a[i] != ref) : (a[i] > ref)) ? 1.f : 0.f;
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  // integer-valued float adds below 2^24 are exact, hence order independent
+  if ((threadIdx.x & 63) == 0 && c != 0.f) atomicAdd(out, c);
+}
+__device__ __forceinline__ float smooth_l1(float x) {
+  const float ax = fabsf(x);
+  return ax < 1.f ? 0.5f * x * x : ax - 0.5f;
+}
+__global__ void smooth_l1_fwd_kernel(const float *pred, const float *target, const float *mask,
+                                     float *loss, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    loss[i] = smooth_l1(mask[i] * (pred[i] - target[i]));
+}
+__global__ void smooth_l1_bwd_kernel(const float *pred, const float *target, const float *mask,
+                                     float *grad, long long n, float grad_scale, const float *valid_count) {
+  const float sc = grad_scale / fmaxf(1.f, *valid_count);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    const float x = m * (pred[i] - target[i]);
+    const float d = fabsf(x) < 1.f ? x : (x > 0.f ? 1.f : -1.f);
+    grad[i] = sc * m * d;
+  }
+}
+// single-block deterministic reductions for the (tiny) metric readouts
+__global__ __launch_bounds__(1024) void ce_sum_kernel(const float *prob, const float *label, long long rows,
+                                                      int C, int ld, float ignore_label, float eps,
+                                                      float *out2) {
+  __shared__ double s_a[1024];
+  __shared__ double s_b[1024];
+  double a = 0, b = 0;
+  for (long long r = threadIdx.x; r < rows; r += 1024) {
+    const float lab = label[r];
+    if (lab == ignore_label) continue;
+    const int li = (int)lab;
+    if (li < 0 || li >= C) continue;
+    a += -log((double)(prob[r * ld + li] + eps));
+    b += 1.0;
+  }
+  s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 512; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) { s_a[threadIdx.x] += s_a[threadIdx.x + s]; s_b[threadIdx.x] += s_b[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = (float)s_a[0]; out2[1] = (float)s_b[0]; }
+}
+__global__ __launch_bounds__(1024) void sum_kernel(const float *a, long long n, float *out) {
+  __shared__ double s_a[1024];
+  double v = 0;
+  for (long long i = threadIdx.x; i < n; i += 1024) v += a[i];
+  s_a[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 512; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) s_a[threadIdx.x] += s_a[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)s_a[0];
+}
+
+__global__ void sgd_kernel(float4 *__restrict__ w, const float4 *__restrict__ g, float4 *__restrict__ m,
+                           long long n4, float lr, float mu, float wd, float rescale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 wv = w[i]; const float4 gv = g[i]; float4 mv = m[i];
+    mv.x = mu * mv.x - lr * (rescale * gv.x + wd * wv.x); wv.x += mv.x;
+    mv.y = mu * mv.y - lr * (rescale * gv.y + wd * wv.y); wv.y += mv.y;
+    mv.z = mu * mv.z - lr * (rescale * gv.z + wd * wv.z); wv.z += mv.z;
+    mv.w = mu * mv.w - lr * (rescale * gv.w + wd * wv.w); wv.w += mv.w;
+    w[i] = wv; m[i] = mv;
+  }
+}
+
+int bn_slabs(long long rows) { return (int)((rows + kSlabRows - 1) / kSlabRows); }
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" {
+
+size_t dspn_bn_workspace_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return sizeof(float) * ((size_t)bn_slabs(rows) * 2 * C + 2 * (size_t)C);
+}
+
+int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, float *mean, float *rstd,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(x && mean && rstd && workspace, "bn_stats: null pointer");
+  DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_stats: C must be a positive multiple of 4");
+  if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_stats: workspace too small");
+  const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
+  float *partial = static_cast<float *>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
+                     sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x), rows,
+                     C4, CL, partial);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), x, partial,
+                     ns, rows, C, eps, mean, rstd);
+  return dspn::check_launch("bn_stats");
+}
+
+int dspn_bn_apply_f32(const float *x, const float *mean, const float *rstd, const float *gamma,
+                      const float *beta, float *y, long long rows, int C, int relu, void *stream) {
+  DSPN_REQUIRE(x && mean && rstd && beta && y, "bn_apply: null pointer");
+  DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_apply: C must be a positive multiple of 4");
+  const long long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), mean, rstd, gamma, beta,
+                     reinterpret_cast<float4 *>(y), n4, C / 4, relu);
+  return dspn::check_launch("bn_apply");
+}
+
+int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const float *mean,
+                         const float *rstd, const float *gamma, float *dx, float *dgamma,
+                         float *dbeta, long long rows, int C, int relu, int accumulate,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace, "bn_backward: null pointer");
+  DSPN_REQUIRE(!relu || y, "bn_backward: relu needs the forward output");
+  DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward: C must be a positive multiple of 4");
+  if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward: workspace too small");
+  const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
+  float *partial = static_cast<float *>(workspace);
+  float *sums = partial + (size_t)ns * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
+                     sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x),
+                     reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy), mean,
+                     rstd, rows, C4, CL, relu, partial);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), partial, ns, C,
+                     sums, dgamma, dbeta);
+  const long long n4 = rows * C4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(y),
+                     reinterpret_cast<const float4 *>(dy), mean, rstd, gamma, sums,
+                     reinterpret_cast<float4 *>(dx), n4, C4, 1.f / (float)rows, relu, accumulate);
+  return dspn::check_launch("bn_backward");
+}
+
+int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream) {
+  DSPN_REQUIRE(a && b && out && n >= 0, "add: bad argument");
+  const long long n4 = n / 4;
+  if (n4 > 0)
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+                       reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                       reinterpret_cast<float4 *>(out), n4);
+  if (n4 * 4 < n)
+    hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(64), 0, S_(stream), a, b, out, n4 * 4, n);
+  return dspn::check_launch("add");
+}
+
+int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long n, int accumulate,
+                           void *stream) {
+  DSPN_REQUIRE(y && dy && dx && n >= 0, "relu_backward: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), y, dy, dx, n, accumulate);
+  return dspn::check_launch("relu_backward");
+}
+
+int dspn_fill_f32(float *p, float v, long long n, void *stream) {
+  DSPN_REQUIRE(p && n >= 0, "fill: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), p, v, n);
+  return dspn::check_launch("fill");
+}
+
+int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(a && out && workspace && rows > 0 && C > 0 && ld >= C, "colsum: bad argument");
+  const int ns = bn_slabs(rows);
+  if (workspace_bytes < sizeof(float) * (size_t)ns * C)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "colsum: workspace too small");
+  float *partial = static_cast<float *>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), a, rows, C, ld, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), partial, ns, C, out);
+  return dspn::check_launch("colsum");
+}
+
+int dspn_nchw_to_nhwc_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream) {
+  DSPN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad argument");
+  const long long HW = (long long)H * W, total = HW * N;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, C, HW, total, Cp);
+  return dspn::check_launch("nchw_to_nhwc");
+}
+int dspn_nhwc_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream) {
+  DSPN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nhwc_to_nchw: bad argument");
+  const long long HW = (long long)H * W, total = HW * N * C;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, C, HW, total, Cp);
+  return dspn::check_launch("nhwc_to_nchw");
+}
+
+int dspn_copy_block_f32(const float *src, float *dst, int samples, long long rows_per_sample, int C,
+                        long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
+                        int ldd, int doff, int accumulate, void *stream) {
+  DSPN_REQUIRE(src && dst && samples > 0 && rows_per_sample > 0 && C > 0, "copy_block: bad argument");
+  const long long total = (long long)samples * rows_per_sample * C;
+  hipLaunchKernelGGL(copy_block_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst,
+                     rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff,
+                     total, accumulate);
+  return dspn::check_launch("copy_block");
+}
+
+int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, void *stream) {
+  DSPN_REQUIRE(src && dst && B > 0 && N > 0 && C > 0, "transpose_bnc: bad argument");
+  const long long total = (long long)B * N * C;
+  hipLaunchKernelGGL(transpose_bnc_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, N, C, total);
+  return dspn::check_launch("transpose_bnc");
+}
+
+int dspn_maxpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride,
+                             int pad, int Ho, int Wo, void *stream) {
+  DSPN_REQUIRE(x && y && C % 4 == 0 && N > 0, "maxpool_forward: bad argument");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k,
+                     stride, pad, Ho, Wo, total);
+  return dspn::check_launch("maxpool_forward");
+}
+int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
+                              int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {
+  DSPN_REQUIRE(x && y && dy && dx && N > 0, "maxpool_backward: bad argument");
+  const long long total = (long long)N * H * W * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), x, y, dy,
+                     dx, H, W, C, k, stride, pad, Ho, Wo, total);
+  return dspn::check_launch("maxpool_backward");
+}
+int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int Ho, int Wo,
+                             void *stream) {
+  DSPN_REQUIRE(x && y && C % 4 == 0 && k > 0 && Ho * k <= H && Wo * k <= W, "avgpool_forward: bad argument");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k, Ho,
+                     Wo, total);
+  return dspn::check_launch("avgpool_forward");
+}
+int dspn_avgpool_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
+                              int accumulate, void *stream) {
+  DSPN_REQUIRE(dy && dx && C % 4 == 0 && k > 0, "avgpool_backward: bad argument");
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k,
+                     Ho, Wo, total, accumulate);
+  return dspn::check_launch("avgpool_backward");
+}
+
+int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
+                              int ldo, int coff, void *stream) {
+  DSPN_REQUIRE(x && y && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_forward: bad argument");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), y, Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
+  return dspn::check_launch("bilinear_forward");
+}
+int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
+                               int ldo, int coff, void *stream) {
+  DSPN_REQUIRE(dy && dx && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_backward: bad argument");
+  const long long total = (long long)N * Hin * Win * (C / 4);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), dy,
+                     reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
+  return dspn::check_launch("bilinear_backward");
+}
+
+int dspn_softmax_output_f32(const float *logits, const float *label, float *prob, float *grad,
+                            long long rows, int C, int ld, float ignore_label, float grad_scale,
+                            const float *valid_count, void *stream) {
+  DSPN_REQUIRE(logits && prob && rows > 0 && C > 0 && C <= kMaxSoftmaxC && ld >= C, "softmax_output: bad argument (C <= 64)");
+  DSPN_REQUIRE(!grad || label, "softmax_output: gradient needs labels");
+  hipLaunchKernelGGL(softmax_output_kernel, dim3(grid_for(rows, 128)), dim3(128), 0, S_(stream), logits, label,
+                     prob, grad, rows, C, ld, ignore_label, grad_scale, valid_count);
+  return dspn::check_launch("softmax_output");
+}
+int dspn_count_f32(const float *a, long long n, int mode, float ref, float *out, void *stream) {
+  DSPN_REQUIRE(a && out && n > 0 && n < (1ll << 24), "count: n must be in (0, 2^24)");
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, S_(stream), out, 0.f, 1ll);
+  hipLaunchKernelGGL(count_kernel, dim3(grid_for(n, kT, 1024)), dim3(kT), 0, S_(stream), a, n, mode, ref, out);
+  return dspn::check_launch("count");
+}
+int dspn_smooth_l1_forward_f32(const float *pred, const float *target, const float *mask, float *loss,
+                               long long n, void *stream) {
+  DSPN_REQUIRE(pred && target && mask && loss && n > 0, "smooth_l1_forward: bad argument");
+  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), pred, target, mask, loss, n);
+  return dspn::check_launch("smooth_l1_forward");
+}
+int dspn_smooth_l1_backward_f32(const float *pred, const float *target, const float *mask, float *grad,
+                                long long n, float grad_scale, const float *valid_count, void *stream) {
+  DSPN_REQUIRE(pred && target && mask && grad && valid_count && n > 0, "smooth_l1_backward: bad argument");
+  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), pred, target, mask, grad,
+                     n, grad_scale, valid_count);
+  return dspn::check_launch("smooth_l1_backward");
+}
+int dspn_cross_entropy_sum_f32(const float *prob, const float *label, long long rows, int C, int ld,
+                               float ignore_label, float eps, float *out2, void *stream) {
+  DSPN_REQUIRE(prob && label && out2 && rows > 0 && C > 0 && ld >= C, "cross_entropy_sum: bad argument");
+  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(1024), 0, S_(stream), prob, label, rows, C, ld, ignore_label, eps, out2);
+  return dspn::check_launch("cross_entropy_sum");
+}
+int dspn_sum_f32(const float *a, long long n, float *out, void *stream) {
+  DSPN_REQUIRE(a && out && n > 0, "sum: bad argument");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, S_(stream), a, n, out);
+  return dspn::check_launch("sum");
+}
+
+int dspn_sgd_momentum_f32(float *w, const float *grad, float *mom, long long n, float lr, float momentum,
+                          float wd, float rescale, void *stream) {
+  DSPN_REQUIRE(w && grad && mom && n > 0 && n % 4 == 0, "sgd_momentum: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4)), dim3(kT), 0, S_(stream), reinterpret_cast<float4 *>(w),
+                     reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(mom), n / 4, lr,
+                     momentum, wd, rescale);
+  return dspn::check_launch("sgd_momentum");
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+"""Thin functional layer over the C ABI of include/dspn_nn.h.
+
+torch tensors are device buffers only; every function launches HIP kernels on
+torch's current stream.  Activations are NHWC float32 with a physical channel
+count that is a multiple of 4; conv weights are [Cout, R, S, Cin]."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+_c = ctypes
+_vp = _c.c_void_p
+_i = _c.c_int
+_ll = _c.c_longlong
+_f = _c.c_float
+_sz = _c.c_size_t
+
+_lib.register({
+    "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                     _ll, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "dspn_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                   _vp, _sz, _vp]),
+    "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
+    "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _sz, _vp]),
+    "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+    "dspn_fill_f32": (_i, [_vp, _f, _ll, _vp]),
+    "dspn_colsum_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
+    "dspn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dspn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dspn_copy_block_f32": (_i, [_vp, _vp, _i, _ll, _i, _ll, _i, _i, _ll, _i, _i, _i, _vp]),
+    "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_maxpool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_avgpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_avgpool_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_bilinear_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_bilinear_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_softmax_output_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
+    "dspn_count_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp]),
+    "dspn_smooth_l1_forward_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    "dspn_smooth_l1_backward_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _vp, _vp]),
+    "dspn_cross_entropy_sum_f32": (_i, [_vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
+    "dspn_sum_f32": (_i, [_vp, _ll, _vp, _vp]),
+    "dspn_sgd_momentum_f32": (_i, [_vp, _vp, _vp, _ll, _f, _f, _f, _f, _vp]),
+})
+
+
+def L():
+    return _lib.lib()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+_ws = {}
+
+
+def workspace(nbytes, device, tag="nn"):
+    key = (tag, device)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def conv_out_size(h, k, stride, pad, dil=1):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def empty(*shape, device=None):
+    return torch.empty(shape, dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def zeros(*shape, device=None):
+    return torch.zeros(shape, dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+# ------------------------------------------------------------------ convolution
+def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False):
+    """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout)"""
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cw = w.shape
+    assert Cw == Cin, (w.shape, x.shape)
+    Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+    if out is None:
+        ldc = pad4(Cout)
+        out = zeros(N, Ho, Wo, ldc, device=x.device) if ldc != Cout else empty(N, Ho, Wo, ldc, device=x.device)
+    ldc = out.shape[3]
+    check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(out), N, H, W, Cin, Cout, R, S, stride,
+                                      pad, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), stream()),
+          "conv2d_forward")
+    return out
+
+
+def weight_transpose(w, out=None):
+    """[Cout,R,S,Cin] -> [Cin,R,S,pad4(Cout)] (zero padded), the operand of conv2d_dgrad"""
+    Cout, R, S, Cin = w.shape
+    Kp = pad4(Cout)
+    if out is None:
+        out = empty(Cin, R, S, Kp, device=w.device)
+    check(L().dspn_conv2d_weight_transpose_f32(ptr(w), ptr(out), Cout, R * S, Cin, Kp, stream()),
+          "weight_transpose")
+    return out
+
+
+def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin)"""
+    N, H, W, Cx = x_shape
+    Cin, R, S, ldy = wt.shape
+    assert dy.shape[3] == ldy, (dy.shape, wt.shape)
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    if out is None:
+        out = zeros(N, H, W, Cx, device=dy.device) if Cx != Cin else empty(N, H, W, Cx, device=dy.device)
+    check(L().dspn_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, pad, dil,
+                                    Ho, Wo, out.shape[3], int(accumulate), stream()), "conv2d_dgrad")
+    return out
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin)"""
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cw = w_shape
+    assert Cw == Cin
+    Ho, Wo, ldy = dy.shape[1], dy.shape[2], dy.shape[3]
+    if out is None:
+        out = empty(Cout, R, S, Cin, device=x.device)
+    nbytes = L().dspn_conv2d_wgrad_workspace_bytes(N, Ho, Wo, Cin, Cout, R, S)
+    ws = workspace(nbytes, x.device, "wgrad")
+    check(L().dspn_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride, pad,
+                                    dil, Ho, Wo, int(accumulate), ptr(ws), ws.numel(), stream()),
+          "conv2d_wgrad")
+    return out
+
+
+# ------------------------------------------------------------------ batch norm
+def _rows(x):
+    return x.numel() // x.shape[-1]
+
+
+def bn_stats(x, eps, mean=None, rstd=None):
+    C = x.shape[-1]
+    rows = _rows(x)
+    mean = empty(C, device=x.device) if mean is None else mean
+    rstd = empty(C, device=x.device) if rstd is None else rstd
+    ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
+    check(L().dspn_bn_stats_f32(ptr(x), rows, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
+          "bn_stats")
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, relu=False, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(L().dspn_bn_apply_f32(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(out), _rows(x),
+                                x.shape[-1], int(relu), stream()), "bn_apply")
+    return out
+
+
+def bn_backward(x, y, dy, mean, rstd, gamma, relu=False, dx=None, dgamma=None, dbeta=None, accumulate=False):
+    C = x.shape[-1]
+    rows = _rows(x)
+    dx = torch.empty_like(x) if dx is None else dx
+    dbeta = empty(C, device=x.device) if dbeta is None else dbeta
+    if gamma is not None and dgamma is None:
+        dgamma = empty(C, device=x.device)
+    ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
+    check(L().dspn_bn_backward_f32(ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+                                   ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(ws),
+                                   ws.numel(), stream()), "bn_backward")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------ element-wise / layout
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    check(L().dspn_add_f32(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "add")
+    return out
+
+
+def relu_backward(y, dy, dx=None, accumulate=False):
+    dx = torch.empty_like(y) if dx is None else dx
+    check(L().dspn_relu_backward_f32(ptr(y), ptr(dy), ptr(dx), y.numel(), int(accumulate), stream()),
+          "relu_backward")
+    return dx
+
+
+def fill(t, v):
+    check(L().dspn_fill_f32(ptr(t), float(v), t.numel(), stream()), "fill")
+    return t
+
+
+def colsum(a, C, out=None):
+    """sum over all rows of the first C channels of a (..., ld) tensor"""
+    ld = a.shape[-1]
+    rows = _rows(a)
+    out = empty(C, device=a.device) if out is None else out
+    ws = workspace(4 * ((rows + 511) // 512) * C, a.device, "colsum")
+    check(L().dspn_colsum_f32(ptr(a), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()), "colsum")
+    return out
+
+
+def nchw_to_nhwc(src, Cp=None, out=None):
+    N, C, H, W = src.shape
+    Cp = pad4(C) if Cp is None else Cp
+    out = empty(N, H, W, Cp, device=src.device) if out is None else out
+    check(L().dspn_nchw_to_nhwc_f32(ptr(src), ptr(out), N, C, H, W, Cp, stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(src, C=None, out=None):
+    N, H, W, Cp = src.shape
+    C = Cp if C is None else C
+    out = empty(N, C, H, W, device=src.device) if out is None else out
+    check(L().dspn_nhwc_to_nchw_f32(ptr(src), ptr(out), N, C, H, W, Cp, stream()), "nhwc_to_nchw")
+    return out
+
+
+def copy_block(src, dst, samples, rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd,
+               doff, accumulate=False):
+    check(L().dspn_copy_block_f32(ptr(src), ptr(dst), samples, rows_per_sample, C, src_sample_stride, lds,
+                                  soff, dst_sample_stride, ldd, doff, int(accumulate), stream()), "copy_block")
+    return dst
+
+
+def transpose_bnc(src, out=None):
+    B, N, C = src.shape
+    out = empty(B, C, N, device=src.device) if out is None else out
+    check(L().dspn_transpose_bnc_f32(ptr(src), ptr(out), B, N, C, stream()), "transpose_bnc")
+    return out
+
+
+# ------------------------------------------------------------------ pooling / sampler
+def maxpool_forward(x, k, stride, pad, out=None):
+    N, H, W, C = x.shape
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
+    check(L().dspn_maxpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
+          "maxpool_forward")
+    return out
+
+
+def maxpool_backward(x, y, dy, k, stride, pad, dx=None):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x) if dx is None else dx
+    check(L().dspn_maxpool_backward_f32(ptr(x), ptr(y), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
+                                        y.shape[1], y.shape[2], stream()), "maxpool_backward")
+    return dx
+
+
+def avgpool_forward(x, k, out=None):
+    N, H, W, C = x.shape
+    Ho, Wo = H // k, W // k
+    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
+    check(L().dspn_avgpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, Ho, Wo, stream()), "avgpool_forward")
+    return out
+
+
+def avgpool_backward(dy, x_shape, k, dx=None, accumulate=False):
+    N, H, W, C = x_shape
+    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
+    check(L().dspn_avgpool_backward_f32(ptr(dy), ptr(dx), N, H, W, C, k, dy.shape[1], dy.shape[2],
+                                        int(accumulate), stream()), "avgpool_backward")
+    return dx
+
+
+def bilinear_forward(x, out, coff):
+    """resize x (N,Hin,Win,C) into channels [coff, coff+C) of out (N,Ho,Wo,ldo)"""
+    N, Hin, Win, C = x.shape
+    check(L().dspn_bilinear_forward_f32(ptr(x), ptr(out), N, Hin, Win, C, out.shape[1], out.shape[2],
+                                        out.shape[3], coff, stream()), "bilinear_forward")
+    return out
+
+
+def bilinear_backward(dy, x_shape, coff, dx=None):
+    N, Hin, Win, C = x_shape
+    dx = empty(N, Hin, Win, C, device=dy.device) if dx is None else dx
+    check(L().dspn_bilinear_backward_f32(ptr(dy), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
+                                         dy.shape[3], coff, stream()), "bilinear_backward")
+    return dx
+
+
+# ------------------------------------------------------------------ losses / optimizer
+def softmax_output(logits, label, C, ignore_label, grad_scale=1.0, valid_count=None, prob=None, grad=None,
+                   want_grad=True):
+    ld = logits.shape[-1]
+    rows = _rows(logits)
+    prob = torch.empty_like(logits) if prob is None else prob
+    if want_grad and grad is None:
+        grad = torch.empty_like(logits)
+    check(L().dspn_softmax_output_f32(ptr(logits), ptr(label), ptr(prob), ptr(grad) if want_grad else 0, rows,
+                                      C, ld, float(ignore_label), float(grad_scale), ptr(valid_count),
+                                      stream()), "softmax_output")
+    return prob, grad
+
+
+def count(a, mode, ref, out=None):
+    """mode 'ne': #(a != ref); mode 'gt': #(a > ref); result is a 1-element device tensor (not clamped)"""
+    out = empty(1, device=a.device) if out is None else out
+    check(L().dspn_count_f32(ptr(a), a.numel(), 0 if mode == "ne" else 1, float(ref), ptr(out), stream()),
+          "count")
+    return out
+
+
+def smooth_l1_forward(pred, target, mask, out=None):
+    out = torch.empty_like(pred) if out is None else out
+    check(L().dspn_smooth_l1_forward_f32(ptr(pred), ptr(target), ptr(mask), ptr(out), pred.numel(), stream()),
+          "smooth_l1_forward")
+    return out
+
+
+def smooth_l1_backward(pred, target, mask, valid_count, grad_scale=1.0, out=None):
+    out = torch.empty_like(pred) if out is None else out
+    check(L().dspn_smooth_l1_backward_f32(ptr(pred), ptr(target), ptr(mask), ptr(out), pred.numel(),
+                                          float(grad_scale), ptr(valid_count), stream()), "smooth_l1_backward")
+    return out
+
+
+def cross_entropy_sum(prob, label, C, ignore_label, eps=1e-8, out=None):
+    out = empty(2, device=prob.device) if out is None else out
+    check(L().dspn_cross_entropy_sum_f32(ptr(prob), ptr(label), _rows(prob), C, prob.shape[-1],
+                                         float(ignore_label), float(eps), ptr(out), stream()),
+          "cross_entropy_sum")
+    return out
+
+
+def sum_all(a, out=None):
+    out = empty(1, device=a.device) if out is None else out
+    check(L().dspn_sum_f32(ptr(a), a.numel(), ptr(out), stream()), "sum")
+    return out
+
+
+def sgd_momentum(w, grad, mom, lr, momentum, wd, rescale):
+    check(L().dspn_sgd_momentum_f32(ptr(w), ptr(grad), ptr(mom), w.numel(), lr, momentum, wd, rescale,
+                                    stream()), "sgd_momentum")

@@ -1,0 +1,160 @@
+/*
+ * dspn_nn.h -- C ABI of the MI355X (gfx950) kernels behind DSPNet's conv-heavy
+ * multi-task forward/backward.
+ *
+ * In the reference these are MXNet built-in operators (Convolution, BatchNorm,
+ * Activation, Pooling, Deconvolution, BilinearSampler + GridGenerator,
+ * SoftmaxOutput, smooth_l1 + MakeLoss, the SGD updater) instantiated by
+ * symbol/resnet.py, symbol/common.py and symbol/multitask_symbol_builder.py;
+ * each entry cites the call site whose arithmetic it provides.  MXNet itself is
+ * not vendored by the reference, so the semantics followed are the documented
+ * MXNet 0.11-1.0 ones, restated in oracle/nn_oracle.py ("parity unpinned").
+ *
+ * Conventions
+ *   - activations are NHWC float32, dense, with a physical channel count that is
+ *     a multiple of 4 (logical channels are zero padded: 3->4, 19->20, ...);
+ *   - convolution weights are [Cout][R][S][Cin] (Cin physical);
+ *   - all tensor pointers are DEVICE pointers; the caller owns every buffer
+ *     including workspaces; nothing allocates or synchronises;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return 0 or a negative dspn_status (see dspn_multibox.h), message in
+ *     dspn_last_error().
+ */
+#ifndef DSPN_NN_H_
+#define DSPN_NN_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Convolution (mx.sym.Convolution: symbol/resnet.py:32-49,95, common.py:32,
+ * 393-409, multitask_symbol_builder.py:543-583).  fp32 MFMA implicit GEMM. -------- */
+
+/* y[n,ho,wo,k] = sum x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c] w[k,r,s,c] (+bias[k]) (relu).
+ * y pixel stride y_ldc (0 = Cout), batch stride y_batch_stride (0 = dense).
+ * accumulate != 0: y += result (before relu). bias may be NULL. */
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y,
+                            int N, int H, int W, int Cin, int Cout, int R, int S,
+                            int stride, int pad, int dil, int Ho, int Wo,
+                            long long y_batch_stride, int y_ldc, int relu, int accumulate,
+                            void *stream);
+
+/* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
+int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
+                                     int Cout_pad, void *stream);
+
+/* Data gradient of the convolution above: dx (N,H,W,dx_ldc) from dy (N,Ho,Wo,ldy) and the
+ * transposed weights wt [Cin][R*S][ldy].  stride 1 (any dilation) or stride 2 (dilation 1; runs
+ * as 4 output-parity classes).  accumulate != 0: dx += result.
+ * The same entry is the FORWARD of mx.sym.Deconvolution (multitask_symbol_builder.py:586:
+ * 4x4, stride 2, pad 1, no bias) with x := dy. */
+int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
+                          int N, int H, int W, int Cin, int ldy, int R, int S,
+                          int stride, int pad, int dil, int Ho, int Wo, int dx_ldc,
+                          int accumulate, void *stream);
+
+size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S);
+
+/* dw[k][r][s][c] (+)= sum_{n,ho,wo} dy[n,ho,wo,k] x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c].
+ * Split-K over pixels into `workspace` slabs, summed in a fixed order (deterministic). */
+int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
+                          int N, int H, int W, int Cin, int Cout, int ldy, int R, int S,
+                          int stride, int pad, int dil, int Ho, int Wo, int accumulate,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
+ * symbol/resnet.py:30-41,91,96; multitask_symbol_builder.py:545-585) ------------------ */
+
+size_t dspn_bn_workspace_bytes(long long rows, int C);
+
+/* mean[c], rstd[c] = 1/sqrt(biased var + eps) over `rows` = N*H*W rows of x (rows, C). */
+int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, float *mean, float *rstd,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* y = gamma*(x-mean)*rstd + beta, optionally max(.,0).  gamma == NULL means fix_gamma (1). */
+int dspn_bn_apply_f32(const float *x, const float *mean, const float *rstd, const float *gamma,
+                      const float *beta, float *y, long long rows, int C, int relu, void *stream);
+
+/* Backward of the fused op.  If relu != 0, dy is first masked with (y > 0).
+ * dx (+)= gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); dgamma = sum dy*xhat; dbeta = sum dy.
+ * dgamma may be NULL (fix_gamma).  accumulate != 0: dx += . */
+int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const float *mean,
+                         const float *rstd, const float *gamma, float *dx, float *dgamma,
+                         float *dbeta, long long rows, int C, int relu, int accumulate,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- element-wise / layout --------------------------------------------------------------- */
+int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream);      /* out = a + b */
+int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long n, int accumulate, void *stream);
+int dspn_fill_f32(float *p, float v, long long n, void *stream);
+/* per-column sum of a (rows, ld) matrix over its first C columns: out[c] = sum_r a[r, c] (bias grads) */
+int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* (N,C,H,W) -> (N,H,W,Cp) with zero padded channels, and back (Cp -> first C channels) */
+int dspn_nchw_to_nhwc_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);
+int dspn_nhwc_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);
+/* copy a (rows, C) block between matrices with different row strides / column offsets:
+ * dst[r*ldd + doff + c] (+)= src[r*lds + soff + c]; rows are grouped per sample:
+ * row r belongs to sample r / rows_per_sample and the sample strides are given explicitly. */
+int dspn_copy_block_f32(const float *src, float *dst, int samples, long long rows_per_sample, int C,
+                        long long src_sample_stride, int lds, int soff,
+                        long long dst_sample_stride, int ldd, int doff, int accumulate, void *stream);
+/* (B, N, C) -> (B, C, N) */
+int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, void *stream);
+
+/* ---- Pooling (mx.sym.Pooling: symbol/resnet.py:98 max 3x3/2 pad 1;
+ * multitask_symbol_builder.py:560-562 avg k x k / k) ----------------------------------------- */
+int dspn_maxpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride,
+                             int pad, int Ho, int Wo, void *stream);
+/* gradient goes to the first maximum of each window in (h, w) scan order */
+int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
+                              int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
+int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int Ho, int Wo, void *stream);
+int dspn_avgpool_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
+                              int accumulate, void *stream);
+
+/* ---- BilinearSampler over GridGenerator(affine = identity) (multitask_symbol_builder.py:
+ * 574-581): align-corners bilinear resize (Hin,Win) -> (Ho,Wo), written into / read from a
+ * channel slice [coff, coff+C) of a (N,Ho,Wo,ldo) concat buffer. ------------------------------ */
+int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
+                              int ldo, int coff, void *stream);
+int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
+                               int ldo, int coff, void *stream);
+
+/* ---- losses ---------------------------------------------------------------------------------- */
+/* SoftmaxOutput(multi_output, use_ignore) over the last (channel) axis of logits (rows, ld):
+ * prob (rows, ld) = softmax over the first C channels (pad channels -> 0);
+ * grad (rows, ld) = (prob - onehot(label)) * scale, 0 for rows whose label == ignore_label.
+ * scale = grad_scale / (*valid_count) if valid_count != NULL (normalization='valid': number of
+ * labels != ignore_label, at least 1, computed on device by dspn_count_f32) else grad_scale.
+ * (multitask_symbol_builder.py:526-528 and :588).  grad may be NULL (forward only). */
+int dspn_softmax_output_f32(const float *logits, const float *label, float *prob, float *grad,
+                            long long rows, int C, int ld, float ignore_label, float grad_scale,
+                            const float *valid_count, void *stream);
+/* out[0] = max(1, #{i : mode 0: a[i] != ref ; mode 1: a[i] > ref}) as float */
+int dspn_count_f32(const float *a, long long n, int mode, float ref, float *out, void *stream);
+/* loc_loss = smooth_l1(mask*(pred-target), sigma=1) (multitask_symbol_builder.py:529-530) */
+int dspn_smooth_l1_forward_f32(const float *pred, const float *target, const float *mask, float *loss,
+                               long long n, void *stream);
+/* MakeLoss(normalization='valid') backward: grad = grad_scale * mask * smooth_l1'(mask*(pred-target))
+ * / *valid_count, valid_count = max(1, #{loss > 0}) (multitask_symbol_builder.py:531-532) */
+int dspn_smooth_l1_backward_f32(const float *pred, const float *target, const float *mask, float *grad,
+                                long long n, float grad_scale, const float *valid_count, void *stream);
+/* MultiBoxMetric / seg cross-entropy readout (train/metric.py:27-46): out[0] = sum_i -log(prob[i,label_i]+eps)
+ * over rows with label != ignore, out[1] = number of such rows.  prob is (rows, ld). */
+int dspn_cross_entropy_sum_f32(const float *prob, const float *label, long long rows, int C, int ld,
+                               float ignore_label, float eps, float *out2, void *stream);
+/* out[0] = sum a[i] */
+int dspn_sum_f32(const float *a, long long n, float *out, void *stream);
+
+/* ---- optimizer (multi_solver.py:221,291-293: mx 'sgd' with momentum) --------------------------
+ * g = rescale*grad + wd*w ; mom = momentum*mom - lr*g ; w += mom, over a flat parameter arena. */
+int dspn_sgd_momentum_f32(float *w, const float *grad, float *mom, long long n, float lr, float momentum,
+                          float wd, float rescale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DSPN_NN_H_ */

@@ -7,6 +7,7 @@ import re
 import pytest
 
 from dspnet_amd import _lib
+from dspnet_amd import functional  # noqa: F401  (registers the include/dspn_nn.h signatures)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,0 +1,305 @@
+"""GPU numerics of the conv / BN / pooling / sampler / loss / SGD kernels (through the C ABI)
+against plain PyTorch CPU references of the same ops in float64.
+
+These ops are MXNet built-ins in the reference (not vendored: "parity unpinned"); the semantics
+checked here are the documented MXNet ones restated in oracle/nn_oracle.py.  Tolerance: the fp32
+MFMA path is an exact fmaf chain, so |err| <= 2e-6 * sum|a*b| is expected; tests use 1e-4 relative to
+the output scale (BASELINE.json: fp32 losses within 1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dspnet_amd import functional as fn
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):  # NCHW cpu double -> NHWC cuda float (channel padded to 4)
+    n, c, h, w = t.shape
+    cp = fn.pad4(c)
+    out = torch.zeros(n, h, w, cp, dtype=torch.float32)
+    out[..., :c] = t.permute(0, 2, 3, 1).float()
+    return out.cuda()
+
+
+def nchw(t, c=None):  # NHWC cuda -> NCHW cpu double
+    t = t.cpu().double().permute(0, 3, 1, 2)
+    return t if c is None else t[:, :c]
+
+
+def wdev(w):  # [Cout,Cin,R,S] cpu -> [Cout,R,S,pad4(Cin)] cuda
+    co, ci, r, s = w.shape
+    out = torch.zeros(co, r, s, fn.pad4(ci), dtype=torch.float32)
+    out[..., :ci] = w.permute(0, 2, 3, 1).float()
+    return out.cuda()
+
+
+def close(got, exp, tol=1e-4):
+    scale = float(exp.abs().max()) + 1e-30
+    err = float((got - exp).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 64, 64, 3, 1, 1, 1),      # backbone 3x3
+    (2, 17, 19, 32, 48, 3, 2, 1, 1),      # stage-entry 3x3 s2, odd sizes
+    (3, 16, 16, 64, 256, 1, 1, 0, 1),     # 1x1 expand
+    (2, 16, 16, 128, 256, 1, 2, 0, 1),    # shortcut 1x1 s2
+    (2, 32, 32, 3, 64, 7, 2, 3, 1),       # conv0 (Cin 3 -> padded 4)
+    (1, 20, 20, 64, 96, 3, 1, 6, 6),      # vgg fc6 dilated
+    (2, 8, 8, 256, 20, 3, 1, 1, 1),       # loc head (Cout 20)
+    (2, 8, 8, 256, 54, 3, 1, 1, 1),       # cls head (Cout 54, not a multiple of 4)
+    (1, 16, 16, 200, 19, 3, 1, 1, 1),     # score3_conv-like (Cout 19)
+    (2, 5, 5, 128, 130, 3, 2, 1, 1),      # extras, tiny maps
+    (1, 3, 3, 128, 128, 3, 2, 1, 1),
+    (4, 64, 64, 64, 128, 3, 1, 1, 1),     # enough tiles for the 128x128 config
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(gpu_device, case):
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    y_ref = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+
+    xd, wd_, bd = nhwc(x.detach()), wdev(w.detach()), b.float().cuda()
+    y = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, dil=dil)
+    close(nchw(y, Cout), y_ref.detach())
+    if y.shape[3] != Cout:
+        assert float(y[..., Cout:].abs().max()) == 0.0      # pad channels untouched (zero)
+    # relu epilogue
+    yr = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, dil=dil, relu=True)
+    close(nchw(yr, Cout), y_ref.detach().clamp(min=0))
+
+    dyd = nhwc(dy)
+    if stride == 1 or dil == 1:
+        wt = fn.weight_transpose(wd_)
+        dx = fn.conv2d_dgrad(dyd, wt, tuple(xd.shape), stride=stride, pad=pad, dil=dil)
+        close(nchw(dx, Cin), x.grad)
+        dx2 = fn.conv2d_dgrad(dyd, wt, tuple(xd.shape), stride=stride, pad=pad, dil=dil, out=dx.clone(),
+                              accumulate=True)
+        close(nchw(dx2, Cin), 2 * x.grad)
+    dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=pad, dil=dil)
+    close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad)
+    close(fn.colsum(dyd, Cout).cpu().double(), dy.sum(dim=(0, 2, 3)))
+
+
+def test_conv_large_k_and_split_k_determinism(gpu_device):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 832, 16, 16, generator=g, dtype=torch.float64)
+    w = torch.randn(19, 832, 3, 3, generator=g, dtype=torch.float64) / 80
+    dy = torch.randn(2, 19, 16, 16, generator=g, dtype=torch.float64)
+    xd, wd_, dyd = nhwc(x), wdev(w), nhwc(dy)
+    y = fn.conv2d_forward(xd, wd_, pad=1)
+    close(nchw(y, 19), F.conv2d(x, w, padding=1))
+    a = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), pad=1)
+    b = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), pad=1)
+    assert torch.equal(a, b)
+    ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+    close(a.cpu().double().permute(0, 3, 1, 2), ref)
+
+
+def test_deconv_4x4_s2_forward_backward(gpu_device):
+    """mx.sym.Deconvolution(kernel 4, stride 2, pad 1, no bias) == dgrad of a 4x4/2 conv"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 19, 12, 10, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(19, 19, 4, 4, generator=g, dtype=torch.float64, requires_grad=True)  # [Cin, Cout, kh, kw]
+    y_ref = F.conv_transpose2d(x, w, stride=2, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    # device weight is the [K=Cin_deconv][R][S][C=Cout_deconv] tensor of the conv whose dgrad this is
+    wk = torch.zeros(20, 4, 4, 20)
+    wk[:19, :, :, :19] = w.detach().permute(0, 2, 3, 1).float()
+    wk = wk.cuda()
+    xd = nhwc(x.detach())                     # (2,12,10,20)
+    wt = fn.weight_transpose(wk)              # [C][R][S][K]
+    y = fn.conv2d_dgrad(xd, wt, (2, 24, 20, 20), stride=2, pad=1)
+    close(nchw(y, 19), y_ref.detach())
+    dyd = nhwc(dy)
+    dx = fn.conv2d_forward(dyd, wk, stride=2, pad=1)          # backward-data of deconv = conv forward
+    close(nchw(dx, 19), x.grad)
+    dw = fn.conv2d_wgrad(dyd, xd, tuple(wk.shape), stride=2, pad=1)   # roles swapped
+    close(dw[:19, :, :, :19].cpu().double().permute(0, 3, 1, 2), w.grad)
+
+
+@pytest.mark.parametrize("shape,relu,fix_gamma", [((4, 16, 16, 64), True, False), ((2, 9, 7, 256), True, False),
+                                                   ((3, 8, 8, 20), False, True), ((2, 4, 4, 2048), False, True),
+                                                   ((8, 64, 64, 4), False, True)])
+def test_batchnorm_forward_backward(gpu_device, shape, relu, fix_gamma):
+    g = torch.Generator().manual_seed(3)
+    C = shape[3]
+    x = (torch.randn(shape, generator=g, dtype=torch.float64) * 3 + 5).requires_grad_()
+    gamma = torch.ones(C, dtype=torch.float64) if fix_gamma else (torch.rand(C, generator=g, dtype=torch.float64) + 0.5)
+    gamma.requires_grad_(not fix_gamma)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_()
+    eps = 2e-5
+    xf = x.reshape(-1, C)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    y_ref = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    if relu:
+        y_ref = y_ref.clamp(min=0)
+    dy = torch.randn(shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+
+    xd = x.detach().float().cuda()
+    gd = None if fix_gamma else gamma.detach().float().cuda()
+    bd = beta.detach().float().cuda()
+    m, r = fn.bn_stats(xd, eps)
+    close(m.cpu().double(), mean.detach(), 1e-6)
+    close(r.cpu().double(), 1 / torch.sqrt(var.detach() + eps), 1e-5)
+    y = fn.bn_apply(xd, m, r, gd, bd, relu=relu)
+    close(y.cpu().double(), y_ref.detach(), 1e-5)
+    dx, dgam, dbet = fn.bn_backward(xd, y, dy.float().cuda(), m, r, gd, relu=relu)
+    close(dx.cpu().double(), x.grad, 1e-4)
+    close(dbet.cpu().double(), beta.grad, 1e-5)
+    if not fix_gamma:
+        close(dgam.cpu().double(), gamma.grad, 1e-5)
+    dx2, _, _ = fn.bn_backward(xd, y, dy.float().cuda(), m, r, gd, relu=relu, dx=dx.clone(), accumulate=True)
+    close(dx2.cpu().double(), 2 * x.grad, 1e-4)
+
+
+def test_maxpool_3x3_s2_p1(gpu_device):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 8, 13, 14, generator=g, dtype=torch.float64).clamp(min=0).requires_grad_()  # many ties at 0
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    xd = nhwc(x.detach())
+    y = fn.maxpool_forward(xd, 3, 2, 1)
+    assert torch.equal(nchw(y), y_ref.detach().float().double())
+    dx = fn.maxpool_backward(xd, y, nhwc(dy), 3, 2, 1)
+    close(nchw(dx), x.grad, 1e-6)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4])
+def test_avgpool(gpu_device, k):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 8, 16, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    y_ref = F.avg_pool2d(x, k, k)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    y = fn.avgpool_forward(nhwc(x.detach()), k)
+    close(nchw(y), y_ref.detach(), 1e-6)
+    dx = fn.avgpool_backward(nhwc(dy), (2, 16, 16, 8), k)
+    close(nchw(dx), x.grad, 1e-6)
+
+
+@pytest.mark.parametrize("hin,win", [(4, 4), (8, 8), (16, 16), (64, 64), (5, 9)])
+def test_bilinear_sampler_identity_grid(gpu_device, hin, win):
+    """BilinearSampler(GridGenerator(identity affine)) == align_corners bilinear resize"""
+    Ho, Wo = 64, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 8, hin, win, generator=g, dtype=torch.float64, requires_grad=True)
+    y_ref = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    out = torch.zeros(2, Ho, Wo, 24, device="cuda")
+    fn.bilinear_forward(nhwc(x.detach()), out, 8)
+    close(nchw(out)[:, 8:16], y_ref.detach(), 1e-5)
+    assert float(out[..., :8].abs().max()) == 0 and float(out[..., 16:].abs().max()) == 0
+    dyc = torch.zeros(2, Ho, Wo, 24, device="cuda")
+    dyc[..., 8:16] = nhwc(dy)
+    dx = fn.bilinear_backward(dyc, (2, hin, win, 8), 8)
+    close(nchw(dx), x.grad, 1e-5)
+
+
+def test_softmax_output_valid_normalisation(gpu_device):
+    """SoftmaxOutput(multi_output, use_ignore, ignore_label=-1, normalization='valid')"""
+    g = torch.Generator().manual_seed(8)
+    rows, C = 5000, 9
+    logits = (torch.randn(rows, C, generator=g, dtype=torch.float64) * 3).requires_grad_()
+    label = torch.randint(-1, C, (rows,), generator=g).double()
+    valid = label != -1
+    p_ref = torch.softmax(logits, dim=1)
+    loss = -(torch.log(p_ref[valid, label[valid].long()])).sum() / valid.sum()
+    loss.backward()
+    ld = logits.detach().float().cuda()
+    lab = label.float().cuda()
+    cnt = fn.count(lab, "ne", -1.0)
+    assert float(cnt) == float(valid.sum())
+    prob, grad = fn.softmax_output(ld, lab, C, -1.0, 1.0, cnt)
+    close(prob.cpu().double(), p_ref.detach(), 1e-6)
+    close(grad.cpu().double(), logits.grad, 1e-5)
+    ce = fn.cross_entropy_sum(prob, lab, C, -1.0, 1e-8).cpu()
+    assert float(ce[1]) == float(valid.sum())
+    metric = -(torch.log(p_ref.detach().float().double()[valid, label[valid].long()] + 1e-8)).sum() / valid.sum()
+    np.testing.assert_allclose(float(ce[0]) / float(ce[1]), float(metric), rtol=1e-5)   # train/metric.py:38-41
+
+
+def test_softmax_output_seg_padded_channels(gpu_device):
+    """seg head: 19 classes in 20 physical channels, ignore 255, grad_scale 4, no normalisation"""
+    g = torch.Generator().manual_seed(10)
+    rows, C = 4096, 19
+    logits = torch.randn(rows, C, generator=g, dtype=torch.float64).requires_grad_()
+    label = torch.randint(0, C, (rows,), generator=g).double()
+    label[torch.rand(rows, generator=g) < 0.1] = 255
+    valid = label != 255
+    p_ref = torch.softmax(logits, dim=1)
+    (-(torch.log(p_ref[valid, label[valid].long()])).sum() * 4).backward()
+    ld = torch.zeros(rows, 20); ld[:, :19] = logits.detach().float(); ld[:, 19] = 7.0
+    prob, grad = fn.softmax_output(ld.cuda(), label.float().cuda(), C, 255.0, 4.0, None)
+    close(prob[:, :19].cpu().double(), p_ref.detach(), 1e-6)
+    close(grad[:, :19].cpu().double(), logits.grad, 1e-5)
+    assert float(prob[:, 19].abs().max()) == 0 and float(grad[:, 19].abs().max()) == 0
+
+
+def test_smooth_l1_makeloss_valid(gpu_device):
+    g = torch.Generator().manual_seed(11)
+    n = 30000
+    pred = (torch.randn(n, generator=g, dtype=torch.float64) * 2).requires_grad_()
+    target = torch.randn(n, generator=g, dtype=torch.float64)
+    mask = (torch.rand(n, generator=g) < 0.2).double()
+    x = mask * (pred - target)
+    loss_ref = torch.where(x.abs() < 1, 0.5 * x * x, x.abs() - 0.5)
+    nvalid = (loss_ref > 0).sum().clamp(min=1)
+    (loss_ref.sum() / nvalid).backward()
+    pd, td, md = pred.detach().float().cuda(), target.float().cuda(), mask.float().cuda()
+    loss = fn.smooth_l1_forward(pd, td, md)
+    close(loss.cpu().double(), loss_ref.detach(), 1e-6)
+    cnt = fn.count(loss, "gt", 0.0)
+    assert abs(float(cnt) - float(nvalid)) <= 2
+    grad = fn.smooth_l1_backward(pd, td, md, cnt)
+    close(grad.cpu().double(), pred.grad, 1e-4)
+    np.testing.assert_allclose(float(fn.sum_all(loss)), float(loss_ref.sum()), rtol=1e-5)
+
+
+def test_sgd_momentum_matches_mxnet_rule(gpu_device):
+    g = torch.Generator().manual_seed(12)
+    n = 4096
+    w = torch.randn(n, generator=g, dtype=torch.float64); grad = torch.randn(n, generator=g, dtype=torch.float64)
+    mom = torch.randn(n, generator=g, dtype=torch.float64)
+    lr, mu, wd, rs = 0.0005, 0.9, 0.0005, 1 / 32
+    m_ref = mu * mom - lr * (rs * grad + wd * w)
+    w_ref = w + m_ref
+    wd_, gd, md = w.float().cuda(), grad.float().cuda(), mom.float().cuda()
+    fn.sgd_momentum(wd_, gd, md, lr, mu, wd, rs)
+    close(wd_.cpu().double(), w_ref, 1e-6)
+    close(md.cpu().double(), m_ref, 1e-6)
+
+
+def test_layout_helpers(gpu_device):
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 3, 6, 5, generator=g)
+    xd = fn.nchw_to_nhwc(x.cuda())
+    assert xd.shape == (2, 6, 5, 4)
+    assert torch.equal(xd[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(xd[..., 3].abs().max()) == 0
+    assert torch.equal(fn.nhwc_to_nchw(xd, 3).cpu(), x)
+    t = torch.randn(3, 7, 9, generator=g)
+    assert torch.equal(fn.transpose_bnc(t.cuda()).cpu(), t.permute(0, 2, 1).contiguous())
+    a, b = torch.randn(1001, generator=g), torch.randn(1001, generator=g)
+    assert torch.equal(fn.add(a.cuda(), b.cuda()).cpu(), a + b)
+    # head packing: (B, H*W, 32-padded 30 channels) -> packed (B, total) at an offset, and back
+    src = torch.randn(2, 12, 32, generator=g)
+    dst = torch.zeros(2, 500)
+    out = fn.copy_block(src.cuda(), dst.cuda(), 2, 12, 30, 12 * 32, 32, 0, 500, 30, 100)
+    exp = dst.clone(); exp[:, 100:100 + 360] = src[:, :, :30].reshape(2, 360)
+    assert torch.equal(out.cpu(), exp)
+    y = torch.randn(64, generator=g).clamp(min=0); dy = torch.randn(64, generator=g)
+    assert torch.equal(fn.relu_backward(y.cuda(), dy.cuda()).cpu(), dy * (y > 0))
