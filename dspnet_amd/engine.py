@@ -1,0 +1,392 @@
+"""Static-graph executor for the DSPNet hot path.
+
+MXNet binds a Symbol to an executor and calls forward()/backward()
+(multi_solver.py:250-290).  This is the counterpart: a list of nodes with
+statically shaped NHWC buffers, run in order for forward and in reverse for
+backward.  Every node launches the HIP kernels of include/dspn_nn.h on torch's
+current stream; nothing here computes with torch ops.
+
+Gradient buffers: the first producer of a tensor's gradient in a backward pass
+writes it, later ones accumulate (kernels take an `accumulate` flag).  A
+residual add hands its output-gradient buffer to its inputs by aliasing, so
+the gradient of a whole ResNet stage lives in one buffer that each unit
+accumulates into (stream order makes this safe: every reader of the old value
+was enqueued before the accumulating kernel).
+
+All parameters live in one flat fp32 arena (with matching gradient and momentum
+arenas) so the optimizer is one kernel and data-parallel reduction works on a
+few large contiguous buckets.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import functional as fn
+
+
+class Tensor:
+    """An activation: NHWC (or any) float32 device buffer + its gradient slot."""
+
+    def __init__(self, shape, name, requires_grad=True, data=None, device=None):
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self.requires_grad = requires_grad
+        self.data = data if data is not None else fn.zeros(*self.shape, device=device)
+        self.grad = None
+        self._own_grad = None
+        self._gw = False  # gradient written in the current backward pass
+
+    def own_grad(self):
+        if self._own_grad is None:
+            self._own_grad = torch.zeros_like(self.data)
+        return self._own_grad
+
+    def grad_target(self):
+        """(buffer, accumulate) for a kernel that produces this tensor's gradient"""
+        if not self._gw:
+            self.grad = self.own_grad()
+            self._gw = True
+            return self.grad, False
+        return self.grad, True
+
+    def give_grad(self, buf):
+        """hand over a finished gradient buffer (alias if first, else accumulate)"""
+        if not self._gw:
+            self.grad = buf
+            self._gw = True
+        else:
+            fn.add(self.grad, buf, out=self.grad)
+
+
+class Param:
+    def __init__(self, name, shape, init, wd_mult=1.0):
+        self.name, self.shape, self.init, self.wd_mult = name, tuple(shape), init, wd_mult
+        self.data = self.grad = None
+        self.offset = 0
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+
+class Node:
+    def forward(self):
+        raise NotImplementedError
+
+    def backward(self):
+        pass
+
+
+class Graph:
+    def __init__(self, device):
+        self.device = device
+        self.nodes = []
+        self.params = {}
+        self.param_order = []
+        self.tensors = {}
+        self.all_tensors = []
+        self.arena = self.grad_arena = self.mom_arena = None
+
+    # -- construction ---------------------------------------------------------
+    def tensor(self, shape, name, requires_grad=True, data=None):
+        t = Tensor(shape, name, requires_grad, data=data, device=self.device)
+        assert name not in self.tensors, "duplicate tensor name " + name
+        self.tensors[name] = t
+        self.all_tensors.append(t)
+        return t
+
+    def param(self, name, shape, init):
+        assert name not in self.params, name
+        p = Param(name, shape, init)
+        self.params[name] = p
+        self.param_order.append(p)
+        return p
+
+    def add(self, node):
+        self.nodes.append(node)
+        return node
+
+    def finalize(self, seed=0):
+        """allocate the flat parameter / gradient / momentum arenas and initialise"""
+        off = 0
+        for p in self.param_order:
+            p.offset = off
+            off += (p.size + 3) // 4 * 4
+        self.arena = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad_arena = torch.zeros_like(self.arena)
+        self.mom_arena = torch.zeros_like(self.arena)
+        rng = np.random.Generator(np.random.PCG64(seed))
+        host = np.zeros(off, np.float32)
+        for p in self.param_order:
+            host[p.offset:p.offset + p.size] = np.asarray(p.init(rng, p.shape), np.float32).reshape(-1)
+        self.arena.copy_(torch.from_numpy(host))
+        for p in self.param_order:
+            p.data = self.arena[p.offset:p.offset + p.size].view(p.shape)
+            p.grad = self.grad_arena[p.offset:p.offset + p.size].view(p.shape)
+        return self
+
+    def load_params(self, values):
+        """values: name -> numpy array in the param's (device-layout) shape"""
+        for k, v in values.items():
+            self.params[k].data.copy_(torch.from_numpy(np.ascontiguousarray(v, np.float32)).view(self.params[k].shape))
+
+    # -- execution ------------------------------------------------------------
+    def forward(self):
+        for n in self.nodes:
+            n.forward()
+
+    def backward(self):
+        for t in self.all_tensors:
+            t._gw = False
+            t.grad = None
+        for n in reversed(self.nodes):
+            n.backward()
+
+    def num_params(self):
+        return sum(p.size for p in self.param_order)
+
+
+# ------------------------------------------------------------------ initialisers
+def init_zeros(rng, shape):
+    return np.zeros(shape, np.float32)
+
+
+def init_ones(rng, shape):
+    return np.ones(shape, np.float32)
+
+
+def init_uniform_maxdim(rng, shape):
+    """multi_init.py:74-76: U(-1/sqrt(max(shape)), 1/sqrt(max(shape))) on the MXNet shape
+    (Cout, Cin, kh, kw); device layout is (Cout, kh, kw, Cin_phys), pad channels stay 0."""
+    return None  # replaced by conv_weight_init below
+
+
+def conv_weight_init(kind, cin_logical):
+    def f(rng, shape):
+        cout, r, s, cin_p = shape
+        w = np.zeros(shape, np.float32)
+        if kind == "maxdim":
+            lim = 1.0 / math.sqrt(max(cout, cin_logical, r, s))
+        else:  # "xavier": mx.init.Xavier(uniform, avg, magnitude 3) (train/train_multitask.py:313)
+            fan_in, fan_out = cin_logical * r * s, cout * r * s
+            lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+        w[..., :cin_logical] = rng.uniform(-lim, lim, size=(cout, r, s, cin_logical))
+        return w
+    return f
+
+
+def deconv_bilinear_init(channels):
+    """multi_init.py:160-168 + upsample_filt: a diagonal bilinear kernel.  Device layout of the
+    Deconvolution weight is [K = in channel][R][S][C = out channel] (phys channels)."""
+    def f(rng, shape):
+        k_p, r, s, c_p = shape
+        factor = (r + 1) // 2
+        center = factor - 1 if r % 2 == 1 else factor - 0.5
+        og = np.ogrid[:r, :s]
+        filt = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
+        w = np.zeros(shape, np.float32)
+        for i in range(channels):
+            w[i, :, :, i] = filt
+        return w
+    return f
+
+
+# ------------------------------------------------------------------ nodes
+class InputNCHW(Node):
+    """data (B,3,H,W) -> NHWC with channels padded to 4 (symbol/resnet.py:89 `data`)"""
+
+    def __init__(self, g, src, name="data_nhwc"):
+        self.src = src
+        N, C, H, W = src.shape
+        self.out = g.tensor((N, H, W, fn.pad4(C)), name, requires_grad=False)
+
+    def forward(self):
+        fn.nchw_to_nhwc(self.src.data, out=self.out.data)
+
+
+class BatchNorm(Node):
+    """mx.sym.BatchNorm with batch statistics (the solver always runs is_train=True,
+    multi_solver.py:284) optionally fused with the following ReLU."""
+
+    def __init__(self, g, x, name, fix_gamma=False, eps=2e-5, relu=False):
+        C = x.shape[-1]
+        self.x, self.eps, self.relu = x, eps, relu
+        self.gamma = None if fix_gamma else g.param(name + "_gamma", (C,), init_ones)
+        self.beta = g.param(name + "_beta", (C,), init_zeros)
+        self.mean = fn.zeros(C, device=g.device)
+        self.rstd = fn.zeros(C, device=g.device)
+        self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), x.requires_grad or True)
+
+    def forward(self):
+        fn.bn_stats(self.x.data, self.eps, self.mean, self.rstd)
+        fn.bn_apply(self.x.data, self.mean, self.rstd, None if self.gamma is None else self.gamma.data,
+                    self.beta.data, relu=self.relu, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        if self.x.requires_grad:
+            dx, acc = self.x.grad_target()
+        else:  # parameters still need their gradients; dx goes to scratch
+            dx, acc = self.out.grad, False
+        fn.bn_backward(self.x.data, self.out.data, self.out.grad, self.mean, self.rstd,
+                       None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
+                       dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
+                       accumulate=acc)
+
+
+class Conv(Node):
+    """mx.sym.Convolution (+ bias) (+ ReLU epilogue); weight [Cout, R, S, Cin_phys]"""
+
+    def __init__(self, g, x, name, num_filter, kernel, stride=1, pad=0, dilate=1, no_bias=True, relu=False,
+                 init="xavier", cin_logical=None, cout_phys=None):
+        N, H, W, Cin = x.shape
+        self.x, self.stride, self.pad, self.dil, self.relu = x, stride, pad, dilate, relu
+        self.cout = num_filter
+        cin_logical = Cin if cin_logical is None else cin_logical
+        self.w = g.param(name + "_weight", (num_filter, kernel, kernel, Cin), conv_weight_init(init, cin_logical))
+        self.b = None if no_bias else g.param(name + "_bias", (num_filter,), init_zeros)
+        Ho, Wo = fn.conv_out_size(H, kernel, stride, pad, dilate), fn.conv_out_size(W, kernel, stride, pad, dilate)
+        ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
+        self.out = g.tensor((N, Ho, Wo, ldc), name + "_out")
+        self.wt = None if not x.requires_grad else fn.zeros(Cin, kernel, kernel, ldc, device=g.device)
+
+    def forward(self):
+        fn.conv2d_forward(self.x.data, self.w.data, None if self.b is None else self.b.data, self.stride,
+                          self.pad, self.dil, relu=self.relu, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        dy = self.out.grad
+        if self.relu:
+            fn.relu_backward(self.out.data, dy, dx=dy)
+        if self.b is not None:
+            fn.colsum(dy, self.cout, out=self.b.grad)
+        fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)
+        if self.x.requires_grad:
+            fn.weight_transpose(self.w.data, out=self.wt)
+            dx, acc = self.x.grad_target()
+            fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc)
+
+
+class Deconv4x4s2(Node):
+    """mx.sym.Deconvolution(kernel 4, stride 2, pad 1, no bias) (multitask_symbol_builder.py:586):
+    forward = data-gradient kernel of the 4x4/2 convolution with weight [K=in][R][S][C=out]."""
+
+    def __init__(self, g, x, name, channels):
+        N, H, W, Cp = x.shape
+        self.x = x
+        self.w = g.param(name + "_weight", (Cp, 4, 4, Cp), deconv_bilinear_init(channels))
+        self.wt = fn.zeros(Cp, 4, 4, Cp, device=g.device)
+        self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
+
+    def forward(self):
+        fn.weight_transpose(self.w.data, out=self.wt)
+        fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        dy = self.out.grad
+        fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad)
+        if self.x.requires_grad:
+            dx, acc = self.x.grad_target()
+            fn.conv2d_forward(dy, self.w.data, None, 2, 1, 1, out=dx, accumulate=acc)
+
+
+class Add(Node):
+    """elementwise sum of the residual unit (symbol/resnet.py:51)"""
+
+    def __init__(self, g, a, b, name):
+        self.a, self.b = a, b
+        self.out = g.tensor(a.shape, name)
+
+    def forward(self):
+        fn.add(self.a.data, self.b.data, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        for t in (self.a, self.b):
+            if t.requires_grad:
+                t.give_grad(self.out.grad)
+
+
+class BlockGrad(Node):
+    """mx.sym.BlockGrad: same values, no gradient (multitask_symbol_builder.py:542,549)"""
+
+    def __init__(self, g, x, name):
+        self.out = g.tensor(x.shape, name, requires_grad=False, data=x.data)
+
+    def forward(self):
+        pass
+
+
+class MaxPool(Node):
+    def __init__(self, g, x, name, kernel, stride, pad):
+        N, H, W, C = x.shape
+        self.x, self.k, self.s, self.p = x, kernel, stride, pad
+        self.out = g.tensor((N, fn.conv_out_size(H, kernel, stride, pad), fn.conv_out_size(W, kernel, stride, pad), C),
+                            name)
+
+    def forward(self):
+        fn.maxpool_forward(self.x.data, self.k, self.s, self.p, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw or not self.x.requires_grad:
+            return
+        assert not self.x._gw, "maxpool input has a single consumer"
+        dx, _ = self.x.grad_target()
+        fn.maxpool_backward(self.x.data, self.out.data, self.out.grad, self.k, self.s, self.p, dx=dx)
+
+
+class AvgPool(Node):
+    """mx.sym.Pooling(pool_type='avg', kernel=(k,k), stride=(k,k)) (multitask_symbol_builder.py:560-562)"""
+
+    def __init__(self, g, x, name, k):
+        N, H, W, C = x.shape
+        self.x, self.k = x, k
+        if k == 1:
+            self.out = x
+        else:
+            self.out = g.tensor((N, H // k, W // k, C), name)
+
+    def forward(self):
+        if self.k > 1:
+            fn.avgpool_forward(self.x.data, self.k, out=self.out.data)
+
+    def backward(self):
+        if self.k == 1 or not self.out._gw or not self.x.requires_grad:
+            return
+        dx, acc = self.x.grad_target()
+        fn.avgpool_backward(self.out.grad, self.x.shape, self.k, dx=dx, accumulate=acc)
+
+
+class BilinearConcat(Node):
+    """GridGenerator(identity affine, target) + BilinearSampler on each input, concatenated along
+    channels (multitask_symbol_builder.py:574-582)."""
+
+    def __init__(self, g, inputs, name, target_hw):
+        N = inputs[0].shape[0]
+        self.inputs = inputs
+        self.offsets = np.cumsum([0] + [t.shape[3] for t in inputs]).tolist()
+        self.out = g.tensor((N, target_hw[0], target_hw[1], self.offsets[-1]), name)
+
+    def forward(self):
+        for t, off in zip(self.inputs, self.offsets):
+            fn.bilinear_forward(t.data, self.out.data, off)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        for t, off in zip(self.inputs, self.offsets):
+            if not t.requires_grad:
+                continue
+            if t._gw:
+                tmp = fn.bilinear_backward(self.out.grad, t.shape, off)
+                fn.add(t.grad, tmp, out=t.grad)
+            else:
+                dx, _ = t.grad_target()
+                fn.bilinear_backward(self.out.grad, t.shape, off, dx=dx)

@@ -1,0 +1,206 @@
+"""Multi-task training graph (counterpart of symbol/multitask_symbol_builder.py:442-593).
+
+backbone -> SSD extras + multibox heads -> MultiBoxTarget -> SoftmaxOutput(cls) / smooth-L1(loc)
+         -> MultiBoxDetection (monitoring output)
+         -> segmentation decoder (pyramid pooling + bilinear sampling + 3x3 conv + 4x4/2 deconv)
+            -> SoftmaxOutput(seg, grad_scale 4, ignore 255)
+
+Outputs, in the reference's order (:592): cls_prob (B,C+1,N), loc_loss (B,N*5), cls_label (B,N),
+det_out (B,N,7), seg_out (B,19,H/4,W/4).
+
+Generalisations that are this build's own: the sampling grid is (H/8, W/8)
+instead of the hard-coded (64,128) (equal at the reference's only consistent shape 512x1024), and
+`affine_matrix` is the constant identity (the reference lets SGD perturb it).
+"""
+import torch
+
+from .. import engine as E
+from .. import functional as fn
+from .. import operator as op
+from . import resnet as resnet_mod
+from .common import multi_layer_feature, multitask_layer
+
+eps = 2e-5          # symbol/multitask_symbol_builder.py:5
+seg_classes = 19    # :7
+
+
+class MultiBoxTargetNode(E.Node):
+    """mx.contrib.symbol.MultiBoxTarget(anchor, label, cls_preds, overlap_threshold=.5, ignore_label=-1,
+    negative_mining_ratio=3, minimum_negative_samples=0, negative_mining_thresh=.5) (:517-521)"""
+
+    def __init__(self, g, anchors, label, cls_flat, num_cls):
+        self.anchors, self.label, self.cls_flat, self.C = anchors, label, cls_flat, num_cls
+        B, N = cls_flat.shape[0], anchors.shape[1]
+        self.cls_preds = g.tensor((B, num_cls, N), "multibox_cls_pred", requires_grad=False)
+        self.loc_target = self.loc_mask = self.cls_target = None
+
+    def forward(self):
+        B, C, N = self.cls_preds.shape
+        fn.transpose_bnc(self.cls_flat.data.view(B, N, C), out=self.cls_preds.data)
+        self.loc_target, self.loc_mask, self.cls_target = op.MultiBoxTarget(
+            self.anchors, self.label.data, self.cls_preds.data, overlap_threshold=.5, ignore_label=-1,
+            negative_mining_ratio=3, minimum_negative_samples=0, negative_mining_thresh=.5,
+            variances=(0.1, 0.1, 0.2, 0.2))
+
+
+class ClsSoftmaxOutput(E.Node):
+    """SoftmaxOutput(cls_preds, cls_target, ignore_label=-1, use_ignore, multi_output,
+    normalization='valid', grad_scale=1) (:526-528)"""
+
+    def __init__(self, g, cls_flat, target_node, num_cls):
+        self.x, self.tn, self.C = cls_flat, target_node, num_cls
+        B = cls_flat.shape[0]
+        N = cls_flat.shape[1] // num_cls
+        self.prob_nc = fn.zeros(B, N, num_cls, device=g.device)
+        self.gbuf = fn.zeros(*cls_flat.shape, device=g.device)   # d loss / d logits, made in forward
+        self.valid = fn.zeros(1, device=g.device)
+        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False)
+
+    def forward(self):
+        B, C, N = self.cls_prob.shape
+        fn.count(self.tn.cls_target, "ne", -1.0, out=self.valid)
+        fn.softmax_output(self.x.data.view(B * N, C), self.tn.cls_target, C, -1.0, 1.0, self.valid,
+                          prob=self.prob_nc.view(B * N, C), grad=self.gbuf.view(B * N, C))
+        fn.transpose_bnc(self.prob_nc, out=self.cls_prob.data)
+
+    def backward(self):
+        self.x.give_grad(self.gbuf)
+
+
+class LocLoss(E.Node):
+    """MakeLoss(smooth_l1(loc_target_mask * (loc_preds - loc_target), scalar=1), normalization='valid')
+    (:529-532)"""
+
+    def __init__(self, g, loc_preds, target_node):
+        self.x, self.tn = loc_preds, target_node
+        self.valid = fn.zeros(1, device=g.device)
+        self.out = g.tensor(loc_preds.shape, "loc_loss", requires_grad=False)
+
+    def forward(self):
+        fn.smooth_l1_forward(self.x.data, self.tn.loc_target, self.tn.loc_mask, out=self.out.data)
+        fn.count(self.out.data, "gt", 0.0, out=self.valid)
+
+    def backward(self):
+        if self.x._gw:
+            tmp = fn.smooth_l1_backward(self.x.data, self.tn.loc_target, self.tn.loc_mask, self.valid, 1.0)
+            fn.add(self.x.grad, tmp, out=self.x.grad)
+        else:
+            dx, _ = self.x.grad_target()
+            fn.smooth_l1_backward(self.x.data, self.tn.loc_target, self.tn.loc_mask, self.valid, 1.0, out=dx)
+
+
+class Detection(E.Node):
+    """MultiBoxDetection(cls_prob, loc_preds, anchors, nms_threshold, force_suppress, nms_topk) wrapped in
+    a zero-gradient MakeLoss (:536-539)"""
+
+    def __init__(self, g, cls_prob, loc_preds, anchors, nms_thresh, force_suppress, nms_topk):
+        self.cls_prob, self.loc_preds, self.anchors = cls_prob, loc_preds, anchors
+        self.kw = dict(nms_threshold=nms_thresh, force_suppress=force_suppress,
+                       variances=(0.1, 0.1, 0.2, 0.2), nms_topk=nms_topk)
+        B, N = cls_prob.shape[0], anchors.shape[1]
+        self.out = g.tensor((B, N, 7), "det_out", requires_grad=False)
+
+    def forward(self):
+        op.MultiBoxDetection(self.cls_prob.data, self.loc_preds.data, self.anchors, out=self.out.data, **self.kw)
+
+
+class SegSoftmaxOutput(E.Node):
+    """SoftmaxOutput(score4_conv, multi_output, grad_scale=4, use_ignore, ignore_label=255) (:588).
+    normalization is the default 'null'; MXNet then divides the gradient by the number of spatial
+    positions of one sample (softmax_output-inl.h, multi_output branch)."""
+
+    def __init__(self, g, logits, label, classes):
+        self.x, self.label, self.C = logits, label, classes
+        B, H, W, Cp = logits.shape
+        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False)
+        self.gbuf = fn.zeros(*logits.shape, device=g.device)
+        self.scale = 4.0 / float(H * W)
+
+    def forward(self):
+        B, H, W, Cp = self.x.shape
+        fn.softmax_output(self.x.data.view(B * H * W, Cp), self.label.data, self.C, 255.0, self.scale, None,
+                          prob=self.prob.data.view(B * H * W, Cp), grad=self.gbuf.view(B * H * W, Cp))
+
+    def backward(self):
+        self.x.give_grad(self.gbuf)
+
+    def nchw(self):
+        """seg_out in the reference's layout (B, 19, H/4, W/4)"""
+        return fn.nhwc_to_nchw(self.prob.data, self.C)
+
+
+class MultiTaskNet:
+    """what symbol.bind(...) returns in the reference: inputs, executor graph, outputs"""
+
+    def __init__(self, g, data, label_det, label_seg, nodes):
+        self.g, self.data, self.label_det, self.label_seg = g, data, label_det, label_seg
+        self.__dict__.update(nodes)
+
+    def outputs(self):
+        """[cls_prob, loc_loss, cls_label, det_out, seg_out] (multitask_symbol_builder.py:592)"""
+        return [self.cls_out.cls_prob.data, self.loc_loss.out.data, self.target.cls_target,
+                self.det.out.data, self.seg_out.nchw()]
+
+
+def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                           normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5, force_suppress=False,
+                           nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), num_labels=200, device=None,
+                           num_layers=50, seed=0, **kwargs):
+    """symbol/multitask_symbol_builder.py:442-593"""
+    assert network == "resnet", "round 1 wires the resnet presets (the only ones the reference builds)"
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    g = E.Graph(device)
+    C, H, W = data_shape
+    data = g.tensor((batch_size, C, H, W), "data", requires_grad=False)
+    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False)
+    seg_label = g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False)
+
+    internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
+    res3 = internals[from_layers[0] + "_output"]
+    res4 = internals[from_layers[1] + "_output"]
+    conv_feat = internals[from_layers[2] + "_output"]
+
+    # remove res3 from the input layers of SSD (:502-508)
+    from_layers, num_filters, strides, pads = from_layers[1:], num_filters[1:], strides[1:], pads[1:]
+    sizes, ratios = sizes[1:], ratios[1:]
+
+    layers = multi_layer_feature(g, internals, from_layers, num_filters, strides, pads, min_filter=min_filter)
+    loc_preds, cls_flat, anchor_boxes = multitask_layer(g, layers, num_classes, sizes=sizes, ratios=ratios,
+                                                        normalization=normalizations, clip=False, steps=steps)
+    ncls = num_classes + 1
+    target = g.add(MultiBoxTargetNode(g, anchor_boxes, label, cls_flat, ncls))
+    cls_out = g.add(ClsSoftmaxOutput(g, cls_flat, target, ncls))
+    loc_loss = g.add(LocLoss(g, loc_preds, target))
+    det = g.add(Detection(g, cls_out.cls_prob, loc_preds, anchor_boxes, nms_thresh, force_suppress, nms_topk))
+
+    # segmentation task (pyramid pooling module) (:541-589)
+    def conv_bn(x, name, nf, k, pad):
+        c = g.add(E.Conv(g, x, name, nf, k, 1, pad, init="maxdim")).out
+        return g.add(E.BatchNorm(g, c, name + "_bn", fix_gamma=True, eps=eps)).out
+
+    res3_block = g.add(E.BlockGrad(g, res3, "res3_block")).out
+    res3_reduced_bn = conv_bn(res3_block, "res3_reduced", 128, 1, 0)
+    res3_reduced2_bn = conv_bn(res3_reduced_bn, "res3_reduced2", 128, 3, 1)
+    res4_block = g.add(E.BlockGrad(g, res4, "res4_block")).out
+    res4_reduced_bn = conv_bn(res4_block, "res4_reduced", 256, 1, 0)
+    res4_reduced2_bn = conv_bn(res4_reduced_bn, "res4_reduced2", 256, 3, 1)
+    # the reference also declares a 1x1 "res5_reduced" conv whose output is never used (:556-558)
+    res5_reduced_bn = g.add(E.BatchNorm(g, conv_feat, "res5_reduced_bn", fix_gamma=True, eps=eps)).out
+    score_pool1 = g.add(E.AvgPool(g, res5_reduced_bn, "score_pool1", 1)).out
+    score_pool2 = g.add(E.AvgPool(g, res5_reduced_bn, "score_pool2", 2)).out
+    score_pool4 = g.add(E.AvgPool(g, res5_reduced_bn, "score_pool4", 4)).out
+    score2_pool4_bn = conv_bn(score_pool4, "score2_pool4", 128, 1, 0)
+    score2_pool2_bn = conv_bn(score_pool2, "score2_pool2", 256, 1, 0)
+    score2_pool1_bn = conv_bn(score_pool1, "score2_pool1", 512, 1, 0)
+    target_hw = (H // 8, W // 8)   # (64,128) at 512x1024 (:575)
+    score3_concat = g.add(E.BilinearConcat(
+        g, [score2_pool4_bn, score2_pool2_bn, score2_pool1_bn, res5_reduced_bn, res4_reduced2_bn,
+            res3_reduced2_bn], "score3_concat", target_hw)).out
+    score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1)
+    score4_conv = g.add(E.Deconv4x4s2(g, score3_conv_bn, "score4_conv", seg_classes)).out
+    seg_out = g.add(SegSoftmaxOutput(g, score4_conv, seg_label, seg_classes))
+
+    g.finalize(seed)
+    return MultiTaskNet(g, data, label, seg_label,
+                        dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=seg_out,
+                             anchors=anchor_boxes, loc_preds=loc_preds, cls_flat=cls_flat))

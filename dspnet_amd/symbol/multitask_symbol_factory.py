@@ -1,0 +1,34 @@
+"""Network presets (counterpart of symbol/multitask_symbol_factory.py)."""
+from . import multitask_symbol_builder as builder
+
+
+def get_config(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:5-98.  Only the presets that build in the reference are
+    offered in round 1 (resnet-50 :68-81; resnet101's list is kept as data for later)."""
+    if network == 'resnet-50':
+        num_layers = 50
+        network = 'resnet'
+        from_layers = ['_plus6', '_plus12', '_plus15', '', '', '', '']
+        num_filters = [-1, -1, -1, 512, 256, 256, 128]
+        strides = [-1, -1, -1, 2, 2, 2, 2]
+        pads = [-1, -1, -1, 1, 1, 1, 1]
+        sizes = [[.5, .705], [.1, .141], [.2, .272], [.37, .447], [.54, .619], [.71, .79], [.88, .961]]
+        ratios = [[1, 2, .5], [1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3],
+                  [1, 2, .5], [1, 2, .5]]
+        normalizations = -1
+        steps = []
+        return locals()
+    msg = 'No configuration found for %s with data_shape %s' % (network, str(data_shape))
+    raise NotImplementedError(msg)
+
+
+def get_multi_symbol_train(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:188-205.  data_shape: int (square) or (C, H, W)."""
+    if isinstance(data_shape, int):
+        data_shape = (3, data_shape, data_shape)
+    config = get_config(network, data_shape, **kwargs)
+    config.pop('kwargs', None)
+    config.pop('data_shape', None)
+    kwargs = dict(kwargs)
+    config.update(kwargs)
+    return builder.get_multi_symbol_train(data_shape=data_shape, **config)

@@ -1,0 +1,193 @@
+"""CPU restatement of the DSPNet multi-task training graph in plain PyTorch ops.
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).
+
+PARITY STATUS: "parity unpinned".  The reference graph (symbol/multitask_symbol_builder.py:442-593
+on symbol/resnet.py, symbol/common.py) is a set of MXNet symbols; MXNet is neither vendored nor
+installable here and the reference has no tests or recorded outputs beyond tensor SHAPES
+(utils.py:38), so the arithmetic of every built-in operator below is this file's reading of the
+documented MXNet 0.11-1.0 semantics:
+  * Convolution / Deconvolution(no bias) / Pooling(max: pad ignored, avg) -> torch conv2d /
+    conv_transpose2d / max_pool2d / avg_pool2d;
+  * BatchNorm(is_train): biased batch variance, eps 2e-5, fix_gamma => gamma == 1;
+  * GridGenerator(affine identity) + BilinearSampler -> bilinear resize with align_corners=True;
+  * SoftmaxOutput(multi_output, use_ignore): backward (p - onehot) * grad_scale, zero on ignored
+    labels, divided by #valid for normalization='valid', by the number of positions per sample for
+    the default normalization; expressed here as the scalar whose autograd gradient is that;
+  * MakeLoss(smooth_l1, normalization='valid'): gradient 1 / max(1, #(loss > 0)).
+The SSD operators inside the graph call oracle/multibox_oracle.c.
+
+The same function doubles as the CPU baseline ("port") timed by bench.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import multibox as om
+
+EPS = 2e-5
+
+
+def bn(x, gamma, beta, relu=False):
+    mean = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    y = (x - mean) / torch.sqrt(var + EPS)
+    if gamma is not None:
+        y = y * gamma.view(1, -1, 1, 1)
+    y = y + beta.view(1, -1, 1, 1)
+    return F.relu(y) if relu else y
+
+
+class Params:
+    """name -> torch tensor (NCHW-style shapes) with requires_grad; built from the device graph's
+    parameters (device layout [Cout,R,S,Cin_phys] -> [Cout,Cin,R,S])."""
+
+    def __init__(self, values, dtype):
+        self.p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in values.items()}
+
+    def __getitem__(self, k):
+        return self.p[k]
+
+    def get(self, k):
+        return self.p.get(k)
+
+
+def residual_unit(P, data, name, stride, dim_match):
+    act1 = bn(data, P[name + "_bn1_gamma"], P[name + "_bn1_beta"], relu=True)
+    conv1 = F.conv2d(act1, P[name + "_conv1_weight"])
+    act2 = bn(conv1, P[name + "_bn2_gamma"], P[name + "_bn2_beta"], relu=True)
+    conv2 = F.conv2d(act2, P[name + "_conv2_weight"], stride=stride, padding=1)
+    act3 = bn(conv2, P[name + "_bn3_gamma"], P[name + "_bn3_beta"], relu=True)
+    conv3 = F.conv2d(act3, P[name + "_conv3_weight"])
+    shortcut = data if dim_match else F.conv2d(act1, P[name + "_sc_weight"], stride=stride)
+    return conv3 + shortcut
+
+
+def resnet50(P, data):
+    x = bn(data, None, P["bn_data_beta"])
+    x = F.conv2d(x, P["conv0_weight"], stride=2, padding=3)
+    x = bn(x, P["bn0_gamma"], P["bn0_beta"], relu=True)
+    body = F.max_pool2d(x, 3, 2, 1)
+    internals, plus = {}, 0
+    for i, n in enumerate([3, 4, 6, 3]):
+        for j in range(n):
+            body = residual_unit(P, body, "stage%d_unit%d" % (i + 1, j + 1), (1 if i == 0 else 2) if j == 0 else 1,
+                                 j != 0)
+            internals["_plus%d" % plus] = body
+            plus += 1
+    return internals
+
+
+def conv_bn(P, x, name, pad):
+    return bn(F.conv2d(x, P[name + "_weight"], padding=pad), None, P[name + "_bn_beta"])
+
+
+def forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes=8, dtype=torch.float64,
+                 nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None):
+    """Runs the multi-task training graph on the CPU.  Returns dict with the five graph outputs, the
+    three loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params."""
+    P = Params(values, dtype)
+    x = torch.tensor(data, dtype=dtype)
+    B, _, H, W = x.shape
+    inter = resnet50(P, x)
+    res3, res4, conv_feat = inter["_plus6"], inter["_plus12"], inter["_plus15"]
+
+    # SSD extras + heads (symbol/common.py:117-133, 393-432)
+    layers, names = [res4, conv_feat], ["_plus12", "_plus15"]
+    for k, nf in zip((2, 3, 4, 5), (512, 256, 256, 128)):
+        n1, n3 = "multi_feat_%d_conv_1x1_conv" % k, "multi_feat_%d_conv_3x3_conv" % k
+        c1 = F.relu(F.conv2d(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
+        c3 = F.relu(F.conv2d(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=2, padding=1))
+        layers.append(c3); names.append("multi_feat_%d_conv_3x3_relu" % k)
+    locs, clss, anchors = [], [], []
+    for layer, nm, sz, rt in zip(layers, names, sizes, ratios):
+        lp = F.conv2d(layer, P[nm + "_loc_pred_conv_weight"], P[nm + "_loc_pred_conv_bias"], padding=1)
+        cp = F.conv2d(layer, P[nm + "_cls_pred_conv_weight"], P[nm + "_cls_pred_conv_bias"], padding=1)
+        locs.append(lp.permute(0, 2, 3, 1).reshape(B, -1))
+        clss.append(cp.permute(0, 2, 3, 1).reshape(B, -1))
+        anchors.append(om.multibox_prior(layer.shape[2], layer.shape[3], sz, rt))
+    loc_preds = torch.cat(locs, dim=1)
+    ncls = num_classes + 1
+    cls_preds = torch.cat(clss, dim=1).reshape(B, -1, ncls).permute(0, 2, 1)       # (B, C+1, N)
+    anchor_boxes = np.concatenate(anchors, axis=1)
+
+    if targets is None:
+        loc_t, loc_m, cls_t = om.multibox_target(anchor_boxes, label_det, cls_preds.detach().float().numpy(),
+                                                 overlap_threshold=.5, ignore_label=-1, negative_mining_ratio=3,
+                                                 minimum_negative_samples=0, negative_mining_thresh=.5)
+    else:   # graph-level numerics checks pin the (discrete) matching to the device's, which is
+        loc_t, loc_m, cls_t = targets   # itself checked bit-exactly against the C oracle
+    cls_prob = torch.softmax(cls_preds, dim=1)
+    ct = torch.tensor(cls_t, dtype=torch.long)
+    valid = ct >= 0
+    nvalid = max(1, int(valid.sum()))
+    logp = torch.log_softmax(cls_preds, dim=1)
+    picked = logp.gather(1, ct.clamp(min=0).unsqueeze(1)).squeeze(1)
+    obj_cls = -(picked * valid.to(dtype)).sum() / nvalid
+    d = torch.tensor(loc_m, dtype=dtype) * (loc_preds - torch.tensor(loc_t, dtype=dtype))
+    loc_loss = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
+    nloc = max(1, int((loc_loss > 0).sum()))
+    obj_loc = loc_loss.sum() / nloc
+    det = om.multibox_detection(cls_prob.detach().float().numpy(), loc_preds.detach().float().numpy(),
+                                anchor_boxes, nms_threshold=nms_thresh, force_suppress=force_suppress,
+                                nms_topk=nms_topk)
+
+    # segmentation decoder (multitask_symbol_builder.py:541-589)
+    r3 = conv_bn(P, conv_bn(P, res3.detach(), "res3_reduced", 0), "res3_reduced2", 1)
+    r4 = conv_bn(P, conv_bn(P, res4.detach(), "res4_reduced", 0), "res4_reduced2", 1)
+    r5 = bn(conv_feat, None, P["res5_reduced_bn_beta"])
+    p4 = conv_bn(P, F.avg_pool2d(r5, 4, 4), "score2_pool4", 0)
+    p2 = conv_bn(P, F.avg_pool2d(r5, 2, 2), "score2_pool2", 0)
+    p1 = conv_bn(P, r5, "score2_pool1", 0)
+    th, tw = H // 8, W // 8
+    samp = [F.interpolate(t, size=(th, tw), mode="bilinear", align_corners=True) for t in (p4, p2, p1, r5, r4, r3)]
+    cat = torch.cat(samp, dim=1)
+    s3 = conv_bn(P, cat, "score3_conv", 1)
+    s4 = F.conv_transpose2d(s3, P["score4_conv_weight"], stride=2, padding=1)
+    seg_prob = torch.softmax(s4, dim=1)
+    sl = torch.tensor(label_seg, dtype=torch.long)
+    svalid = sl != 255
+    slogp = torch.log_softmax(s4, dim=1).gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1)
+    seg_ce_sum = -(slogp * svalid.to(dtype)).sum()
+    obj_seg = seg_ce_sum * (4.0 / float(s4.shape[2] * s4.shape[3]))
+
+    objective = obj_cls + obj_loc + obj_seg
+    # readouts of train/metric.py:27-46 (+ seg cross-entropy)
+    ce = float(-(torch.log(cls_prob.gather(1, ct.clamp(min=0).unsqueeze(1)).squeeze(1) + 1e-8)
+                 * valid.to(dtype)).sum() / nvalid)
+    seg_ce = float(-(torch.log(seg_prob.gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1) + 1e-8)
+                     * svalid.to(dtype)).sum() / max(1, int(svalid.sum())))
+    return dict(cls_prob=cls_prob.detach(), loc_loss=loc_loss.detach(), cls_label=cls_t, det=det,
+                seg_out=seg_prob.detach(), CrossEntropy=ce, SmoothL1=float(loc_loss.sum()) / nvalid,
+                SegCrossEntropy=seg_ce, objective=objective, params=P, anchors=anchor_boxes,
+                loc_preds=loc_preds.detach(), cls_preds=cls_preds.detach())
+
+
+def export_params(graph):
+    """device graph parameters -> {name: numpy in NCHW-style logical shapes}"""
+    out = {}
+    for p in graph.param_order:
+        v = p.data.detach().cpu().numpy()
+        if p.name == "score4_conv_weight":          # [K=in][R][S][C=out] phys 20 -> (in 19, out 19, 4, 4)
+            v = v[:19, :, :, :19].transpose(0, 3, 1, 2)
+        elif v.ndim == 4:                            # [Cout][R][S][Cin_phys] -> [Cout][Cin][R][S]
+            v = v.transpose(0, 3, 1, 2)
+            if p.name == "conv0_weight":
+                v = v[:, :3]
+            if p.name == "score4_conv_weight":
+                pass
+        elif p.name in ("score3_conv_bn_beta",):
+            v = v[:19]
+        elif p.name == "bn_data_beta":
+            v = v[:3]
+        out[p.name] = np.ascontiguousarray(v)
+    return out
+
+
+def import_grad(name, g):
+    """oracle gradient (torch, logical shape) -> device layout numpy for comparison (pads dropped)"""
+    g = g.detach().cpu().numpy()
+    if name == "score4_conv_weight":
+        return g.transpose(0, 2, 3, 1)               # (in,out,4,4) -> [in][R][S][out]
+    if g.ndim == 4:
+        return g.transpose(0, 2, 3, 1)
+    return g
