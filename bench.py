@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: multi-task DSPNet training images/sec at 512x512 on N MI355X.
+
+One "step" = forward + backward (+ RCCL gradient all-reduce for N > 1) + SGD-momentum update of the
+resnet-50 multi-task graph (SSD det + depth + seg) on one synthetic Cityscapes-shaped batch that is
+already resident in HBM.  Workload: resnet-50, 512x512, 8 det classes, 19 seg classes, 32 images per
+GPU, fp32 (the only preset the reference's graph builder accepts, SURVEY.md 2.1, and the shape
+BASELINE.json's scaling target is quoted on).  Weak scaling: every rank holds a replica and its own
+32-image shard; the only collective is the gradient all-reduce.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     - the implicit-GEMM convolution family (fp32 MFMA, peak 157.3 TFLOP/s): algorithmic
+                 conv FLOPs executed per step / conv kernel time per step, the latter measured live
+                 with HIP events on the launch stream over the timed region;
+  cpu_baseline - the CPU restatement of the same step (oracle/dspnet_torch.py, fp32, all host cores)
+                 on a bounded sample; rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    return ap.parse_args()
+
+
+def host_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(size, images, cfg):
+    """forward + backward of the same graph with torch CPU ops, fp32, all cores"""
+    import numpy as np
+    import torch
+    from dspnet_amd import synthetic
+    from oracle import dspnet_torch as ot
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    gen = synthetic.rng(233)
+    data = synthetic.images(images, size, size, gen)
+    lab = synthetic.det_labels(images, gen=gen, height=size, width=size, first_empty=False)
+    seg = synthetic.seg_labels(images, size, size, gen=gen)
+    values = cpu_baseline.values
+
+    def once():
+        ref = ot.forward_loss(values, data, lab, seg, cfg["sizes"][1:], cfg["ratios"][1:], dtype=torch.float32)
+        ref["objective"].backward()
+
+    once()                                  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        once()
+        reps += 1
+        if time.perf_counter() - t0 > 12.0 or reps >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(images * reps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d x (forward+backward of the same resnet-50 multitask graph, %d images %dx%d, fp32 torch-CPU "
+                      "ops + C multibox oracle; no optimizer step)" % (reps, images, size, size)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from dspnet_amd import _lib, engine as E, synthetic
+    from dspnet_amd.symbol.multitask_symbol_factory import get_config, get_multi_symbol_train
+    from dspnet_amd.train.solver import MultiTaskSolver
+
+    B, S = args.batch, args.size
+    net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=dev, seed=0)
+    solver = MultiTaskSolver(net, process_group=None, world_size=world)
+    gen = synthetic.rng(233 + rank)
+    solver.set_batch(torch.from_numpy(synthetic.images(B, S, S, gen)).to(dev),
+                     torch.from_numpy(synthetic.det_labels(B, gen=gen, height=S, width=S)).to(dev),
+                     torch.from_numpy(synthetic.seg_labels(B, S, S, gen=gen)).to(dev))
+    convs = [n for n in net.g.nodes if isinstance(n, (E.Conv, E.Deconv4x4s2))]
+    flops_step = sum(n.flops_fwd + n.flops_bwd for n in convs)          # executed
+    flops_3x = 3.0 * sum(n.flops_fwd for n in convs)                    # SURVEY.md 8(d) convention
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.step()
+    sync()
+    lib = _lib.lib()
+    prof = not args.no_roofline
+    if prof:
+        lib.dspn_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step()
+    sync()
+    dt = time.perf_counter() - t0
+    lib.dspn_profile_enable(0)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    roofline = None
+    if prof:
+        tot, cnt = ctypes.c_double(), ctypes.c_longlong()
+        lib.dspn_profile_collect(0, ctypes.byref(tot), ctypes.byref(cnt))
+        nt_ms, nt_n = tot.value, cnt.value
+        lib.dspn_profile_collect(1, ctypes.byref(tot), ctypes.byref(cnt))
+        wg_ms, wg_n = tot.value, cnt.value
+        conv_s = (nt_ms + wg_ms) / 1e3 / args.steps
+        ach = flops_step / conv_s / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: fp32 implicit-GEMM family",
+                    "launches_per_step": (nt_n + wg_n) // args.steps,
+                    "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
+                    "conv_ms_per_step": round(conv_s * 1e3, 3),
+                    "nt_ms_per_step": round(nt_ms / args.steps, 3), "wgrad_ms_per_step": round(wg_ms / args.steps, 3),
+                    "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
+                    "share_of_step_time": round(conv_s / (dt / args.steps), 3)}
+
+    if rank == 0:
+        cfg = get_config("resnet-50", S)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import dspnet_torch as ot
+            cpu_baseline.values = ot.export_params(net.g)
+            cpu = cpu_baseline(S, args.cpu_images, cfg)
+        line = {
+            "metric": "training images/sec at 512x512 multitask",
+            "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "resnet-50 multitask (det+depth+seg) %dx%d, 8 det classes, 19 seg classes, "
+                                   "N=%d anchors, forward+backward+SGD" % (S, S, net.anchors.shape[1]),
+                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "train_gflop_per_image_3x_convention": round(flops_3x / B / 1e9, 2),
+                       "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

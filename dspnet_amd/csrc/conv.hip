@@ -376,7 +376,10 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt);
+  {
+    dspn::ProfScope prof(0, s);
+    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt);
+  }
   return dspn::check_launch("conv_nt");
 }
 
@@ -509,6 +512,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
   const size_t lds = sizeof(float) * 2 * kBK * (BM + BN);
+  dspn::ProfScope prof(1, s);
   if (narrow) {
     auto kern = conv_wgrad_kernel<2, 2, 1, 2>;   // 64 x 128
     static bool attr = false;

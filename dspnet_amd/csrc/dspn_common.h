@@ -28,6 +28,15 @@ inline int check_launch(const char *what) {
   return 0;
 }
 
+bool prof_enabled();
+void prof_begin(int family, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s; bool on;
+  ProfScope(int family, hipStream_t st) : s(st), on(prof_enabled()) { if (on) prof_begin(family, st); }
+  ~ProfScope() { if (on) prof_end(s); }
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

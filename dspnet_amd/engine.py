@@ -251,6 +251,9 @@ class Conv(Node):
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), name + "_out")
         self.wt = None if not x.requires_grad else fn.zeros(Cin, kernel, kernel, ldc, device=g.device)
+        # algorithmic FLOPs per batch (direct-conv count, logical channels)
+        self.flops_fwd = 2.0 * cin_logical * num_filter * kernel * kernel * Ho * Wo * N
+        self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
         fn.conv2d_forward(self.x.data, self.w.data, None if self.b is None else self.b.data, self.stride,
@@ -281,6 +284,8 @@ class Deconv4x4s2(Node):
         self.w = g.param(name + "_weight", (Cp, 4, 4, Cp), deconv_bilinear_init(channels))
         self.wt = fn.zeros(Cp, 4, 4, Cp, device=g.device)
         self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
+        self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
+        self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
         fn.weight_transpose(self.w.data, out=self.wt)

@@ -41,6 +41,12 @@ enum dspn_status {
 const char *dspn_last_error(void);
 /* library / ABI version, bumped when a signature changes */
 int dspn_abi_version(void);
+/* Optional kernel timing with HIP events on the launch stream (off by default).  Families:
+ * 0 = implicit-GEMM conv forward / data-gradient kernel, 1 = conv weight-gradient (+ slab reduce).
+ * dspn_profile_collect synchronises the recorded events, returns their summed duration and count
+ * for one family and forgets them. */
+int dspn_profile_enable(int on);
+int dspn_profile_collect(int family, double *total_ms, long long *launches);
 
 /* Replaces MultiBoxPriorOp::Forward (operator/multibox_prior-inl.h:97-129) +
  * MultiBoxPriorForward (operator/multibox_prior.cc:30-71; GPU twin
