@@ -56,7 +56,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles) {
+    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
+    const int ksteps_per_split, float *__restrict__ slab) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per k-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   const int M = g.N * g.Hg * g.Wg;
   const int CQ = g.Cin >> 2;
   const int total_q = g.TR * g.TS * CQ;
-  const int nk = (total_q + 7) >> 3;
+  const int nk_all = (total_q + 7) >> 3;
+  // split-K: this workgroup handles k-steps [k_begin, k_begin + nk)
+  const int k_begin = slab ? blockIdx.y * ksteps_per_split : 0;
+  const int nk = slab ? max(0, min(nk_all - k_begin, ksteps_per_split)) : nk_all;
 
   const int chunk = tid & 7, row0 = tid >> 3;
 
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
 
   float4 ra[A_LD], rb[B_LD];
   auto load_tiles = [&](int kt) {
-    const int q = kt * 8 + chunk;
+    const int q = (k_begin + kt) * 8 + chunk;
     const bool qv = q < total_q;
     const int tap = q / CQ, cq = q - tap * CQ;
     const int tr = tap / g.TS, ts = tap - tr * g.TS;
@@ -170,6 +174,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   }
 
   // epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+  if (slab) {   // raw partial sums, dense [split][M][Cout]; bias / relu / accumulate happen in the reduce
+    float *o = slab + (long long)blockIdx.y * M * g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + wn + j * 32 + (lane & 31);
+      if (co >= g.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) o[(long long)m * g.Cout + co] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -361,9 +381,31 @@ __global__ void weight_transpose_kernel(const float *__restrict__ w, float *__re
   }
 }
 
+// out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
+__global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
+                                       float *__restrict__ out, long long M, int Cout, int ldc, int splits,
+                                       int flags) {
+  const long long total = M * Cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / Cout;
+    const int co = (int)(i - m * Cout);
+    float v = slab[i];
+    for (int k = 1; k < splits; ++k) v += slab[(long long)k * total + i];
+    if (flags & 1) v += bias[co];
+    float *o = out + m * ldc + co;
+    if (flags & 4) v += *o;
+    if (flags & 2) v = v > 0.f ? v : 0.f;
+    *o = v;
+  }
+}
+
+// caller-provided scratch for split-K partial tiles (set per call by the C entry points)
+struct SplitWs { float *ptr; size_t bytes; };
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-              hipStream_t s) {
+              hipStream_t s, int splits, int ksteps_per_split, float *slab) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
@@ -378,30 +420,80 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
   }
   {
     dspn::ProfScope prof(0, s);
-    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt);
+    hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt,
+                       ksteps_per_split, splits > 1 ? slab : nullptr);
+    if (splits > 1) {
+      const long long total = M * g.Cout;
+      const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+      hipLaunchKernelGGL(nt_split_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, bias, out, M, g.Cout,
+                         g.ldc, splits, g.flags);
+    }
   }
   return dspn::check_launch("conv_nt");
 }
 
+// Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
+// leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
 int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-                hipStream_t s) {
+                hipStream_t s, SplitWs ws) {
   const long long M = (long long)g.N * g.Hg * g.Wg;
-  if (g.Cout <= 32) return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s);   // 256 x 32
-  if (g.Cout <= 64) return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s);   // 128 x 64
-  // 128x128 unless that leaves most of the chip idle
-  const long long tiles128 = ((M + 127) / 128) * ((g.Cout + 127) / 128);
-  if (tiles128 < 256) return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s);
-  return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s);                     // 128 x 128
+  if (M <= 0) return 0;
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
+  int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32
+  if (g.Cout <= 32) cfg = tiles(256, 32) >= 256 ? 3 : 2;
+  else if (g.Cout <= 64) cfg = tiles(128, 64) >= 256 ? 1 : 2;
+  else cfg = tiles(128, 128) >= 256 ? 0 : (tiles(128, 64) >= 256 ? 1 : 2);
+  static const int bm_[4] = {128, 128, 64, 256}, bn_[4] = {128, 64, 64, 32};
+  const long long nblk = tiles(bm_[cfg], bn_[cfg]);
+  const int nk = (g.TR * g.TS * (g.Cin >> 2) + 7) >> 3;
+  int splits = 1, per = nk;
+  if (g.dense && nblk < 192 && nk >= 16 && ws.ptr) {
+    splits = (int)std::min<long long>((384 + nblk - 1) / nblk, nk / 8);
+    splits = std::max(1, std::min(splits, 32));
+    while (splits > 1 && sizeof(float) * (size_t)splits * M * g.Cout > ws.bytes) --splits;
+    per = (nk + splits - 1) / splits;
+    splits = (nk + per - 1) / per;
+  }
+  switch (cfg) {
+    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr);
+    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
+    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
+    default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
+  }
+}
+
+struct WgradPlan { int bm; int splits; int pps; };
+// Weight-gradient decomposition: tile height by Cout, split-K over pixels for >= ~4 workgroups per CU,
+// at least 128 pixels (4 k-steps) per split, at most 256 splits.
+WgradPlan wgrad_plan(long long P, int Cout, int J) {
+  WgradPlan p;
+  p.bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+  const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + 127) / 128);
+  long long want = (1024 + tiles - 1) / tiles;
+  long long max_by_pix = std::max<long long>(1, P / 128);
+  long long splits = std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_pix), 256));
+  long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
+  p.splits = (int)((P + pps - 1) / pps);
+  p.pps = (int)pps;
+  return p;
 }
 
 }  // namespace
 
 extern "C" {
 
+size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
+  if (out_pixels <= 0 || Cout <= 0) return 0;
+  // split-K is only taken below 192 workgroups (<= 192*64 x 192*64 outputs) with <= 32 splits
+  const long long capped = std::min<long long>(out_pixels * Cout, 192ll * 64 * 64 * 4);
+  return sizeof(float) * 32 * (size_t)capped;
+}
+
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
-                            int relu, int accumulate, void *stream) {
+                            int relu, int accumulate, void *workspace, size_t workspace_bytes,
+                            void *stream) {
   DSPN_REQUIRE(x && w && y, "conv2d_forward: null pointer");
   DSPN_REQUIRE(Cin % 4 == 0, "conv2d_forward: Cin must be a multiple of 4 (pad channels), got %d", Cin);
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0,
@@ -420,7 +512,8 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, f
   g.OW = Wo; g.osh = 1; g.osw = 1; g.ooh = 0; g.oow = 0;
   g.dense = (g.obs == (long long)Ho * Wo * g.ldc);
   g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0);
-  return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream);
+  return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
+                     SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0});
 }
 
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -438,7 +531,8 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
 // Also the forward of a transposed convolution (x := dy).
 int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
-                          int Wo, int dx_ldc, int accumulate, void *stream) {
+                          int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
   DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
   DSPN_REQUIRE(ldy % 4 == 0, "conv2d_dgrad: dy channel stride must be a multiple of 4");
   DSPN_REQUIRE(stride == 1 || (stride == 2 && dil == 1), "conv2d_dgrad: stride 1, or stride 2 with dilation 1");
@@ -452,11 +546,12 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
   g.OW = W;
   g.flags = accumulate ? 4 : 0;
   hipStream_t s = (hipStream_t)stream;
+  const SplitWs sws{static_cast<float *>(workspace), workspace ? workspace_bytes : 0};
   if (stride == 1) {
     g.Hg = H; g.Wg = W; g.ish = 1; g.isw = 1; g.ioh = pad; g.iow = pad; g.idh = -dil; g.idw = -dil;
     g.TR = R; g.TS = S; g.wr0 = 0; g.wrs = 1; g.ws0 = 0; g.wss = 1;
     g.osh = 1; g.osw = 1; g.dense = 1;
-    return dispatch_nt(dy, wt, nullptr, dx, g, s);
+    return dispatch_nt(dy, wt, nullptr, dx, g, s, sws);
   }
   for (int ph = 0; ph < 2; ++ph)
     for (int pw = 0; pw < 2; ++pw) {
@@ -474,15 +569,17 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
       c.idh = -1; c.idw = -1;
       c.wr0 = r0; c.wrs = 2; c.ws0 = s0; c.wss = 2;
       c.osh = 2; c.osw = 2; c.ooh = ph; c.oow = pw; c.dense = 0;
-      const int rc = dispatch_nt(dy, wt, nullptr, dx, c, s);
+      const int rc = dispatch_nt(dy, wt, nullptr, dx, c, s, sws);
       if (rc) return rc;
     }
   return 0;
 }
 
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S) {
-  // upper bound on splits is 64
-  return sizeof(float) * (size_t)64 * Cout * R * S * Cin;
+  const long long P = (long long)N * Ho * Wo;
+  const int J = R * S * Cin;
+  if (P <= 0 || J <= 0 || Cout <= 0) return 0;
+  return sizeof(float) * (size_t)wgrad_plan(P, Cout, J).splits * Cout * J;
 }
 
 int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
@@ -496,16 +593,11 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
   g.sh = stride; g.sw = stride; g.ph = pad; g.pw = pad; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
-  const bool narrow = Cout <= 64;
-  const int BM = narrow ? 64 : 128, BN = 128;
+  const WgradPlan plan = wgrad_plan(P, Cout, J);
+  const int BM = plan.bm, BN = 128;
   const int kt = (Cout + BM - 1) / BM, jt = (J + BN - 1) / BN;
-  // enough workgroups for ~3 waves of the chip, at least 256 pixels per split, at most 64 splits
-  long long want = (768 + (long long)kt * jt - 1) / ((long long)kt * jt);
-  long long max_by_pix = (P + 255) / 256;
-  long long splits = std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_pix), 64));
-  long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
-  splits = (P + pps - 1) / pps;
-  g.pix_per_split = (int)pps;
+  const long long splits = plan.splits;
+  g.pix_per_split = plan.pps;
   const size_t need = sizeof(float) * (size_t)splits * Cout * J;
   if (workspace_bytes < need)
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
@@ -513,17 +605,21 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
   float *slab = static_cast<float *>(workspace);
   const size_t lds = sizeof(float) * 2 * kBK * (BM + BN);
   dspn::ProfScope prof(1, s);
-  if (narrow) {
-    auto kern = conv_wgrad_kernel<2, 2, 1, 2>;   // 64 x 128
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt);
-  } else {
-    auto kern = conv_wgrad_kernel<2, 2, 2, 2>;   // 128 x 128
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt);
+#define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
+  {                                                                                                      \
+    auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_>;                                                     \
+    static bool attr = false;                                                                            \
+    if (!attr) {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      attr = true;                                                                                       \
+    }                                                                                                    \
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt); \
   }
+  if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)        // 32 x 128
+  else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)   // 64 x 128
+  else DSPN_WGRAD_LAUNCH(2, 2, 2, 2)                 // 128 x 128
+#undef DSPN_WGRAD_LAUNCH
   int rc = dspn::check_launch("conv_wgrad");
   if (rc) return rc;
   const long long n4 = (long long)Cout * J / 4;

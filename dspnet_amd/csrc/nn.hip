@@ -58,42 +58,52 @@ __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__re
   }
 }
 
-__global__ void bn_stats_final_kernel(const float *__restrict__ x, const float *__restrict__ partial,
-                                      int nslabs, long long rows, int C, float eps,
-                                      float *__restrict__ mean, float *__restrict__ rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 channels x 16 slab-lanes per block; also folds gamma/beta into scale/shift for the apply pass
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(
+    const float *__restrict__ x, const float *__restrict__ partial, int nslabs, long long rows, int C,
+    float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ scale,
+    float *__restrict__ shift) {
+  __shared__ double s_S[16][64];
+  __shared__ double s_SS[16][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double S = 0, SS = 0;
-  for (int k = 0; k < nslabs; ++k) {
-    S += partial[(long long)k * 2 * C + c];
-    SS += partial[(long long)k * 2 * C + C + c];
+  if (c < C)
+    for (int k = sl; k < nslabs; k += 16) {
+      S += partial[(long long)k * 2 * C + c];
+      SS += partial[(long long)k * 2 * C + C + c];
+    }
+  s_S[sl][cl] = S; s_SS[sl][cl] = SS;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) { S += s_S[k][cl]; SS += s_SS[k][cl]; }
+    const double n = (double)rows;
+    const double m = S / n;
+    double var = SS / n - m * m;
+    if (var < 0) var = 0;
+    const float mu = (float)((double)x[c] + m);
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mu; rstd[c] = rs;
+    const float sc = (gamma ? gamma[c] : 1.f) * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
   }
-  const double n = (double)rows;
-  const double m = S / n;
-  double var = SS / n - m * m;
-  if (var < 0) var = 0;
-  mean[c] = (float)((double)x[c] + m);
-  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-__global__ void bn_apply_kernel(const float4 *__restrict__ x, const float *__restrict__ mean,
-                                const float *__restrict__ rstd, const float *__restrict__ gamma,
-                                const float *__restrict__ beta, float4 *__restrict__ y,
+__global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+                                const float4 *__restrict__ shift, float4 *__restrict__ y,
                                 long long n4, int C4, int relu) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const float4 v = x[i];
-    float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float g = gamma ? gamma[c + q] : 1.f;
-      const float sc = g * rstd[c + q];
-      float t = (o[q] - mean[c + q]) * sc + beta[c + q];
-      if (relu) t = t > 0.f ? t : 0.f;
-      o[q] = t;
+    const int c4 = (int)(i % C4);
+    const float4 v = x[i], a = scale[c4], b = shift[c4];
+    float4 o = make_float4(v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w);
+    if (relu) {
+      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
-    y[i] = make_float4(o[0], o[1], o[2], o[3]);
+    y[i] = o;
   }
 }
 
@@ -139,50 +149,56 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
   }
 }
 
-// sums[0][c] = sum dy', sums[1][c] = sum dy' xhat (kept after the partials in the workspace)
-__global__ void bn_bwd_final_kernel(const float *__restrict__ partial, int nslabs, int C,
-                                    float *__restrict__ sums, float *__restrict__ dgamma,
-                                    float *__restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// finalize: dgamma / dbeta and the three per-channel coefficients of
+//   dx = a*dy' + c1*x + c0,  a = gamma*rstd, c1 = -a*rstd*mean(dy' xhat), c0 = -a*mean(dy') - c1*mean
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
+    const float *__restrict__ partial, int nslabs, int C, double inv_rows,
+    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+    float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ double s_S[16][64];
+  __shared__ double s_SS[16][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double S = 0, SS = 0;
-  for (int k = 0; k < nslabs; ++k) {
-    S += partial[(long long)k * 2 * C + c];
-    SS += partial[(long long)k * 2 * C + C + c];
+  if (c < C)
+    for (int k = sl; k < nslabs; k += 16) {
+      S += partial[(long long)k * 2 * C + c];
+      SS += partial[(long long)k * 2 * C + C + c];
+    }
+  s_S[sl][cl] = S; s_SS[sl][cl] = SS;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) { S += s_S[k][cl]; SS += s_SS[k][cl]; }
+    if (dbeta) dbeta[c] = (float)S;
+    if (dgamma) dgamma[c] = (float)SS;
+    const double rs = rstd[c], mu = mean[c];
+    const double a = (gamma ? (double)gamma[c] : 1.0) * rs;
+    const double c1 = -a * rs * (SS * inv_rows);
+    coef[c] = (float)a;
+    coef[C + c] = (float)c1;
+    coef[2 * C + c] = (float)(-a * (S * inv_rows) - c1 * mu);
   }
-  sums[c] = (float)S; sums[C + c] = (float)SS;
-  if (dbeta) dbeta[c] = (float)S;
-  if (dgamma) dgamma[c] = (float)SS;
 }
 
 __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ y,
-                                    const float4 *__restrict__ dy, const float *__restrict__ mean,
-                                    const float *__restrict__ rstd, const float *__restrict__ gamma,
-                                    const float *__restrict__ sums, float4 *__restrict__ dx,
-                                    long long n4, int C4, float inv_rows, int relu, int accumulate) {
-  const int C = C4 * 4;
+                                    const float4 *__restrict__ dy, const float4 *__restrict__ coef,
+                                    float4 *__restrict__ dx, long long n4, int C4, int relu,
+                                    int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
+    const int c4 = (int)(i % C4);
     const float4 xv = x[i];
-    const float4 gv = dy[i];
-    float g[4] = {gv.x, gv.y, gv.z, gv.w};
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float4 g = dy[i];
     if (relu) {
       const float4 yv = y[i];
-      g[0] = yv.x > 0.f ? g[0] : 0.f; g[1] = yv.y > 0.f ? g[1] : 0.f;
-      g[2] = yv.z > 0.f ? g[2] : 0.f; g[3] = yv.w > 0.f ? g[3] : 0.f;
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
-    float o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float rs = rstd[c + q];
-      const float xh = (xs[q] - mean[c + q]) * rs;
-      const float ga = gamma ? gamma[c + q] : 1.f;
-      o[q] = ga * rs * (g[q] - sums[c + q] * inv_rows - xh * (sums[C + c + q] * inv_rows));
-    }
-    if (accumulate) { const float4 d = dx[i]; o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
-    dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
+    float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
+                           a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);
+    if (accumulate) { const float4 d = dx[i]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+    dx[i] = o;
   }
 }
 
@@ -588,12 +604,13 @@ extern "C" {
 
 size_t dspn_bn_workspace_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
-  return sizeof(float) * ((size_t)bn_slabs(rows) * 2 * C + 2 * (size_t)C);
+  return sizeof(float) * ((size_t)bn_slabs(rows) * 2 * C + 4 * (size_t)C);
 }
 
-int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, float *mean, float *rstd,
+int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const float *gamma,
+                      const float *beta, float *mean, float *rstd, float *scale, float *shift,
                       void *workspace, size_t workspace_bytes, void *stream) {
-  DSPN_REQUIRE(x && mean && rstd && workspace, "bn_stats: null pointer");
+  DSPN_REQUIRE(x && beta && mean && rstd && scale && shift && workspace, "bn_stats: null pointer");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_stats: C must be a positive multiple of 4");
   if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_stats: workspace too small");
@@ -602,19 +619,20 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, float *m
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x), rows,
                      C4, CL, partial);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), x, partial,
-                     ns, rows, C, eps, mean, rstd);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), x, partial,
+                     ns, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
   return dspn::check_launch("bn_stats");
 }
 
-int dspn_bn_apply_f32(const float *x, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, float *y, long long rows, int C, int relu, void *stream) {
-  DSPN_REQUIRE(x && mean && rstd && beta && y, "bn_apply: null pointer");
+int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
+                      int C, int relu, void *stream) {
+  DSPN_REQUIRE(x && scale && shift && y, "bn_apply: null pointer");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_apply: C must be a positive multiple of 4");
   const long long n4 = rows * (C / 4);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), mean, rstd, gamma, beta,
-                     reinterpret_cast<float4 *>(y), n4, C / 4, relu);
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(y), n4, C / 4,
+                     relu);
   return dspn::check_launch("bn_apply");
 }
 
@@ -629,18 +647,18 @@ int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const 
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward: workspace too small");
   const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
   float *partial = static_cast<float *>(workspace);
-  float *sums = partial + (size_t)ns * 2 * C;
+  float *coef = partial + (size_t)ns * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x),
                      reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy), mean,
                      rstd, rows, C4, CL, relu, partial);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), partial, ns, C,
-                     sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
                      reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(y),
-                     reinterpret_cast<const float4 *>(dy), mean, rstd, gamma, sums,
-                     reinterpret_cast<float4 *>(dx), n4, C4, 1.f / (float)rows, relu, accumulate);
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(coef),
+                     reinterpret_cast<float4 *>(dx), n4, C4, relu, accumulate);
   return dspn::check_launch("bn_backward");
 }
 

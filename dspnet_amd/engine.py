@@ -216,12 +216,14 @@ class BatchNorm(Node):
         self.beta = g.param(name + "_beta", (C,), init_zeros)
         self.mean = fn.zeros(C, device=g.device)
         self.rstd = fn.zeros(C, device=g.device)
+        self.scale = fn.zeros(C, device=g.device)
+        self.shift = fn.zeros(C, device=g.device)
         self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), x.requires_grad or True)
 
     def forward(self):
-        fn.bn_stats(self.x.data, self.eps, self.mean, self.rstd)
-        fn.bn_apply(self.x.data, self.mean, self.rstd, None if self.gamma is None else self.gamma.data,
-                    self.beta.data, relu=self.relu, out=self.out.data)
+        fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
+                    self.mean, self.rstd, self.scale, self.shift)
+        fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data)
 
     def backward(self):
         if not self.out._gw:

@@ -18,16 +18,18 @@ _f = _c.c_float
 _sz = _c.c_size_t
 
 _lib.register({
+    "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                     _ll, _i, _i, _i, _vp]),
+                                     _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
+                                   _sz, _vp]),
     "dspn_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "dspn_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _vp, _sz, _vp]),
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
-    "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _sz, _vp]),
-    "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
@@ -104,9 +106,10 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
         ldc = pad4(Cout)
         out = zeros(N, Ho, Wo, ldc, device=x.device) if ldc != Cout else empty(N, Ho, Wo, ldc, device=x.device)
     ldc = out.shape[3]
+    ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
     check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(out), N, H, W, Cin, Cout, R, S, stride,
-                                      pad, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), stream()),
-          "conv2d_forward")
+                                      pad, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), ptr(ws), ws.numel(),
+                                      stream()), "conv2d_forward")
     return out
 
 
@@ -129,8 +132,10 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
         out = zeros(N, H, W, Cx, device=dy.device) if Cx != Cin else empty(N, H, W, Cx, device=dy.device)
+    ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
     check(L().dspn_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, pad, dil,
-                                    Ho, Wo, out.shape[3], int(accumulate), stream()), "conv2d_dgrad")
+                                    Ho, Wo, out.shape[3], int(accumulate), ptr(ws), ws.numel(), stream()),
+          "conv2d_dgrad")
     return out
 
 
@@ -155,21 +160,24 @@ def _rows(x):
     return x.numel() // x.shape[-1]
 
 
-def bn_stats(x, eps, mean=None, rstd=None):
+def bn_stats(x, eps, gamma, beta, mean=None, rstd=None, scale=None, shift=None):
+    """batch statistics + folded affine; returns (mean, rstd, scale, shift)"""
     C = x.shape[-1]
     rows = _rows(x)
     mean = empty(C, device=x.device) if mean is None else mean
     rstd = empty(C, device=x.device) if rstd is None else rstd
+    scale = empty(C, device=x.device) if scale is None else scale
+    shift = empty(C, device=x.device) if shift is None else shift
     ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
-    check(L().dspn_bn_stats_f32(ptr(x), rows, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
-          "bn_stats")
-    return mean, rstd
+    check(L().dspn_bn_stats_f32(ptr(x), rows, C, eps, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(scale),
+                                ptr(shift), ptr(ws), ws.numel(), stream()), "bn_stats")
+    return mean, rstd, scale, shift
 
 
-def bn_apply(x, mean, rstd, gamma, beta, relu=False, out=None):
+def bn_apply(x, scale, shift, relu=False, out=None):
     out = torch.empty_like(x) if out is None else out
-    check(L().dspn_bn_apply_f32(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(out), _rows(x),
-                                x.shape[-1], int(relu), stream()), "bn_apply")
+    check(L().dspn_bn_apply_f32(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
+                                stream()), "bn_apply")
     return out
 
 

@@ -34,12 +34,16 @@ extern "C" {
 
 /* y[n,ho,wo,k] = sum x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c] w[k,r,s,c] (+bias[k]) (relu).
  * y pixel stride y_ldc (0 = Cout), batch stride y_batch_stride (0 = dense).
- * accumulate != 0: y += result (before relu). bias may be NULL. */
+ * accumulate != 0: y += result (before relu). bias may be NULL.
+ * workspace (optional, may be NULL): scratch for split-K partial tiles, used when the output grid is
+ * too small to fill the chip (SSD heads / extras); any size, dspn_conv2d_split_workspace_bytes() is
+ * always enough.  Partials are summed in a fixed order (deterministic). */
+size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
                             int stride, int pad, int dil, int Ho, int Wo,
                             long long y_batch_stride, int y_ldc, int relu, int accumulate,
-                            void *stream);
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -53,7 +57,7 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
 int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
                           int N, int H, int W, int Cin, int ldy, int R, int S,
                           int stride, int pad, int dil, int Ho, int Wo, int dx_ldc,
-                          int accumulate, void *stream);
+                          int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S);
 
@@ -69,13 +73,16 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
 
 size_t dspn_bn_workspace_bytes(long long rows, int C);
 
-/* mean[c], rstd[c] = 1/sqrt(biased var + eps) over `rows` = N*H*W rows of x (rows, C). */
-int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, float *mean, float *rstd,
+/* mean[c], rstd[c] = 1/sqrt(biased var + eps) over `rows` = N*H*W rows of x (rows, C), plus the folded
+ * affine of the apply pass: scale = gamma*rstd, shift = beta - mean*scale.  gamma == NULL means
+ * fix_gamma (gamma == 1). */
+int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const float *gamma,
+                      const float *beta, float *mean, float *rstd, float *scale, float *shift,
                       void *workspace, size_t workspace_bytes, void *stream);
 
-/* y = gamma*(x-mean)*rstd + beta, optionally max(.,0).  gamma == NULL means fix_gamma (1). */
-int dspn_bn_apply_f32(const float *x, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, float *y, long long rows, int C, int relu, void *stream);
+/* y = x*scale + shift, optionally max(.,0). */
+int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
+                      int C, int relu, void *stream);
 
 /* Backward of the fused op.  If relu != 0, dy is first masked with (y > 0).
  * dx (+)= gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); dgamma = sum dy*xhat; dbeta = sum dy.

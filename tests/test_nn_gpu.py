@@ -151,10 +151,10 @@ def test_batchnorm_forward_backward(gpu_device, shape, relu, fix_gamma):
     xd = x.detach().float().cuda()
     gd = None if fix_gamma else gamma.detach().float().cuda()
     bd = beta.detach().float().cuda()
-    m, r = fn.bn_stats(xd, eps)
+    m, r, sc, sh = fn.bn_stats(xd, eps, gd, bd)
     close(m.cpu().double(), mean.detach(), 1e-6)
     close(r.cpu().double(), 1 / torch.sqrt(var.detach() + eps), 1e-5)
-    y = fn.bn_apply(xd, m, r, gd, bd, relu=relu)
+    y = fn.bn_apply(xd, sc, sh, relu=relu)
     close(y.cpu().double(), y_ref.detach(), 1e-5)
     dx, dgam, dbet = fn.bn_backward(xd, y, dy.float().cuda(), m, r, gd, relu=relu)
     close(dx.cpu().double(), x.grad, 1e-4)
