@@ -352,6 +352,79 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// g[c] = sum over all input pixels of the data gradient, WITHOUT forming it:
+//   sum_p dx[p,c] = sum_{k,tap} w[k,tap,c] * D[tap,k],
+//   D[tap,k] = sum of dy[n,ho,wo,k] over the output positions whose tap lands inside the image.
+// Used for the first convolution, whose input only feeds the beta of bn_data (symbol/resnet.py:91):
+// the full data gradient there would be a GEMM with N = 3 useful columns.
+// ---------------------------------------------------------------------------
+__global__ void batch_sum_kernel(const float4 *__restrict__ dy, float4 *__restrict__ p2, int N,
+                                 long long per_image4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < per_image4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 s = dy[i];
+    for (int n = 1; n < N; ++n) {
+      const float4 v = dy[(long long)n * per_image4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    p2[i] = s;
+  }
+}
+struct SumGradGeom { int H, W, Ho, Wo, ldy, R, S, sh, sw, ph, pw, dh, dw, chunks; };
+// partial[tap][chunk][k]: rows of the chunk that are valid for the tap, all valid columns
+__global__ __launch_bounds__(256) void tap_sum_kernel(const float *__restrict__ p2, float *__restrict__ partial,
+                                                      const SumGradGeom g) {
+  __shared__ float sm[256];
+  const int tap = blockIdx.x, chunk = blockIdx.y;
+  const int r = tap / g.S, q = tap - r * g.S;
+  auto lo = [](int num, int den) { return num <= 0 ? 0 : (num + den - 1) / den; };
+  const int ho_lo = lo(g.ph - r * g.dh, g.sh), wo_lo = lo(g.pw - q * g.dw, g.sw);
+  const int ho_hi = min(g.Ho - 1, (g.H - 1 + g.ph - r * g.dh) / g.sh);
+  const int wo_hi = min(g.Wo - 1, (g.W - 1 + g.pw - q * g.dw) / g.sw);
+  const int rows_per = (g.Ho + g.chunks - 1) / g.chunks;
+  const int h0 = max(ho_lo, chunk * rows_per), h1 = min(ho_hi, (chunk + 1) * rows_per - 1);
+  const int KL = min(g.ldy, 256), PL = 256 / KL;    // channel lanes x pixel lanes
+  const int kl = threadIdx.x % KL, pl = threadIdx.x / KL;
+  for (int kb = 0; kb < g.ldy; kb += KL) {
+    const int k = kb + kl;
+    float s = 0.f;
+    if (pl < PL && k < g.ldy && (g.H - 1 + g.ph - r * g.dh) >= 0 && (g.W - 1 + g.pw - q * g.dw) >= 0)
+      for (int ho = h0; ho <= h1; ++ho)
+        for (int wo = wo_lo + pl; wo <= wo_hi; wo += PL) s += p2[((long long)ho * g.Wo + wo) * g.ldy + k];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && k < g.ldy) {
+      for (int j = 1; j < PL; ++j) s += sm[j * KL + kl];
+      partial[((long long)tap * g.chunks + chunk) * g.ldy + k] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(1024) void sum_grad_final_kernel(const float *__restrict__ partial,
+                                                              const float *__restrict__ w, float *__restrict__ out,
+                                                              int taps, int chunks, int ldy, int Cout, int Cin) {
+  __shared__ double sm[1024];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < taps * Cout; i += 1024) {
+    const int tap = i / Cout, k = i - tap * Cout;
+    double d = 0;
+    for (int c = 0; c < chunks; ++c) d += partial[((long long)tap * chunks + c) * ldy + k];
+    for (int c = 0; c < Cin; ++c) acc[c] += d * (double)w[((long long)k * taps + tap) * Cin + c];
+  }
+  for (int c = 0; c < Cin; ++c) {
+    sm[threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int st = 512; st >= 1; st >>= 1) {
+      if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)sm[0];
+    __syncthreads();
+  }
+}
+
 // dw[i] (+)= sum_s slab[s][i], fixed order
 __global__ void slab_reduce_kernel(const float4 *__restrict__ slab, float4 *__restrict__ dw,
                                    long long n4, int splits, int accumulate) {
@@ -573,6 +646,29 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
       if (rc) return rc;
     }
   return 0;
+}
+
+size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {
+  return sizeof(float) * ((size_t)Ho * Wo * ldy + (size_t)R * S * 32 * ldy);
+}
+
+int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, int N, int H, int W,
+                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad, int dil,
+                                   int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(dy && w && out && workspace, "conv2d_input_sum_grad: null pointer");
+  DSPN_REQUIRE(ldy % 4 == 0 && Cin >= 1 && Cin <= 8, "conv2d_input_sum_grad: Cin <= 8, ldy % 4 == 0");
+  if (workspace_bytes < dspn_conv2d_input_sum_grad_workspace_bytes(Ho, Wo, ldy, R, S))
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_input_sum_grad: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float *p2 = static_cast<float *>(workspace);
+  float *partial = p2 + (size_t)Ho * Wo * ldy;
+  const long long per4 = (long long)Ho * Wo * ldy / 4;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((int)std::min<long long>((per4 + 255) / 256, 8192)), dim3(256), 0, s,
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(p2), N, per4);
+  SumGradGeom g{H, W, Ho, Wo, ldy, R, S, stride, stride, pad, pad, dil, dil, 32};
+  hipLaunchKernelGGL(tap_sum_kernel, dim3(R * S, 32), dim3(256), 0, s, p2, partial, g);
+  hipLaunchKernelGGL(sum_grad_final_kernel, dim3(1), dim3(1024), 0, s, partial, w, out, R * S, 32, ldy, Cout, Cin);
+  return dspn::check_launch("conv2d_input_sum_grad");
 }
 
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S) {

@@ -108,10 +108,12 @@ __global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__re
 }
 
 // partial[slab][0][c] = sum dy', partial[slab][1][c] = sum dy' * xhat ; dy' = relu ? dy*(y>0) : dy
+// The ReLU mask is recomputed as (x*scale + shift > 0) -- the very fma of the forward apply pass --
+// so the forward output is never re-read.
 __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
-    const float4 *__restrict__ x, const float4 *__restrict__ y, const float4 *__restrict__ dy,
-    const float *__restrict__ mean, const float *__restrict__ rstd, long long rows, int C4, int CL,
-    int relu, float *__restrict__ partial) {
+    const float4 *__restrict__ x, const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+    const float4 *__restrict__ dy, const float *__restrict__ mean, const float *__restrict__ rstd,
+    long long rows, int C4, int CL, int relu, float *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -122,13 +124,13 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
   if (rl < RL && c4 < C4) {
     const float4 m = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 rs = reinterpret_cast<const float4 *>(rstd)[c4];
+    const float4 sa = scale[c4], sb = shift[c4];
     for (long long r = r0 + rl; r < r1; r += RL) {
       const float4 xv = x[r * C4 + c4];
       float4 g = dy[r * C4 + c4];
       if (relu) {
-        const float4 yv = y[r * C4 + c4];
-        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        g.x = xv.x * sa.x + sb.x > 0.f ? g.x : 0.f; g.y = xv.y * sa.y + sb.y > 0.f ? g.y : 0.f;
+        g.z = xv.z * sa.z + sb.z > 0.f ? g.z : 0.f; g.w = xv.w * sa.w + sb.w > 0.f ? g.w : 0.f;
       }
       s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
       ss.x += g.x * ((xv.x - m.x) * rs.x); ss.y += g.y * ((xv.y - m.y) * rs.y);
@@ -180,19 +182,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
   }
 }
 
-__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ y,
-                                    const float4 *__restrict__ dy, const float4 *__restrict__ coef,
-                                    float4 *__restrict__ dx, long long n4, int C4, int relu,
-                                    int accumulate) {
+__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+                                    const float4 *__restrict__ shift, const float4 *__restrict__ dy,
+                                    const float4 *__restrict__ coef, float4 *__restrict__ dx,
+                                    long long n4, int C4, int relu, int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
     const float4 xv = x[i];
     float4 g = dy[i];
     if (relu) {
-      const float4 yv = y[i];
-      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      const float4 sa = scale[c4], sb = shift[c4];
+      g.x = xv.x * sa.x + sb.x > 0.f ? g.x : 0.f; g.y = xv.y * sa.y + sb.y > 0.f ? g.y : 0.f;
+      g.z = xv.z * sa.z + sb.z > 0.f ? g.z : 0.f; g.w = xv.w * sa.w + sb.w > 0.f ? g.w : 0.f;
     }
     const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
     float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
@@ -331,42 +333,49 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
 }
 
 // gather form: for every input pixel, visit the windows covering it in a fixed order and take
-// dy where this pixel is the FIRST maximum of the window in (h, w) scan order.
-__global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                   const float *__restrict__ dy, float *__restrict__ dx, int H, int W,
-                                   int C, int k, int stride, int pad, int Ho, int Wo, long long total) {
+// dy where this pixel is the FIRST maximum of the window in (h, w) scan order.  4 channels per thread.
+__global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ y,
+                                   const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W,
+                                   int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long long t = i / C;
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H);
     const long long n = t / H;
-    const float xv = x[i];
-    float g = 0.f;
+    const float4 xv = x[i];
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
     int ho_lo = (h + pad - k + stride) / stride; if (h + pad - k + 1 <= 0) ho_lo = 0;
     int wo_lo = (w + pad - k + stride) / stride; if (w + pad - k + 1 <= 0) wo_lo = 0;
     const int ho_hi = min(Ho - 1, (h + pad) / stride), wo_hi = min(Wo - 1, (w + pad) / stride);
     for (int ho = ho_lo; ho <= ho_hi; ++ho)
       for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        const long long oi = ((n * Ho + ho) * Wo + wo) * C + c;
-        if (y[oi] != xv) continue;
-        // is there an earlier position in this window with the same (max) value?
-        bool first = true;
+        const long long oi = ((n * Ho + ho) * Wo + wo) * C4 + c4;
+        const float4 yv = y[oi];
+        bool cand[4] = {yv.x == xv.x, yv.y == xv.y, yv.z == xv.z, yv.w == xv.w};
+        if (!(cand[0] | cand[1] | cand[2] | cand[3])) continue;
+        // an earlier position of this window holding the same (max) value takes the gradient instead
         const int h0 = ho * stride - pad, w0 = wo * stride - pad;
-        for (int r = 0; r < k && first; ++r) {
+        bool done = false;
+        for (int r = 0; r < k && !done; ++r) {
           const int hh = h0 + r;
           if ((unsigned)hh >= (unsigned)H) continue;
-          for (int s = 0; s < k; ++s) {
-            const int ww = w0 + s;
+          for (int q = 0; q < k; ++q) {
+            const int ww = w0 + q;
             if ((unsigned)ww >= (unsigned)W) continue;
-            if (hh == h && ww == w) { r = k; break; }   // reached ourselves: no earlier max
-            if (x[((n * H + hh) * W + ww) * C + c] == xv) { first = false; break; }
+            if (hh == h && ww == w) { done = true; break; }
+            const float4 e = x[((n * H + hh) * W + ww) * C4 + c4];
+            cand[0] &= e.x != xv.x; cand[1] &= e.y != xv.y; cand[2] &= e.z != xv.z; cand[3] &= e.w != xv.w;
           }
         }
-        if (first) g += dy[oi];
+        const float4 d = dy[oi];
+        if (cand[0]) g[0] += d.x;
+        if (cand[1]) g[1] += d.y;
+        if (cand[2]) g[2] += d.z;
+        if (cand[3]) g[3] += d.w;
       }
-    dx[i] = g;
+    dx[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
 }
 
@@ -636,12 +645,12 @@ int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, fl
   return dspn::check_launch("bn_apply");
 }
 
-int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const float *mean,
-                         const float *rstd, const float *gamma, float *dx, float *dgamma,
-                         float *dbeta, long long rows, int C, int relu, int accumulate,
+int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift, const float *dy,
+                         const float *mean, const float *rstd, const float *gamma, float *dx,
+                         float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
                          void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace, "bn_backward: null pointer");
-  DSPN_REQUIRE(!relu || y, "bn_backward: relu needs the forward output");
+  DSPN_REQUIRE(!relu || (scale && shift), "bn_backward: relu needs the forward scale/shift");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward: C must be a positive multiple of 4");
   if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward: workspace too small");
@@ -650,15 +659,16 @@ int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const 
   float *coef = partial + (size_t)ns * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x),
-                     reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy), mean,
-                     rstd, rows, C4, CL, relu, partial);
+                     reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
+                     reinterpret_cast<const float4 *>(dy), mean, rstd, rows, C4, CL, relu, partial);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(y),
-                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(coef),
-                     reinterpret_cast<float4 *>(dx), n4, C4, relu, accumulate);
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<const float4 *>(dy),
+                     reinterpret_cast<const float4 *>(coef), reinterpret_cast<float4 *>(dx), n4, C4, relu,
+                     accumulate);
   return dspn::check_launch("bn_backward");
 }
 
@@ -743,10 +753,12 @@ int dspn_maxpool_forward_f32(const float *x, float *y, int N, int H, int W, int 
 }
 int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
                               int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {
-  DSPN_REQUIRE(x && y && dy && dx && N > 0, "maxpool_backward: bad argument");
-  const long long total = (long long)N * H * W * C;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), x, y, dy,
-                     dx, H, W, C, k, stride, pad, Ho, Wo, total);
+  DSPN_REQUIRE(x && y && dy && dx && N > 0 && C % 4 == 0, "maxpool_backward: bad argument");
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(y),
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k,
+                     stride, pad, Ho, Wo, total);
   return dspn::check_launch("maxpool_backward");
 }
 int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int Ho, int Wo,

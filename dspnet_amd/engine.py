@@ -209,7 +209,7 @@ class BatchNorm(Node):
     """mx.sym.BatchNorm with batch statistics (the solver always runs is_train=True,
     multi_solver.py:284) optionally fused with the following ReLU."""
 
-    def __init__(self, g, x, name, fix_gamma=False, eps=2e-5, relu=False):
+    def __init__(self, g, x, name, fix_gamma=False, eps=2e-5, relu=False, beta_grad_from_consumer=False):
         C = x.shape[-1]
         self.x, self.eps, self.relu = x, eps, relu
         self.gamma = None if fix_gamma else g.param(name + "_gamma", (C,), init_ones)
@@ -218,7 +218,8 @@ class BatchNorm(Node):
         self.rstd = fn.zeros(C, device=g.device)
         self.scale = fn.zeros(C, device=g.device)
         self.shift = fn.zeros(C, device=g.device)
-        self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), x.requires_grad or True)
+        # an input BN whose data has no gradient only needs sum(dy) for beta: its consumer supplies it
+        self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer)
 
     def forward(self):
         fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
@@ -232,7 +233,7 @@ class BatchNorm(Node):
             dx, acc = self.x.grad_target()
         else:  # parameters still need their gradients; dx goes to scratch
             dx, acc = self.out.grad, False
-        fn.bn_backward(self.x.data, self.out.data, self.out.grad, self.mean, self.rstd,
+        fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
                        accumulate=acc)
@@ -242,10 +243,12 @@ class Conv(Node):
     """mx.sym.Convolution (+ bias) (+ ReLU epilogue); weight [Cout, R, S, Cin_phys]"""
 
     def __init__(self, g, x, name, num_filter, kernel, stride=1, pad=0, dilate=1, no_bias=True, relu=False,
-                 init="xavier", cin_logical=None, cout_phys=None):
+                 init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None):
         N, H, W, Cin = x.shape
         self.x, self.stride, self.pad, self.dil, self.relu = x, stride, pad, dilate, relu
         self.cout = num_filter
+        # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
+        self.input_sum_grad = input_sum_grad
         cin_logical = Cin if cin_logical is None else cin_logical
         self.w = g.param(name + "_weight", (num_filter, kernel, kernel, Cin), conv_weight_init(init, cin_logical))
         self.b = None if no_bias else g.param(name + "_bias", (num_filter,), init_zeros)
@@ -270,6 +273,9 @@ class Conv(Node):
         if self.b is not None:
             fn.colsum(dy, self.cout, out=self.b.grad)
         fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)
+        if self.input_sum_grad is not None:
+            fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
+                                     out=self.input_sum_grad.grad)
         if self.x.requires_grad:
             fn.weight_transpose(self.w.data, out=self.wt)
             dx, acc = self.x.grad_target()

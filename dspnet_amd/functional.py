@@ -24,13 +24,17 @@ _lib.register({
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
+    "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                            _vp, _sz, _vp]),
     "dspn_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "dspn_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _vp, _sz, _vp]),
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
-    "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _sz, _vp]),
+    "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _sz,
+                                  _vp]),
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "dspn_fill_f32": (_i, [_vp, _f, _ll, _vp]),
@@ -155,6 +159,19 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     return out
 
 
+def conv2d_input_sum_grad(dy, w, x_shape, stride=1, pad=0, dil=1, out=None):
+    """sum over all pixels of the conv's data gradient, per input channel: (Cin,) without forming dx"""
+    N, H, W, Cin = x_shape
+    Cout, R, S, _ = w.shape
+    Ho, Wo, ldy = dy.shape[1], dy.shape[2], dy.shape[3]
+    out = empty(Cin, device=dy.device) if out is None else out
+    ws = workspace(L().dspn_conv2d_input_sum_grad_workspace_bytes(Ho, Wo, ldy, R, S), dy.device, "sumgrad")
+    check(L().dspn_conv2d_input_sum_grad_f32(ptr(dy), ptr(w), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride,
+                                             pad, dil, Ho, Wo, ptr(ws), ws.numel(), stream()),
+          "conv2d_input_sum_grad")
+    return out
+
+
 # ------------------------------------------------------------------ batch norm
 def _rows(x):
     return x.numel() // x.shape[-1]
@@ -181,7 +198,8 @@ def bn_apply(x, scale, shift, relu=False, out=None):
     return out
 
 
-def bn_backward(x, y, dy, mean, rstd, gamma, relu=False, dx=None, dgamma=None, dbeta=None, accumulate=False):
+def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dgamma=None, dbeta=None,
+                accumulate=False):
     C = x.shape[-1]
     rows = _rows(x)
     dx = torch.empty_like(x) if dx is None else dx
@@ -189,7 +207,7 @@ def bn_backward(x, y, dy, mean, rstd, gamma, relu=False, dx=None, dgamma=None, d
     if gamma is not None and dgamma is None:
         dgamma = empty(C, device=x.device)
     ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
-    check(L().dspn_bn_backward_f32(ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+    check(L().dspn_bn_backward_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
                                    ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(ws),
                                    ws.numel(), stream()), "bn_backward")
     return dx, dgamma, dbeta

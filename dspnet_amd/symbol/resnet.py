@@ -35,8 +35,11 @@ def resnet(g, data, units, num_stages, filter_list, bottle_neck=True):
     """symbol/resnet.py:70-116 without the classifier tail; returns {internal name: Tensor}"""
     internals = {}
     x = g.add(E.InputNCHW(g, data)).out
-    x = g.add(E.BatchNorm(g, x, "bn_data", fix_gamma=True)).out
-    x = g.add(E.Conv(g, x, "conv0", filter_list[0], 7, 2, 3, cin_logical=3)).out
+    # bn_data's only trainable parameter is beta, whose gradient is sum_pixels(d conv0 / d input): conv0
+    # computes that sum directly instead of a 3-channel data gradient
+    bn_data = g.add(E.BatchNorm(g, x, "bn_data", fix_gamma=True, beta_grad_from_consumer=True))
+    x = g.add(E.Conv(g, bn_data.out, "conv0", filter_list[0], 7, 2, 3, cin_logical=3,
+                     input_sum_grad=bn_data.beta)).out
     x = g.add(E.BatchNorm(g, x, "bn0", relu=True)).out
     body = g.add(E.MaxPool(g, x, "pooling0", 3, 2, 1)).out
     plus = 0

@@ -59,6 +59,14 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
                           int stride, int pad, int dil, int Ho, int Wo, int dx_ldc,
                           int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
+ * from per-tap sums of dy without forming the gradient (the first convolution's input only feeds the
+ * beta of the fix_gamma BatchNorm on the image, symbol/resnet.py:91).  w is [Cout][R][S][Cin]. */
+size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S);
+int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, int N, int H, int W,
+                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad, int dil,
+                                   int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream);
+
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S);
 
 /* dw[k][r][s][c] (+)= sum_{n,ho,wo} dy[n,ho,wo,k] x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c].
@@ -84,12 +92,13 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
                       int C, int relu, void *stream);
 
-/* Backward of the fused op.  If relu != 0, dy is first masked with (y > 0).
+/* Backward of the fused op.  If relu != 0, dy is first masked with (x*scale + shift > 0), i.e. the
+ * forward output's sign recomputed from x (the forward output itself is not read).
  * dx (+)= gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); dgamma = sum dy*xhat; dbeta = sum dy.
  * dgamma may be NULL (fix_gamma).  accumulate != 0: dx += . */
-int dspn_bn_backward_f32(const float *x, const float *y, const float *dy, const float *mean,
-                         const float *rstd, const float *gamma, float *dx, float *dgamma,
-                         float *dbeta, long long rows, int C, int relu, int accumulate,
+int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift, const float *dy,
+                         const float *mean, const float *rstd, const float *gamma, float *dx,
+                         float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- element-wise / layout --------------------------------------------------------------- */

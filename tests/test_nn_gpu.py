@@ -156,12 +156,12 @@ def test_batchnorm_forward_backward(gpu_device, shape, relu, fix_gamma):
     close(r.cpu().double(), 1 / torch.sqrt(var.detach() + eps), 1e-5)
     y = fn.bn_apply(xd, sc, sh, relu=relu)
     close(y.cpu().double(), y_ref.detach(), 1e-5)
-    dx, dgam, dbet = fn.bn_backward(xd, y, dy.float().cuda(), m, r, gd, relu=relu)
+    dx, dgam, dbet = fn.bn_backward(xd, sc, sh, dy.float().cuda(), m, r, gd, relu=relu)
     close(dx.cpu().double(), x.grad, 1e-4)
     close(dbet.cpu().double(), beta.grad, 1e-5)
     if not fix_gamma:
         close(dgam.cpu().double(), gamma.grad, 1e-5)
-    dx2, _, _ = fn.bn_backward(xd, y, dy.float().cuda(), m, r, gd, relu=relu, dx=dx.clone(), accumulate=True)
+    dx2, _, _ = fn.bn_backward(xd, sc, sh, dy.float().cuda(), m, r, gd, relu=relu, dx=dx.clone(), accumulate=True)
     close(dx2.cpu().double(), 2 * x.grad, 1e-4)
 
 
@@ -303,3 +303,17 @@ def test_layout_helpers(gpu_device):
     assert torch.equal(out.cpu(), exp)
     y = torch.randn(64, generator=g).clamp(min=0); dy = torch.randn(64, generator=g)
     assert torch.equal(fn.relu_backward(y.cuda(), dy.cuda()).cpu(), dy * (y > 0))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 3, 64, 7, 2, 3, 1), (3, 9, 11, 3, 16, 3, 1, 1, 1), (2, 12, 12, 4, 8, 3, 2, 0, 1)])
+def test_conv_input_sum_grad(gpu_device, case):
+    """sum over pixels of the data gradient without forming it (bn_data beta gradient through conv0)"""
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, w, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    got = fn.conv2d_input_sum_grad(nhwc(dy), wdev(w), (N, H, W, fn.pad4(Cin)), stride, pad, dil)
+    close(got[:Cin].cpu().double(), x.grad.sum(dim=(0, 2, 3)), 1e-4)
