@@ -17,6 +17,53 @@ import torch
 from .. import functional as fn
 
 
+def plan_buckets(params, owner_index, total, bucket_elems):
+    """Cut the flat gradient arena into contiguous buckets.
+
+    params: [(name, offset, padded_size)] in arena order; owner_index[name] = index of the graph node
+    that produces the gradient.  Returns [(lo, hi, first_node)] sorted by the order in which backward
+    (which runs nodes from last to first) completes them: a bucket is complete once the node with the
+    smallest index among its owners has run."""
+    buckets, lo, first = [], 0, None
+    for name, offset, size in params:
+        idx = owner_index[name]
+        first = idx if first is None else min(first, idx)
+        end = offset + size
+        if end - lo >= bucket_elems:
+            buckets.append((lo, end, first))
+            lo, first = end, None
+    if lo < total:
+        buckets.append((lo, total, first if first is not None else 0))
+    buckets.sort(key=lambda b: -b[2])
+    return buckets
+
+
+class GradBucketReducer:
+    """Sum-all-reduce of the gradient arena in buckets, each launched (async) as soon as backward has
+    passed the first node that writes into it, so RCCL traffic overlaps the remaining kernels.
+    Device-agnostic (used with RCCL on GPUs, exercised with gloo on CPU tensors in the tests)."""
+
+    def __init__(self, grad_arena, buckets, process_group=None):
+        self.arena, self.buckets, self.pg = grad_arena, buckets, process_group
+        self.pending, self.works, self.launched = [], [], []
+
+    def begin(self):
+        self.pending = list(self.buckets)
+        self.works, self.launched = [], []
+
+    def node_done(self, idx):
+        import torch.distributed as dist
+        while self.pending and self.pending[0][2] >= idx:
+            lo, hi, _ = self.pending.pop(0)
+            self.launched.append((lo, hi))
+            self.works.append(dist.all_reduce(self.arena[lo:hi], group=self.pg, async_op=True))
+
+    def finish(self):
+        assert not self.pending, "backward ended before every bucket was released"
+        for w in self.works:
+            w.wait()
+
+
 class MultiTaskSolver:
     def __init__(self, net, learning_rate=0.0005, momentum=0.9, wd=0.0005, process_group=None,
                  world_size=1, bucket_mb=16.0):
@@ -24,30 +71,16 @@ class MultiTaskSolver:
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
-        self._plan_buckets(bucket_mb)
-
-    def _plan_buckets(self, bucket_mb):
-        """contiguous arena slices, each ready once backward has passed its first node"""
         g = self.g
         owner = {}
         for idx, n in enumerate(g.nodes):
             for v in vars(n).values():
                 if hasattr(v, "offset") and hasattr(v, "wd_mult"):
-                    owner[v.name] = idx
-        self.buckets = []   # (lo, hi, first_node_index)
-        limit = int(bucket_mb * (1 << 20) / 4)
-        lo, first = 0, None
-        total = g.arena.numel()
-        for p in g.param_order:
-            if first is None:
-                first = owner[p.name]
-            end = p.offset + (p.size + 3) // 4 * 4
-            if end - lo >= limit:
-                self.buckets.append((lo, end, first))
-                lo, first = end, None
-        if lo < total:
-            self.buckets.append((lo, total, first if first is not None else 0))
-        self.buckets.sort(key=lambda b: -b[2])     # order in which backward completes them
+                    owner.setdefault(v.name, idx)
+                    owner[v.name] = min(owner[v.name], idx)
+        params = [(p.name, p.offset, (p.size + 3) // 4 * 4) for p in g.param_order]
+        self.buckets = plan_buckets(params, owner, g.arena.numel(), int(bucket_mb * (1 << 20) / 4))
+        self.reducer = GradBucketReducer(g.grad_arena, self.buckets, process_group) if world_size > 1 else None
 
     def set_batch(self, data, label_det, label_seg):
         """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4)"""
@@ -63,15 +96,14 @@ class MultiTaskSolver:
         for t in g.all_tensors:
             t._gw = False
             t.grad = None
-        pending = list(self.buckets) if self.world_size > 1 else []
-        works = []
+        if self.reducer is not None:
+            self.reducer.begin()
         for idx in range(len(g.nodes) - 1, -1, -1):
             g.nodes[idx].backward()
-            while pending and pending[0][2] >= idx:
-                lo, hi, _ = pending.pop(0)
-                works.append(torch.distributed.all_reduce(g.grad_arena[lo:hi], group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
+            if self.reducer is not None:
+                self.reducer.node_done(idx)
+        if self.reducer is not None:
+            self.reducer.finish()
 
     def update(self):
         g = self.g
