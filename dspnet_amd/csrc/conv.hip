@@ -43,6 +43,8 @@ struct ConvGeom {
   int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
   int flags;                       // 1 bias, 2 relu, 4 accumulate
   int dense;                       // output address = m*ldc (no decomposition needed)
+  int dbg;                         // timing-only ablation bits (dspn_debug_set), 0 in production
+  unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -53,7 +55,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -78,9 +80,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
 
   const int chunk = tid & 7, row0 = tid >> 3;
 
-  // per-thread gather state of its A rows
-  int a_ih0[A_LD], a_iw0[A_LD];
-  long long a_base[A_LD];
+  // Buffer descriptors over the gathered tensor and the weights: a tap outside the image (or a row
+  // past M / Cout, or a chunk past K) is given an out-of-range offset and the hardware bounds check
+  // returns zeros -- no branch, no select, and all loads of a k-step sit in one basic block.
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  int a_ih0[A_LD], a_iw0[A_LD], a_eoff[A_LD];   // element offset of tap (0,0) (may be negative)
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = m0 + row0 + 32 * i;
@@ -90,35 +98,67 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
       a_ih0[i] = oi * g.ish + g.ioh;
       a_iw0[i] = oj * g.isw + g.iow;
-      a_base[i] = (long long)n * g.Hin * g.Win * g.Cin;
+      a_eoff[i] = ((n * g.Hin + a_ih0[i]) * g.Win + a_iw0[i]) * g.Cin;
     } else {
-      a_ih0[i] = -0x40000000; a_iw0[i] = 0; a_base[i] = 0;
+      a_ih0[i] = -0x40000000; a_iw0[i] = 0; a_eoff[i] = 0;
     }
+  }
+  int b_eoff[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int k = n0 + row0 + 32 * i;
+    b_eoff[i] = k < g.Cout ? k * g.WTAPS * g.Cin : -1;
+  }
+  // When a k-step (8 chunks = 32 channels) never straddles a tap, the tap is wave-uniform and is
+  // tracked incrementally; otherwise (Cin = 4, 20, 36 ...) each lane derives its own tap.
+  constexpr bool uniform_tap = UNIFORM_TAP;   // host guarantees (Cin/4) % 8 == 0
+  int u_tr = 0, u_ts = 0, u_cq = 0;   // tap / channel-chunk of chunk 0 of the NEXT k-step to load
+  if (uniform_tap) {
+    const int q0 = k_begin * 8;
+    const int tap0 = q0 / CQ;
+    u_cq = q0 - tap0 * CQ; u_tr = tap0 / g.TS; u_ts = tap0 - u_tr * g.TS;
   }
 
   float4 ra[A_LD], rb[B_LD];
   auto load_tiles = [&](int kt) {
-    const int q = (k_begin + kt) * 8 + chunk;
-    const bool qv = q < total_q;
-    const int tap = q / CQ, cq = q - tap * CQ;
-    const int tr = tap / g.TS, ts = tap - tr * g.TS;
+    int tr, ts, cq;
+    bool qv;
+    if constexpr (uniform_tap) {
+      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = tr < g.TR;
+      u_cq += 8;
+      const bool wrap = u_cq >= CQ;            // branch-free wave-uniform tap advance
+      u_cq = wrap ? 0 : u_cq;
+      u_ts += wrap ? 1 : 0;
+      const bool wrap2 = u_ts == g.TS;
+      u_ts = wrap2 ? 0 : u_ts;
+      u_tr += wrap2 ? 1 : 0;
+    } else {
+      const int q = (k_begin + kt) * 8 + chunk;
+      qv = q < total_q;
+      const int tap = q / CQ;
+      cq = q - tap * CQ; tr = tap / g.TS; ts = tap - tr * g.TS;
+    }
     const int dh = tr * g.idh, dw = ts * g.idw;
+    const int a_off = (dh * g.Win + dw) * g.Cin + cq * 4;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
       const bool v = qv && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
-      ra[i] = v ? *reinterpret_cast<const float4 *>(
-                      in + a_base[i] + ((long long)ih * g.Win + iw) * g.Cin + cq * 4)
-                : make_float4(0.f, 0.f, 0.f, 0.f);
+      // valid offsets are < 2^31; setting bit 31 pushes an invalid one past num_records
+      const unsigned off = ((unsigned)(a_eoff[i] + a_off) * 4u) | (v ? 0u : kOOB);
+      const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
+      ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                          __uint_as_float(t[3]));
     }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
+    const int b_off = wtap * g.Cin + cq * 4;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const int k = n0 + row0 + 32 * i;
-      const bool v = qv && k < g.Cout;
-      rb[i] = v ? *reinterpret_cast<const float4 *>(
-                      wgt + ((long long)k * g.WTAPS + wtap) * g.Cin + cq * 4)
-                : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool v = qv && b_eoff[i] >= 0;
+      const unsigned off = ((unsigned)(b_eoff[i] + b_off) * 4u) | (v ? 0u : kOOB);
+      const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off, 0, 0);
+      rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                          __uint_as_float(t[3]));
     }
   };
   auto store_tiles = [&](int buf) {
@@ -147,30 +187,48 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     store_tiles(0);
   }
   __syncthreads();
+  const int dbg = g.dbg;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    const bool more = kt + 1 < nk;
+    load_tiles(kt + 1);   // past the last k-step every offset is out of range: zero-cost dummy loads
     const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
     const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
+    // fragments of group gq+1 are fetched from LDS before the MFMAs of group gq are issued
+    float2 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow);
 #pragma unroll
     for (int gq = 0; gq < kBK / 4; ++gq) {
-      float2 fa[TM], fb[TN];
+      const int cur = gq & 1, nxt = cur ^ 1;
+      if (gq + 1 < kBK / 4) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + gq * 4);
+        for (int i = 0; i < TM; ++i)
+          fa[nxt][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + (gq + 1) * 4);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow + gq * 4);
+        for (int j = 0; j < TN; ++j)
+          fb[nxt][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow + (gq + 1) * 4);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
         }
+      // pin the order: the LDS reads of the NEXT group are issued ahead of this group's MFMAs, so their
+      // latency hides under 2*TM*TN MFMAs instead of one (hipcc otherwise sinks them next to their use)
+      if (gq + 1 < kBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      // ... and the next tile's global loads (with their address arithmetic) are spread over the
+      // groups instead of delaying the first MFMA of the k-step
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, (A_LD + B_LD + 7) / 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    __syncthreads();
+    if (more && !(dbg & 2)) store_tiles(buf ^ 1);
+    if (!(dbg & 4)) __syncthreads();
   }
 
   // epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
@@ -476,15 +534,15 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-              hipStream_t s, int splits, int ksteps_per_split, float *slab) {
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
+int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
+                   hipStream_t s, int splits, int ksteps_per_split, float *slab) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   const size_t lds = sizeof(float) * 2 * (BM + BN) * kLdsRow;
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -505,17 +563,36 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
   return dspn::check_launch("conv_nt");
 }
 
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
+              hipStream_t s, int splits, int ksteps_per_split, float *slab) {
+  if (((g.Cin >> 2) & 7) == 0)
+    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab);
+  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab);
+}
+
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
 // leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
-int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
+int g_debug_bits = 0;
+int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g_in,
                 hipStream_t s, SplitWs ws) {
+  ConvGeom g = g_in;
+  g.dbg = g_debug_bits;
+  {
+    const long long ib = 4ll * g.N * g.Hin * g.Win * g.Cin, wb = 4ll * g.Cout * g.WTAPS * g.Cin;
+    if (ib >= (1ll << 31) || wb >= (1ll << 31))
+      return dspn::fail(DSPN_ERR_ARG_, "conv: tensors of 2 GiB or more are not supported by the buffer-addressed kernel");
+    g.in_bytes = (unsigned)ib; g.w_bytes = (unsigned)wb;
+  }
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
   int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32
-  if (g.Cout <= 32) cfg = tiles(256, 32) >= 256 ? 3 : 2;
-  else if (g.Cout <= 64) cfg = tiles(128, 64) >= 256 ? 1 : 2;
-  else cfg = tiles(128, 128) >= 256 ? 0 : (tiles(128, 64) >= 256 ? 1 : 2);
+  // measured on MI355X (scratch/cfgtest.py): 128x128 wins once it yields >= 2 workgroups per CU,
+  // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
+  if (g.Cout <= 32) cfg = tiles(256, 32) >= 512 ? 3 : 2;
+  else cfg = (g.Cout > 64 && tiles(128, 128) >= 512) ? 0 : 2;
+  if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
   static const int bm_[4] = {128, 128, 64, 256}, bn_[4] = {128, 64, 64, 32};
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
   const int nk = (g.TR * g.TS * (g.Cin >> 2) + 7) >> 3;
@@ -554,6 +631,8 @@ WgradPlan wgrad_plan(long long P, int Cout, int J) {
 }  // namespace
 
 extern "C" {
+
+int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
 
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   if (out_pixels <= 0 || Cout <= 0) return 0;

@@ -19,6 +19,7 @@ _sz = _c.c_size_t
 
 _lib.register({
     "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
+    "dspn_debug_set": (_i, [_i]),
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

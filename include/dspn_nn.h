@@ -39,6 +39,8 @@ extern "C" {
  * too small to fill the chip (SSD heads / extras); any size, dspn_conv2d_split_workspace_bytes() is
  * always enough.  Partials are summed in a fixed order (deterministic). */
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
+/* timing-only ablation switches of the conv kernel (results are WRONG when non-zero); 0 = production */
+int dspn_debug_set(int bits);
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
                             int stride, int pad, int dil, int Ho, int Wo,

@@ -1,0 +1,28 @@
+import sys
+sys.path.insert(0, '/root/repo')
+import torch
+from dspnet_amd import functional as fn
+dev = torch.device("cuda", 0)
+def timeit(f, reps=10):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+shapes = [(32, 16, 16, 512, 512, 3), (32, 16, 16, 2048, 512, 1), (32, 16, 16, 512, 2048, 1), (32, 32, 32, 256, 256, 3), (32, 32, 32, 1024, 256, 1), (32, 32, 32, 256, 1024, 1),
+          (32, 64, 64, 128, 128, 3), (32, 64, 64, 512, 128, 1), (32, 64, 64, 128, 512, 1), (32, 128, 128, 64, 64, 3), (32, 128, 128, 64, 256, 1), (32, 128, 128, 256, 64, 1), (32, 128, 128, 64, 64, 1)]
+for (N, H, W, Cin, Cout, k) in shapes:
+    x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+    out = torch.empty(N, H, W, Cout, device=dev)
+    fl = 2.0 * N * H * W * Cin * Cout * k * k
+    res = []
+    for cfg in (0, 1, 2, 3):
+        fn.L().dspn_debug_set((cfg + 1) << 8 if cfg else 0)
+        t = timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=out))
+        res.append("%s %.3fms %5.1fTF" % (["auto", "128x64", "64x64", "256x32"][cfg] if cfg else "auto", t, fl / t / 1e9))
+    fn.L().dspn_debug_set(1 << 8)
+    t = timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=out))
+    res.append("128x128 %.3fms %5.1fTF" % (t, fl / t / 1e9))
+    fn.L().dspn_debug_set(0)
+    print((N, H, W, Cin, Cout, k), " | ".join(res))
