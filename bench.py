@@ -146,8 +146,13 @@ def main():
         wg_ms, wg_n = tot.value, cnt.value
         conv_s = (nt_ms + wg_ms) / 1e3 / args.steps
         ach = flops_step / conv_s / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
+        try:
+            traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_conv_family.json")))["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: fp32 implicit-GEMM family",
                     "launches_per_step": (nt_n + wg_n) // args.steps,
                     "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
