@@ -38,7 +38,43 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="infer = BASELINE.json configs[4]: forward-only test graph + MultiBoxDetection/NMS, p50 latency")
     return ap.parse_args()
+
+
+def run_infer(args):
+    """configs[4]: Inference-only path, bs=64 512x512, HIP multibox_detection + NMS, p50 latency over
+    >= 100 iterations after 10 warm-ups."""
+    import numpy as np
+    import torch
+    from dspnet_amd import synthetic
+    from dspnet_amd.detect.multitask_detector import Detector
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B = args.batch if args.batch != 32 else 64
+    det = Detector("resnet-50", args.size, num_classes=8, batch_size=B, device=dev)
+    data = torch.from_numpy(synthetic.images(B, args.size, args.size, synthetic.rng(233))).to(dev)
+    det.net.data.data.copy_(data)
+    iters = max(args.steps, 100)
+    for _ in range(10):
+        det.forward()
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        det.forward()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.sort(np.asarray(lat))
+    p50 = float(np.percentile(lat, 50))
+    print(json.dumps({"metric": "inference p50 latency, multitask detector forward + MultiBoxDetection/NMS", "value": round(p50, 3),
+                      "unit": "ms/batch", "n_gpus": 1, "steps": iters, "warmup": 10, "ms_per_step": round(p50, 3),
+                      "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                      "data": "synthetic", "p90_ms": round(float(np.percentile(lat, 90)), 3),
+                      "images_per_s": round(B / p50 * 1e3, 1),
+                      "config": {"workload": "resnet-50 multitask test graph %dx%d, batch %d, random-init weights "
+                                             "(nearly all 6132 rows valid: worst case for sort + NMS)" % (args.size, args.size, B)}}))
 
 
 def host_cores():
@@ -87,6 +123,8 @@ def cpu_baseline(size, images, cfg):
 
 def main():
     args = parse()
+    if args.mode == "infer":
+        return run_infer(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -659,7 +659,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   return sizeof(float) * 32 * (size_t)capped;
 }
 
-int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
+static int conv2d_forward_one(const float *x, const float *w, const float *bias, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -686,6 +686,32 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, f
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0});
 }
 
+// images per launch such that no per-launch tensor reaches 2 GiB (32-bit buffer offsets, bit 31 = out of range)
+static int batch_chunk(int N, long long bytes_per_image) {
+  const long long lim = (1ll << 31) - 1;
+  if (bytes_per_image <= 0 || N * bytes_per_image <= lim) return N;
+  return (int)std::max<long long>(1, lim / bytes_per_image);
+}
+
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
+                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                            int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
+                            int relu, int accumulate, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
+  const int ldc = y_ldc > 0 ? y_ldc : Cout;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * ldc;
+  const int nb = batch_chunk(N, 4ll * H * W * Cin);
+  for (int n0 = 0; n0 < N; n0 += nb) {
+    const int n = std::min(nb, N - n0);
+    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, w, bias, y + (long long)n0 * ybs, n, H, W,
+                                      Cin, Cout, R, S, stride, pad, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
+                                      accumulate, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
                                      int Cout_pad, void *stream) {
   DSPN_REQUIRE(w && wt && Cout > 0 && taps > 0 && Cin > 0 && Cout_pad >= Cout && Cout_pad % 4 == 0,
@@ -699,7 +725,7 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
 
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
 // Also the forward of a transposed convolution (x := dy).
-int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -745,6 +771,23 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
   return 0;
 }
 
+int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+                          int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
+  const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
+  const int nb = batch_chunk(N, 4ll * Ho * Wo * ldy);
+  for (int n0 = 0; n0 < N; n0 += nb) {
+    const int n = std::min(nb, N - n0);
+    const int rc = conv2d_dgrad_one(dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
+                                    W, Cin, ldy, R, S, stride, pad, dil, Ho, Wo, dx_ldc, accumulate, workspace,
+                                    workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {
   return sizeof(float) * ((size_t)Ho * Wo * ldy + (size_t)R * S * 32 * ldy);
 }
@@ -777,7 +820,7 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
   return sizeof(float) * std::max(a, std::max(b, (size_t)64)) * Cout * J;
 }
 
-int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
+static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
                           int Cout, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -829,6 +872,22 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
                      reinterpret_cast<const float4 *>(slab), reinterpret_cast<float4 *>(dw), n4,
                      (int)splits, accumulate);
   return dspn::check_launch("conv_wgrad_reduce");
+}
+
+int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
+                          int Cout, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Wo, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
+  const int nb = std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy));
+  for (int n0 = 0; n0 < N; n0 += nb) {
+    const int n = std::min(nb, N - n0);
+    const int rc = conv2d_wgrad_one(x + (long long)n0 * H * W * Cin, dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
+                                    Cin, Cout, ldy, R, S, stride, pad, dil, Ho, Wo, accumulate || n0 > 0,
+                                    workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // extern "C"

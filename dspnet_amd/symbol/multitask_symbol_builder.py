@@ -129,6 +129,39 @@ class SegSoftmaxOutput(E.Node):
         return fn.nhwc_to_nchw(self.prob.data, self.C)
 
 
+class ClsSoftmaxActivation(E.Node):
+    """SoftmaxActivation(cls_preds, mode='channel') of the test graph (:667-668): probabilities only"""
+
+    def __init__(self, g, cls_flat, num_cls):
+        self.x, self.C = cls_flat, num_cls
+        B = cls_flat.shape[0]
+        N = cls_flat.shape[1] // num_cls
+        self.prob_nc = fn.zeros(B, N, num_cls, device=g.device)
+        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False)
+
+    def forward(self):
+        B, C, N = self.cls_prob.shape
+        fn.softmax_output(self.x.data.view(B * N, C), None, C, -1.0, 1.0, None,
+                          prob=self.prob_nc.view(B * N, C), want_grad=False)
+        fn.transpose_bnc(self.prob_nc, out=self.cls_prob.data)
+
+
+class SegSoftmax(E.Node):
+    """mx.symbol.softmax over the class axis of score4_conv (:723): probabilities only"""
+
+    def __init__(self, g, logits, classes):
+        self.x, self.C = logits, classes
+        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False)
+
+    def forward(self):
+        B, H, W, Cp = self.x.shape
+        fn.softmax_output(self.x.data.view(B * H * W, Cp), None, self.C, 255.0, 1.0, None,
+                          prob=self.prob.data.view(B * H * W, Cp), want_grad=False)
+
+    def nchw(self):
+        return fn.nhwc_to_nchw(self.prob.data, self.C)
+
+
 class MultiTaskNet:
     """what symbol.bind(...) returns in the reference: inputs, executor graph, outputs"""
 
@@ -137,7 +170,10 @@ class MultiTaskNet:
         self.__dict__.update(nodes)
 
     def outputs(self):
-        """[cls_prob, loc_loss, cls_label, det_out, seg_out] (multitask_symbol_builder.py:592)"""
+        """training graph: [cls_prob, loc_loss, cls_label, det_out, seg_out] (multitask_symbol_builder.py:592);
+        test graph: [det, seg_out] (:726)"""
+        if self.target is None:
+            return [self.det.out.data, self.seg_out.nchw()]
         return [self.cls_out.cls_prob.data, self.loc_loss.out.data, self.target.cls_target,
                 self.det.out.data, self.seg_out.nchw()]
 
@@ -147,13 +183,35 @@ def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strid
                            nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), num_labels=200, device=None,
                            num_layers=50, seed=0, **kwargs):
     """symbol/multitask_symbol_builder.py:442-593"""
+    return _build(True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
+                  steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
+                  num_layers, seed)
+
+
+def get_multi_symbol(network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                     normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5, force_suppress=False,
+                     nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), device=None, num_layers=50, seed=0,
+                     **kwargs):
+    """Test graph, symbol/multitask_symbol_builder.py:595-726: outputs [det, seg_out].  No label inputs, no
+    MultiBoxTarget, no losses; class probabilities by SoftmaxActivation(mode='channel').  BatchNorm still
+    uses batch statistics, as every shipped caller runs with is_train=True (detect/multitask_detector.py:228).
+    The reference's `mx.symbol.softmax(..., multi_output=True)` on the seg logits is read as a softmax over
+    the class axis."""
+    return _build(False, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                  normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
+                  200, device, num_layers, seed)
+
+
+def _build(train, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
+           steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
+           num_layers, seed):
     assert network == "resnet", "round 1 wires the resnet presets (the only ones the reference builds)"
     device = device or torch.device("cuda", torch.cuda.current_device())
     g = E.Graph(device)
     C, H, W = data_shape
     data = g.tensor((batch_size, C, H, W), "data", requires_grad=False)
-    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False)
-    seg_label = g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False)
+    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False) if train else None
+    seg_label = g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False) if train else None
 
     internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
     res3 = internals[from_layers[0] + "_output"]
@@ -168,9 +226,13 @@ def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strid
     loc_preds, cls_flat, anchor_boxes = multitask_layer(g, layers, num_classes, sizes=sizes, ratios=ratios,
                                                         normalization=normalizations, clip=False, steps=steps)
     ncls = num_classes + 1
-    target = g.add(MultiBoxTargetNode(g, anchor_boxes, label, cls_flat, ncls))
-    cls_out = g.add(ClsSoftmaxOutput(g, cls_flat, target, ncls))
-    loc_loss = g.add(LocLoss(g, loc_preds, target))
+    if train:
+        target = g.add(MultiBoxTargetNode(g, anchor_boxes, label, cls_flat, ncls))
+        cls_out = g.add(ClsSoftmaxOutput(g, cls_flat, target, ncls))
+        loc_loss = g.add(LocLoss(g, loc_preds, target))
+    else:
+        target, loc_loss = None, None
+        cls_out = g.add(ClsSoftmaxActivation(g, cls_flat, ncls))
     det = g.add(Detection(g, cls_out.cls_prob, loc_preds, anchor_boxes, nms_thresh, force_suppress, nms_topk))
 
     # segmentation task (pyramid pooling module) (:541-589)
@@ -198,7 +260,10 @@ def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strid
             res3_reduced2_bn], "score3_concat", target_hw)).out
     score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1)
     score4_conv = g.add(E.Deconv4x4s2(g, score3_conv_bn, "score4_conv", seg_classes)).out
-    seg_out = g.add(SegSoftmaxOutput(g, score4_conv, seg_label, seg_classes))
+    if train:
+        seg_out = g.add(SegSoftmaxOutput(g, score4_conv, seg_label, seg_classes))
+    else:
+        seg_out = g.add(SegSoftmax(g, score4_conv, seg_classes))
 
     g.finalize(seed)
     return MultiTaskNet(g, data, label, seg_label,

@@ -32,3 +32,14 @@ def get_multi_symbol_train(network, data_shape, **kwargs):
     kwargs = dict(kwargs)
     config.update(kwargs)
     return builder.get_multi_symbol_train(data_shape=data_shape, **config)
+
+
+def get_multi_symbol(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:207-224 (test graph: outputs [det, seg_out])"""
+    if isinstance(data_shape, int):
+        data_shape = (3, data_shape, data_shape)
+    config = get_config(network, data_shape, **kwargs)
+    config.pop('kwargs', None)
+    config.pop('data_shape', None)
+    config.update(dict(kwargs))
+    return builder.get_multi_symbol(data_shape=data_shape, **config)

@@ -128,3 +128,20 @@ def test_training_reduces_losses_and_is_deterministic(gpu_device):
         m.reset(); m.update(net2); hist2.append(m.get()[1])
     assert hist == hist2                      # bitwise run-to-run reproducible
     assert torch.equal(net.g.arena, net2.g.arena)
+
+
+def test_test_graph_matches_training_graph_outputs(gpu_device):
+    """get_multi_symbol (symbol/multitask_symbol_builder.py:595-726) yields the det / seg values of the
+    training graph's outputs[3], outputs[4] (what detect/multitask_detector.py:234 reads)"""
+    from dspnet_amd.detect.multitask_detector import Detector
+    net, solver, data, lab, seg = make(2, 256, 256)
+    solver.forward()
+    outs = net.outputs()
+    det = Detector("resnet-50", 256, num_classes=8, batch_size=2, seed=1)
+    assert torch.equal(det.net.g.arena, net.g.arena)
+    d, s = det.forward(torch.from_numpy(data).cuda())
+    assert torch.equal(d, outs[3])
+    assert torch.allclose(det.net.outputs()[1], outs[4], atol=0, rtol=0)
+    rows, segp = det.detect(torch.from_numpy(data).cuda())
+    assert len(rows) == 2 and rows[0].shape[1] == 7 and (rows[0][:, 0] >= 0).all()
+    assert segp.shape == (2, 19, 64, 64)
