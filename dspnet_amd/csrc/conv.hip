@@ -660,7 +660,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 }
 
 static int conv2d_forward_one(const float *x, const float *w, const float *bias, float *y, int N,
-                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
@@ -668,13 +668,13 @@ static int conv2d_forward_one(const float *x, const float *w, const float *bias,
   DSPN_REQUIRE(Cin % 4 == 0, "conv2d_forward: Cin must be a multiple of 4 (pad channels), got %d", Cin);
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0,
                "conv2d_forward: bad geometry");
-  DSPN_REQUIRE(Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 &&
-                   Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1,
+  DSPN_REQUIRE(Ho == (H + 2 * pad_h - dil * (R - 1) - 1) / stride + 1 &&
+                   Wo == (W + 2 * pad_w - dil * (S - 1) - 1) / stride + 1,
                "conv2d_forward: output size mismatch");
   ConvGeom g;
   memset(&g, 0, sizeof(g));
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Hg = Ho; g.Wg = Wo;
-  g.ish = stride; g.isw = stride; g.ioh = -pad; g.iow = -pad; g.idh = dil; g.idw = dil;
+  g.ish = stride; g.isw = stride; g.ioh = -pad_h; g.iow = -pad_w; g.idh = dil; g.idw = dil;
   g.TR = R; g.TS = S; g.WTAPS = R * S; g.WS = S; g.wr0 = 0; g.wrs = 1; g.ws0 = 0; g.wss = 1;
   g.Cout = Cout;
   g.ldc = y_ldc > 0 ? y_ldc : Cout;
@@ -694,7 +694,7 @@ static int batch_chunk(int N, long long bytes_per_image) {
 }
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
-                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
@@ -705,7 +705,7 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, f
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, w, bias, y + (long long)n0 * ybs, n, H, W,
-                                      Cin, Cout, R, S, stride, pad, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
+                                      Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
     if (rc) return rc;
   }
@@ -726,7 +726,7 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
 // Also the forward of a transposed convolution (x := dy).
 static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, int H, int W,
-                          int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
@@ -744,7 +744,7 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
   hipStream_t s = (hipStream_t)stream;
   const SplitWs sws{static_cast<float *>(workspace), workspace ? workspace_bytes : 0};
   if (stride == 1) {
-    g.Hg = H; g.Wg = W; g.ish = 1; g.isw = 1; g.ioh = pad; g.iow = pad; g.idh = -dil; g.idw = -dil;
+    g.Hg = H; g.Wg = W; g.ish = 1; g.isw = 1; g.ioh = pad_h; g.iow = pad_w; g.idh = -dil; g.idw = -dil;
     g.TR = R; g.TS = S; g.wr0 = 0; g.wrs = 1; g.ws0 = 0; g.wss = 1;
     g.osh = 1; g.osw = 1; g.dense = 1;
     return dispatch_nt(dy, wt, nullptr, dx, g, s, sws);
@@ -754,14 +754,14 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
       ConvGeom c = g;
       c.Hg = (H - ph + 1) / 2; c.Wg = (W - pw + 1) / 2;
       if (c.Hg <= 0 || c.Wg <= 0) continue;
-      const int r0 = (ph + pad) & 1, s0 = (pw + pad) & 1;
+      const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
       c.TR = r0 < R ? (R - r0 + 1) / 2 : 0;
       c.TS = s0 < S ? (S - s0 + 1) / 2 : 0;
       if (c.TR == 0 || c.TS == 0) {
         c.TR = 0; c.TS = 1;
         if (accumulate) continue;   // nothing to add
       }
-      c.ish = 1; c.isw = 1; c.ioh = (ph + pad - r0) / 2; c.iow = (pw + pad - s0) / 2;
+      c.ish = 1; c.isw = 1; c.ioh = (ph + pad_h - r0) / 2; c.iow = (pw + pad_w - s0) / 2;
       c.idh = -1; c.idw = -1;
       c.wr0 = r0; c.wrs = 2; c.ws0 = s0; c.wss = 2;
       c.osh = 2; c.osw = 2; c.ooh = ph; c.oow = pw; c.dense = 0;
@@ -772,7 +772,7 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
 }
 
 int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
-                          int Cin, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
@@ -781,7 +781,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_dgrad_one(dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
-                                    W, Cin, ldy, R, S, stride, pad, dil, Ho, Wo, dx_ldc, accumulate, workspace,
+                                    W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate, workspace,
                                     workspace_bytes, stream);
     if (rc) return rc;
   }
@@ -793,7 +793,7 @@ size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R
 }
 
 int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, int N, int H, int W,
-                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad, int dil,
+                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil,
                                    int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(dy && w && out && workspace, "conv2d_input_sum_grad: null pointer");
   DSPN_REQUIRE(ldy % 4 == 0 && Cin >= 1 && Cin <= 8, "conv2d_input_sum_grad: Cin <= 8, ldy % 4 == 0");
@@ -805,7 +805,7 @@ int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, 
   const long long per4 = (long long)Ho * Wo * ldy / 4;
   hipLaunchKernelGGL(batch_sum_kernel, dim3((int)std::min<long long>((per4 + 255) / 256, 8192)), dim3(256), 0, s,
                      reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(p2), N, per4);
-  SumGradGeom g{H, W, Ho, Wo, ldy, R, S, stride, stride, pad, pad, dil, dil, 32};
+  SumGradGeom g{H, W, Ho, Wo, ldy, R, S, stride, stride, pad_h, pad_w, dil, dil, 32};
   hipLaunchKernelGGL(tap_sum_kernel, dim3(R * S, 32), dim3(256), 0, s, p2, partial, g);
   hipLaunchKernelGGL(sum_grad_final_kernel, dim3(1), dim3(1024), 0, s, partial, w, out, R * S, 32, ldy, Cout, Cin);
   return dspn::check_launch("conv2d_input_sum_grad");
@@ -821,14 +821,14 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
 }
 
 static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
-                          int Cout, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
   DSPN_REQUIRE(Cin % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: channel strides must be multiples of 4");
   WgradGeom g;
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
-  g.sh = stride; g.sw = stride; g.ph = pad; g.pw = pad; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
+  g.sh = stride; g.sw = stride; g.ph = pad_h; g.pw = pad_w; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
   {
     const long long xb = 4ll * N * H * W * Cin, yb = 4ll * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -875,7 +875,7 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
 }
 
 int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
-                          int Cout, int ldy, int R, int S, int stride, int pad, int dil, int Ho,
+                          int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
@@ -883,7 +883,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_wgrad_one(x + (long long)n0 * H * W * Cin, dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
-                                    Cin, Cout, ldy, R, S, stride, pad, dil, Ho, Wo, accumulate || n0 > 0,
+                                    Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, accumulate || n0 > 0,
                                     workspace, workspace_bytes, stream);
     if (rc) return rc;
   }

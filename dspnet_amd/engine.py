@@ -245,19 +245,21 @@ class Conv(Node):
     def __init__(self, g, x, name, num_filter, kernel, stride=1, pad=0, dilate=1, no_bias=True, relu=False,
                  init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None):
         N, H, W, Cin = x.shape
-        self.x, self.stride, self.pad, self.dil, self.relu = x, stride, pad, dilate, relu
+        kh, kw = fn._hw(kernel)
+        ph, pw = fn._hw(pad)
+        self.x, self.stride, self.pad, self.dil, self.relu = x, stride, (ph, pw), dilate, relu
         self.cout = num_filter
         # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
         self.input_sum_grad = input_sum_grad
         cin_logical = Cin if cin_logical is None else cin_logical
-        self.w = g.param(name + "_weight", (num_filter, kernel, kernel, Cin), conv_weight_init(init, cin_logical))
+        self.w = g.param(name + "_weight", (num_filter, kh, kw, Cin), conv_weight_init(init, cin_logical))
         self.b = None if no_bias else g.param(name + "_bias", (num_filter,), init_zeros)
-        Ho, Wo = fn.conv_out_size(H, kernel, stride, pad, dilate), fn.conv_out_size(W, kernel, stride, pad, dilate)
+        Ho, Wo = fn.conv_out_size(H, kh, stride, ph, dilate), fn.conv_out_size(W, kw, stride, pw, dilate)
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), name + "_out")
-        self.wt = None if not x.requires_grad else fn.zeros(Cin, kernel, kernel, ldc, device=g.device)
+        self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device)
         # algorithmic FLOPs per batch (direct-conv count, logical channels)
-        self.flops_fwd = 2.0 * cin_logical * num_filter * kernel * kernel * Ho * Wo * N
+        self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
@@ -338,11 +340,18 @@ class BlockGrad(Node):
 
 
 class MaxPool(Node):
-    def __init__(self, g, x, name, kernel, stride, pad):
+    """mx.sym.Pooling(pool_type='max'); pooling_convention='full' (symbol/vgg16_reduced.py:40-42) rounds the
+    output size up, windows that stick out of the image just see fewer pixels"""
+
+    def __init__(self, g, x, name, kernel, stride, pad, full=False):
         N, H, W, C = x.shape
         self.x, self.k, self.s, self.p = x, kernel, stride, pad
-        self.out = g.tensor((N, fn.conv_out_size(H, kernel, stride, pad), fn.conv_out_size(W, kernel, stride, pad), C),
-                            name)
+
+        def osz(h):
+            if not full:
+                return fn.conv_out_size(h, kernel, stride, pad)
+            return -(-(h + 2 * pad - kernel) // stride) + 1
+        self.out = g.tensor((N, osz(H), osz(W), C), name)
 
     def forward(self):
         fn.maxpool_forward(self.x.data, self.k, self.s, self.p, out=self.out.data)

@@ -20,16 +20,16 @@ _sz = _c.c_size_t
 _lib.register({
     "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_debug_set": (_i, [_i]),
-    "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
+    "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                             _vp, _sz, _vp]),
     "dspn_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
-    "dspn_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _vp, _sz, _vp]),
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -84,6 +84,11 @@ def workspace(nbytes, device, tag="nn"):
     return buf
 
 
+def _hw(v):
+    """int or (h, w) pair -> (h, w)"""
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
 def conv_out_size(h, k, stride, pad, dil=1):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -106,14 +111,15 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
-    Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+    ph, pw = _hw(pad)
+    Ho, Wo = conv_out_size(H, R, stride, ph, dil), conv_out_size(W, S, stride, pw, dil)
     if out is None:
         ldc = pad4(Cout)
         out = zeros(N, Ho, Wo, ldc, device=x.device) if ldc != Cout else empty(N, Ho, Wo, ldc, device=x.device)
     ldc = out.shape[3]
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
     check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(out), N, H, W, Cin, Cout, R, S, stride,
-                                      pad, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), ptr(ws), ws.numel(),
+                                      ph, pw, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), ptr(ws), ws.numel(),
                                       stream()), "conv2d_forward")
     return out
 
@@ -138,7 +144,8 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     if out is None:
         out = zeros(N, H, W, Cx, device=dy.device) if Cx != Cin else empty(N, H, W, Cx, device=dy.device)
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
-    check(L().dspn_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, pad, dil,
+    ph, pw = _hw(pad)
+    check(L().dspn_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
                                     Ho, Wo, out.shape[3], int(accumulate), ptr(ws), ws.numel(), stream()),
           "conv2d_dgrad")
     return out
@@ -154,7 +161,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
         out = empty(Cout, R, S, Cin, device=x.device)
     nbytes = L().dspn_conv2d_wgrad_workspace_bytes(N, Ho, Wo, Cin, Cout, R, S)
     ws = workspace(nbytes, x.device, "wgrad")
-    check(L().dspn_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride, pad,
+    ph, pw = _hw(pad)
+    check(L().dspn_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride, ph, pw,
                                     dil, Ho, Wo, int(accumulate), ptr(ws), ws.numel(), stream()),
           "conv2d_wgrad")
     return out
@@ -167,8 +175,9 @@ def conv2d_input_sum_grad(dy, w, x_shape, stride=1, pad=0, dil=1, out=None):
     Ho, Wo, ldy = dy.shape[1], dy.shape[2], dy.shape[3]
     out = empty(Cin, device=dy.device) if out is None else out
     ws = workspace(L().dspn_conv2d_input_sum_grad_workspace_bytes(Ho, Wo, ldy, R, S), dy.device, "sumgrad")
+    ph, pw = _hw(pad)
     check(L().dspn_conv2d_input_sum_grad_f32(ptr(dy), ptr(w), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride,
-                                             pad, dil, Ho, Wo, ptr(ws), ws.numel(), stream()),
+                                             ph, pw, dil, Ho, Wo, ptr(ws), ws.numel(), stream()),
           "conv2d_input_sum_grad")
     return out
 
@@ -276,8 +285,9 @@ def transpose_bnc(src, out=None):
 # ------------------------------------------------------------------ pooling / sampler
 def maxpool_forward(x, k, stride, pad, out=None):
     N, H, W, C = x.shape
-    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
+    if out is None:
+        out = empty(N, conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad), C, device=x.device)
+    Ho, Wo = out.shape[1], out.shape[2]     # a larger (pooling_convention='full') output is the caller's choice
     check(L().dspn_maxpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
           "maxpool_forward")
     return out

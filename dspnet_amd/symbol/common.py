@@ -20,12 +20,15 @@ def multi_layer_feature(g, internals, from_layers, num_filters, strides, pads, m
     layers = []
     for k, (from_layer, num_filter, s, p) in enumerate(zip(from_layers, num_filters, strides, pads)):
         if from_layer.strip():
-            layers.append(internals[from_layer.strip() + "_output"])
+            t = internals[from_layer.strip() + "_output"]
+            t.ssd_name = from_layer.strip()          # the symbol name the reference derives head names from
+            layers.append(t)
         else:
             assert len(layers) > 0 and num_filter > 0
             num_1x1 = max(min_filter, num_filter // 2)
             c1 = conv_act_layer(g, layers[-1], "multi_feat_%d_conv_1x1" % k, num_1x1, 1, 0, 1)
             c3 = conv_act_layer(g, c1, "multi_feat_%d_conv_3x3" % k, num_filter, 3, p, s)
+            c3.ssd_name = "multi_feat_%d_conv_3x3_relu" % k
             layers.append(c3)
     return layers
 
@@ -73,7 +76,7 @@ def multitask_layer(g, from_layers, num_classes, sizes, ratios, normalization=-1
     num_classes += 1
     loc_maps, cls_maps, loc_w, cls_w, anchors = [], [], [], [], []
     for k, from_layer in enumerate(from_layers):
-        from_name = from_layer.name.replace("_conv_out", "_relu").replace("_out", "")
+        from_name = from_layer.ssd_name              # symbol/common.py:367 `from_layer.name`
         size, ratio = sizes[k], ratios[k]
         num_anchors = len(size) - 1 + len(ratio)
         loc = g.add(E.Conv(g, from_layer, "{}_loc_pred_conv".format(from_name), num_anchors * 5, 3, 1, 1,

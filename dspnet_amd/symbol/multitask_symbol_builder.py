@@ -18,6 +18,7 @@ from .. import engine as E
 from .. import functional as fn
 from .. import operator as op
 from . import resnet as resnet_mod
+from . import vgg16_reduced as vgg_mod
 from .common import multi_layer_feature, multitask_layer
 
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
@@ -174,8 +175,8 @@ class MultiTaskNet:
         test graph: [det, seg_out] (:726)"""
         if self.target is None:
             return [self.det.out.data, self.seg_out.nchw()]
-        return [self.cls_out.cls_prob.data, self.loc_loss.out.data, self.target.cls_target,
-                self.det.out.data, self.seg_out.nchw()]
+        outs = [self.cls_out.cls_prob.data, self.loc_loss.out.data, self.target.cls_target, self.det.out.data]
+        return outs if self.seg_out is None else outs + [self.seg_out.nchw()]
 
 
 def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
@@ -183,7 +184,7 @@ def get_multi_symbol_train(network, num_classes, from_layers, num_filters, strid
                            nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), num_labels=200, device=None,
                            num_layers=50, seed=0, **kwargs):
     """symbol/multitask_symbol_builder.py:442-593"""
-    return _build(True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
+    return _build(True, True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
                   steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
                   num_layers, seed)
 
@@ -197,32 +198,55 @@ def get_multi_symbol(network, num_classes, from_layers, num_filters, strides, pa
     uses batch statistics, as every shipped caller runs with is_train=True (detect/multitask_detector.py:228).
     The reference's `mx.symbol.softmax(..., multi_output=True)` on the seg logits is read as a softmax over
     the class axis."""
-    return _build(False, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+    return _build(False, True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
                   normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
                   200, device, num_layers, seed)
 
 
-def _build(train, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
+def get_det_symbol_train(network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                         normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5, force_suppress=False,
+                         nms_topk=400, batch_size=1, data_shape=(3, 300, 300), num_labels=200, device=None,
+                         num_layers=50, seed=0, **kwargs):
+    """Detection + depth only, symbol/multitask_symbol_builder.py:20-121: outputs [cls_prob, loc_loss, cls_label,
+    det_out]; the same graph without the segmentation decoder."""
+    return _build(True, False, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                  normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
+                  num_labels, device, num_layers, seed)
+
+
+def _build(train, with_seg, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
            steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
            num_layers, seed):
-    assert network == "resnet", "round 1 wires the resnet presets (the only ones the reference builds)"
+    assert network in ("resnet", "vgg16_reduced"), "backbones wired so far: resnet, vgg16_reduced"
     device = device or torch.device("cuda", torch.cuda.current_device())
     g = E.Graph(device)
     C, H, W = data_shape
     data = g.tensor((batch_size, C, H, W), "data", requires_grad=False)
     label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False) if train else None
-    seg_label = g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False) if train else None
+    seg_label = (g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False)
+                 if (train and with_seg) else None)
 
-    internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
+    if network == "resnet":
+        internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
+    else:
+        internals = vgg_mod.get_symbol(g, data)
     res3 = internals[from_layers[0] + "_output"]
     res4 = internals[from_layers[1] + "_output"]
-    conv_feat = internals[from_layers[2] + "_output"]
 
-    # remove res3 from the input layers of SSD (:502-508)
+    # remove res3 from the input layers of SSD (:502-508).  The reference slices from_layers / num_filters /
+    # strides / pads / sizes / ratios but not `normalizations` and `steps` (a list-valued preset then trips
+    # the length asserts of symbol/common.py:350,356); this build slices those too.
     from_layers, num_filters, strides, pads = from_layers[1:], num_filters[1:], strides[1:], pads[1:]
     sizes, ratios = sizes[1:], ratios[1:]
+    if isinstance(normalizations, (list, tuple)):
+        normalizations = list(normalizations)[1:]
+    steps = list(steps)[1:] if steps else steps
 
     layers = multi_layer_feature(g, internals, from_layers, num_filters, strides, pads, min_filter=min_filter)
+    # conv_feat: the reference reads internals[from_layers[2]] (:500), which only exists for the resnet-50
+    # preset; presets whose third entry is '' (an extra layer) use that extra layer -- the stride-32 map --
+    # in the same role (build's own wiring, SURVEY.md section 2.1)
+    conv_feat = layers[1]
     loc_preds, cls_flat, anchor_boxes = multitask_layer(g, layers, num_classes, sizes=sizes, ratios=ratios,
                                                         normalization=normalizations, clip=False, steps=steps)
     ncls = num_classes + 1
@@ -234,6 +258,12 @@ def _build(train, network, num_classes, from_layers, num_filters, strides, pads,
         target, loc_loss = None, None
         cls_out = g.add(ClsSoftmaxActivation(g, cls_flat, ncls))
     det = g.add(Detection(g, cls_out.cls_prob, loc_preds, anchor_boxes, nms_thresh, force_suppress, nms_topk))
+
+    if not with_seg:
+        g.finalize(seed)
+        return MultiTaskNet(g, data, label, None,
+                            dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=None,
+                                 anchors=anchor_boxes, loc_preds=loc_preds, cls_flat=cls_flat))
 
     # segmentation task (pyramid pooling module) (:541-589)
     def conv_bn(x, name, nf, k, pad):

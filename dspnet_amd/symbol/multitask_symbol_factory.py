@@ -5,6 +5,30 @@ from . import multitask_symbol_builder as builder
 def get_config(network, data_shape, **kwargs):
     """symbol/multitask_symbol_factory.py:5-98.  Only the presets that build in the reference are
     offered in round 1 (resnet-50 :68-81; resnet101's list is kept as data for later)."""
+    if isinstance(data_shape, (tuple, list)):
+        data_shape = data_shape[1]
+    if network == 'vgg16_reduced':   # symbol/multitask_symbol_factory.py:17-42
+        if data_shape >= 448:
+            from_layers = ['relu4_3', 'relu7', '', '', '', '', '']
+            num_filters = [512, -1, 512, 256, 256, 256, 256]
+            strides = [-1, -1, 2, 2, 2, 2, 1]
+            pads = [-1, -1, 1, 1, 1, 1, 1]
+            sizes = [[.07, .1025], [.15, .2121], [.3, .3674], [.45, .5196], [.6, .6708], [.75, .8216], [.9, .9721]]
+            ratios = [[1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3],
+                      [1, 2, .5, 3, 1. / 3], [1, 2, .5], [1, 2, .5]]
+            normalizations = [20, -1, -1, -1, -1, -1, -1]
+            steps = [] if data_shape != 512 else [x / 512.0 for x in [8, 16, 32, 64, 128, 256, 512]]
+        else:
+            from_layers = ['relu4_3', 'relu7', '', '', '', '']
+            num_filters = [512, -1, 512, 256, 256, 256]
+            strides = [-1, -1, 2, 2, 1, 1]
+            pads = [-1, -1, 1, 1, 0, 0]
+            sizes = [[.1, .141], [.2, .272], [.37, .447], [.54, .619], [.71, .79], [.88, .961]]
+            ratios = [[1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5],
+                      [1, 2, .5]]
+            normalizations = [20, -1, -1, -1, -1, -1]
+            steps = [] if data_shape != 300 else [x / 300.0 for x in [8, 16, 32, 64, 100, 300]]
+        return locals()
     if network == 'resnet-50':
         num_layers = 50
         network = 'resnet'
@@ -32,6 +56,17 @@ def get_multi_symbol_train(network, data_shape, **kwargs):
     kwargs = dict(kwargs)
     config.update(kwargs)
     return builder.get_multi_symbol_train(data_shape=data_shape, **config)
+
+
+def get_det_symbol_train(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:104-121 (detection + depth only)"""
+    if isinstance(data_shape, int):
+        data_shape = (3, data_shape, data_shape)
+    config = get_config(network, data_shape, **kwargs)
+    config.pop('kwargs', None)
+    config.pop('data_shape', None)
+    config.update(dict(kwargs))
+    return builder.get_det_symbol_train(data_shape=data_shape, **config)
 
 
 def get_multi_symbol(network, data_shape, **kwargs):

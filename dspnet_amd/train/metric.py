@@ -22,10 +22,14 @@ class MultiBoxMetric:
         B, C, N = net.cls_out.cls_prob.shape
         ce = fn.cross_entropy_sum(net.cls_out.prob_nc.view(B * N, C), net.target.cls_target, C, -1.0, self.eps)
         sl1 = fn.sum_all(net.loc_loss.out.data)
-        sp = net.seg_out.prob.data
-        rows = sp.numel() // sp.shape[-1]
-        seg = fn.cross_entropy_sum(sp.view(rows, sp.shape[-1]), net.label_seg.data, net.seg_out.C, 255.0, self.eps)
-        ce, sl1, seg = ce.cpu(), sl1.cpu(), seg.cpu()
+        if net.seg_out is not None:
+            sp = net.seg_out.prob.data
+            rows = sp.numel() // sp.shape[-1]
+            seg = fn.cross_entropy_sum(sp.view(rows, sp.shape[-1]), net.label_seg.data, net.seg_out.C, 255.0,
+                                       self.eps).cpu()
+        else:   # detection-only graph
+            seg = [0.0, 0.0]
+        ce, sl1 = ce.cpu(), sl1.cpu()
         valid = float(ce[1])
         self.sum_metric[0] += float(ce[0]); self.num_inst[0] += valid
         self.sum_metric[1] += float(sl1[0]); self.num_inst[1] += valid

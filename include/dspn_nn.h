@@ -32,7 +32,8 @@ extern "C" {
 /* ---- Convolution (mx.sym.Convolution: symbol/resnet.py:32-49,95, common.py:32,
  * 393-409, multitask_symbol_builder.py:543-583).  fp32 MFMA implicit GEMM. -------- */
 
-/* y[n,ho,wo,k] = sum x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c] w[k,r,s,c] (+bias[k]) (relu).
+/* y[n,ho,wo,k] = sum x[n,ho*stride-pad_h+r*dil, wo*stride-pad_w+s*dil, c] w[k,r,s,c] (+bias[k]) (relu).
+ * R x S kernels with separate pads cover the inception 1x7 / 7x1 / 1x3 / 3x1 classes (symbol/inceptionv3.py).
  * y pixel stride y_ldc (0 = Cout), batch stride y_batch_stride (0 = dense).
  * accumulate != 0: y += result (before relu). bias may be NULL.
  * workspace (optional, may be NULL): scratch for split-K partial tiles, used when the output grid is
@@ -43,7 +44,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
 int dspn_debug_set(int bits);
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
-                            int stride, int pad, int dil, int Ho, int Wo,
+                            int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                             long long y_batch_stride, int y_ldc, int relu, int accumulate,
                             void *workspace, size_t workspace_bytes, void *stream);
 
@@ -58,7 +59,7 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
  * 4x4, stride 2, pad 1, no bias) with x := dy. */
 int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
                           int N, int H, int W, int Cin, int ldy, int R, int S,
-                          int stride, int pad, int dil, int Ho, int Wo, int dx_ldc,
+                          int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                           int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
@@ -66,7 +67,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
  * beta of the fix_gamma BatchNorm on the image, symbol/resnet.py:91).  w is [Cout][R][S][Cin]. */
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S);
 int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, int N, int H, int W,
-                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad, int dil,
+                                   int Cin, int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil,
                                    int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream);
 
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S);
@@ -75,7 +76,7 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
  * Split-K over pixels into `workspace` slabs, summed in a fixed order (deterministic). */
 int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
                           int N, int H, int W, int Cin, int Cout, int ldy, int R, int S,
-                          int stride, int pad, int dil, int Ho, int Wo, int accumulate,
+                          int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int accumulate,
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:

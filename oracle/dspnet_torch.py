@@ -81,30 +81,67 @@ def conv_bn(P, x, name, pad):
     return bn(F.conv2d(x, P[name + "_weight"], padding=pad), None, P[name + "_bn_beta"])
 
 
-def forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes=8, dtype=torch.float64,
-                 nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None):
-    """Runs the multi-task training graph on the CPU.  Returns dict with the five graph outputs, the
-    three loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params."""
+def vgg16_reduced(P, data):
+    """symbol/vgg16_reduced.py:3-75"""
+    def c(x, name, pad=1, dil=1):
+        return F.relu(F.conv2d(x, P[name + "_weight"], P[name + "_bias"], padding=pad, dilation=dil))
+    inter = {}
+    x = c(c(data, "conv1_1"), "conv1_2")
+    x = F.max_pool2d(x, 2, 2)
+    x = c(c(x, "conv2_1"), "conv2_2")
+    x = F.max_pool2d(x, 2, 2)
+    x = c(c(c(x, "conv3_1"), "conv3_2"), "conv3_3")
+    x = F.max_pool2d(x, 2, 2, ceil_mode=True)          # pooling_convention="full"
+    x = c(c(c(x, "conv4_1"), "conv4_2"), "conv4_3")
+    inter["relu4_3"] = x
+    x = F.max_pool2d(x, 2, 2)
+    x = c(c(c(x, "conv5_1"), "conv5_2"), "conv5_3")
+    x = F.max_pool2d(x, 3, 1, 1)
+    x = c(x, "fc6", pad=6, dil=6)
+    x = c(x, "fc7", pad=0)
+    inter["relu7"] = x
+    return inter
+
+
+def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, num_classes=8, dtype=torch.float64,
+                 nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True):
+    """Runs the multi-task (or, with_seg=False, the detection+depth) training graph on the CPU.
+    `config` is the preset of multitask_symbol_factory.get_config (un-sliced); without it the resnet-50
+    preset wiring is assumed and sizes/ratios are the already sliced lists.  Returns dict with the graph
+    outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params."""
     P = Params(values, dtype)
     x = torch.tensor(data, dtype=dtype)
     B, _, H, W = x.shape
-    inter = resnet50(P, x)
-    res3, res4, conv_feat = inter["_plus6"], inter["_plus12"], inter["_plus15"]
+    if config is None:
+        config = dict(network="resnet", from_layers=['_plus6', '_plus12', '_plus15', '', '', '', ''],
+                      num_filters=[-1, -1, -1, 512, 256, 256, 128], strides=[-1, -1, -1, 2, 2, 2, 2],
+                      pads=[-1, -1, -1, 1, 1, 1, 1], sizes=[None] + list(sizes), ratios=[None] + list(ratios), steps=[])
+    inter = resnet50(P, x) if config["network"] == "resnet" else vgg16_reduced(P, x)
+    fl = config["from_layers"]
+    res3, res4 = inter[fl[0]], inter[fl[1]]
+    fl, nfs, sts, pds = fl[1:], config["num_filters"][1:], config["strides"][1:], config["pads"][1:]
+    sizes, ratios = config["sizes"][1:], config["ratios"][1:]
+    steps = list(config.get("steps") or [])[1:]
 
     # SSD extras + heads (symbol/common.py:117-133, 393-432)
-    layers, names = [res4, conv_feat], ["_plus12", "_plus15"]
-    for k, nf in zip((2, 3, 4, 5), (512, 256, 256, 128)):
-        n1, n3 = "multi_feat_%d_conv_1x1_conv" % k, "multi_feat_%d_conv_3x3_conv" % k
-        c1 = F.relu(F.conv2d(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
-        c3 = F.relu(F.conv2d(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=2, padding=1))
-        layers.append(c3); names.append("multi_feat_%d_conv_3x3_relu" % k)
+    layers, names = [], []
+    for k, (name, nf, st, pd) in enumerate(zip(fl, nfs, sts, pds)):
+        if name:
+            layers.append(inter[name]); names.append(name)
+        else:
+            n1, n3 = "multi_feat_%d_conv_1x1_conv" % k, "multi_feat_%d_conv_3x3_conv" % k
+            c1 = F.relu(F.conv2d(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
+            c3 = F.relu(F.conv2d(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=st, padding=pd))
+            layers.append(c3); names.append("multi_feat_%d_conv_3x3_relu" % k)
+    conv_feat = layers[1]
     locs, clss, anchors = [], [], []
-    for layer, nm, sz, rt in zip(layers, names, sizes, ratios):
+    for k, (layer, nm, sz, rt) in enumerate(zip(layers, names, sizes, ratios)):
         lp = F.conv2d(layer, P[nm + "_loc_pred_conv_weight"], P[nm + "_loc_pred_conv_bias"], padding=1)
         cp = F.conv2d(layer, P[nm + "_cls_pred_conv_weight"], P[nm + "_cls_pred_conv_bias"], padding=1)
         locs.append(lp.permute(0, 2, 3, 1).reshape(B, -1))
         clss.append(cp.permute(0, 2, 3, 1).reshape(B, -1))
-        anchors.append(om.multibox_prior(layer.shape[2], layer.shape[3], sz, rt))
+        st = (steps[k], steps[k]) if steps else (-1.0, -1.0)
+        anchors.append(om.multibox_prior(layer.shape[2], layer.shape[3], sz, rt, steps=st))
     loc_preds = torch.cat(locs, dim=1)
     ncls = num_classes + 1
     cls_preds = torch.cat(clss, dim=1).reshape(B, -1, ncls).permute(0, 2, 1)       # (B, C+1, N)
@@ -131,6 +168,15 @@ def forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes=
                                 anchor_boxes, nms_threshold=nms_thresh, force_suppress=force_suppress,
                                 nms_topk=nms_topk)
 
+    ce = float(-(torch.log(cls_prob.detach().gather(1, ct.clamp(min=0).unsqueeze(1)).squeeze(1) + 1e-8)
+                 * valid.to(dtype)).sum() / nvalid)
+    out = dict(cls_prob=cls_prob.detach(), loc_loss=loc_loss.detach(), cls_label=cls_t, det=det, CrossEntropy=ce,
+               SmoothL1=float(loc_loss.detach().sum()) / nvalid, params=P, anchors=anchor_boxes,
+               loc_preds=loc_preds.detach(), cls_preds=cls_preds.detach())
+    if not with_seg:
+        out["objective"] = obj_cls + obj_loc
+        return out
+
     # segmentation decoder (multitask_symbol_builder.py:541-589)
     r3 = conv_bn(P, conv_bn(P, res3.detach(), "res3_reduced", 0), "res3_reduced2", 1)
     r4 = conv_bn(P, conv_bn(P, res4.detach(), "res4_reduced", 0), "res4_reduced2", 1)
@@ -149,17 +195,11 @@ def forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes=
     slogp = torch.log_softmax(s4, dim=1).gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1)
     seg_ce_sum = -(slogp * svalid.to(dtype)).sum()
     obj_seg = seg_ce_sum * (4.0 / float(s4.shape[2] * s4.shape[3]))
-
-    objective = obj_cls + obj_loc + obj_seg
-    # readouts of train/metric.py:27-46 (+ seg cross-entropy)
-    ce = float(-(torch.log(cls_prob.gather(1, ct.clamp(min=0).unsqueeze(1)).squeeze(1) + 1e-8)
-                 * valid.to(dtype)).sum() / nvalid)
-    seg_ce = float(-(torch.log(seg_prob.gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1) + 1e-8)
-                     * svalid.to(dtype)).sum() / max(1, int(svalid.sum())))
-    return dict(cls_prob=cls_prob.detach(), loc_loss=loc_loss.detach(), cls_label=cls_t, det=det,
-                seg_out=seg_prob.detach(), CrossEntropy=ce, SmoothL1=float(loc_loss.sum()) / nvalid,
-                SegCrossEntropy=seg_ce, objective=objective, params=P, anchors=anchor_boxes,
-                loc_preds=loc_preds.detach(), cls_preds=cls_preds.detach())
+    out["objective"] = obj_cls + obj_loc + obj_seg
+    out["seg_out"] = seg_prob.detach()
+    out["SegCrossEntropy"] = float(-(torch.log(seg_prob.detach().gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1) + 1e-8)
+                                     * svalid.to(dtype)).sum() / max(1, int(svalid.sum())))
+    return out
 
 
 def export_params(graph):
@@ -171,7 +211,7 @@ def export_params(graph):
             v = v[:19, :, :, :19].transpose(0, 3, 1, 2)
         elif v.ndim == 4:                            # [Cout][R][S][Cin_phys] -> [Cout][Cin][R][S]
             v = v.transpose(0, 3, 1, 2)
-            if p.name == "conv0_weight":
+            if p.name in ("conv0_weight", "conv1_1_weight"):
                 v = v[:, :3]
             if p.name == "score4_conv_weight":
                 pass

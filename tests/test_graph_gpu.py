@@ -145,3 +145,66 @@ def test_test_graph_matches_training_graph_outputs(gpu_device):
     rows, segp = det.detect(torch.from_numpy(data).cuda())
     assert len(rows) == 2 and rows[0].shape[1] == 7 and (rows[0][:, 0] >= 0).all()
     assert segp.shape == (2, 19, 64, 64)
+
+
+def _vgg_case(kind, size, batch, classes):
+    from dspnet_amd.symbol.multitask_symbol_factory import get_det_symbol_train
+    dev = torch.device("cuda", 0)
+    f = get_det_symbol_train if kind == "det" else get_multi_symbol_train
+    net = f("vgg16_reduced", size, num_classes=classes, batch_size=batch, device=dev, seed=3)
+    gen = synthetic.rng(77)
+    data = synthetic.images(batch, size, size, gen)
+    lab = synthetic.det_labels(batch, gen=gen, num_classes=classes, height=size, width=size, first_empty=False)
+    seg = synthetic.seg_labels(batch, size, size, gen=gen) if kind != "det" else None
+    solver = MultiTaskSolver(net)
+    net.data.data.copy_(torch.from_numpy(data).to(dev))
+    net.label_det.data.copy_(torch.from_numpy(lab).to(dev))
+    if seg is not None:
+        net.label_seg.data.copy_(torch.from_numpy(seg).to(dev))
+    return net, solver, data, lab, seg
+
+
+@pytest.mark.parametrize("kind,size,batch,classes", [("det", 300, 1, 20), ("multi", 320, 2, 8)])
+def test_vgg16_reduced_graphs_match_cpu_restatement(gpu_device, kind, size, batch, classes):
+    """BASELINE.json configs[0] (vgg16_reduced SSD-300 single-task det, bs=1, 20 VOC classes: N = 2956 anchors
+    after the reference's [1:] slice of the 8732-anchor preset) and the build's vgg16_reduced multi-task wiring"""
+    net, solver, data, lab, seg = _vgg_case(kind, size, batch, classes)
+    solver.forward(); solver.backward(); torch.cuda.synchronize()
+    cfg = get_config("vgg16_reduced", size)
+    if kind == "det":
+        assert tuple(net.anchors.shape) == (1, 2956, 4)
+    anchors = net.anchors.cpu().numpy()
+    dev_targets = [net.target.loc_target.cpu().numpy(), net.target.loc_mask.cpu().numpy(),
+                   net.target.cls_target.cpu().numpy()]
+    mc.assert_target_equal(dev_targets, om.multibox_target(anchors, lab, net.target.cls_preds.data.cpu().numpy(),
+                                                           negative_mining_ratio=3))
+    ref = ot.forward_loss(ot.export_params(net.g), data, lab, seg, num_classes=classes, dtype=torch.float64,
+                          targets=dev_targets, config=cfg, with_seg=(kind != "det"))
+    np.testing.assert_array_equal(ref["anchors"], anchors)
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+    outs = [o.cpu().numpy() for o in net.outputs()]
+    assert rel(net.loc_preds.data.cpu().numpy(), ref["loc_preds"].numpy()) < 1e-4
+    assert rel(outs[0], ref["cls_prob"].numpy()) < 1e-4
+    assert rel(outs[1], ref["loc_loss"].numpy()) < 1e-4
+    np.testing.assert_array_equal(outs[3], om.multibox_detection(outs[0], net.loc_preds.data.cpu().numpy(), anchors,
+                                                                 nms_threshold=.5, nms_topk=400))
+    if kind != "det":
+        assert rel(outs[4], ref["seg_out"].numpy()) < 1e-4
+    m = MultiBoxMetric(); m.update(net)
+    names, vals = m.get()
+    for n, v in zip(names, vals):
+        if n in ref:
+            assert abs(v - ref[n]) <= 1e-4 * abs(ref[n]), (n, v, ref[n])
+    ref["objective"].backward()
+    num = den = 0.0
+    for p in net.g.param_order:
+        gref = ot.import_grad(p.name, ref["params"][p.name].grad)
+        gdev = p.grad.cpu().numpy()
+        gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
+        if p.name.endswith(("pred_conv_weight", "pred_conv_bias")):      # nothing but the loss below them
+            assert rel(gdev, gref) < 1e-3, p.name
+        num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2

@@ -317,3 +317,37 @@ def test_conv_input_sum_grad(gpu_device, case):
     y.backward(dy)
     got = fn.conv2d_input_sum_grad(nhwc(dy), wdev(w), (N, H, W, fn.pad4(Cin)), stride, pad, dil)
     close(got[:Cin].cpu().double(), x.grad.sum(dim=(0, 2, 3)), 1e-4)
+
+
+@pytest.mark.parametrize("kh,kw,ph,pw,stride", [(1, 7, 0, 3, 1), (7, 1, 3, 0, 1), (1, 3, 0, 1, 1), (3, 1, 1, 0, 1),
+                                                (5, 5, 2, 2, 1), (3, 3, 0, 0, 2)])
+def test_conv_inception_kernel_classes(gpu_device, kh, kw, ph, pw, stride):
+    """asymmetric kernels / pads of symbol/inceptionv3.py (1x7, 7x1, 1x3, 3x1, 5x5 p2, 3x3 s2 p0)"""
+    g = torch.Generator().manual_seed(kh * 10 + kw)
+    N, H, W, Cin, Cout = 2, 17, 17, 32, 48
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) / np.sqrt(Cin * kh * kw)).requires_grad_()
+    y_ref = F.conv2d(x, w, stride=stride, padding=(ph, pw))
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    xd, wd_, dyd = nhwc(x.detach()), wdev(w.detach()), nhwc(dy)
+    y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=(ph, pw))
+    close(nchw(y, Cout), y_ref.detach())
+    dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=(ph, pw))
+    close(nchw(dx, Cin), x.grad)
+    dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=(ph, pw))
+    close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad)
+
+
+def test_maxpool_full_convention(gpu_device):
+    """pooling_convention='full' (symbol/vgg16_reduced.py:40-42): ceil output size, clipped windows"""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 8, 75, 75, generator=g, dtype=torch.float64, requires_grad=True)
+    y_ref = F.max_pool2d(x, 2, 2, ceil_mode=True)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    xd = nhwc(x.detach())
+    y = fn.maxpool_forward(xd, 2, 2, 0, out=torch.empty(2, 38, 38, 8, device="cuda"))
+    assert torch.equal(nchw(y), y_ref.detach().float().double())
+    dx = fn.maxpool_backward(xd, y, nhwc(dy), 2, 2, 0)
+    close(nchw(dx), x.grad, 1e-6)
