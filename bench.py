@@ -130,8 +130,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DSPN_FORCE_DIST=1 runs the RCCL code path (init, bucketed async all-reduce, barrier) even at
+    # world_size 1, so that it can be exercised on a single-GPU box
+    use_dist = world > 1 or os.environ.get("DSPN_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
@@ -143,7 +148,7 @@ def main():
 
     B, S = args.batch, args.size
     net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=dev, seed=0)
-    solver = MultiTaskSolver(net, process_group=None, world_size=world)
+    solver = MultiTaskSolver(net, process_group=None, world_size=world, force_reducer=use_dist)
     gen = synthetic.rng(233 + rank)
     solver.set_batch(torch.from_numpy(synthetic.images(B, S, S, gen)).to(dev),
                      torch.from_numpy(synthetic.det_labels(B, gen=gen, height=S, width=S)).to(dev),
@@ -153,7 +158,7 @@ def main():
     flops_3x = 3.0 * sum(n.flops_fwd for n in convs)                    # SURVEY.md 8(d) convention
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +176,7 @@ def main():
     dt = time.perf_counter() - t0
     lib.dspn_profile_enable(0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -219,7 +224,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -66,7 +66,7 @@ class GradBucketReducer:
 
 class MultiTaskSolver:
     def __init__(self, net, learning_rate=0.0005, momentum=0.9, wd=0.0005, process_group=None,
-                 world_size=1, bucket_mb=16.0):
+                 world_size=1, bucket_mb=16.0, force_reducer=False):
         self.net, self.g = net, net.g
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
@@ -80,7 +80,8 @@ class MultiTaskSolver:
                     owner[v.name] = min(owner[v.name], idx)
         params = [(p.name, p.offset, (p.size + 3) // 4 * 4) for p in g.param_order]
         self.buckets = plan_buckets(params, owner, g.arena.numel(), int(bucket_mb * (1 << 20) / 4))
-        self.reducer = GradBucketReducer(g.grad_arena, self.buckets, process_group) if world_size > 1 else None
+        self.reducer = (GradBucketReducer(g.grad_arena, self.buckets, process_group)
+                        if (world_size > 1 or force_reducer) else None)
 
     def set_batch(self, data, label_det, label_seg):
         """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4)"""
