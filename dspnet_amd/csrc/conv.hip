@@ -41,7 +41,7 @@ struct ConvGeom {
   int Cout;
   long long obs;                   // output batch stride (floats)
   int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
-  int flags;                       // 1 bias, 2 relu, 4 accumulate
+  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out)
   int dense;                       // output address = m*ldc (no decomposition needed)
   int dbg;                         // timing-only ablation bits (dspn_debug_set), 0 in production
   unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
@@ -59,7 +59,7 @@ template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
-    const int ksteps_per_split, float *__restrict__ slab) {
+    const int ksteps_per_split, float *__restrict__ slab, const float *__restrict__ residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per k-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
                 ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
         }
         float v = acc[i][j][r] + bv;
+        if (g.flags & 8) v += residual[off];
         if (accum) v += out[off];
         if (relu) v = v > 0.f ? v : 0.f;
         out[off] = v;
@@ -530,7 +531,7 @@ __global__ void weight_transpose_kernel(const float *__restrict__ w, float *__re
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
 __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
                                        float *__restrict__ out, long long M, int Cout, int ldc, int splits,
-                                       int flags) {
+                                       int flags, const float *__restrict__ residual) {
   const long long total = M * Cout;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -539,6 +540,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
     float v = slab[i];
     for (int k = 1; k < splits; ++k) v += slab[(long long)k * total + i];
     if (flags & 1) v += bias[co];
+    if (flags & 8) v += residual[m * ldc + co];
     float *o = out + m * ldc + co;
     if (flags & 4) v += *o;
     if (flags & 2) v = v > 0.f ? v : 0.f;
@@ -551,7 +553,7 @@ struct SplitWs { float *ptr; size_t bytes; };
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
 int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-                   hipStream_t s, int splits, int ksteps_per_split, float *slab) {
+                   hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
@@ -567,12 +569,12 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
   {
     dspn::ProfScope prof(0, s);
     hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt,
-                       ksteps_per_split, splits > 1 ? slab : nullptr);
+                       ksteps_per_split, splits > 1 ? slab : nullptr, residual);
     if (splits > 1) {
       const long long total = M * g.Cout;
       const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
       hipLaunchKernelGGL(nt_split_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, bias, out, M, g.Cout,
-                         g.ldc, splits, g.flags);
+                         g.ldc, splits, g.flags, residual);
     }
   }
   return dspn::check_launch("conv_nt");
@@ -580,17 +582,17 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-              hipStream_t s, int splits, int ksteps_per_split, float *slab) {
+              hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   if (((g.Cin >> 2) & 7) == 0)
-    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab);
-  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab);
+    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
 }
 
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
 // leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
 int g_debug_bits = 0;
 int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g_in,
-                hipStream_t s, SplitWs ws) {
+                hipStream_t s, SplitWs ws, const float *residual = nullptr) {
   ConvGeom g = g_in;
   g.dbg = g_debug_bits;
   {
@@ -620,10 +622,10 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
     splits = (nk + per - 1) / per;
   }
   switch (cfg) {
-    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr);
-    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
-    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
-    default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr);
+    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   }
 }
 
@@ -659,7 +661,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   return sizeof(float) * 32 * (size_t)capped;
 }
 
-static int conv2d_forward_one(const float *x, const float *w, const float *bias, float *y, int N,
+static int conv2d_forward_one(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -681,9 +683,9 @@ static int conv2d_forward_one(const float *x, const float *w, const float *bias,
   g.obs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * g.ldc;
   g.OW = Wo; g.osh = 1; g.osw = 1; g.ooh = 0; g.oow = 0;
   g.dense = (g.obs == (long long)Ho * Wo * g.ldc);
-  g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0);
+  g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0);
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
-                     SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0});
+                     SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
 
 // images per launch such that no per-launch tensor reaches 2 GiB (32-bit buffer offsets, bit 31 = out of range)
@@ -693,7 +695,7 @@ static int batch_chunk(int N, long long bytes_per_image) {
   return (int)std::max<long long>(1, lim / bytes_per_image);
 }
 
-int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y, int N,
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -704,7 +706,8 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, f
   const int nb = batch_chunk(N, 4ll * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, w, bias, y + (long long)n0 * ybs, n, H, W,
+    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, w, bias,
+                                      residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
     if (rc) return rc;

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__re
   const bool act = rl < RL && c4 < C4;
   if (act) {
     const float4 K = x[c4];
+#pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += RL) {
       const float4 v = x[r * C4 + c4];
       const float a = v.x - K.x, b = v.y - K.y, c = v.z - K.z, d = v.w - K.w;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
     const float4 m = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 rs = reinterpret_cast<const float4 *>(rstd)[c4];
     const float4 sa = scale[c4], sb = shift[c4];
+#pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += RL) {
       const float4 xv = x[r * C4 + c4];
       float4 g = dy[r * C4 + c4];

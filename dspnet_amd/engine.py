@@ -243,7 +243,7 @@ class Conv(Node):
     """mx.sym.Convolution (+ bias) (+ ReLU epilogue); weight [Cout, R, S, Cin_phys]"""
 
     def __init__(self, g, x, name, num_filter, kernel, stride=1, pad=0, dilate=1, no_bias=True, relu=False,
-                 init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None):
+                 init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None, residual=None, out_name=None):
         N, H, W, Cin = x.shape
         kh, kw = fn._hw(kernel)
         ph, pw = fn._hw(pad)
@@ -256,7 +256,11 @@ class Conv(Node):
         self.b = None if no_bias else g.param(name + "_bias", (num_filter,), init_zeros)
         Ho, Wo = fn.conv_out_size(H, kh, stride, ph, dilate), fn.conv_out_size(W, kw, stride, pw, dilate)
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
-        self.out = g.tensor((N, Ho, Wo, ldc), name + "_out")
+        self.out = g.tensor((N, Ho, Wo, ldc), out_name or (name + "_out"))
+        # residual: a tensor of the output's shape added in the conv epilogue (`conv3 + shortcut`,
+        # symbol/resnet.py:51); its gradient is the output gradient itself
+        self.residual = residual
+        assert residual is None or residual.shape == self.out.shape
         self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device)
         # algorithmic FLOPs per batch (direct-conv count, logical channels)
         self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
@@ -264,7 +268,8 @@ class Conv(Node):
 
     def forward(self):
         fn.conv2d_forward(self.x.data, self.w.data, None if self.b is None else self.b.data, self.stride,
-                          self.pad, self.dil, relu=self.relu, out=self.out.data)
+                          self.pad, self.dil, relu=self.relu, out=self.out.data,
+                          residual=None if self.residual is None else self.residual.data)
 
     def backward(self):
         if not self.out._gw:
@@ -272,6 +277,8 @@ class Conv(Node):
         dy = self.out.grad
         if self.relu:
             fn.relu_backward(self.out.data, dy, dx=dy)
+        if self.residual is not None and self.residual.requires_grad:
+            self.residual.give_grad(dy)
         if self.b is not None:
             fn.colsum(dy, self.cout, out=self.b.grad)
         fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)

@@ -20,7 +20,7 @@ _sz = _c.c_size_t
 _lib.register({
     "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_debug_set": (_i, [_i]),
-    "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
@@ -106,7 +106,7 @@ def zeros(*shape, device=None):
 
 
 # ------------------------------------------------------------------ convolution
-def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False):
+def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout)"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
@@ -118,7 +118,8 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
         out = zeros(N, Ho, Wo, ldc, device=x.device) if ldc != Cout else empty(N, Ho, Wo, ldc, device=x.device)
     ldc = out.shape[3]
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
-    check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(out), N, H, W, Cin, Cout, R, S, stride,
+    assert residual is None or residual.shape == out.shape
+    check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S, stride,
                                       ph, pw, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), ptr(ws), ws.numel(),
                                       stream()), "conv2d_forward")
     return out

@@ -35,14 +35,16 @@ extern "C" {
 /* y[n,ho,wo,k] = sum x[n,ho*stride-pad_h+r*dil, wo*stride-pad_w+s*dil, c] w[k,r,s,c] (+bias[k]) (relu).
  * R x S kernels with separate pads cover the inception 1x7 / 7x1 / 1x3 / 3x1 classes (symbol/inceptionv3.py).
  * y pixel stride y_ldc (0 = Cout), batch stride y_batch_stride (0 = dense).
- * accumulate != 0: y += result (before relu). bias may be NULL.
+ * accumulate != 0: y += result (before relu). bias may be NULL.  residual (may be NULL): a tensor laid out
+ * like y that is added in the epilogue -- the `conv3 + shortcut` of a residual unit (symbol/resnet.py:51)
+ * without a separate pass.
  * workspace (optional, may be NULL): scratch for split-K partial tiles, used when the output grid is
  * too small to fill the chip (SSD heads / extras); any size, dspn_conv2d_split_workspace_bytes() is
  * always enough.  Partials are summed in a fixed order (deterministic). */
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
 /* timing-only ablation switches of the conv kernel (results are WRONG when non-zero); 0 = production */
 int dspn_debug_set(int bits);
-int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, float *y,
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
                             int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                             long long y_batch_stride, int y_ldc, int relu, int accumulate,

@@ -99,12 +99,12 @@ def test_forward_backward_matches_cpu_restatement(gpu_device):
         emax[p.name], el2[p.name] = rel(gdev, gref), l2(gdev, gref)
         num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
     print("largest gradient L2 errs", sorted(el2.items(), key=lambda kv: -kv[1])[:5], "global", (num / den) ** 0.5)
-    # Everything downstream of the last backbone ReLU (heads, extras' last layers, the whole seg decoder and
-    # the last residual unit's final conv) must agree element-wise.  Below that, an fp32 and an fp64 forward
-    # disagree on the sign of ~1e-4 of the pre-activations that sit within rounding of zero; each such
-    # ReLU flip changes individual gradient entries by O(1), so the backbone is held to an L2 bound.
-    top = [n for n in emax if n.startswith(("score", "res3_", "res4_", "res5_", "_plus", "multi_feat", "stage4_unit3_conv3"))]
-    assert len(top) > 40
+    # Parameters with no ReLU between them and the losses (the SSD head convs and the whole ReLU-free seg
+    # decoder) must agree element-wise.  Everywhere else an fp32 and an fp64 forward disagree on the sign of
+    # ~1e-4 of the pre-activations that sit within rounding of zero; each such ReLU flip changes individual
+    # gradient entries by O(1), so those tensors are held to an L2 bound.
+    top = [n for n in emax if n.startswith(("score", "res3_", "res4_", "res5_")) or "_pred_conv_" in n]
+    assert len(top) > 35
     for name in top:
         assert emax[name] < 1e-3, (name, emax[name])
     for name, e in el2.items():
