@@ -41,7 +41,7 @@ struct ConvGeom {
   int Cout;
   long long obs;                   // output batch stride (floats)
   int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
-  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out)
+  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal
   int dense;                       // output address = m*ldc (no decomposition needed)
   int dbg;                         // timing-only ablation bits (dspn_debug_set), 0 in production
   unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
@@ -251,33 +251,70 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     }
     return;
   }
-  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4;
+  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
+  // Output tile -> LDS (the mainloop's last barrier has retired every fragment read) -> rows of
+  // float4: a 128-wide row leaves as one 512-B contiguous store per 32 lanes, and the residual /
+  // accumulate operands are read the same way, instead of 64 dword stores of two 128-B segments.
+  constexpr int SLD = BN + 4;
+  static_assert(BM * SLD <= 2 * (BM + BN) * kLdsRow, "output tile must fit in the mainloop's LDS");
+  float *st = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn + j * 32 + (lane & 31);
-    const bool cv = co < g.Cout;
-    const float bv = (has_bias && cv) ? bias[co] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (!cv || m >= M) continue;
-        long long off;
-        if (g.dense) {
-          off = (long long)m * g.ldc + co;
-        } else {
-          const int hw = g.Hg * g.Wg;
-          const int n = m / hw, rem = m - n * hw;
-          const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-          off = (long long)n * g.obs +
-                ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
-        }
-        float v = acc[i][j][r] + bv;
-        if (g.flags & 8) v += residual[off];
-        if (accum) v += out[off];
-        if (relu) v = v > 0.f ? v : 0.f;
-        out[off] = v;
+      for (int r = 0; r < 16; ++r)
+        st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+  __syncthreads();
+  constexpr int C4 = BN / 4, RPP = kThreads / C4;   // float4 columns per row, rows per pass
+  const int c4 = tid % C4, er0 = tid / C4;
+  const int co = n0 + c4 * 4;
+  if (co >= g.Cout) return;
+  const bool vec = (g.flags & 16) && co + 3 < g.Cout;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
+  }
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int ml = er0 + p * RPP, m = m0 + ml;
+    if (m >= M) break;
+    long long off;
+    if (g.dense) {
+      off = (long long)m * g.ldc + co;
+    } else {
+      const int hw = g.Hg * g.Wg;
+      const int n = m / hw, rem = m - n * hw;
+      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+      off = (long long)n * g.obs +
+            ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+    }
+    const float4 t = *reinterpret_cast<const float4 *>(st + ml * SLD + c4 * 4);
+    float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
+    if (vec) {
+      if (has_res) {
+        const float4 q = *reinterpret_cast<const float4 *>(residual + off);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      if (accum) {
+        const float4 q = *reinterpret_cast<const float4 *>(out + off);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (co + e >= g.Cout) break;
+        float x = v[e];
+        if (has_res) x += residual[off + e];
+        if (accum) x += out[off + e];
+        if (relu) x = x > 0.f ? x : 0.f;
+        out[off + e] = x;
       }
     }
   }
@@ -595,6 +632,10 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
                 hipStream_t s, SplitWs ws, const float *residual = nullptr) {
   ConvGeom g = g_in;
   g.dbg = g_debug_bits;
+  // float4 epilogue needs 16-byte aligned rows in every operand it touches
+  if (g.ldc % 4 == 0 && g.obs % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0))
+    g.flags |= 16;
   {
     const long long ib = 4ll * g.N * g.Hin * g.Win * g.Cin, wb = 4ll * g.Cout * g.WTAPS * g.Cin;
     if (ib >= (1ll << 31) || wb >= (1ll << 31))
