@@ -447,19 +447,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
-  // slab[split][k][J]
+  // slab[split][k][J]: the tile goes through LDS (free after the mainloop's last barrier) and leaves as
+  // float4 rows along J (J % 4 == 0 because Cin % 4 == 0)
   float *o = slab + (long long)split * g.Cout * J;
+  constexpr int SLD = BN + 4;
+  float *st = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int jj = j0 + wn + j * 32 + (lane & 31);
-    if (jj >= J) continue;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (k < g.Cout) o[(long long)k * J + jj] = acc[i][j][r];
-      }
+      for (int r = 0; r < 16; ++r)
+        st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+  __syncthreads();
+  constexpr int C4 = BN / 4, RPP = kThreads / C4;
+  const int c4 = tid % C4, er0 = tid / C4;
+  const int jj = j0 + c4 * 4;
+  if (jj >= J) return;
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int kl = er0 + p * RPP, k = k0 + kl;
+    if (k >= g.Cout) break;
+    *reinterpret_cast<float4 *>(o + (long long)k * J + jj) = *reinterpret_cast<const float4 *>(st + kl * SLD + c4 * 4);
   }
 }
 
@@ -650,6 +659,9 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
   if (g.Cout <= 32) cfg = tiles(256, 32) >= 512 ? 3 : 2;
   else cfg = (g.Cout > 64 && tiles(128, 128) >= 512) ? 0 : 2;
+  // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
+  // 128-wide column tile: 64-wide columns cut the padding to < 64
+  if (cfg == 0 && (g.Cout + 63) / 64 * 64 < (g.Cout + 127) / 128 * 128) cfg = 1;
   if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
   static const int bm_[4] = {128, 128, 64, 256}, bn_[4] = {128, 64, 64, 32};
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
@@ -671,18 +683,36 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
 }
 
 struct WgradPlan { int bm; int splits; int pps; };
-// Weight-gradient decomposition: tile height by Cout, split-K over pixels for >= ~4 workgroups per CU,
-// at least 128 pixels (4 k-steps) per split, at most 256 splits.
+// Weight-gradient decomposition: tile height by Cout, split-K over pixels.  The number of splits is
+// the one that minimises a small cost model: workgroups run in rounds of `slots` (workgroups the chip
+// holds at once, set by LDS per workgroup), each costs its pixels plus a fixed prologue/epilogue, and
+// every split adds one slab to write and re-read.  (A plain "about 1024 workgroups" rule lands just
+// past a round boundary for the 3x3 layers: 36 tiles x 29 splits = 1044 = 2.04 rounds.)
 WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   WgradPlan p;
   p.bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+  if (p.bm == 128 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) p.bm = 64;   // less row padding
   const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + 127) / 128);
-  long long want = std::min<long long>((1024 + tiles - 1) / tiles, 256);
+  const long long lds = 4ll * std::max(2 * kBK * (p.bm + 128), p.bm * 132);
+  const long long slots = 256 * std::min<long long>(8, (160ll << 10) / lds);
   // every tap re-reads the same pixels of x: keep one split's share of x within the Infinity Cache /
   // L2 so that only the first tap's workgroups fetch it from HBM
-  if (x_bytes > 0) want = std::max<long long>(want, (x_bytes + (32ll << 20) - 1) / (32ll << 20));
-  long long max_by_pix = std::max<long long>(1, P / 128);
-  long long splits = std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_pix), 1024));
+  long long s_min = 1;
+  if (x_bytes > 0) s_min = (x_bytes + (32ll << 20) - 1) / (32ll << 20);
+  const long long s_max = std::max<long long>(1, std::min<long long>(P / 128, 1024));
+  s_min = std::min(s_min, s_max);
+  const double flop_per_pix = 2.0 * p.bm * 128, slot_rate = 120e12 / (double)slots, ovh_pix = 160;
+  double best = 1e30;
+  long long splits = s_min;
+  for (long long sp = s_min; sp <= s_max; ++sp) {
+    const long long pps = ((P + sp - 1) / sp + kBK - 1) / kBK * kBK;
+    const long long real = (P + pps - 1) / pps;
+    const long long rounds = (tiles * real + slots - 1) / slots;
+    const double t = (double)rounds * ((double)pps + ovh_pix) * flop_per_pix / slot_rate +
+                     (double)real * Cout * J * 8.0 / 4e12;
+    if (t < best * 0.999) { best = t; splits = sp; }
+    if (tiles * sp > 8 * slots) break;
+  }
   long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
   p.splits = (int)((P + pps - 1) / pps);
   p.pps = (int)pps;
@@ -859,9 +889,11 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
   if (P <= 0 || J <= 0 || Cout <= 0) return 0;
-  // upper bound over the optional x-footprint rule (x <= 2 GiB -> at most 64 extra splits)
-  const size_t a = (size_t)wgrad_plan(P, Cout, J).splits, b = (size_t)wgrad_plan(P, Cout, J, 4ll * N * Cin * (long long)Ho * Wo * 4).splits;
-  return sizeof(float) * std::max(a, std::max(b, (size_t)64)) * Cout * J;
+  // the plan depends on (P, Cout, J) and, for R*S > 1, on the stride (1 or 2) through the x footprint
+  size_t m = (size_t)wgrad_plan(P, Cout, J).splits;
+  for (int stride = 1; stride <= 2; ++stride)
+    m = std::max(m, (size_t)wgrad_plan(P, Cout, J, 4ll * P * Cin * stride * stride).splits);
+  return sizeof(float) * m * Cout * J;
 }
 
 static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
@@ -881,7 +913,7 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   }
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
-  const WgradPlan plan = wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * N * H * W * Cin : 0);
+  const WgradPlan plan = wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0);
   const int BM = plan.bm, BN = 128;
   const int kt = (Cout + BM - 1) / BM, jt = (J + BN - 1) / BN;
   const long long splits = plan.splits;
@@ -891,7 +923,7 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
-  const size_t lds = sizeof(float) * 2 * kBK * (BM + BN);
+  const size_t lds = sizeof(float) * std::max(2 * kBK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
   dspn::ProfScope prof(1, s);
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \

@@ -308,8 +308,66 @@ __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__res
   }
 }
 
+// ------------------------------------------------------------------ tap-expanded convolution
+// A stride-1 RxS convolution with very few output channels (score3_conv: 3328 -> 19) starves the
+// 32-wide MFMA column dimension.  It is computed instead as a 1x1 convolution with Cout*R*S output
+// channels (the weight [Cout][R][S][Cin] read as [(Cout*R*S)][Cin], no re-layout) followed by a
+// shifted sum over taps; the backward pass spreads dy into the same (co, tap) channel layout and runs
+// the 1x1 weight-gradient on it.
+//   y[n,h,w,co] = bias[co] + sum_{r,s} z[n, h + r - ph, w + s - pw, co*R*S + r*S + s]
+__global__ void tap_sum_kernel_(const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ y,
+                                int H, int W, int Cout, int ldy, int ldz, int R, int S, int ph, int pw,
+                                long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % ldy);
+    long long t = i / ldy;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    float acc = 0.f;
+    if (co < Cout) {
+      for (int r = 0; r < R; ++r) {
+        const int hh = h + r - ph;
+        if ((unsigned)hh >= (unsigned)H) continue;
+        for (int q = 0; q < S; ++q) {
+          const int ww = w + q - pw;
+          if ((unsigned)ww >= (unsigned)W) continue;
+          acc += z[((n * H + hh) * W + ww) * ldz + co * R * S + r * S + q];
+        }
+      }
+      if (bias) acc += bias[co];
+    }
+    y[i] = acc;
+  }
+}
+//   dz[n,h,w,co*R*S + r*S + s] = dy[n, h - (r - ph), w - (s - pw), co]   (0 outside / in pad channels)
+__global__ void tap_spread_kernel_(const float *__restrict__ dy, float *__restrict__ dz, int H, int W, int Cout,
+                                   int ldy, int ldz, int R, int S, int ph, int pw, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % ldz);
+    long long t = i / ldz;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    float v = 0.f;
+    if (ch < Cout * R * S) {
+      const int co = ch / (R * S), tap = ch - co * R * S;
+      const int r = tap / S, q = tap - r * S;
+      const int hh = h - (r - ph), ww = w - (q - pw);
+      if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = dy[((n * H + hh) * W + ww) * ldy + co];
+    }
+    dz[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------ pooling
-__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W,
+// optional argmax record: position r*k+s of the FIRST maximum of each window in (h, w) scan order, one
+// byte per element (255 = no finite maximum); the backward pass then needs neither x nor y
+template <bool IDX>
+__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+                                   uchar4 *__restrict__ argmax, int H, int W,
                                    int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -319,6 +377,7 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
     const int ho = (int)(t % Ho);
     const long long n = t / Ho;
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int ix = 255, iy = 255, iz = 255, iw = 255;
     for (int r = 0; r < k; ++r) {
       const int h = ho * stride - pad + r;
       if ((unsigned)h >= (unsigned)H) continue;
@@ -326,11 +385,44 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
         const int w = wo * stride - pad + s;
         if ((unsigned)w >= (unsigned)W) continue;
         const float4 v = x[((n * H + h) * W + w) * C4 + c4];
-        m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
-        m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+        const int pos = r * k + s;
+        if (v.x > m.x) { m.x = v.x; ix = pos; }
+        if (v.y > m.y) { m.y = v.y; iy = pos; }
+        if (v.z > m.z) { m.z = v.z; iz = pos; }
+        if (v.w > m.w) { m.w = v.w; iw = pos; }
       }
     }
     y[i] = m;
+    if constexpr (IDX) argmax[i] = make_uchar4((unsigned char)ix, (unsigned char)iy, (unsigned char)iz, (unsigned char)iw);
+  }
+}
+
+// gather form over the argmax record: every input pixel visits the (at most ceil(k/stride)^2) windows
+// covering it in a fixed order and takes dy where the record names its position.  No atomics.
+__global__ void maxpool_bwd_idx_kernel(const uchar4 *__restrict__ argmax, const float4 *__restrict__ dy,
+                                       float4 *__restrict__ dx, int H, int W, int C4, int k, int stride,
+                                       int pad, int Ho, int Wo, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ho_lo = (h + pad - k + stride) / stride; if (h + pad - k + 1 <= 0) ho_lo = 0;
+    int wo_lo = (w + pad - k + stride) / stride; if (w + pad - k + 1 <= 0) wo_lo = 0;
+    const int ho_hi = min(Ho - 1, (h + pad) / stride), wo_hi = min(Wo - 1, (w + pad) / stride);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const long long oi = ((n * Ho + ho) * Wo + wo) * C4 + c4;
+        const int pos = (h - (ho * stride - pad)) * k + (w - (wo * stride - pad));
+        const uchar4 a = argmax[oi];
+        const float4 d = dy[oi];
+        g.x += a.x == pos ? d.x : 0.f; g.y += a.y == pos ? d.y : 0.f;
+        g.z += a.z == pos ? d.z : 0.f; g.w += a.w == pos ? d.w : 0.f;
+      }
+    dx[i] = g;
   }
 }
 
@@ -744,14 +836,47 @@ int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, vo
   return dspn::check_launch("transpose_bnc");
 }
 
-int dspn_maxpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride,
-                             int pad, int Ho, int Wo, void *stream) {
+int dspn_tap_sum_f32(const float *z, const float *bias, float *y, int N, int H, int W, int Cout, int ldy,
+                     int ldz, int R, int S, int pad_h, int pad_w, void *stream) {
+  DSPN_REQUIRE(z && y && N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldz >= Cout * R * S,
+               "tap_sum: bad argument");
+  const long long total = (long long)N * H * W * ldy;
+  hipLaunchKernelGGL(tap_sum_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), z, bias, y, H, W,
+                     Cout, ldy, ldz, R, S, pad_h, pad_w, total);
+  return dspn::check_launch("tap_sum");
+}
+int dspn_tap_spread_f32(const float *dy, float *dz, int N, int H, int W, int Cout, int ldy, int ldz, int R,
+                        int S, int pad_h, int pad_w, void *stream) {
+  DSPN_REQUIRE(dy && dz && N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldz >= Cout * R * S,
+               "tap_spread: bad argument");
+  const long long total = (long long)N * H * W * ldz;
+  hipLaunchKernelGGL(tap_spread_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), dy, dz, H, W,
+                     Cout, ldy, ldz, R, S, pad_h, pad_w, total);
+  return dspn::check_launch("tap_spread");
+}
+int dspn_maxpool_forward_f32(const float *x, float *y, unsigned char *argmax, int N, int H, int W, int C, int k,
+                             int stride, int pad, int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && N > 0, "maxpool_forward: bad argument");
+  DSPN_REQUIRE(!argmax || k * k < 255, "maxpool_forward: argmax record needs k*k < 255");
   const long long total = (long long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k,
-                     stride, pad, Ho, Wo, total);
+  if (argmax)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       reinterpret_cast<uchar4 *>(argmax), H, W, C / 4, k, stride, pad, Ho, Wo, total);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       static_cast<uchar4 *>(nullptr), H, W, C / 4, k, stride, pad, Ho, Wo, total);
   return dspn::check_launch("maxpool_forward");
+}
+int dspn_maxpool_backward_argmax_f32(const unsigned char *argmax, const float *dy, float *dx, int N, int H,
+                                     int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {
+  DSPN_REQUIRE(argmax && dy && dx && N > 0 && C % 4 == 0, "maxpool_backward_argmax: bad argument");
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<const float4 *>(dy),
+                     reinterpret_cast<float4 *>(dx), H, W, C / 4, k, stride, pad, Ho, Wo, total);
+  return dspn::check_launch("maxpool_backward_argmax");
 }
 int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
                               int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {

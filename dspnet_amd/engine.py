@@ -243,7 +243,8 @@ class Conv(Node):
     """mx.sym.Convolution (+ bias) (+ ReLU epilogue); weight [Cout, R, S, Cin_phys]"""
 
     def __init__(self, g, x, name, num_filter, kernel, stride=1, pad=0, dilate=1, no_bias=True, relu=False,
-                 init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None, residual=None, out_name=None):
+                 init="xavier", cin_logical=None, cout_phys=None, input_sum_grad=None, residual=None, out_name=None,
+                 tap_expand=False):
         N, H, W, Cin = x.shape
         kh, kw = fn._hw(kernel)
         ph, pw = fn._hw(pad)
@@ -262,11 +263,23 @@ class Conv(Node):
         self.residual = residual
         assert residual is None or residual.shape == self.out.shape
         self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device)
+        # tap-expanded evaluation (few output channels, stride 1): 1x1 convolution to Cout*kh*kw channels
+        # on the same weight buffer + shifted sum over taps (include/dspn_nn.h, dspn_tap_sum_f32)
+        self.tap_expand = bool(tap_expand) and kh * kw > 1
+        if self.tap_expand:
+            assert stride == 1 and dilate == 1 and not relu and residual is None
+            assert (Ho, Wo) == (H, W), "tap expansion needs a 'same' convolution"
+            self.z = fn.zeros(N, H, W, fn.pad4(num_filter * kh * kw), device=g.device)   # also holds dz in backward
         # algorithmic FLOPs per batch (direct-conv count, logical channels)
         self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
+        if self.tap_expand:
+            cout, kh, kw, cin = self.w.shape
+            fn.conv2d_forward(self.x.data, self.w.data.view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z)
+            fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
+            return
         fn.conv2d_forward(self.x.data, self.w.data, None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
                           residual=None if self.residual is None else self.residual.data)
@@ -281,7 +294,13 @@ class Conv(Node):
             self.residual.give_grad(dy)
         if self.b is not None:
             fn.colsum(dy, self.cout, out=self.b.grad)
-        fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)
+        if self.tap_expand:
+            cout, kh, kw, cin = self.w.shape
+            fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
+            fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
+                            out=self.w.grad.view(cout * kh * kw, 1, 1, cin))
+        else:
+            fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                      out=self.input_sum_grad.grad)
@@ -359,16 +378,23 @@ class MaxPool(Node):
                 return fn.conv_out_size(h, kernel, stride, pad)
             return -(-(h + 2 * pad - kernel) // stride) + 1
         self.out = g.tensor((N, osz(H), osz(W), C), name)
+        # one byte per output element: which window position held the maximum (read by backward
+        # instead of x and y)
+        self.argmax = (torch.zeros(self.out.shape, dtype=torch.uint8, device=g.device)
+                       if x.requires_grad and kernel * kernel < 255 else None)
 
     def forward(self):
-        fn.maxpool_forward(self.x.data, self.k, self.s, self.p, out=self.out.data)
+        fn.maxpool_forward(self.x.data, self.k, self.s, self.p, out=self.out.data, argmax=self.argmax)
 
     def backward(self):
         if not self.out._gw or not self.x.requires_grad:
             return
         assert not self.x._gw, "maxpool input has a single consumer"
         dx, _ = self.x.grad_target()
-        fn.maxpool_backward(self.x.data, self.out.data, self.out.grad, self.k, self.s, self.p, dx=dx)
+        if self.argmax is not None:
+            fn.maxpool_backward_argmax(self.argmax, self.out.grad, self.x.shape, self.k, self.s, self.p, dx=dx)
+        else:
+            fn.maxpool_backward(self.x.data, self.out.data, self.out.grad, self.k, self.s, self.p, dx=dx)
 
 
 class AvgPool(Node):

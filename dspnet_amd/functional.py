@@ -44,7 +44,10 @@ _lib.register({
     "dspn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dspn_copy_block_f32": (_i, [_vp, _vp, _i, _ll, _i, _ll, _i, _i, _ll, _i, _i, _i, _vp]),
     "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_maxpool_backward_argmax_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -169,6 +172,24 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     return out
 
 
+def tap_sum(z, bias, cout, R, S, pad, out):
+    """z (N,H,W,ldz >= cout*R*S) -> out (N,H,W,ldy): shifted sum over taps (+ bias); pad channels of out zeroed"""
+    N, H, W, ldz = z.shape
+    ph, pw = _hw(pad)
+    check(L().dspn_tap_sum_f32(ptr(z), ptr(bias), ptr(out), N, H, W, cout, out.shape[3], ldz, R, S, ph, pw, stream()),
+          "tap_sum")
+    return out
+
+
+def tap_spread(dy, cout, R, S, pad, out):
+    """dy (N,H,W,ldy) -> out (N,H,W,ldz >= cout*R*S): gradient of tap_sum with respect to z"""
+    N, H, W, ldy = dy.shape
+    ph, pw = _hw(pad)
+    check(L().dspn_tap_spread_f32(ptr(dy), ptr(out), N, H, W, cout, ldy, out.shape[3], R, S, ph, pw, stream()),
+          "tap_spread")
+    return out
+
+
 def conv2d_input_sum_grad(dy, w, x_shape, stride=1, pad=0, dil=1, out=None):
     """sum over all pixels of the conv's data gradient, per input channel: (Cin,) without forming dx"""
     N, H, W, Cin = x_shape
@@ -284,14 +305,24 @@ def transpose_bnc(src, out=None):
 
 
 # ------------------------------------------------------------------ pooling / sampler
-def maxpool_forward(x, k, stride, pad, out=None):
+def maxpool_forward(x, k, stride, pad, out=None, argmax=None):
+    """argmax: optional uint8 tensor of the output's shape receiving the window position of each maximum"""
     N, H, W, C = x.shape
     if out is None:
         out = empty(N, conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad), C, device=x.device)
     Ho, Wo = out.shape[1], out.shape[2]     # a larger (pooling_convention='full') output is the caller's choice
-    check(L().dspn_maxpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
+    assert argmax is None or (argmax.dtype == torch.uint8 and argmax.shape == out.shape)
+    check(L().dspn_maxpool_forward_f32(ptr(x), ptr(out), ptr(argmax), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
           "maxpool_forward")
     return out
+
+
+def maxpool_backward_argmax(argmax, dy, x_shape, k, stride, pad, dx=None):
+    N, H, W, C = x_shape
+    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
+    check(L().dspn_maxpool_backward_argmax_f32(ptr(argmax), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
+                                               dy.shape[1], dy.shape[2], stream()), "maxpool_backward_argmax")
+    return dx
 
 
 def maxpool_backward(x, y, dy, k, stride, pad, dx=None):

@@ -266,8 +266,8 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
                                  anchors=anchor_boxes, loc_preds=loc_preds, cls_flat=cls_flat))
 
     # segmentation task (pyramid pooling module) (:541-589)
-    def conv_bn(x, name, nf, k, pad):
-        c = g.add(E.Conv(g, x, name, nf, k, 1, pad, init="maxdim")).out
+    def conv_bn(x, name, nf, k, pad, tap_expand=False):
+        c = g.add(E.Conv(g, x, name, nf, k, 1, pad, init="maxdim", tap_expand=tap_expand)).out
         return g.add(E.BatchNorm(g, c, name + "_bn", fix_gamma=True, eps=eps)).out
 
     res3_block = g.add(E.BlockGrad(g, res3, "res3_block")).out
@@ -288,7 +288,7 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     score3_concat = g.add(E.BilinearConcat(
         g, [score2_pool4_bn, score2_pool2_bn, score2_pool1_bn, res5_reduced_bn, res4_reduced2_bn,
             res3_reduced2_bn], "score3_concat", target_hw)).out
-    score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1)
+    score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1, tap_expand=True)
     score4_conv = g.add(E.Deconv4x4s2(g, score3_conv_bn, "score4_conv", seg_classes)).out
     if train:
         seg_out = g.add(SegSoftmaxOutput(g, score4_conv, seg_label, seg_classes))

@@ -125,11 +125,27 @@ int dspn_copy_block_f32(const float *src, float *dst, int samples, long long row
 /* (B, N, C) -> (B, C, N) */
 int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, void *stream);
 
+/* ---- Tap-expanded form of a stride-1 RxS convolution with few output channels (score3_conv,
+ * multitask_symbol_builder.py:583: 3328 -> 19, 3x3): run dspn_conv2d_forward_f32 as a 1x1 convolution
+ * with Cout*R*S output channels on the unchanged weight buffer ([Cout][R][S][Cin] == [(Cout*R*S)][Cin]),
+ * then tap_sum; in backward tap_spread builds the (co, tap) gradient for the 1x1 weight-gradient.
+ *   y[n,h,w,co]              = bias[co] + sum_{r,s} z[n, h+r-pad_h, w+s-pad_w, co*R*S + r*S + s]
+ *   dz[n,h,w,co*R*S + r*S+s] = dy[n, h-(r-pad_h), w-(s-pad_w), co]                                   */
+int dspn_tap_sum_f32(const float *z, const float *bias, float *y, int N, int H, int W, int Cout, int ldy,
+                     int ldz, int R, int S, int pad_h, int pad_w, void *stream);
+int dspn_tap_spread_f32(const float *dy, float *dz, int N, int H, int W, int Cout, int ldy, int ldz, int R,
+                        int S, int pad_h, int pad_w, void *stream);
+
 /* ---- Pooling (mx.sym.Pooling: symbol/resnet.py:98 max 3x3/2 pad 1;
  * multitask_symbol_builder.py:560-562 avg k x k / k) ----------------------------------------- */
-int dspn_maxpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride,
-                             int pad, int Ho, int Wo, void *stream);
-/* gradient goes to the first maximum of each window in (h, w) scan order */
+/* argmax (optional, N*Ho*Wo*C bytes): position r*k+s of the first maximum of each window in (h, w)
+ * scan order, 255 if none */
+int dspn_maxpool_forward_f32(const float *x, float *y, unsigned char *argmax, int N, int H, int W, int C, int k,
+                             int stride, int pad, int Ho, int Wo, void *stream);
+/* gradient goes to the first maximum of each window in (h, w) scan order; from the argmax record ... */
+int dspn_maxpool_backward_argmax_f32(const unsigned char *argmax, const float *dy, float *dx, int N, int H,
+                                     int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
+/* ... or recomputed from x and y */
 int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
                               int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
 int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int Ho, int Wo, void *stream);

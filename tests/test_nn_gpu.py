@@ -176,6 +176,11 @@ def test_maxpool_3x3_s2_p1(gpu_device):
     assert torch.equal(nchw(y), y_ref.detach().float().double())
     dx = fn.maxpool_backward(xd, y, nhwc(dy), 3, 2, 1)
     close(nchw(dx), x.grad, 1e-6)
+    # the argmax-record path (what the graph uses) must give the same bits
+    am = torch.zeros(y.shape, dtype=torch.uint8, device="cuda")
+    y2 = fn.maxpool_forward(xd, 3, 2, 1, argmax=am)
+    assert torch.equal(y2, y)
+    assert torch.equal(fn.maxpool_backward_argmax(am, nhwc(dy), xd.shape, 3, 2, 1), dx)
 
 
 @pytest.mark.parametrize("k", [1, 2, 4])
@@ -351,3 +356,31 @@ def test_maxpool_full_convention(gpu_device):
     assert torch.equal(nchw(y), y_ref.detach().float().double())
     dx = fn.maxpool_backward(xd, y, nhwc(dy), 2, 2, 0)
     close(nchw(dx), x.grad, 1e-6)
+    am = torch.zeros(y.shape, dtype=torch.uint8, device="cuda")
+    fn.maxpool_forward(xd, 2, 2, 0, out=torch.empty(2, 38, 38, 8, device="cuda"), argmax=am)
+    assert torch.equal(fn.maxpool_backward_argmax(am, nhwc(dy), xd.shape, 2, 2, 0), dx)
+
+
+@pytest.mark.parametrize("case", [(2, 12, 10, 40, 19, 3, 3, 1, 1), (1, 9, 9, 64, 5, 1, 7, 0, 3), (2, 64, 64, 256, 19, 3, 3, 1, 1)])
+def test_tap_expanded_conv_matches_direct(gpu_device, case):
+    """1x1 convolution to Cout*R*S channels + tap_sum == the RxS convolution; tap_spread + 1x1 wgrad == its
+    weight gradient (score3_conv's evaluation, engine.Conv(tap_expand=True))"""
+    N, H, W, Cin, Cout, R, S, ph, pw = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, R, S, generator=g, dtype=torch.float64) * 0.1).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    y_ref = F.conv2d(x, w, b, 1, (ph, pw))
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    y_ref.backward(dy)
+    xd, wd_, bd = nhwc(x.detach()), wdev(w.detach()), b.float().cuda()
+    ldz = fn.pad4(Cout * R * S)
+    z = fn.conv2d_forward(xd, wd_.view(Cout * R * S, 1, 1, wd_.shape[3]), None, 1, 0, 1,
+                          out=torch.empty(N, H, W, ldz, device="cuda"))
+    y = fn.tap_sum(z, bd, Cout, R, S, (ph, pw), out=torch.full((N, H, W, fn.pad4(Cout)), 7.0, device="cuda"))
+    close(nchw(y, Cout), y_ref.detach())
+    assert float(y[..., Cout:].abs().sum()) == 0.0          # pad channels are written as zeros
+    dz = fn.tap_spread(nhwc(dy), Cout, R, S, (ph, pw), out=torch.full((N, H, W, ldz), 7.0, device="cuda"))
+    assert float(dz[..., Cout * R * S:].abs().sum()) == 0.0
+    dw = fn.conv2d_wgrad(xd, dz, (Cout * R * S, 1, 1, wd_.shape[3]), 1, 0, 1).view(Cout, R, S, -1)
+    close(dw[..., :Cin].cpu().double().permute(0, 3, 1, 2), w.grad)
