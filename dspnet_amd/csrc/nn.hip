@@ -513,6 +513,59 @@ __global__ void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__rest
   }
 }
 
+// overlapping average pooling (symbol/inceptionv3.py:31,74,115: 3x3 stride 1 pad 1): the sum over the
+// in-image part of the window divided by k*k -- MXNet counts the padding (mshadow pool over a padded
+// tensor times 1/(ky*kx))
+__global__ void avgpool2d_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4,
+                                     int k, int stride, int pad, int Ho, int Wo, long long total) {
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < k; ++r) {
+      const int h = ho * stride - pad + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int q = 0; q < k; ++q) {
+        const int w = wo * stride - pad + q;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const float4 v = x[((n * H + h) * W + w) * C4 + c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    y[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+// gather form: every input pixel sums dy over the windows that contain it, in a fixed order
+__global__ void avgpool2d_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W, int C4,
+                                     int k, int stride, int pad, int Ho, int Wo, long long total, int accumulate) {
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    int ho_lo = (h + pad - k + stride) / stride; if (h + pad - k + 1 <= 0) ho_lo = 0;
+    int wo_lo = (w + pad - k + stride) / stride; if (w + pad - k + 1 <= 0) wo_lo = 0;
+    const int ho_hi = min(Ho - 1, (h + pad) / stride), wo_hi = min(Wo - 1, (w + pad) / stride);
+    float4 g = make_float4(0, 0, 0, 0);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const float4 v = dy[((n * Ho + ho) * Wo + wo) * C4 + c4];
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+      }
+    g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+    if (accumulate) { const float4 d = dx[i]; g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w; }
+    dx[i] = g;
+  }
+}
+
 // ------------------------------------------------------------------ bilinear sampler
 // GridGenerator(affine identity, target (Ho,Wo)) + BilinearSampler: normalised target coordinate
 // g = -1 + o*2/(O-1); source coordinate s = (g+1)*(I-1)/2; corners outside [0,I-1] contribute 0.
@@ -905,6 +958,27 @@ int dspn_avgpool_backward_f32(const float *dy, float *dx, int N, int H, int W, i
                      reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k,
                      Ho, Wo, total, accumulate);
   return dspn::check_launch("avgpool_backward");
+}
+
+int dspn_avgpool2d_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride, int pad,
+                               int Ho, int Wo, void *stream) {
+  DSPN_REQUIRE(x && y && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && pad < k, "avgpool2d_forward: bad argument");
+  DSPN_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1,
+               "avgpool2d_forward: output size mismatch");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(avgpool2d_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k, stride,
+                     pad, Ho, Wo, total);
+  return dspn::check_launch("avgpool2d_forward");
+}
+int dspn_avgpool2d_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int stride, int pad,
+                                int Ho, int Wo, int accumulate, void *stream) {
+  DSPN_REQUIRE(dy && dx && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && pad < k, "avgpool2d_backward: bad argument");
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool2d_bwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k, stride,
+                     pad, Ho, Wo, total, accumulate);
+  return dspn::check_launch("avgpool2d_backward");
 }
 
 int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,

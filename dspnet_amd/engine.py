@@ -419,6 +419,55 @@ class AvgPool(Node):
         fn.avgpool_backward(self.out.grad, self.x.shape, self.k, dx=dx, accumulate=acc)
 
 
+class AvgPool2d(Node):
+    """mx.sym.Pooling(pool_type='avg', kernel k, stride, pad) with overlapping windows
+    (symbol/inceptionv3.py:31,74,115); the divisor is k*k including padding"""
+
+    def __init__(self, g, x, name, kernel, stride, pad):
+        N, H, W, C = x.shape
+        self.x, self.k, self.s, self.p = x, kernel, stride, pad
+        self.out = g.tensor((N, fn.conv_out_size(H, kernel, stride, pad), fn.conv_out_size(W, kernel, stride, pad), C),
+                            name)
+
+    def forward(self):
+        fn.avgpool2d_forward(self.x.data, self.k, self.s, self.p, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw or not self.x.requires_grad:
+            return
+        dx, acc = self.x.grad_target()
+        fn.avgpool2d_backward(self.out.grad, self.x.shape, self.k, self.s, self.p, dx=dx, accumulate=acc)
+
+
+class Concat(Node):
+    """mx.sym.Concat along channels (symbol/inceptionv3.py:33): each input is copied into its channel
+    slice of the NHWC output; backward copies (or accumulates) the slice of the output gradient back"""
+
+    def __init__(self, g, inputs, name):
+        N, H, W, _ = inputs[0].shape
+        assert all(t.shape[:3] == (N, H, W) for t in inputs), [t.shape for t in inputs]
+        self.inputs = inputs
+        self.offsets = np.cumsum([0] + [t.shape[3] for t in inputs]).tolist()
+        self.out = g.tensor((N, H, W, self.offsets[-1]), name)
+
+    def forward(self):
+        N, H, W, C = self.out.shape
+        for t, off in zip(self.inputs, self.offsets):
+            c = t.shape[3]
+            fn.copy_block(t.data, self.out.data, N, H * W, c, H * W * c, c, 0, H * W * C, C, off)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        N, H, W, C = self.out.shape
+        for t, off in zip(self.inputs, self.offsets):
+            if not t.requires_grad:
+                continue
+            c = t.shape[3]
+            dx, acc = t.grad_target()
+            fn.copy_block(self.out.grad, dx, N, H * W, c, H * W * C, C, off, H * W * c, c, 0, accumulate=acc)
+
+
 class BilinearConcat(Node):
     """GridGenerator(identity affine, target) + BilinearSampler on each input, concatenated along
     channels (multitask_symbol_builder.py:574-582)."""

@@ -44,6 +44,8 @@ _lib.register({
     "dspn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dspn_copy_block_f32": (_i, [_vp, _vp, _i, _ll, _i, _ll, _i, _i, _ll, _i, _i, _i, _vp]),
     "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "dspn_avgpool2d_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_avgpool2d_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -339,6 +341,24 @@ def avgpool_forward(x, k, out=None):
     out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
     check(L().dspn_avgpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, Ho, Wo, stream()), "avgpool_forward")
     return out
+
+
+def avgpool2d_forward(x, k, stride, pad, out=None):
+    """overlapping average pooling, divisor k*k (padding counted)"""
+    N, H, W, C = x.shape
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
+    check(L().dspn_avgpool2d_forward_f32(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
+          "avgpool2d_forward")
+    return out
+
+
+def avgpool2d_backward(dy, x_shape, k, stride, pad, dx=None, accumulate=False):
+    N, H, W, C = x_shape
+    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
+    check(L().dspn_avgpool2d_backward_f32(ptr(dy), ptr(dx), N, H, W, C, k, stride, pad, dy.shape[1], dy.shape[2],
+                                          int(accumulate), stream()), "avgpool2d_backward")
+    return dx
 
 
 def avgpool_backward(dy, x_shape, k, dx=None, accumulate=False):

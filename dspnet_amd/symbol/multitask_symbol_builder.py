@@ -19,6 +19,7 @@ from .. import functional as fn
 from .. import operator as op
 from . import resnet as resnet_mod
 from . import vgg16_reduced as vgg_mod
+from . import inceptionv3 as inception_mod
 from .common import multi_layer_feature, multitask_layer
 
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
@@ -217,7 +218,7 @@ def get_det_symbol_train(network, num_classes, from_layers, num_filters, strides
 def _build(train, with_seg, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
            steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
            num_layers, seed):
-    assert network in ("resnet", "vgg16_reduced"), "backbones wired so far: resnet, vgg16_reduced"
+    assert network in ("resnet", "vgg16_reduced", "inceptionv3"), "backbones: resnet, vgg16_reduced, inceptionv3"
     device = device or torch.device("cuda", torch.cuda.current_device())
     g = E.Graph(device)
     C, H, W = data_shape
@@ -228,6 +229,8 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
 
     if network == "resnet":
         internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
+    elif network == "inceptionv3":
+        internals = inception_mod.get_symbol(g, data)
     else:
         internals = vgg_mod.get_symbol(g, data)
     res3 = internals[from_layers[0] + "_output"]

@@ -4,7 +4,8 @@ from . import multitask_symbol_builder as builder
 
 def get_config(network, data_shape, **kwargs):
     """symbol/multitask_symbol_factory.py:5-98.  Only the presets that build in the reference are
-    offered in round 1 (resnet-50 :68-81; resnet101's list is kept as data for later)."""
+    offered (resnet-50 :68-81) plus vgg16_reduced (:17-42) and inceptionv3 (:43-53), whose multi-task wiring
+    is this build's (their presets do not build in the reference)."""
     if isinstance(data_shape, (tuple, list)):
         data_shape = data_shape[1]
     if network == 'vgg16_reduced':   # symbol/multitask_symbol_factory.py:17-42
@@ -28,6 +29,17 @@ def get_config(network, data_shape, **kwargs):
                       [1, 2, .5]]
             normalizations = [20, -1, -1, -1, -1, -1]
             steps = [] if data_shape != 300 else [x / 300.0 for x in [8, 16, 32, 64, 100, 300]]
+        return locals()
+    if network == 'inceptionv3':     # symbol/multitask_symbol_factory.py:43-53
+        from_layers = ['ch_concat_mixed_7_chconcat', 'ch_concat_mixed_10_chconcat', '', '', '', '']
+        num_filters = [-1, -1, 512, 256, 256, 128]
+        strides = [-1, -1, 2, 2, 2, 2]
+        pads = [-1, -1, 1, 1, 1, 1]
+        sizes = [[.1, .141], [.2, .272], [.37, .447], [.54, .619], [.71, .79], [.88, .961]]
+        ratios = [[1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3],
+                  [1, 2, .5], [1, 2, .5]]
+        normalizations = -1
+        steps = []
         return locals()
     if network == 'resnet-50':
         num_layers = 50

@@ -152,6 +152,13 @@ int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int 
 int dspn_avgpool_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
                               int accumulate, void *stream);
 
+/* overlapping average pooling, floor ("valid") output size, padding counted in the divisor k*k
+ * (symbol/inceptionv3.py:31 `Pooling(kernel=(3,3), stride=(1,1), pad=(1,1), pool_type='avg')`) */
+int dspn_avgpool2d_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride, int pad,
+                               int Ho, int Wo, void *stream);
+int dspn_avgpool2d_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int stride, int pad,
+                                int Ho, int Wo, int accumulate, void *stream);
+
 /* ---- BilinearSampler over GridGenerator(affine = identity) (multitask_symbol_builder.py:
  * 574-581): align-corners bilinear resize (Hin,Win) -> (Ho,Wo), written into / read from a
  * channel slice [coff, coff+C) of a (N,Ho,Wo,ldo) concat buffer. ------------------------------ */

@@ -103,6 +103,70 @@ def vgg16_reduced(P, data):
     return inter
 
 
+def inceptionv3(P, data):
+    """symbol/inceptionv3.py:10-160: Conv = conv(no bias) -> BN(fix_gamma, MXNet default eps 1e-3) -> ReLU"""
+    def C(x, name, suffix='', stride=1, pad=(0, 0)):
+        n = '%s%s' % (name, suffix)
+        y = F.conv2d(x, P[n + "_conv2d_weight"], stride=stride, padding=pad)
+        mean = y.mean(dim=(0, 2, 3), keepdim=True)
+        var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        return F.relu((y - mean) / torch.sqrt(var + 1e-3) + P[n + "_batchnorm_beta"].view(1, -1, 1, 1))
+
+    def pool(x, kind, k, s, p):
+        return F.max_pool2d(x, k, s, p) if kind == "max" else F.avg_pool2d(x, k, s, p, count_include_pad=True)
+
+    def A(x, kind, name):
+        t1 = C(x, name + '_conv')
+        t5 = C(C(x, name + '_tower', '_conv'), name + '_tower', '_conv_1', pad=(2, 2))
+        t3 = C(C(C(x, name + '_tower_1', '_conv'), name + '_tower_1', '_conv_1', pad=(1, 1)), name + '_tower_1', '_conv_2',
+               pad=(1, 1))
+        return torch.cat([t1, t5, t3, C(pool(x, kind, 3, 1, 1), name + '_tower_2', '_conv')], dim=1)
+
+    def Bk(x, name):
+        t3 = C(x, name + '_conv', stride=2)
+        td = C(C(C(x, name + '_tower', '_conv'), name + '_tower', '_conv_1', pad=(1, 1)), name + '_tower', '_conv_2', stride=2)
+        return torch.cat([t3, td, pool(x, "max", 3, 2, 0)], dim=1)
+
+    def Ck(x, kind, name):
+        t1 = C(x, name + '_conv')
+        td = C(C(C(x, name + '_tower', '_conv'), name + '_tower', '_conv_1', pad=(0, 3)), name + '_tower', '_conv_2', pad=(3, 0))
+        tq = C(x, name + '_tower_1', '_conv')
+        for sfx, pd in (('_conv_1', (3, 0)), ('_conv_2', (0, 3)), ('_conv_3', (3, 0)), ('_conv_4', (0, 3))):
+            tq = C(tq, name + '_tower_1', sfx, pad=pd)
+        return torch.cat([t1, td, tq, C(pool(x, kind, 3, 1, 1), name + '_tower_2', '_conv')], dim=1)
+
+    def Dk(x, kind, name):
+        t3 = C(C(x, name + '_tower', '_conv'), name + '_tower', '_conv_1', stride=2)
+        td = C(x, name + '_tower_1', '_conv')
+        td = C(C(td, name + '_tower_1', '_conv_1', pad=(0, 3)), name + '_tower_1', '_conv_2', pad=(3, 0))
+        td = C(td, name + '_tower_1', '_conv_3', stride=2)
+        return torch.cat([t3, td, pool(x, kind, 3, 2, 0)], dim=1)
+
+    def Ek(x, kind, name):
+        t1 = C(x, name + '_conv')
+        td = C(x, name + '_tower', '_conv')
+        ta, tb = C(td, name + '_tower', '_mixed_conv', pad=(0, 1)), C(td, name + '_tower', '_mixed_conv_1', pad=(1, 0))
+        t3 = C(C(x, name + '_tower_1', '_conv'), name + '_tower_1', '_conv_1', pad=(1, 1))
+        t3a, t3b = C(t3, name + '_tower_1', '_mixed_conv', pad=(0, 1)), C(t3, name + '_tower_1', '_mixed_conv_1', pad=(1, 0))
+        return torch.cat([t1, ta, tb, t3a, t3b, C(pool(x, kind, 3, 1, 1), name + '_tower_2', '_conv')], dim=1)
+
+    inter = {}
+    x = C(C(C(data, "conv", stride=2), "conv_1"), "conv_2", pad=(1, 1))
+    x = F.max_pool2d(x, 3, 2)
+    x = C(C(x, "conv_3"), "conv_4")
+    x = F.max_pool2d(x, 3, 2)
+    x = A(x, "avg", "mixed"); x = A(x, "avg", "mixed_1"); x = A(x, "avg", "mixed_2")
+    x = Bk(x, "mixed_3")
+    for nm in ("mixed_4", "mixed_5", "mixed_6", "mixed_7"):
+        x = Ck(x, "avg", nm)
+    inter["ch_concat_mixed_7_chconcat"] = x
+    x = Dk(x, "max", "mixed_8")
+    x = Ek(x, "avg", "mixed_9")
+    x = Ek(x, "max", "mixed_10")
+    inter["ch_concat_mixed_10_chconcat"] = x
+    return inter
+
+
 def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, num_classes=8, dtype=torch.float64,
                  nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True):
     """Runs the multi-task (or, with_seg=False, the detection+depth) training graph on the CPU.
@@ -116,7 +180,7 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
         config = dict(network="resnet", from_layers=['_plus6', '_plus12', '_plus15', '', '', '', ''],
                       num_filters=[-1, -1, -1, 512, 256, 256, 128], strides=[-1, -1, -1, 2, 2, 2, 2],
                       pads=[-1, -1, -1, 1, 1, 1, 1], sizes=[None] + list(sizes), ratios=[None] + list(ratios), steps=[])
-    inter = resnet50(P, x) if config["network"] == "resnet" else vgg16_reduced(P, x)
+    inter = {"resnet": resnet50, "vgg16_reduced": vgg16_reduced, "inceptionv3": inceptionv3}[config["network"]](P, x)
     fl = config["from_layers"]
     res3, res4 = inter[fl[0]], inter[fl[1]]
     fl, nfs, sts, pds = fl[1:], config["num_filters"][1:], config["strides"][1:], config["pads"][1:]
@@ -211,7 +275,7 @@ def export_params(graph):
             v = v[:19, :, :, :19].transpose(0, 3, 1, 2)
         elif v.ndim == 4:                            # [Cout][R][S][Cin_phys] -> [Cout][Cin][R][S]
             v = v.transpose(0, 3, 1, 2)
-            if p.name in ("conv0_weight", "conv1_1_weight"):
+            if p.name in ("conv0_weight", "conv1_1_weight", "conv_conv2d_weight"):
                 v = v[:, :3]
             if p.name == "score4_conv_weight":
                 pass

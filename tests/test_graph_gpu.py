@@ -147,11 +147,11 @@ def test_test_graph_matches_training_graph_outputs(gpu_device):
     assert segp.shape == (2, 19, 64, 64)
 
 
-def _vgg_case(kind, size, batch, classes):
+def _vgg_case(kind, size, batch, classes, network="vgg16_reduced"):
     from dspnet_amd.symbol.multitask_symbol_factory import get_det_symbol_train
     dev = torch.device("cuda", 0)
     f = get_det_symbol_train if kind == "det" else get_multi_symbol_train
-    net = f("vgg16_reduced", size, num_classes=classes, batch_size=batch, device=dev, seed=3)
+    net = f(network, size, num_classes=classes, batch_size=batch, device=dev, seed=3)
     gen = synthetic.rng(77)
     data = synthetic.images(batch, size, size, gen)
     lab = synthetic.det_labels(batch, gen=gen, num_classes=classes, height=size, width=size, first_empty=False)
@@ -164,13 +164,29 @@ def _vgg_case(kind, size, batch, classes):
     return net, solver, data, lab, seg
 
 
-@pytest.mark.parametrize("kind,size,batch,classes", [("det", 300, 1, 20), ("multi", 320, 2, 8)])
-def test_vgg16_reduced_graphs_match_cpu_restatement(gpu_device, kind, size, batch, classes):
+def test_inceptionv3_shapes_1024x512(gpu_device):
+    """BASELINE.json configs[3] shape: the reference's stem/tower geometry (symbol/inceptionv3.py:114-160) at 512x1024"""
+    net = get_multi_symbol_train("inceptionv3", (3, 512, 1024), num_classes=8, batch_size=1)
+    t = net.g.tensors
+    assert t["ch_concat_mixed_2_chconcat"].shape == (1, 61, 125, 288)
+    assert t["ch_concat_mixed_7_chconcat"].shape == (1, 30, 62, 768)
+    assert t["ch_concat_mixed_10_chconcat"].shape == (1, 14, 30, 2048)
+    net.g.forward()
+    outs = net.outputs()
+    assert tuple(outs[4].shape) == (1, 19, 128, 256)
+    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[4]).all()
+
+
+@pytest.mark.parametrize("network,kind,size,batch,classes", [("vgg16_reduced", "det", 300, 1, 20),
+                                                             ("vgg16_reduced", "multi", 320, 2, 8),
+                                                             ("inceptionv3", "multi", 512, 1, 8)])
+def test_other_backbone_graphs_match_cpu_restatement(gpu_device, network, kind, size, batch, classes):
     """BASELINE.json configs[0] (vgg16_reduced SSD-300 single-task det, bs=1, 20 VOC classes: N = 2956 anchors
-    after the reference's [1:] slice of the 8732-anchor preset) and the build's vgg16_reduced multi-task wiring"""
-    net, solver, data, lab, seg = _vgg_case(kind, size, batch, classes)
+    after the reference's [1:] slice of the 8732-anchor preset), the build's vgg16_reduced multi-task wiring, and
+    the inceptionv3 multi-task wiring (configs[3]'s backbone; every conv class of symbol/inceptionv3.py)"""
+    net, solver, data, lab, seg = _vgg_case(kind, size, batch, classes, network)
     solver.forward(); solver.backward(); torch.cuda.synchronize()
-    cfg = get_config("vgg16_reduced", size)
+    cfg = get_config(network, size)
     if kind == "det":
         assert tuple(net.anchors.shape) == (1, 2956, 4)
     anchors = net.anchors.cpu().numpy()
@@ -186,13 +202,19 @@ def test_vgg16_reduced_graphs_match_cpu_restatement(gpu_device, kind, size, batc
         return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
     outs = [o.cpu().numpy() for o in net.outputs()]
-    assert rel(net.loc_preds.data.cpu().numpy(), ref["loc_preds"].numpy()) < 1e-4
-    assert rel(outs[0], ref["cls_prob"].numpy()) < 1e-4
-    assert rel(outs[1], ref["loc_loss"].numpy()) < 1e-4
+    # element-wise tensor bound: 1e-4 of the tensor's scale.  The 94-layer inceptionv3 stack of batch-statistics
+    # BatchNorms over small maps is worse conditioned in fp32: the CPU restatement itself run in float32 differs from
+    # its float64 run by 2.2e-4 (loc_preds) and 2.9e-4 .. 9e-4 (seg_out) on this input (scratch/incep_dbg.py on the
+    # MI355X box; the device shows 2.3e-4 / 4.3e-4 .. 6.1e-4), so tensors get 2e-3 there.  The loss readouts -- the
+    # quantity BASELINE.json's 1e-4 is stated for -- are held to 1e-4 for every backbone below.
+    ttol = 2e-3 if network == "inceptionv3" else 1e-4
+    assert rel(net.loc_preds.data.cpu().numpy(), ref["loc_preds"].numpy()) < ttol
+    assert rel(outs[0], ref["cls_prob"].numpy()) < ttol
+    assert rel(outs[1], ref["loc_loss"].numpy()) < ttol
     np.testing.assert_array_equal(outs[3], om.multibox_detection(outs[0], net.loc_preds.data.cpu().numpy(), anchors,
                                                                  nms_threshold=.5, nms_topk=400))
     if kind != "det":
-        assert rel(outs[4], ref["seg_out"].numpy()) < 1e-4
+        assert rel(outs[4], ref["seg_out"].numpy()) < ttol
     m = MultiBoxMetric(); m.update(net)
     names, vals = m.get()
     for n, v in zip(names, vals):
@@ -205,6 +227,9 @@ def test_vgg16_reduced_graphs_match_cpu_restatement(gpu_device, kind, size, batc
         gdev = p.grad.cpu().numpy()
         gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
         if p.name.endswith(("pred_conv_weight", "pred_conv_bias")):      # nothing but the loss below them
-            assert rel(gdev, gref) < 1e-3, p.name
+            assert rel(gdev, gref) < 10 * ttol, p.name
         num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
-    assert (num / den) ** 0.5 < 2e-2
+    # global relative L2 over all parameter gradients (ReLU sign flips of pre-activations within rounding of zero
+    # make an element-wise bound meaningless below the heads).  inceptionv3: the float32 CPU
+    # restatement is itself 3.6e-2 away from the float64 one on this input; the device measures 2.8e-2.
+    assert (num / den) ** 0.5 < (6e-2 if network == "inceptionv3" else 2e-2)
