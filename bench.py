@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
 def parse():
@@ -34,7 +35,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--size", type=int, default=512, help="image height (and width unless --width is given)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--network", default="resnet-50", choices=["resnet-50", "vgg16_reduced", "inceptionv3"],
+                    help="backbone preset; the headline workload is resnet-50 (the other BASELINE.json configs: "
+                         "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16"],
+                    help="conv MFMA math: exact fp32 (default) or bf16 inputs with fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
@@ -89,8 +96,9 @@ def host_cores():
     return n
 
 
-def cpu_baseline(size, images, cfg):
+def cpu_baseline(size, images, cfg, width=None):
     """forward + backward of the same graph with torch CPU ops, fp32, all cores"""
+    width = width or size
     import numpy as np
     import torch
     from dspnet_amd import synthetic
@@ -98,13 +106,13 @@ def cpu_baseline(size, images, cfg):
     cores = host_cores()
     torch.set_num_threads(cores)
     gen = synthetic.rng(233)
-    data = synthetic.images(images, size, size, gen)
-    lab = synthetic.det_labels(images, gen=gen, height=size, width=size, first_empty=False)
-    seg = synthetic.seg_labels(images, size, size, gen=gen)
+    data = synthetic.images(images, size, width, gen)
+    lab = synthetic.det_labels(images, gen=gen, height=size, width=width, first_empty=False)
+    seg = synthetic.seg_labels(images, size, width, gen=gen)
     values = cpu_baseline.values
 
     def once():
-        ref = ot.forward_loss(values, data, lab, seg, cfg["sizes"][1:], cfg["ratios"][1:], dtype=torch.float32)
+        ref = ot.forward_loss(values, data, lab, seg, dtype=torch.float32, config=cfg)
         ref["objective"].backward()
 
     once()                                  # warm-up (allocator, thread pool)
@@ -117,8 +125,8 @@ def cpu_baseline(size, images, cfg):
             break
     dt = time.perf_counter() - t0
     return {"value": round(images * reps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d x (forward+backward of the same resnet-50 multitask graph, %d images %dx%d, fp32 torch-CPU "
-                      "ops + C multibox oracle; no optimizer step)" % (reps, images, size, size)}
+            "sample": "%d x (forward+backward of the same %s multitask graph, %d images %dx%d, fp32 torch-CPU "
+                      "ops + C multibox oracle; no optimizer step)" % (reps, cfg["network"], images, size, width)}
 
 
 def main():
@@ -147,12 +155,15 @@ def main():
     from dspnet_amd.train.solver import MultiTaskSolver
 
     B, S = args.batch, args.size
-    net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=dev, seed=0)
+    Wd = args.width or S
+    from dspnet_amd import functional as fn
+    fn.set_conv_math(args.math)
+    net = get_multi_symbol_train(args.network, (3, S, Wd), num_classes=8, batch_size=B, device=dev, seed=0)
     solver = MultiTaskSolver(net, process_group=None, world_size=world, force_reducer=use_dist)
     gen = synthetic.rng(233 + rank)
-    solver.set_batch(torch.from_numpy(synthetic.images(B, S, S, gen)).to(dev),
-                     torch.from_numpy(synthetic.det_labels(B, gen=gen, height=S, width=S)).to(dev),
-                     torch.from_numpy(synthetic.seg_labels(B, S, S, gen=gen)).to(dev))
+    solver.set_batch(torch.from_numpy(synthetic.images(B, S, Wd, gen)).to(dev),
+                     torch.from_numpy(synthetic.det_labels(B, gen=gen, height=S, width=Wd)).to(dev),
+                     torch.from_numpy(synthetic.seg_labels(B, S, Wd, gen=gen)).to(dev))
     convs = [n for n in net.g.nodes if isinstance(n, (E.Conv, E.Deconv4x4s2))]
     flops_step = sum(n.flops_fwd + n.flops_bwd for n in convs)          # executed
     flops_3x = 3.0 * sum(n.flops_fwd for n in convs)                    # SURVEY.md 8(d) convention
@@ -194,9 +205,12 @@ def main():
             traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_conv_family.json")))["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: fp32 implicit-GEMM family",
+        peak = FP32_MATRIX_PEAK_TFLOPS if args.math == "fp32" else BF16_MATRIX_PEAK_TFLOPS
+        if args.math != "fp32" or args.network != "resnet-50" or (S, Wd, B) != (512, 512, 32):
+            traffic = None          # the committed PMC passes are of the headline workload only
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: %s implicit-GEMM family" % args.math,
                     "launches_per_step": (nt_n + wg_n) // args.steps,
                     "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
                     "conv_ms_per_step": round(conv_s * 1e3, 3),
@@ -205,19 +219,20 @@ def main():
                     "share_of_step_time": round(conv_s / (dt / args.steps), 3)}
 
     if rank == 0:
-        cfg = get_config("resnet-50", S)
+        cfg = get_config(args.network, S)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import dspnet_torch as ot
             cpu_baseline.values = ot.export_params(net.g)
-            cpu = cpu_baseline(S, args.cpu_images, cfg)
+            cpu = cpu_baseline(S, args.cpu_images, cfg, Wd)
         line = {
-            "metric": "training images/sec at 512x512 multitask",
+            "metric": "training images/sec at %dx%d multitask" % (S, Wd),
             "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "resnet-50 multitask (det+depth+seg) %dx%d, 8 det classes, 19 seg classes, "
-                                   "N=%d anchors, forward+backward+SGD" % (S, S, net.anchors.shape[1]),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.math == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "%s multitask (det+depth+seg) %dx%d, 8 det classes, 19 seg classes, "
+                                   "N=%d anchors, forward+backward+SGD" % (args.network, S, Wd, net.anchors.shape[1]),
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
                        "train_gflop_per_image_3x_convention": round(flops_3x / B / 1e9, 2),
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},

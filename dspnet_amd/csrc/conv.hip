@@ -27,6 +27,17 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// bf16-MFMA math mode (dspn_conv2d_set_math): tensors stay fp32 in HBM, the loaders round to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on the way into LDS, v_mfma_f32_32x32x16_bf16 accumulates in fp32.
+constexpr int kLdsRowH = 40;   // padded LDS row of the bf16 NT tiles, in bf16 (80 B: conflict-free ds_read_b128)
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+  bf16x4 r = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return r;
+}
 
 constexpr int kBK = 32;        // floats per k-step
 constexpr int kLdsRow = 36;    // padded LDS row (floats)
@@ -55,7 +66,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -65,6 +76,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [2][BM][kLdsRowH], then [2][BN][kLdsRowH]
+  __bf16 *hB = hA + 2 * BM * kLdsRowH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
@@ -165,13 +178,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     }
   };
   auto store_tiles = [&](int buf) {
-    float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
+    if constexpr (BF16) {
+      __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) = ra[i];
+      for (int i = 0; i < A_LD; ++i)
+        *reinterpret_cast<bf16x4 *>(a + (row0 + 32 * i) * kLdsRowH + chunk * 4) = to_bf16x4(ra[i]);
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) = rb[i];
+      for (int i = 0; i < B_LD; ++i)
+        *reinterpret_cast<bf16x4 *>(b + (row0 + 32 * i) * kLdsRowH + chunk * 4) = to_bf16x4(rb[i]);
+    } else {
+      float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) = rb[i];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -195,6 +218,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const int buf = kt & 1;
     const bool more = kt + 1 < nk;
     load_tiles(kt + 1);   // past the last k-step every offset is out of range: zero-cost dummy loads
+    if constexpr (BF16) {
+      // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
+      const __bf16 *a = hA + buf * BM * kLdsRowH + (wm + frow) * kLdsRowH + (lane >> 5) * 8;
+      const __bf16 *b = hB + buf * BN * kLdsRowH + (wn + frow) * kLdsRowH + (lane >> 5) * 8;
+      bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * kLdsRowH + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * kLdsRowH + kk * 16);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+    } else {
     const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
     const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
     // fragments of group gq+1 are fetched from LDS before the MFMAs of group gq are issued
@@ -230,6 +273,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       __builtin_amdgcn_sched_group_barrier(0x020, (A_LD + B_LD + 7) / 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
     }
+    }
     if (more && !(dbg & 2)) store_tiles(buf ^ 1);
     if (!(dbg & 4)) __syncthreads();
   }
@@ -256,7 +300,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   // float4: a 128-wide row leaves as one 512-B contiguous store per 32 lanes, and the residual /
   // accumulate operands are read the same way, instead of 64 dword stores of two 128-B segments.
   constexpr int SLD = BN + 4;
-  static_assert(BM * SLD <= 2 * (BM + BN) * kLdsRow, "output tile must fit in the mainloop's LDS");
   float *st = smem;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -333,7 +376,12 @@ struct WgradGeom {
   unsigned x_bytes, dy_bytes;
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+// bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
+// four pixel rows of a transposed block fall on disjoint banks; ds_read_b64_tr_b16 hands every lane the 4
+// consecutive pixels (= MFMA k) of its channel, two reads per 8-k fragment.
+constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
@@ -396,14 +444,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
       rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
     }
   };
+  constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
+  char *hA = reinterpret_cast<char *>(smem);            // [2][kBK][RAB]
+  char *hB = hA + 2 * kBK * RAB;                        // [2][kBK][RBB]
   auto store_tiles = [&](int buf) {
-    float *a = sA + buf * kBK * BM, *b = sB + buf * kBK * BN;
+    if constexpr (BF16) {
+      char *a = hA + buf * kBK * RAB, *b = hB + buf * kBK * RBB;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<float4 *>(a + (a_row0 + i * A_RSTEP) * BM + a_chunk * 4) = ra[i];
+      for (int i = 0; i < A_LD; ++i)
+        *reinterpret_cast<bf16x4 *>(a + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8) = to_bf16x4(ra[i]);
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<float4 *>(b + (b_row0 + i * B_RSTEP) * BN + b_chunk * 4) = rb[i];
+      for (int i = 0; i < B_LD; ++i)
+        *reinterpret_cast<bf16x4 *>(b + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8) = to_bf16x4(rb[i]);
+    } else {
+      float *a = sA + buf * kBK * BM, *b = sB + buf * kBK * BN;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        *reinterpret_cast<float4 *>(a + (a_row0 + i * A_RSTEP) * BM + a_chunk * 4) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        *reinterpret_cast<float4 *>(b + (b_row0 + i * B_RSTEP) * BN + b_chunk * 4) = rb[i];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -420,6 +481,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     load_tiles(kt + 1);   // past the last k-step: every offset out of range, zero-cost
+    if constexpr (BF16) {
+      // transposed-read addressing: 16-lane group gl = lane >> 4 covers channels 16*(gl&1) .. +15 of a 32-channel
+      // block and pixels 8*(gl>>1) .. +7 of a 16-pixel MFMA k block; lane 4q+p of the group supplies the address
+      // of pixel row q, channels 4p .. 4p+3, and receives its own channel's 4 pixels.
+      const int gl = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+      const char *a = hA + buf * kBK * RAB + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *b = hB + buf * kBK * RBB + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
+      auto frag = [](const char *base, int row_bytes) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base + 4 * row_bytes));
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+      };
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = frag(a + kk * 16 * RAB + i * 64, RAB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = frag(b + kk * 16 * RBB + j * 64, RBB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
     const float *a = sA + buf * kBK * BM + (lane >> 5) * BM + wm + (lane & 31);
     const float *b = sB + buf * kBK * BN + (lane >> 5) * BN + wn + (lane & 31);
     float fa[2][TM], fb[2][TN];
@@ -443,6 +531,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       if (ks + 1 < kBK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    }
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
@@ -597,15 +686,19 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP>
+int g_math_bf16 = 0;   // dspn_conv2d_set_math
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16>
 int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * kLdsRow;
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP>;
+  // mainloop buffers | staged output tile of the epilogue
+  const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
+                                      sizeof(float) * BM * (BN + 4));
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -629,9 +722,13 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
               hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
-  if (((g.Cin >> 2) & 7) == 0)
-    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
-  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+  const bool uni = ((g.Cin >> 2) & 7) == 0;
+  if (g_math_bf16) {
+    if (uni) return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+  }
+  if (uni) return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
 }
 
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
@@ -724,6 +821,13 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
 extern "C" {
 
 int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
+
+int dspn_conv2d_set_math(int mode) {
+  DSPN_REQUIRE(mode == 0 || mode == 1, "conv2d_set_math: 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulate");
+  g_math_bf16 = mode;
+  return 0;
+}
+int dspn_conv2d_get_math(void) { return g_math_bf16; }
 
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   if (out_pixels <= 0 || Cout <= 0) return 0;
@@ -926,8 +1030,10 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   const size_t lds = sizeof(float) * std::max(2 * kBK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
   dspn::ProfScope prof(1, s);
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
+  { if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true) else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false) }
+#define DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, BF)                                                         \
   {                                                                                                      \
-    auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_>;                                                     \
+    auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF>;                                                 \
     static bool attr = false;                                                                            \
     if (!attr) {                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
@@ -940,6 +1046,7 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)   // 64 x 128
   else DSPN_WGRAD_LAUNCH(2, 2, 2, 2)                 // 128 x 128
 #undef DSPN_WGRAD_LAUNCH
+#undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");
   if (rc) return rc;
   const long long n4 = (long long)Cout * J / 4;

@@ -46,6 +46,8 @@ _lib.register({
     "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dspn_avgpool2d_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool2d_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_set_math": (_i, [_i]),
+    "dspn_conv2d_get_math": (_i, []),
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -111,6 +113,15 @@ def zeros(*shape, device=None):
 
 
 # ------------------------------------------------------------------ convolution
+def set_conv_math(mode):
+    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA, fp32 accumulate) for every conv kernel"""
+    check(L().dspn_conv2d_set_math({"fp32": 0, "f32": 0, "bf16": 1}[mode]), "conv2d_set_math")
+
+
+def get_conv_math():
+    return "bf16" if L().dspn_conv2d_get_math() else "fp32"
+
+
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout)"""
     N, H, W, Cin = x.shape

@@ -42,6 +42,13 @@ extern "C" {
  * too small to fill the chip (SSD heads / extras); any size, dspn_conv2d_split_workspace_bytes() is
  * always enough.  Partials are summed in a fixed order (deterministic). */
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
+/* Math mode of the convolution family (forward, dgrad, wgrad; process-wide, like cudnnSetConvolutionMathType):
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fmaf chains (default)
+ *   1  bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: tensors stay fp32 in HBM and are rounded to bf16
+ *      (round-to-nearest-even) on the way into LDS -- BASELINE.json configs[3] "bf16 MFMA convs" */
+int dspn_conv2d_set_math(int mode);
+int dspn_conv2d_get_math(void);
+
 /* timing-only ablation switches of the conv kernel (results are WRONG when non-zero); 0 = production */
 int dspn_debug_set(int bits);
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,

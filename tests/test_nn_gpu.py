@@ -384,3 +384,38 @@ def test_tap_expanded_conv_matches_direct(gpu_device, case):
     assert float(dz[..., Cout * R * S:].abs().sum()) == 0.0
     dw = fn.conv2d_wgrad(xd, dz, (Cout * R * S, 1, 1, wd_.shape[3]), 1, 0, 1).view(Cout, R, S, -1)
     close(dw[..., :Cin].cpu().double().permute(0, 3, 1, 2), w.grad)
+
+
+@pytest.fixture
+def bf16_math():
+    fn.set_conv_math("bf16")
+    yield
+    fn.set_conv_math("fp32")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16_mfma_math(gpu_device, bf16_math, case):
+    """dspn_conv2d_set_math(1): bf16 MFMA, fp32 accumulate (BASELINE.json configs[3]).  With operands that are exactly
+    representable in bf16 every product is exact in fp32, so the result must agree with the float64 reference as
+    tightly as the fp32 path does; with general fp32 operands the error is the bf16 rounding of the inputs
+    (2^-9 relative per operand)."""
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    rb = lambda t: t.float().bfloat16().double()  # noqa: E731   round to bf16, keep as float64
+    x = rb(torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)).requires_grad_()
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)).requires_grad_()
+    y_ref = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)
+    dy = rb(torch.randn(y_ref.shape, generator=g, dtype=torch.float64))
+    y_ref.backward(dy)
+    assert fn.get_conv_math() == "bf16"
+    xd, wd_, dyd = nhwc(x.detach()), wdev(w.detach()), nhwc(dy)
+    close(nchw(fn.conv2d_forward(xd, wd_, None, stride=stride, pad=pad, dil=dil), Cout), y_ref.detach(), 1e-5)
+    if stride == 1 or dil == 1:
+        dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=pad, dil=dil)
+        close(nchw(dx, Cin), x.grad, 1e-5)
+    dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=pad, dil=dil)
+    close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad, 1e-5)
+    # general fp32 operands: bounded by the input rounding
+    x2 = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    y2 = fn.conv2d_forward(nhwc(x2), wd_, None, stride=stride, pad=pad, dil=dil)
+    close(nchw(y2, Cout), F.conv2d(x2, w.detach(), None, stride=stride, padding=pad, dilation=dil), 2e-2)
