@@ -16,7 +16,8 @@
 // double buffered: the loads of k-step t+1 are issued before the MFMAs of step
 // t and written to the other LDS buffer after them (one barrier per k-step).
 // LDS rows are padded to 36 floats: 16 B aligned for ds_write_b128 and at most
-// 2-way conflicts for the ds_read_b64 fragment reads.  Each ds_read_b64 feeds
+// 2-way conflicts for the ds_read_b64 fragment reads (a half-swap swizzle that
+// removes them was measured perf-neutral -- LDS is ~25 % busy -- and dropped).  Each ds_read_b64 feeds
 // two MFMAs: within a group of 4 k values lanes 0-31 take k={0,1} and lanes
 // 32-63 take k={2,3} for BOTH operands (the k order inside a sum is free).
 //
@@ -80,9 +81,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   __bf16 *hB = hA + 2 * BM * kLdsRowH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-  const int mt = tile / n_tiles, nt = tile - mt * n_tiles;   // n fastest: A tile reuse in L2
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int ntiles = m_tiles * n_tiles;
   const int M = g.N * g.Hg * g.Wg;
   const int CQ = g.Cin >> 2;
   const int total_q = g.TR * g.TS * CQ;
@@ -101,46 +100,59 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_b =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
-  int a_ih0[A_LD], a_iw0[A_LD], a_eoff[A_LD];   // element offset of tap (0,0) (may be negative)
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + row0 + 32 * i;
-    if (m < M) {
-      const int hw = g.Hg * g.Wg;
-      const int n = m / hw, rem = m - n * hw;
-      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-      a_ih0[i] = oi * g.ish + g.ioh;
-      a_iw0[i] = oj * g.isw + g.iow;
-      a_eoff[i] = ((n * g.Hin + a_ih0[i]) * g.Win + a_iw0[i]) * g.Cin;
-    } else {
-      a_ih0[i] = -0x40000000; a_iw0[i] = 0; a_eoff[i] = 0;
-    }
-  }
-  int b_eoff[B_LD];
-#pragma unroll
-  for (int i = 0; i < B_LD; ++i) {
-    const int k = n0 + row0 + 32 * i;
-    b_eoff[i] = k < g.Cout ? k * g.WTAPS * g.Cin : -1;
-  }
+
+  // ---- loader state of ONE output tile (re-initialised by setup_tile) -----------------------------
+  int ld_m0 = 0, ld_n0 = 0;
+  // (vector types, not arrays: the state is rewritten inside the tile loop and must stay in registers --
+  // as arrays hipcc demoted it to scratch memory, whose loads serialise with the tile loads in vmcnt order)
+  typedef int ivec8 __attribute__((ext_vector_type(8)));
+  static_assert(A_LD <= 8 && B_LD <= 8, "loader state vectors hold 8 rows");
+  ivec8 a_ih0 = {0, 0, 0, 0, 0, 0, 0, 0}, a_iw0 = a_ih0, a_eoff = a_ih0;   // element offset of tap (0,0) (may be negative)
+  ivec8 b_eoff = a_ih0;
   // When a k-step (8 chunks = 32 channels) never straddles a tap, the tap is wave-uniform and is
   // tracked incrementally; otherwise (Cin = 4, 20, 36 ...) each lane derives its own tap.
   constexpr bool uniform_tap = UNIFORM_TAP;   // host guarantees (Cin/4) % 8 == 0
   int u_tr = 0, u_ts = 0, u_cq = 0;   // tap / channel-chunk of chunk 0 of the NEXT k-step to load
+  int ld_kt = 0;                      // index (within this workgroup's K range) of the NEXT k-step to load
   // K order of the uniform path is CHANNEL-major: for each block of 32 channels all taps are visited
   // back to back, so the (overlapping) input pixels of neighbouring taps are re-read while they are
   // still in L1/L2 instead of once per sweep over all channels (3328-channel score3_conv: 9x less HBM).
   const int ntaps = g.TR * g.TS;
-  if (uniform_tap && ntaps > 0) {
-    const int cb = k_begin / ntaps, tap0 = k_begin - cb * ntaps;
-    u_cq = cb * 8; u_tr = tap0 / g.TS; u_ts = tap0 - u_tr * g.TS;
-  }
+  auto setup_tile = [&](int t) __attribute__((always_inline)) {
+    const int tile = xcd_remap(t, ntiles);
+    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;   // n fastest: A tile reuse in L2
+    ld_m0 = mt * BM; ld_n0 = nt * BN;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = ld_m0 + row0 + 32 * i;
+      const int hw = g.Hg * g.Wg;
+      const int n = m / hw, rem = m - n * hw;
+      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+      const int ih0 = oi * g.ish + g.ioh, iw0 = oj * g.isw + g.iow;
+      const bool mv = m < M;                       // rows past M: every tap fails the bounds test
+      a_ih0[i] = mv ? ih0 : -0x40000000;
+      a_iw0[i] = mv ? iw0 : 0;
+      a_eoff[i] = mv ? ((n * g.Hin + ih0) * g.Win + iw0) * g.Cin : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int k = ld_n0 + row0 + 32 * i;
+      b_eoff[i] = k < g.Cout ? k * g.WTAPS * g.Cin : -1;
+    }
+    ld_kt = 0;
+    u_tr = 0; u_ts = 0; u_cq = 0;
+    if (uniform_tap && ntaps > 0) {
+      const int cb = k_begin / ntaps, tap0 = k_begin - cb * ntaps;
+      u_cq = cb * 8; u_tr = tap0 / g.TS; u_ts = tap0 - u_tr * g.TS;
+    }
+  };
 
   float4 ra[A_LD], rb[B_LD];
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&]() __attribute__((always_inline)) {     // issues the global loads of k-step ld_kt of the tile set up last
     int tr, ts, cq;
     bool qv;
     if constexpr (uniform_tap) {
-      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = u_cq < CQ;
+      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0;
       ++u_ts;                                   // branch-free wave-uniform advance: taps inner, channels outer
       const bool wrap = u_ts == g.TS;
       u_ts = wrap ? 0 : u_ts;
@@ -149,11 +161,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       u_tr = wrap2 ? 0 : u_tr;
       u_cq += wrap2 ? 8 : 0;
     } else {
-      const int q = (k_begin + kt) * 8 + chunk;
-      qv = q < total_q;
+      const int q = (k_begin + ld_kt) * 8 + chunk;
+      qv = q < total_q && nk > 0;
       const int tap = q / CQ;
       cq = q - tap * CQ; tr = tap / g.TS; ts = tap - tr * g.TS;
     }
+    ++ld_kt;
     const int dh = tr * g.idh, dw = ts * g.idw;
     const int a_off = (dh * g.Win + dw) * g.Cin + cq * 4;
 #pragma unroll
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
                           __uint_as_float(t[3]));
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if constexpr (BF16) {
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
@@ -187,43 +200,41 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       for (int i = 0; i < B_LD; ++i)
         *reinterpret_cast<bf16x4 *>(b + (row0 + 32 * i) * kLdsRowH + chunk * 4) = to_bf16x4(rb[i]);
     } else {
-      // Rows r and r+16 start on the same bank (16 * 36 floats = 9 * 64): rows with bit 4 set store the two
-      // 8-byte halves of every 16-byte chunk swapped, and the fragment reads below look in the other half,
-      // so that the 32 rows of a ds_read_b64 cover all 64 banks (no conflicts; it was 2-way).
-      const bool swz = (row0 & 16) && !(g.dbg & 64);
       float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
-        *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) =
-            swz ? make_float4(ra[i].z, ra[i].w, ra[i].x, ra[i].y) : ra[i];
+        *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) = ra[i];
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
-        *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) =
-            swz ? make_float4(rb[i].z, rb[i].w, rb[i].x, rb[i].y) : rb[i];
+        *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) = rb[i];
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
-  const int frow = lane & 31, fk = ((lane >> 5) * 2) ^ ((g.dbg & 64) ? 0 : ((lane & 16) >> 3));   // half swap of rows 16..31, see store_tiles
-
-  if (nk > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
-  __syncthreads();
+  const int frow = lane & 31, fk = (lane >> 5) * 2;
   const int dbg = g.dbg;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < nk;
-    load_tiles(kt + 1);   // past the last k-step every offset is out of range: zero-cost dummy loads
+  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
+
+  // ---- persistent loop over output tiles ----------------------------------------------------------
+  // The workgroup walks tiles t, t + gridDim.x, ...  While the last k-step of a tile is in the matrix
+  // pipe the loads of the NEXT tile's first k-step are already in flight (they stay in registers across
+  // the epilogue, whose staging uses all of the LDS), so neither the first-load latency nor the store
+  // tail of the epilogue is exposed: short-K layers (1x1 expansions, K = 64..256) were serialised
+  // load -> MFMA -> store per workgroup.
+  const int nk1 = max(nk, 1);   // a K range without taps (parity class of a strided data gradient) runs one all-zero k-step
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // one k-step of matrix work on LDS buffer `buf`
+  auto mma_step = [&](const int buf) __attribute__((always_inline)) {
     if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
       const __bf16 *a = hA + buf * BM * kLdsRowH + (wm + frow) * kLdsRowH + (lane >> 5) * 8;
@@ -244,132 +255,156 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     } else {
-    const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
-    const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
-    // fragments of group gq+1 are fetched from LDS before the MFMAs of group gq are issued
-    float2 fa[2][TM], fb[2][TN];
+      const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
+      const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
+      // fragments of group gq+1 are fetched from LDS before the MFMAs of group gq are issued
+      float2 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow);
+      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow);
+      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow);
 #pragma unroll
-    for (int gq = 0; gq < kBK / 4; ++gq) {
-      const int cur = gq & 1, nxt = cur ^ 1;
-      if (gq + 1 < kBK / 4) {
+      for (int gq = 0; gq < kBK / 4; ++gq) {
+        const int cur = gq & 1, nxt = cur ^ 1;
+        if (gq + 1 < kBK / 4) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            fa[nxt][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + (gq + 1) * 4);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            fb[nxt][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow + (gq + 1) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[nxt][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + (gq + 1) * 4);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[nxt][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow + (gq + 1) * 4);
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+          }
+        // pin the order: the LDS reads of the NEXT group are issued ahead of this group's MFMAs, so their
+        // latency hides under 2*TM*TN MFMAs instead of one (hipcc otherwise sinks them next to their use)
+        if (gq + 1 < kBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        // ... and the next tile's global loads (with their address arithmetic) are spread over the
+        // groups instead of delaying the first MFMA of the k-step
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, (A_LD + B_LD + 7) / 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+    }
+  };
+  setup_tile(t);
+  load_tiles();
+  store_tiles(0);
+  __syncthreads();
+  zero_acc();
+  int m0 = ld_m0, n0 = ld_n0;
+  int tn = t + gridDim.x;
+  int kt = 0, buf = 0;
+  // ONE loop over (tile, k-step): a single copy of the load + MFMA block; the end-of-tile work hangs off it
+  while (true) {
+    const bool last = kt == nk1 - 1;
+    const bool has_next = tn < ntiles;
+    if (last && has_next) setup_tile(tn);
+    load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
+    mma_step(buf);
+    if (last) {
+      __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
+      // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+      if (slab) {   // raw partial sums, dense [split][M][Cout]; bias / relu / accumulate happen in the reduce
+        float *o = slab + (long long)blockIdx.y * M * g.Cout;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+          const int co = n0 + wn + j * 32 + (lane & 31);
+          if (co >= g.Cout) continue;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              if (m < M) o[(long long)m * g.Cout + co] = acc[i][j][r];
+            }
         }
-      // pin the order: the LDS reads of the NEXT group are issued ahead of this group's MFMAs, so their
-      // latency hides under 2*TM*TN MFMAs instead of one (hipcc otherwise sinks them next to their use)
-      if (gq + 1 < kBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      // ... and the next tile's global loads (with their address arithmetic) are spread over the
-      // groups instead of delaying the first MFMA of the k-step
-      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, (A_LD + B_LD + 7) / 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
-    }
-    }
-    if (more && !(dbg & 2)) store_tiles(buf ^ 1);
-    if (!(dbg & 4)) __syncthreads();
-  }
-
-  // epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
-  if (slab) {   // raw partial sums, dense [split][M][Cout]; bias / relu / accumulate happen in the reduce
-    float *o = slab + (long long)blockIdx.y * M * g.Cout;
+      } else if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
+        if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5];
+      } else {
+        // Output tile -> LDS (the mainloop's last barrier has retired every fragment read) -> rows of
+        // float4: a 128-wide row leaves as one 512-B contiguous store per 32 lanes, and the residual /
+        // accumulate operands are read the same way, instead of 64 dword stores of two 128-B segments.
+        constexpr int SLD = BN + 4;
+        float *st = smem;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co = n0 + wn + j * 32 + (lane & 31);
-      if (co >= g.Cout) continue;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) o[(long long)m * g.Cout + co] = acc[i][j][r];
-        }
-    }
-    return;
-  }
-  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
-  if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
-    if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5];
-    return;
-  }
-  // Output tile -> LDS (the mainloop's last barrier has retired every fragment read) -> rows of
-  // float4: a 128-wide row leaves as one 512-B contiguous store per 32 lanes, and the residual /
-  // accumulate operands are read the same way, instead of 64 dword stores of two 128-B segments.
-  constexpr int SLD = BN + 4;
-  float *st = smem;
+            for (int r = 0; r < 16; ++r)
+              st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4, RPP = kThreads / C4;   // float4 columns per row, rows per pass
+        const int c4 = tid % C4, er0 = tid / C4;
+        const int co = n0 + c4 * 4;
+        if (co < g.Cout) {
+          const bool vec = (g.flags & 16) && co + 3 < g.Cout;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
-  __syncthreads();
-  constexpr int C4 = BN / 4, RPP = kThreads / C4;   // float4 columns per row, rows per pass
-  const int c4 = tid % C4, er0 = tid / C4;
-  const int co = n0 + c4 * 4;
-  if (co >= g.Cout) return;
-  const bool vec = (g.flags & 16) && co + 3 < g.Cout;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (has_bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
-  }
+            for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
+          }
 #pragma unroll 4
-  for (int p = 0; p < BM / RPP; ++p) {
-    const int ml = er0 + p * RPP, m = m0 + ml;
-    if (m >= M) break;
-    long long off;
-    if (g.dense) {
-      off = (long long)m * g.ldc + co;
-    } else {
-      const int hw = g.Hg * g.Wg;
-      const int n = m / hw, rem = m - n * hw;
-      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-      off = (long long)n * g.obs +
-            ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
-    }
-    const float4 t = *reinterpret_cast<const float4 *>(st + ml * SLD + c4 * 4);
-    float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
-    if (vec) {
-      if (has_res) {
-        const float4 q = *reinterpret_cast<const float4 *>(residual + off);
-        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-      }
-      if (accum) {
-        const float4 q = *reinterpret_cast<const float4 *>(out + off);
-        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-      }
-      if (relu) {
+          for (int p = 0; p < BM / RPP; ++p) {
+            const int ml = er0 + p * RPP, m = m0 + ml;
+            if (m >= M) break;
+            long long off;
+            if (g.dense) {
+              off = (long long)m * g.ldc + co;
+            } else {
+              const int hw = g.Hg * g.Wg;
+              const int n = m / hw, rem = m - n * hw;
+              const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+              off = (long long)n * g.obs +
+                    ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+            }
+            const float4 tv = *reinterpret_cast<const float4 *>(st + ml * SLD + c4 * 4);
+            float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
+            if (vec) {
+              if (has_res) {
+                const float4 q = *reinterpret_cast<const float4 *>(residual + off);
+                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+              }
+              if (accum) {
+                const float4 q = *reinterpret_cast<const float4 *>(out + off);
+                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+              }
+              if (relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      }
-      if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+              }
+              if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (co + e >= g.Cout) break;
-        float x = v[e];
-        if (has_res) x += residual[off + e];
-        if (accum) x += out[off + e];
-        if (relu) x = x > 0.f ? x : 0.f;
-        out[off + e] = x;
+              for (int e = 0; e < 4; ++e) {
+                if (co + e >= g.Cout) break;
+                float x = v[e];
+                if (has_res) x += residual[off + e];
+                if (accum) x += out[off + e];
+                if (relu) x = x > 0.f ? x : 0.f;
+                out[off + e] = x;
+              }
+            }
+          }
+        }
       }
+      if (!has_next) break;
+      zero_acc();
+      t = tn; tn += gridDim.x;
+      m0 = ld_m0; n0 = ld_n0;
+      kt = -1;
+      __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
     }
+    if (!(dbg & 2)) store_tiles(buf ^ 1);
+    if (!(dbg & 4)) __syncthreads();
+    buf ^= 1;
+    ++kt;
   }
 }
 
@@ -709,15 +744,22 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
   const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
   auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16>;
-  static bool attr = false;
-  if (!attr) {
+  // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
+  // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
+  static int slots = 0;
+  if (!slots) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
+    int per_cu = 0, dev = 0, cus = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), kThreads, lds);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
   }
+  const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
     dspn::ProfScope prof(0, s);
-    hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt,
+    hipLaunchKernelGGL(kern, dim3(grid_x, splits), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt,
                        ksteps_per_split, splits > 1 ? slab : nullptr, residual);
     if (splits > 1) {
       const long long total = M * g.Cout;
