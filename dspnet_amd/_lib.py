@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdspn_hip.so")
+# DSPN_LIB: another build of the SAME library (A/B timing of two builds on one box); never a fallback
+LIB_PATH = os.environ.get("DSPN_LIB") or os.path.join(_HERE, "libdspn_hip.so")
 
 _c = ctypes
 _f32p = _c.POINTER(_c.c_float)

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const bool has_next = tn < ntiles;
     if (last && has_next) setup_tile(tn);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
-    mma_step(buf);
+    if (nk > 0) mma_step(buf);   // nk == 0: a parity class without taps only writes zeros (or is skipped by the host)
     if (last) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
@@ -327,11 +327,40 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       } else if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
         if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5];
       } else {
-        // Output tile -> LDS (the mainloop's last barrier has retired every fragment read) -> rows of
-        // float4: a 128-wide row leaves as one 512-B contiguous store per 32 lanes, and the residual /
-        // accumulate operands are read the same way, instead of 64 dword stores of two 128-B segments.
+        // Output tile -> LDS (the barrier above has retired every fragment read) -> rows of float4: a
+        // 128-wide row leaves as one 512-B contiguous store per 32 lanes.  The residual / accumulate operand
+        // is read the same way, and ALL of a thread's rows are requested before the staging pass, so that
+        // their HBM latency overlaps the LDS round trip instead of serialising with the stores (4 loads in
+        // flight per thread held the residual convolutions to ~3 TB/s).
         constexpr int SLD = BN + 4;
+        constexpr int C4 = BN / 4, RPP = kThreads / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
         float *st = smem;
+        const int c4 = tid % C4, er0 = tid / C4;
+        const int co = n0 + c4 * 4;
+        const bool cvalid = co < g.Cout;
+        const bool vec = (g.flags & 16) && co + 3 < g.Cout;
+        long long offs[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int m = m0 + er0 + p * RPP;
+          if (g.dense) {
+            offs[p] = (long long)m * g.ldc + co;
+          } else {
+            const int hw = g.Hg * g.Wg;
+            const int n = m / hw, rem = m - n * hw;
+            const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+            offs[p] = (long long)n * g.obs +
+                      ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+          }
+          if (m >= M || !cvalid) offs[p] = -1;
+        }
+        const float *addsrc = has_res ? residual : (accum ? out : nullptr);   // first additive operand
+        float4 rq[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (addsrc && vec && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -340,56 +369,37 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
             for (int r = 0; r < 16; ++r)
               st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
         __syncthreads();
-        constexpr int C4 = BN / 4, RPP = kThreads / C4;   // float4 columns per row, rows per pass
-        const int c4 = tid % C4, er0 = tid / C4;
-        const int co = n0 + c4 * 4;
-        if (co < g.Cout) {
-          const bool vec = (g.flags & 16) && co + 3 < g.Cout;
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (has_bias) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias && cvalid) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
-          }
-#pragma unroll 4
-          for (int p = 0; p < BM / RPP; ++p) {
-            const int ml = er0 + p * RPP, m = m0 + ml;
-            if (m >= M) break;
-            long long off;
-            if (g.dense) {
-              off = (long long)m * g.ldc + co;
-            } else {
-              const int hw = g.Hg * g.Wg;
-              const int n = m / hw, rem = m - n * hw;
-              const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-              off = (long long)n * g.obs +
-                    ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+          for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const long long off = offs[p];
+          if (off < 0) continue;
+          const float4 tv = *reinterpret_cast<const float4 *>(st + (er0 + p * RPP) * SLD + c4 * 4);
+          float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
+          if (vec) {
+            v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
+            if (has_res && accum) {
+              const float4 q = *reinterpret_cast<const float4 *>(out + off);
+              v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
             }
-            const float4 tv = *reinterpret_cast<const float4 *>(st + ml * SLD + c4 * 4);
-            float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
-            if (vec) {
-              if (has_res) {
-                const float4 q = *reinterpret_cast<const float4 *>(residual + off);
-                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-              }
-              if (accum) {
-                const float4 q = *reinterpret_cast<const float4 *>(out + off);
-                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-              }
-              if (relu) {
+            if (relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-              }
-              if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
+              for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (co + e >= g.Cout) break;
-                float x = v[e];
-                if (has_res) x += residual[off + e];
-                if (accum) x += out[off + e];
-                if (relu) x = x > 0.f ? x : 0.f;
-                out[off + e] = x;
-              }
+            for (int e = 0; e < 4; ++e) {
+              if (co + e >= g.Cout) break;
+              float x = v[e];
+              if (has_res) x += residual[off + e];
+              if (accum) x += out[off + e];
+              if (relu) x = x > 0.f ? x : 0.f;
+              out[off + e] = x;
             }
           }
         }

@@ -237,11 +237,11 @@ __global__ void fill_kernel(float *p, float v, long long n) {
 // column sums, two stage
 __global__ __launch_bounds__(kT) void colsum_partial_kernel(const float *__restrict__ a,
                                                             long long rows, int C, int ld,
-                                                            float *__restrict__ partial) {
+                                                            float *__restrict__ partial, int slab_rows) {
   __shared__ float sm[kT];
   const int CL = min(C, kT), RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-  const long long r0 = (long long)blockIdx.x * kSlabRows, r1 = min(rows, r0 + kSlabRows);
+  const long long r0 = (long long)blockIdx.x * slab_rows, r1 = min(rows, r0 + slab_rows);
   for (int cb = 0; cb < C; cb += CL) {
     const int c = cb + cl;
     float s = 0.f;
@@ -846,14 +846,23 @@ int dspn_fill_f32(float *p, float v, long long n, void *stream) {
   return dspn::check_launch("fill");
 }
 
+// bias gradients are column sums of small, narrow tensors (20..54 channels): slabs of 64 rows keep a few
+// hundred workgroups busy instead of rows/512
+static int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64, (rows + 4095) / 4096); }
+size_t dspn_colsum_workspace_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int sr = colsum_slab_rows(rows);
+  return sizeof(float) * (size_t)((rows + sr - 1) / sr) * C;
+}
 int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out, void *workspace,
                     size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(a && out && workspace && rows > 0 && C > 0 && ld >= C, "colsum: bad argument");
-  const int ns = bn_slabs(rows);
+  const int sr = colsum_slab_rows(rows);
+  const int ns = (int)((rows + sr - 1) / sr);
   if (workspace_bytes < sizeof(float) * (size_t)ns * C)
     return dspn::fail(DSPN_ERR_WORKSPACE_, "colsum: workspace too small");
   float *partial = static_cast<float *>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), a, rows, C, ld, partial);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), a, rows, C, ld, partial, sr);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), partial, ns, C, out);
   return dspn::check_launch("colsum");
 }

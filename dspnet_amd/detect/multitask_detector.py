@@ -30,6 +30,7 @@ class Detector:
         if data is not None:
             self.net.data.data.copy_(data)
         self.net.g.forward()
+        self.net.det.join()        # MultiBoxDetection runs on a side stream beside the seg decoder
         return self.net.det.out.data, self.net.seg_out.prob.data
 
     def detect(self, data, thresh=0.0):

@@ -86,6 +86,7 @@ class Graph:
         self.param_order = []
         self.tensors = {}
         self.all_tensors = []
+        self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
         self.arena = self.grad_arena = self.mom_arena = None
 
     # -- construction ---------------------------------------------------------
@@ -133,6 +134,8 @@ class Graph:
 
     # -- execution ------------------------------------------------------------
     def forward(self):
+        for f in self.pre_forward:
+            f()
         for n in self.nodes:
             n.forward()
 

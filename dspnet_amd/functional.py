@@ -39,6 +39,7 @@ _lib.register({
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "dspn_fill_f32": (_i, [_vp, _f, _ll, _vp]),
+    "dspn_colsum_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_colsum_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
     "dspn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dspn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -282,7 +283,7 @@ def colsum(a, C, out=None):
     ld = a.shape[-1]
     rows = _rows(a)
     out = empty(C, device=a.device) if out is None else out
-    ws = workspace(4 * ((rows + 511) // 512) * C, a.device, "colsum")
+    ws = workspace(L().dspn_colsum_workspace_bytes(rows, C), a.device, "colsum")
     check(L().dspn_colsum_f32(ptr(a), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()), "colsum")
     return out
 

@@ -118,6 +118,7 @@ int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *
 int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long n, int accumulate, void *stream);
 int dspn_fill_f32(float *p, float v, long long n, void *stream);
 /* per-column sum of a (rows, ld) matrix over its first C columns: out[c] = sum_r a[r, c] (bias grads) */
+size_t dspn_colsum_workspace_bytes(long long rows, int C);
 int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out,
                     void *workspace, size_t workspace_bytes, void *stream);
 /* (N,C,H,W) -> (N,H,W,Cp) with zero padded channels, and back (Cp -> first C channels) */
