@@ -53,10 +53,13 @@ struct ConvGeom {
   int Cout;
   long long obs;                   // output batch stride (floats)
   int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
-  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal
+  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal, 32 ReLU after the input affine
   int dense;                       // output address = m*ldc (no decomposition needed)
   int dbg;                         // timing-only ablation bits (dspn_debug_set), 0 in production
   unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
+  // optional per-input-channel affine (+ReLU when flags & 32) applied to the gathered tensor on its way into
+  // LDS: the BatchNorm(+ReLU) in front of a convolution (symbol/resnet.py:30-45) without materialising its output
+  const float *in_scale, *in_shift;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -67,7 +70,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -100,6 +103,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_b =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(g.in_scale), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(g.in_shift), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
+  float4 tf_sc = make_float4(0.f, 0.f, 0.f, 0.f), tf_sh = tf_sc;   // affine of this thread's 4 channels (INTF)
+  unsigned tf_mask = 0;                                            // bit i: A row i of the k-step is inside the image
 
   // ---- loader state of ONE output tile (re-initialised by setup_tile) -----------------------------
   int ld_m0 = 0, ld_n0 = 0;
@@ -169,10 +178,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     ++ld_kt;
     const int dh = tr * g.idh, dw = ts * g.idw;
     const int a_off = (dh * g.Win + dw) * g.Cin + cq * 4;
+    if constexpr (INTF) {
+      const unsigned coff = qv ? (unsigned)cq * 16u : kOOB;
+      const auto s4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)coff, 0, 0);
+      const auto h4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)coff, 0, 0);
+      tf_sc = make_float4(__uint_as_float(s4[0]), __uint_as_float(s4[1]), __uint_as_float(s4[2]), __uint_as_float(s4[3]));
+      tf_sh = make_float4(__uint_as_float(h4[0]), __uint_as_float(h4[1]), __uint_as_float(h4[2]), __uint_as_float(h4[3]));
+      tf_mask = 0;
+    }
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
       const bool v = qv && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      if constexpr (INTF) tf_mask |= v ? (1u << i) : 0u;
       // valid offsets are < 2^31; setting bit 31 pushes an invalid one past num_records
       const unsigned off = ((unsigned)(a_eoff[i] + a_off) * 4u) | (v ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
@@ -191,6 +209,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (INTF) {   // u = x * scale[c] + shift[c] (ReLU), zero where the tap is outside the image
+      const bool in_relu = g.flags & 32;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        float4 u = make_float4(ra[i].x * tf_sc.x + tf_sh.x, ra[i].y * tf_sc.y + tf_sh.y,
+                               ra[i].z * tf_sc.z + tf_sh.z, ra[i].w * tf_sc.w + tf_sh.w);
+        if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+        const bool v = (tf_mask >> i) & 1u;
+        ra[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
+      }
+    }
     if constexpr (BF16) {
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
@@ -429,6 +458,8 @@ struct WgradGeom {
   int R, S;
   int pix_per_split;         // multiple of kBK
   unsigned x_bytes, dy_bytes;
+  const float *in_scale, *in_shift;   // optional affine (+ReLU) on x, as in ConvGeom
+  int in_relu;
 };
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
@@ -436,7 +467,7 @@ struct WgradGeom {
 // consecutive pixels (= MFMA k) of its channel, two reads per 8-k fragment.
 constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16, bool INTF>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
@@ -476,9 +507,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_dy =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy), 0, g.dy_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
+  // this thread's x chunk is a fixed (tap, 4 channels): its affine is loaded once
+  float4 tf_sc = make_float4(0.f, 0.f, 0.f, 0.f), tf_sh = tf_sc;
+  unsigned tf_mask = 0;
+  if constexpr (INTF) {
+    if (jv) {
+      tf_sc = *reinterpret_cast<const float4 *>(g.in_scale + cq * 4);
+      tf_sh = *reinterpret_cast<const float4 *>(g.in_shift + cq * 4);
+    }
+  }
   float4 ra[A_LD], rb[B_LD];
   auto load_tiles = [&](int kt) {
     const int pb = p_begin + kt * kBK;
+    if constexpr (INTF) tf_mask = 0;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int p = pb + a_row0 + i * A_RSTEP;
@@ -494,6 +535,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
       const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
       const int ih = ho * g.sh + tdh, iw = wo * g.sw + tdw;
       const bool v = jv && p < p_end && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      if constexpr (INTF) tf_mask |= v ? (1u << i) : 0u;
       const unsigned off = ((unsigned)(((n * g.Hin + ih) * g.Win + iw) * g.Cin + cq * 4) * 4u) | (v ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)off, 0, 0);
       rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
@@ -503,6 +545,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   char *hA = reinterpret_cast<char *>(smem);            // [2][kBK][RAB]
   char *hB = hA + 2 * kBK * RAB;                        // [2][kBK][RBB]
   auto store_tiles = [&](int buf) {
+    if constexpr (INTF) {
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        float4 u = make_float4(rb[i].x * tf_sc.x + tf_sh.x, rb[i].y * tf_sc.y + tf_sh.y,
+                               rb[i].z * tf_sc.z + tf_sh.z, rb[i].w * tf_sc.w + tf_sh.w);
+        if (g.in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+        const bool v = (tf_mask >> i) & 1u;
+        rb[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
+      }
+    }
     if constexpr (BF16) {
       char *a = hA + buf * kBK * RAB, *b = hB + buf * kBK * RBB;
 #pragma unroll
@@ -743,7 +795,7 @@ struct SplitWs { float *ptr; size_t bytes; };
 
 int g_math_bf16 = 0;   // dspn_conv2d_set_math
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF>
 int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -753,7 +805,7 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
   // mainloop buffers | staged output tile of the epilogue
   const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16, INTF>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
   static int slots = 0;
@@ -785,12 +837,14 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
               hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   const bool uni = ((g.Cin >> 2) & 7) == 0;
-  if (g_math_bf16) {
-    if (uni) return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
-    return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false, true>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+#define DSPN_NT_(U, B, T) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+  if (g.in_scale) {
+    if (g_math_bf16) return uni ? DSPN_NT_(true, true, true) : DSPN_NT_(false, true, true);
+    return uni ? DSPN_NT_(true, false, true) : DSPN_NT_(false, false, true);
   }
-  if (uni) return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
-  return launch_nt_impl<WAVES_M, WAVES_N, TM, TN, false, false>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual);
+  if (g_math_bf16) return uni ? DSPN_NT_(true, true, false) : DSPN_NT_(false, true, false);
+  return uni ? DSPN_NT_(true, false, false) : DSPN_NT_(false, false, false);
+#undef DSPN_NT_
 }
 
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
@@ -898,7 +952,9 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   return sizeof(float) * 32 * (size_t)capped;
 }
 
-static int conv2d_forward_one(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
+struct InAffine { const float *scale, *shift; int relu; };
+
+static int conv2d_forward_one(const float *x, InAffine tf, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -920,7 +976,8 @@ static int conv2d_forward_one(const float *x, const float *w, const float *bias,
   g.obs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * g.ldc;
   g.OW = Wo; g.osh = 1; g.osw = 1; g.ooh = 0; g.oow = 0;
   g.dense = (g.obs == (long long)Ho * Wo * g.ldc);
-  g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0);
+  g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0) | ((tf.scale && tf.relu) ? 32 : 0);
+  g.in_scale = tf.scale; g.in_shift = tf.shift;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -932,24 +989,36 @@ static int batch_chunk(int N, long long bytes_per_image) {
   return (int)std::max<long long>(1, lim / bytes_per_image);
 }
 
-int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
-                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
-                            int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
-                            int relu, int accumulate, void *workspace, size_t workspace_bytes,
-                            void *stream) {
+int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                               const float *w, const float *bias, const float *residual, float *y, int N,
+                               int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
+                               int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
+                               int relu, int accumulate, void *workspace, size_t workspace_bytes,
+                               void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
+  DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   const int ldc = y_ldc > 0 ? y_ldc : Cout;
   const long long ybs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * ldc;
   const int nb = batch_chunk(N, 4ll * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, w, bias,
+    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, w, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
     if (rc) return rc;
   }
   return 0;
+}
+
+int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
+                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
+                            int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
+                            int relu, int accumulate, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+  return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
+                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, workspace,
+                                    workspace_bytes, stream);
 }
 
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -1062,7 +1131,7 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
   return sizeof(float) * m * Cout * J;
 }
 
-static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
+static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float *dw, int N, int H, int W, int Cin,
                           int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -1071,6 +1140,7 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   WgradGeom g;
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
   g.sh = stride; g.sw = stride; g.ph = pad_h; g.pw = pad_w; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
+  g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
   {
     const long long xb = 4ll * N * H * W * Cin, yb = 4ll * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -1092,10 +1162,18 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   const size_t lds = sizeof(float) * std::max(2 * kBK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
   dspn::ProfScope prof(1, s);
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
-  { if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true) else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false) }
-#define DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, BF)                                                         \
   {                                                                                                      \
-    auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF>;                                                 \
+    if (g.in_scale) {                                                                                    \
+      if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                  \
+      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, true)                                             \
+    } else {                                                                                             \
+      if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                 \
+      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, false)                                            \
+    }                                                                                                    \
+  }
+#define DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, BF, TF)                                                     \
+  {                                                                                                      \
+    auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF, TF>;                                             \
     static bool attr = false;                                                                            \
     if (!attr) {                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
@@ -1119,20 +1197,31 @@ static int conv2d_wgrad_one(const float *x, const float *dy, float *dw, int N, i
   return dspn::check_launch("conv_wgrad_reduce");
 }
 
-int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
-                          int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                          int Wo, int accumulate, void *workspace, size_t workspace_bytes,
-                          void *stream) {
+int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                             const float *dy, float *dw, int N, int H, int W, int Cin,
+                             int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                             int Wo, int accumulate, void *workspace, size_t workspace_bytes,
+                             void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
+  DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
   const int nb = std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_wgrad_one(x + (long long)n0 * H * W * Cin, dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
+    const int rc = conv2d_wgrad_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
+                                    dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
                                     Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, accumulate || n0 > 0,
                                     workspace, workspace_bytes, stream);
     if (rc) return rc;
   }
   return 0;
+}
+
+int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,
+                          int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                          int Wo, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  return dspn_conv2d_wgrad_bn_f32(x, nullptr, nullptr, 0, dy, dw, N, H, W, Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil,
+                                  Ho, Wo, accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -28,18 +28,22 @@ from . import functional as fn
 class Tensor:
     """An activation: NHWC (or any) float32 device buffer + its gradient slot."""
 
-    def __init__(self, shape, name, requires_grad=True, data=None, device=None):
+    def __init__(self, shape, name, requires_grad=True, data=None, device=None, virtual=False):
         self.name = name
         self.shape = tuple(int(s) for s in shape)
         self.requires_grad = requires_grad
-        self.data = data if data is not None else fn.zeros(*self.shape, device=device)
+        self.device = device
+        # virtual: never materialised (a BatchNorm output that only convolutions consume: they apply the affine in
+        # their tile loaders, see BatchNorm(defer_apply=True)); .data stays None so any other consumer fails loudly
+        self.affine_src = None
+        self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device))
         self.grad = None
         self._own_grad = None
         self._gw = False  # gradient written in the current backward pass
 
     def own_grad(self):
         if self._own_grad is None:
-            self._own_grad = torch.zeros_like(self.data)
+            self._own_grad = torch.zeros_like(self.data) if self.data is not None else fn.zeros(*self.shape, device=self.device)
         return self._own_grad
 
     def grad_target(self):
@@ -90,8 +94,8 @@ class Graph:
         self.arena = self.grad_arena = self.mom_arena = None
 
     # -- construction ---------------------------------------------------------
-    def tensor(self, shape, name, requires_grad=True, data=None):
-        t = Tensor(shape, name, requires_grad, data=data, device=self.device)
+    def tensor(self, shape, name, requires_grad=True, data=None, virtual=False):
+        t = Tensor(shape, name, requires_grad, data=data, device=self.device, virtual=virtual)
         assert name not in self.tensors, "duplicate tensor name " + name
         self.tensors[name] = t
         self.all_tensors.append(t)
@@ -212,7 +216,11 @@ class BatchNorm(Node):
     """mx.sym.BatchNorm with batch statistics (the solver always runs is_train=True,
     multi_solver.py:284) optionally fused with the following ReLU."""
 
-    def __init__(self, g, x, name, fix_gamma=False, eps=2e-5, relu=False, beta_grad_from_consumer=False):
+    def __init__(self, g, x, name, fix_gamma=False, eps=2e-5, relu=False, beta_grad_from_consumer=False,
+                 defer_apply=False):
+        """defer_apply: the output is only consumed by convolutions, which apply scale/shift(+ReLU) to x in their
+        tile loaders (dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32): forward is the statistics pass alone and
+        the normalised tensor is never written"""
         C = x.shape[-1]
         self.x, self.eps, self.relu = x, eps, relu
         self.gamma = None if fix_gamma else g.param(name + "_gamma", (C,), init_ones)
@@ -222,12 +230,17 @@ class BatchNorm(Node):
         self.scale = fn.zeros(C, device=g.device)
         self.shift = fn.zeros(C, device=g.device)
         # an input BN whose data has no gradient only needs sum(dy) for beta: its consumer supplies it
-        self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer)
+        self.defer_apply = defer_apply
+        self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer,
+                            virtual=defer_apply)
+        if defer_apply:
+            self.out.affine_src = (x, self.scale, self.shift, relu)
 
     def forward(self):
         fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                     self.mean, self.rstd, self.scale, self.shift)
-        fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data)
+        if not self.defer_apply:
+            fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data)
 
     def backward(self):
         if not self.out._gw:
@@ -252,6 +265,12 @@ class Conv(Node):
         kh, kw = fn._hw(kernel)
         ph, pw = fn._hw(pad)
         self.x, self.stride, self.pad, self.dil, self.relu = x, stride, (ph, pw), dilate, relu
+        # input produced by a deferred BatchNorm: read the raw tensor and apply the affine in the loader
+        self.x_raw, self.in_affine = x, None
+        if x.affine_src is not None:
+            raw, sc, sh, arelu = x.affine_src
+            self.x_raw, self.in_affine = raw, (sc, sh, arelu)
+            assert not tap_expand
         self.cout = num_filter
         # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
         self.input_sum_grad = input_sum_grad
@@ -283,9 +302,9 @@ class Conv(Node):
             fn.conv2d_forward(self.x.data, self.w.data.view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
-        fn.conv2d_forward(self.x.data, self.w.data, None if self.b is None else self.b.data, self.stride,
+        fn.conv2d_forward(self.x_raw.data, self.w.data, None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
-                          residual=None if self.residual is None else self.residual.data)
+                          residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine)
 
     def backward(self):
         if not self.out._gw:
@@ -303,7 +322,8 @@ class Conv(Node):
             fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
                             out=self.w.grad.view(cout * kh * kw, 1, 1, cin))
         else:
-            fn.conv2d_wgrad(self.x.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad)
+            fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
+                            in_affine=self.in_affine)
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                      out=self.input_sum_grad.grad)

@@ -22,6 +22,10 @@ _lib.register({
     "dspn_debug_set": (_i, [_i]),
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
+    "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                        _i, _ll, _i, _i, _i, _vp, _sz, _vp]),
+    "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                      _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
@@ -123,8 +127,10 @@ def get_conv_math():
     return "bf16" if L().dspn_conv2d_get_math() else "fp32"
 
 
-def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None):
-    """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout)"""
+def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
+                   in_affine=None):
+    """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
+    in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
@@ -136,9 +142,10 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     ldc = out.shape[3]
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
     assert residual is None or residual.shape == out.shape
-    check(L().dspn_conv2d_forward_f32(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S, stride,
-                                      ph, pw, dil, Ho, Wo, 0, ldc, int(relu), int(accumulate), ptr(ws), ws.numel(),
-                                      stream()), "conv2d_forward")
+    sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
+    check(L().dspn_conv2d_forward_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
+                                         N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
+                                         int(accumulate), ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
 
 
@@ -169,8 +176,8 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     return out
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
-    """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin)"""
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None):
+    """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
     assert Cw == Cin
@@ -180,8 +187,9 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     nbytes = L().dspn_conv2d_wgrad_workspace_bytes(N, Ho, Wo, Cin, Cout, R, S)
     ws = workspace(nbytes, x.device, "wgrad")
     ph, pw = _hw(pad)
-    check(L().dspn_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride, ph, pw,
-                                    dil, Ho, Wo, int(accumulate), ptr(ws), ws.numel(), stream()),
+    sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
+    check(L().dspn_conv2d_wgrad_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
+                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), ptr(ws), ws.numel(), stream()),
           "conv2d_wgrad")
     return out
 

@@ -13,18 +13,19 @@ def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottl
     # The unit's `+ shortcut` (symbol/resnet.py:51,67) is folded into the epilogue of its last convolution,
     # whose output tensor therefore IS `_plusN`; the projection shortcut is built before that conv.
     if not bottle_neck:
-        bn1 = g.add(E.BatchNorm(g, data, name + "_bn1", relu=True)).out
+        bn1 = g.add(E.BatchNorm(g, data, name + "_bn1", relu=True, defer_apply=True)).out
         shortcut = data if dim_match else g.add(E.Conv(g, bn1, name + "_sc", num_filter, 1, stride, 0)).out
         conv1 = g.add(E.Conv(g, bn1, name + "_conv1", num_filter, 3, stride, 1)).out
-        bn2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True)).out
+        bn2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True, defer_apply=True)).out
         return g.add(E.Conv(g, bn2, name + "_conv2", num_filter, 3, 1, 1, residual=shortcut, out_name=plus_name)).out
     q = int(num_filter * 0.25)
-    act1 = g.add(E.BatchNorm(g, data, name + "_bn1", relu=True)).out
+    # act1/act2/act3 feed convolutions only: their BN-apply + ReLU runs inside those convolutions' loaders
+    act1 = g.add(E.BatchNorm(g, data, name + "_bn1", relu=True, defer_apply=True)).out
     shortcut = data if dim_match else g.add(E.Conv(g, act1, name + "_sc", num_filter, 1, stride, 0)).out
     conv1 = g.add(E.Conv(g, act1, name + "_conv1", q, 1, 1, 0)).out
-    act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True)).out
+    act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True, defer_apply=True)).out
     conv2 = g.add(E.Conv(g, act2, name + "_conv2", q, 3, stride, 1)).out
-    act3 = g.add(E.BatchNorm(g, conv2, name + "_bn3", relu=True)).out
+    act3 = g.add(E.BatchNorm(g, conv2, name + "_bn3", relu=True, defer_apply=True)).out
     return g.add(E.Conv(g, act3, name + "_conv3", num_filter, 1, 1, 0, residual=shortcut, out_name=plus_name)).out
 
 

@@ -57,6 +57,18 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
                             long long y_batch_stride, int y_ldc, int relu, int accumulate,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same convolution on u = x * in_scale[c] + in_shift[c] (then max(u, 0) if in_relu), with u == 0 outside
+ * the image: the BatchNorm(+ReLU) that precedes every convolution of a pre-activation residual unit
+ * (symbol/resnet.py:30-45: bn -> relu -> conv) folded into the convolution's tile loader, so the normalised
+ * tensor is never written to or re-read from HBM.  in_scale / in_shift: Cin floats each, e.g. the scale / shift
+ * outputs of dspn_bn_stats_f32; both NULL = plain convolution. */
+int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                               const float *w, const float *bias, const float *residual, float *y,
+                               int N, int H, int W, int Cin, int Cout, int R, int S,
+                               int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
+                               long long y_batch_stride, int y_ldc, int relu, int accumulate,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
                                      int Cout_pad, void *stream);
@@ -87,6 +99,11 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
                           int N, int H, int W, int Cin, int Cout, int ldy, int R, int S,
                           int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int accumulate,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* weight gradient with respect to the same u = (relu)(x * in_scale + in_shift) as dspn_conv2d_forward_bn_f32 */
+int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                             const float *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
+                             int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
+                             int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
  * symbol/resnet.py:30-41,91,96; multitask_symbol_builder.py:545-585) ------------------ */

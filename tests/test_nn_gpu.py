@@ -419,3 +419,31 @@ def test_conv_bf16_mfma_math(gpu_device, bf16_math, case):
     x2 = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
     y2 = fn.conv2d_forward(nhwc(x2), wd_, None, stride=stride, pad=pad, dil=dil)
     close(nchw(y2, Cout), F.conv2d(x2, w.detach(), None, stride=stride, padding=pad, dilation=dil), 2e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1, 1), (2, 17, 19, 32, 48, 3, 2, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0, 1),
+                                  (2, 16, 16, 128, 256, 1, 2, 0, 1), (1, 9, 9, 36, 40, 3, 1, 1, 1), (4, 64, 64, 64, 128, 3, 1, 1, 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv_with_input_affine(gpu_device, case, relu):
+    """dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32: BatchNorm-apply (+ReLU) folded into the tile loader ==
+    the convolution of the materialised (relu)(x*scale+shift), including zero padding AFTER the affine"""
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cin, generator=g, dtype=torch.float64)
+    u = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    u = u.clamp(min=0) if relu else u
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k))
+    y_ref = F.conv2d(u, w, None, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    dw_ref = torch.nn.grad.conv2d_weight(u, w.shape, dy, stride=stride, padding=pad, dilation=dil)
+    aff = (sc.float().cuda(), sh.float().cuda(), relu)
+    cp = fn.pad4(Cin)
+    if cp != Cin:   # pad channels: scale/shift padded with zeros -> u == 0 there
+        aff = (torch.cat([aff[0], torch.zeros(cp - Cin, device="cuda")]), torch.cat([aff[1], torch.zeros(cp - Cin, device="cuda")]), relu)
+    xd, wd_ = nhwc(x), wdev(w)
+    y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=pad, dil=dil, in_affine=aff)
+    close(nchw(y, Cout), y_ref)
+    dw = fn.conv2d_wgrad(xd, nhwc(dy), tuple(wd_.shape), stride=stride, pad=pad, dil=dil, in_affine=aff)
+    close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], dw_ref)
