@@ -60,6 +60,9 @@ struct ConvGeom {
   // optional per-input-channel affine (+ReLU when flags & 32) applied to the gathered tensor on its way into
   // LDS: the BatchNorm(+ReLU) in front of a convolution (symbol/resnet.py:30-45) without materialising its output
   const float *in_scale, *in_shift;
+  // optional BatchNorm statistics of the OUTPUT, per row tile: stats[(mt*2 + 0)*Cout + c] = mean over the tile's
+  // rows, stats[(mt*2 + 1)*Cout + c] = sum of squared deviations from that mean (merged by dspn_bn_stats_from_tiles_f32)
+  float *stats;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -403,6 +406,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) bv[e] = co + e < g.Cout ? bias[co + e] : 0.f;
         }
+        // BatchNorm statistics of the stored values (g.stats): shifted sums about the thread's first row
+        float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        int scnt = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const long long off = offs[p];
@@ -420,6 +426,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
             if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (g.stats) {
+              if (scnt == 0) { sK[0] = v[0]; sK[1] = v[1]; sK[2] = v[2]; sK[3] = v[3]; }
+              ++scnt;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const float d = v[e] - sK[e]; s1[e] += d; s2[e] += d * d; }
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -430,6 +442,38 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
               if (relu) x = x > 0.f ? x : 0.f;
               out[off + e] = x;
             }
+          }
+        }
+        if (g.stats) {
+          // per-thread (mean, M2) of its rows -> LDS -> one thread per column merges the RPP row groups with
+          // Chan's update in a fixed order -> stats[m tile][mean | M2][column]
+          __syncthreads();               // every staged row has been read
+          float *red = smem;             // [RPP][BN][2]
+          if (vec) {
+            const float inv = scnt > 0 ? 1.f / (float)scnt : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              red[((er0 * BN) + c4 * 4 + e) * 2] = sK[e] + s1[e] * inv;
+              red[((er0 * BN) + c4 * 4 + e) * 2 + 1] = s2[e] - s1[e] * s1[e] * inv;
+            }
+          }
+          __syncthreads();
+          if (tid < BN && n0 + tid < g.Cout) {
+            const int lim = min(M - m0, BM);
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            for (int er = 0; er < RPP; ++er) {
+              const int ne_i = lim > er ? (lim - er + RPP - 1) / RPP : 0;   // rows er, er + RPP, ... of this tile below M
+              if (ne_i <= 0) continue;
+              const float ne = (float)ne_i;
+              const float me = red[(er * BN + tid) * 2], m2e = red[(er * BN + tid) * 2 + 1];
+              const float tot = n + ne, delta = me - mean;
+              mean += delta * (ne / tot);
+              m2 += m2e + delta * delta * (n * ne / tot);
+              n = tot;
+            }
+            const long long mt_ = m0 / BM;
+            g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
+            g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
           }
         }
       }
@@ -850,6 +894,21 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
 // leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
 int g_debug_bits = 0;
+static const int kNtBm[4] = {128, 128, 64, 256}, kNtBn[4] = {128, 64, 64, 32};
+// Tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32) for an M x Cout output
+int nt_config(long long M, int Cout) {
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+  int cfg;
+  // measured on MI355X (scratch/cfgtest.py): 128x128 wins once it yields >= 2 workgroups per CU,
+  // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
+  if (Cout <= 32) cfg = tiles(256, 32) >= 512 ? 3 : 2;
+  else cfg = (Cout > 64 && tiles(128, 128) >= 512) ? 0 : 2;
+  // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
+  // 128-wide column tile: 64-wide columns cut the padding to < 64
+  if (cfg == 0 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) cfg = 1;
+  if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
+  return cfg;
+}
 int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g_in,
                 hipStream_t s, SplitWs ws, const float *residual = nullptr) {
   ConvGeom g = g_in;
@@ -867,20 +926,14 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
-  int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32
-  // measured on MI355X (scratch/cfgtest.py): 128x128 wins once it yields >= 2 workgroups per CU,
-  // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
-  if (g.Cout <= 32) cfg = tiles(256, 32) >= 512 ? 3 : 2;
-  else cfg = (g.Cout > 64 && tiles(128, 128) >= 512) ? 0 : 2;
-  // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
-  // 128-wide column tile: 64-wide columns cut the padding to < 64
-  if (cfg == 0 && (g.Cout + 63) / 64 * 64 < (g.Cout + 127) / 128 * 128) cfg = 1;
-  if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
-  static const int bm_[4] = {128, 128, 64, 256}, bn_[4] = {128, 64, 64, 32};
+  const int cfg = nt_config(M, g.Cout);
+  const int *bm_ = kNtBm, *bn_ = kNtBn;
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
   const int nk = (g.TR * g.TS * (g.Cin >> 2) + 7) >> 3;
   int splits = 1, per = nk;
-  if (g.dense && nblk < 192 && nk >= 16 && ws.ptr) {
+  if (g.stats && (!g.dense || !(g.flags & 16) || g.Cout % 4 != 0))
+    return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: output statistics need a dense, 16-byte aligned output with Cout %% 4 == 0");
+  if (g.dense && nblk < 192 && nk >= 16 && ws.ptr && !g.stats) {
     splits = (int)std::min<long long>((384 + nblk - 1) / nblk, nk / 8);
     splits = std::max(1, std::min(splits, 32));
     while (splits > 1 && sizeof(float) * (size_t)splits * M * g.Cout > ws.bytes) --splits;
@@ -954,7 +1007,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 
 struct InAffine { const float *scale, *shift; int relu; };
 
-static int conv2d_forward_one(const float *x, InAffine tf, const float *w, const float *bias, const float *residual, float *y, int N,
+static int conv2d_forward_one(const float *x, InAffine tf, float *stats, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -978,6 +1031,7 @@ static int conv2d_forward_one(const float *x, InAffine tf, const float *w, const
   g.dense = (g.obs == (long long)Ho * Wo * g.ldc);
   g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0) | ((tf.scale && tf.relu) ? 32 : 0);
   g.in_scale = tf.scale; g.in_shift = tf.shift;
+  g.stats = stats;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -989,20 +1043,34 @@ static int batch_chunk(int N, long long bytes_per_image) {
   return (int)std::max<long long>(1, lim / bytes_per_image);
 }
 
+int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows) {
+  if (out_pixels <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
+  const int bm = kNtBm[nt_config(out_pixels, Cout)];
+  if (tile_rows) *tile_rows = bm;
+  return (int)((out_pixels + bm - 1) / bm);
+}
+
 int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                                const float *w, const float *bias, const float *residual, float *y, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                                int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
-                               int relu, int accumulate, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+                               int relu, int accumulate, float *out_stats, size_t out_stats_bytes,
+                               void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
+  if (out_stats) {
+    int tile_rows = 0;
+    const int mt = dspn_conv2d_stats_layout((long long)N * Ho * Wo, Cout, &tile_rows);
+    DSPN_REQUIRE(mt > 0 && out_stats_bytes >= sizeof(float) * 2 * (size_t)mt * Cout,
+                 "conv2d_forward: out_stats needs dspn_conv2d_stats_layout() tiles x 2 x Cout floats and Cout %% 4 == 0");
+    DSPN_REQUIRE(batch_chunk(N, 4ll * H * W * Cin) == N, "conv2d_forward: out_stats is not available for inputs of 2 GiB or more");
+  }
   const int ldc = y_ldc > 0 ? y_ldc : Cout;
   const long long ybs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * ldc;
   const int nb = batch_chunk(N, 4ll * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, w, bias,
+    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
@@ -1017,7 +1085,7 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
   return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
-                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, workspace,
+                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, workspace,
                                     workspace_bytes, stream);
 }
 

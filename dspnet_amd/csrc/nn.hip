@@ -70,11 +70,13 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double S = 0, SS = 0;
-  if (c < C)
-    for (int k = sl; k < nslabs; k += 16) {
+  if (c < C) {
+#pragma unroll 8
+    for (int k = sl; k < nslabs; k += 16) {   // unrolled: the kernel is pure load latency
       S += partial[(long long)k * 2 * C + c];
       SS += partial[(long long)k * 2 * C + C + c];
     }
+  }
   s_S[sl][cl] = S; s_SS[sl][cl] = SS;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -84,6 +86,45 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(
     double var = SS / n - m * m;
     if (var < 0) var = 0;
     const float mu = (float)((double)x[c] + m);
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mu; rstd[c] = rs;
+    const float sc = (gamma ? gamma[c] : 1.f) * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+  }
+}
+
+// merge of per-tile (mean, M2) pairs, 16 channels x 64 tile-lanes per block, ONE sweep in double, fixed order:
+//   mean = A / rows, var = B / rows - mean^2  with  A = sum_t n_t mean_t,  B = sum_t (M2_t + n_t mean_t^2)
+// (the cancellation in B/rows - mean^2 is harmless in double: the per-tile quantities carry 24 bits)
+// The loop is unrolled so that 8 loads per accumulator are in flight: the kernel sits alone between two
+// convolutions and is pure load latency.
+__global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
+    const float *__restrict__ ts, int tiles, int tile_rows, long long rows, int C, float eps,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ mean,
+    float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift) {
+  __shared__ double sA[64][17], sB[64][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const long long last_n = rows - (long long)(tiles - 1) * tile_rows;
+  double A = 0, B = 0;
+  if (c < C) {
+#pragma unroll 8
+    for (int t = sl; t < tiles; t += 64) {
+      const double n = (double)(t == tiles - 1 ? last_n : (long long)tile_rows);
+      const double mt = ts[((long long)t * 2 + 0) * C + c], qt = ts[((long long)t * 2 + 1) * C + c];
+      A += n * mt;
+      B += qt + n * mt * mt;
+    }
+  }
+  sA[sl][cl] = A; sB[sl][cl] = B;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 64; ++k) { A += sA[k][cl]; B += sB[k][cl]; }
+    const double m = A / (double)rows;
+    double var = B / (double)rows - m * m;
+    if (var < 0) var = 0;
+    const float mu = (float)m;
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = mu; rstd[c] = rs;
     const float sc = (gamma ? gamma[c] : 1.f) * rs;
@@ -164,11 +205,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double S = 0, SS = 0;
-  if (c < C)
-    for (int k = sl; k < nslabs; k += 16) {
+  if (c < C) {
+#pragma unroll 8
+    for (int k = sl; k < nslabs; k += 16) {   // unrolled: the kernel is pure load latency
       S += partial[(long long)k * 2 * C + c];
       SS += partial[(long long)k * 2 * C + C + c];
     }
+  }
   s_S[sl][cl] = S; s_SS[sl][cl] = SS;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -260,6 +303,7 @@ __global__ void colsum_final_kernel(const float *partial, int nslabs, int C, flo
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0;
+#pragma unroll 8
   for (int k = 0; k < nslabs; ++k) s += partial[(long long)k * C + c];
   out[c] = (float)s;
 }
@@ -780,6 +824,16 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
   return dspn::check_launch("bn_stats");
 }
 
+int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
+                                 const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
+                                 float *shift, void *stream) {
+  DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
+                   rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
+               "bn_stats_from_tiles: bad argument");
+  hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
+                     tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
+  return dspn::check_launch("bn_stats_from_tiles");
+}
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
                       int C, int relu, void *stream) {
   DSPN_REQUIRE(x && scale && shift && y, "bn_apply: null pointer");

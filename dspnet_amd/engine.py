@@ -36,6 +36,7 @@ class Tensor:
         # virtual: never materialised (a BatchNorm output that only convolutions consume: they apply the affine in
         # their tile loaders, see BatchNorm(defer_apply=True)); .data stays None so any other consumer fails loudly
         self.affine_src = None
+        self.producer = None       # the Conv node that writes this tensor (it can emit BatchNorm tile statistics)
         self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device))
         self.grad = None
         self._own_grad = None
@@ -231,14 +232,24 @@ class BatchNorm(Node):
         self.shift = fn.zeros(C, device=g.device)
         # an input BN whose data has no gradient only needs sum(dy) for beta: its consumer supplies it
         self.defer_apply = defer_apply
+        # statistics gathered by the producing convolution's epilogue (one (mean, M2) pair per row tile) instead of a
+        # separate pass over x
+        self.tile_stats = x.producer.enable_out_stats() if getattr(x, "producer", None) is not None else None
         self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer,
                             virtual=defer_apply)
         if defer_apply:
             self.out.affine_src = (x, self.scale, self.shift, relu)
 
     def forward(self):
-        fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
-                    self.mean, self.rstd, self.scale, self.shift)
+        if self.tile_stats is not None:
+            buf, tiles, tile_rows = self.tile_stats
+            rows = int(np.prod(self.x.shape[:-1]))
+            fn.bn_stats_from_tiles(buf, tiles, tile_rows, rows, self.x.shape[-1], self.eps,
+                                   None if self.gamma is None else self.gamma.data, self.beta.data,
+                                   self.mean, self.rstd, self.scale, self.shift)
+        else:
+            fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
+                        self.mean, self.rstd, self.scale, self.shift)
         if not self.defer_apply:
             fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data)
 
@@ -280,6 +291,9 @@ class Conv(Node):
         Ho, Wo = fn.conv_out_size(H, kh, stride, ph, dilate), fn.conv_out_size(W, kw, stride, pw, dilate)
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), out_name or (name + "_out"))
+        self.out.producer = self
+        self.out_stats = None      # (buffer, tiles, rows per tile) once a BatchNorm asked for them
+        self._g = g
         # residual: a tensor of the output's shape added in the conv epilogue (`conv3 + shortcut`,
         # symbol/resnet.py:51); its gradient is the output gradient itself
         self.residual = residual
@@ -296,6 +310,18 @@ class Conv(Node):
         self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
+    def enable_out_stats(self):
+        """called by a BatchNorm on self.out: have the epilogue write per-tile statistics (None if unavailable)"""
+        if self.tap_expand or self.out.shape[3] != self.cout or self.cout % 4 != 0:
+            return None
+        if self.out_stats is None:
+            rows = self.out.shape[0] * self.out.shape[1] * self.out.shape[2]
+            tiles, tile_rows = fn.conv_stats_layout(rows, self.cout)
+            if tiles == 0:
+                return None
+            self.out_stats = (fn.zeros(tiles, 2, self.cout, device=self._g.device), tiles, tile_rows)
+        return self.out_stats
+
     def forward(self):
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
@@ -304,7 +330,8 @@ class Conv(Node):
             return
         fn.conv2d_forward(self.x_raw.data, self.w.data, None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
-                          residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine)
+                          residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine,
+                          out_stats=None if self.out_stats is None else self.out_stats[0])
 
     def backward(self):
         if not self.out._gw:

@@ -23,7 +23,9 @@ _lib.register({
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                        _i, _ll, _i, _i, _i, _vp, _sz, _vp]),
+                                        _i, _ll, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
+    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _vp, _sz, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -127,8 +129,20 @@ def get_conv_math():
     return "bf16" if L().dspn_conv2d_get_math() else "fp32"
 
 
+def conv_stats_layout(out_pixels, cout):
+    """(tiles, rows per tile) of the per-tile BatchNorm statistics a convolution can emit; (0, 0) if it cannot"""
+    tr = _c.c_int(0)
+    n = L().dspn_conv2d_stats_layout(int(out_pixels), int(cout), _c.byref(tr))
+    return (n, tr.value) if n > 0 else (0, 0)
+
+
+def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift):
+    check(L().dspn_bn_stats_from_tiles_f32(ptr(tile_stats), tiles, tile_rows, rows, C, eps, ptr(gamma), ptr(beta), ptr(mean),
+                                           ptr(rstd), ptr(scale), ptr(shift), stream()), "bn_stats_from_tiles")
+
+
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
-                   in_affine=None):
+                   in_affine=None, out_stats=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
     in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x"""
     N, H, W, Cin = x.shape
@@ -145,7 +159,8 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     check(L().dspn_conv2d_forward_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
-                                         int(accumulate), ptr(ws), ws.numel(), stream()), "conv2d_forward")
+                                         int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
+                                         ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
 
 

@@ -67,7 +67,14 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                long long y_batch_stride, int y_ldc, int relu, int accumulate,
+                               float *out_stats, size_t out_stats_bytes,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* out_stats (optional): BatchNorm statistics of y gathered in the convolution's epilogue, one (mean, M2) pair per
+ * channel and row tile: out_stats[(t*2 + 0)*Cout + c] = mean of tile t's rows, [(t*2 + 1)*Cout + c] = their sum of
+ * squared deviations.  dspn_conv2d_stats_layout() gives the number of tiles (0: not available, Cout % 4 != 0) and
+ * the rows per tile for an output of out_pixels x Cout; dspn_bn_stats_from_tiles_f32 merges them.  Requires a dense
+ * output (y_ldc == Cout or 0). */
+int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
 
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -118,6 +125,12 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* y = x*scale + shift, optionally max(.,0). */
+/* the same outputs as dspn_bn_stats_f32 from the per-tile (mean, M2) pairs a convolution wrote (out_stats of
+ * dspn_conv2d_forward_bn_f32): tiles of tile_rows rows (the last one shorter) over `rows` rows, merged pairwise in
+ * double (Chan et al.), fixed order */
+int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
+                                 const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
+                                 float *shift, void *stream);
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
                       int C, int relu, void *stream);
 

@@ -447,3 +447,38 @@ def test_conv_with_input_affine(gpu_device, case, relu):
     close(nchw(y, Cout), y_ref)
     dw = fn.conv2d_wgrad(xd, nhwc(dy), tuple(wd_.shape), stride=stride, pad=pad, dil=dil, in_affine=aff)
     close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], dw_ref)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
+                                  (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
+    """out_stats of dspn_conv2d_forward_bn_f32 + dspn_bn_stats_from_tiles_f32 == dspn_bn_stats_f32 on the stored
+    output (mean / rstd / scale / shift), including a large common offset (cancellation) and the residual add"""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) * 30.0          # |mean| >> std
+    xd, wd_, bd = nhwc(x), wdev(w), b.float().cuda()
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).cuda() if with_res else None
+    tiles, tile_rows = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    assert tiles > 0
+    st = torch.full((tiles, 2, Cout), float("nan"), device="cuda")
+    y = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, residual=res, out_stats=st)
+    y_plain = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, residual=res)
+    # (not bit-equal in general: small grids take the split-K path without out_stats, a different summation order)
+    assert float((y - y_plain).abs().max()) <= 1e-5 * float(y_plain.abs().max())
+    gamma = (torch.rand(Cout, generator=g) + 0.5).cuda(); beta = torch.randn(Cout, generator=g).cuda()
+    outs = [torch.empty(Cout, device="cuda") for _ in range(4)]
+    fn.bn_stats_from_tiles(st, tiles, tile_rows, N * Ho * Wo, Cout, 2e-5, gamma, beta, *outs)
+    yd = y.double().view(-1, Cout)
+    mean_ref = yd.mean(0); var_ref = yd.var(0, unbiased=False)
+    rstd_ref = 1.0 / torch.sqrt(var_ref + 2e-5)
+    assert float((outs[0].double() - mean_ref).abs().max()) <= 1e-6 * float(mean_ref.abs().max())
+    assert float((outs[1].double() / rstd_ref - 1).abs().max()) <= 2e-6
+    ref = [torch.empty(Cout, device="cuda") for _ in range(4)]
+    fn.bn_stats(y, 2e-5, gamma, beta, *ref)                      # the separate-pass kernel
+    for a, r in zip(outs, ref):
+        assert float((a - r).abs().max()) <= 5e-6 * float(r.abs().max())
