@@ -948,7 +948,7 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   }
 }
 
-struct WgradPlan { int bm; int splits; int pps; };
+struct WgradPlan { int bm; int bn; int splits; int pps; };
 // Weight-gradient decomposition: tile height by Cout, split-K over pixels.  The number of splits is
 // the one that minimises a small cost model: workgroups run in rounds of `slots` (workgroups the chip
 // holds at once, set by LDS per workgroup), each costs its pixels plus a fixed prologue/epilogue, and
@@ -958,8 +958,11 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   WgradPlan p;
   p.bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
   if (p.bm == 128 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) p.bm = 64;   // less row padding
-  const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + 127) / 128);
-  const long long lds = 4ll * std::max(2 * kBK * (p.bm + 128), p.bm * 132);
+  // J = taps x channels <= 64 (the 1x1 convolutions on 64 channels of stage 1): a 128-wide column tile would be
+  // half padding
+  p.bn = (J <= 64 && p.bm == 128) ? 64 : 128;   // (64 x 64 tiles measured slower than 64 x 128 for Cout <= 64)
+  const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + p.bn - 1) / p.bn);
+  const long long lds = 4ll * std::max(2 * kBK * (p.bm + p.bn), p.bm * (p.bn + 4));
   const long long slots = 256 * std::min<long long>(8, (160ll << 10) / lds);
   // every tap re-reads the same pixels of x: keep one split's share of x within the Infinity Cache /
   // L2 so that only the first tap's workgroups fetch it from HBM
@@ -967,7 +970,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   if (x_bytes > 0) s_min = (x_bytes + (32ll << 20) - 1) / (32ll << 20);
   const long long s_max = std::max<long long>(1, std::min<long long>(P / 128, 1024));
   s_min = std::min(s_min, s_max);
-  const double flop_per_pix = 2.0 * p.bm * 128, slot_rate = 120e12 / (double)slots, ovh_pix = 160;
+  const double flop_per_pix = 2.0 * p.bm * p.bn, slot_rate = 120e12 / (double)slots, ovh_pix = 160;
   double best = 1e30;
   long long splits = s_min;
   for (long long sp = s_min; sp <= s_max; ++sp) {
@@ -1218,7 +1221,7 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
   const WgradPlan plan = wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0);
-  const int BM = plan.bm, BN = 128;
+  const int BM = plan.bm, BN = plan.bn;
   const int kt = (Cout + BM - 1) / BM, jt = (J + BN - 1) / BN;
   const long long splits = plan.splits;
   g.pix_per_split = plan.pps;
@@ -1250,9 +1253,10 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
     }                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt); \
   }
-  if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)        // 32 x 128
-  else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)   // 64 x 128
-  else DSPN_WGRAD_LAUNCH(2, 2, 2, 2)                 // 128 x 128
+  if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
+  else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
+  else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64
+  else DSPN_WGRAD_LAUNCH(2, 2, 2, 2)                              // 128 x 128
 #undef DSPN_WGRAD_LAUNCH
 #undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");

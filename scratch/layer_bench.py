@@ -31,7 +31,7 @@ for n in net.g.nodes:
     fl = n.flops_fwd
     tf = timeit(n.forward)
     dy = n.out.own_grad()
-    tw = timeit(lambda: fn.conv2d_wgrad(n.x.data, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad))
+    tw = timeit(lambda: fn.conv2d_wgrad(n.x_raw.data, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad, in_affine=n.in_affine))
     td = None
     if n.x.requires_grad:
         dx = n.x.own_grad()
