@@ -63,6 +63,13 @@ struct ConvGeom {
   // optional BatchNorm statistics of the OUTPUT, per row tile: stats[(mt*2 + 0)*Cout + c] = mean over the tile's
   // rows, stats[(mt*2 + 1)*Cout + c] = sum of squared deviations from that mean (merged by dspn_bn_stats_from_tiles_f32)
   float *stats;
+  // optional BatchNorm-backward sums of the OUTPUT (a data gradient dy of a BatchNorm(+ReLU) output whose input was
+  // bn_x, same layout as out): per row tile t, bn_sums[((tile_base + t)*2 + 0)*Cout + c] = sum of dy' and
+  // [... + 1 ...] = sum of dy' * xhat, with dy' = dy where (bn_x*bn_scale + bn_shift > 0 or no ReLU) else 0 and
+  // xhat = (bn_x - bn_mean) * bn_rstd: the layout dspn_bn_backward_from_sums_f32 reads
+  const float *bn_x, *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
+  float *bn_sums;
+  int bn_relu, bn_tile_base;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -73,7 +80,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF>
+// EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -366,33 +374,44 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
         // flight per thread held the residual convolutions to ~3 TB/s).
         constexpr int SLD = BN + 4;
         constexpr int C4 = BN / 4, RPP = kThreads / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
+        // rows are handled RC at a time: all of them, or half of them when the BatchNorm-backward sums hold a second
+        // operand row in registers
+        constexpr int RC = (EPI == 2 && NP > 8) ? NP / 2 : NP;
         float *st = smem;
         const int c4 = tid % C4, er0 = tid / C4;
         const int co = n0 + c4 * 4;
         const bool cvalid = co < g.Cout;
         const bool vec = (g.flags & 16) && co + 3 < g.Cout;
-        long long offs[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int m = m0 + er0 + p * RPP;
-          if (g.dense) {
-            offs[p] = (long long)m * g.ldc + co;
-          } else {
-            const int hw = g.Hg * g.Wg;
-            const int n = m / hw, rem = m - n * hw;
-            const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-            offs[p] = (long long)n * g.obs +
-                      ((long long)(oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
-          }
-          if (m >= M || !cvalid) offs[p] = -1;
-        }
         const float *addsrc = has_res ? residual : (accum ? out : nullptr);   // first additive operand
-        float4 rq[NP];
+        int offs[RC];   // element offsets (the host checks that the output holds < 2^31 elements)
+        float4 rq[RC], xq[EPI == 2 ? RC : 1];
+        auto rows_begin = [&](const int ch) __attribute__((always_inline)) {   // addresses + additive operand of chunk ch
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (addsrc && vec && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
-        }
+          for (int p = 0; p < RC; ++p) {
+            const int m = m0 + er0 + (ch * RC + p) * RPP;
+            if (g.dense) {
+              offs[p] = m * g.ldc + co;
+            } else {
+              const int hw = g.Hg * g.Wg;
+              const int n = m / hw, rem = m - n * hw;
+              const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+              offs[p] = n * (int)g.obs + ((oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+            }
+            if (m >= M || !cvalid) offs[p] = -1;
+            rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (addsrc && vec && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
+          }
+        };
+        auto rows_bn_x = [&]() __attribute__((always_inline)) {   // the BatchNorm input rows of the current chunk
+          if constexpr (EPI == 2) {
+#pragma unroll
+            for (int p = 0; p < RC; ++p) {
+              xq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (vec && offs[p] >= 0) xq[p] = *reinterpret_cast<const float4 *>(g.bn_x + offs[p]);
+            }
+          }
+        };
+        rows_begin(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -400,7 +419,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+        rows_bn_x();   // requested once the accumulators are staged (their registers are free), ahead of the barrier
         __syncthreads();
+        float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == 2 && vec) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bmu[e] = g.bn_mean[co + e]; brs[e] = g.bn_rstd[co + e];
+            if (g.bn_relu) { bsc[e] = g.bn_scale[co + e]; bsh[e] = g.bn_shift[co + e]; }
+          }
+        }
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (has_bias && cvalid) {
 #pragma unroll
@@ -410,41 +439,54 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
         float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         int scnt = 0;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const long long off = offs[p];
-          if (off < 0) continue;
-          const float4 tv = *reinterpret_cast<const float4 *>(st + (er0 + p * RPP) * SLD + c4 * 4);
-          float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
-          if (vec) {
-            v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
-            if (has_res && accum) {
-              const float4 q = *reinterpret_cast<const float4 *>(out + off);
-              v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-            }
-            if (relu) {
+        for (int ch = 0; ch < NP / RC; ++ch) {
+          if (ch > 0) { rows_begin(ch); rows_bn_x(); }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
-            if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
-            if (g.stats) {
-              if (scnt == 0) { sK[0] = v[0]; sK[1] = v[1]; sK[2] = v[2]; sK[3] = v[3]; }
-              ++scnt;
+          for (int p = 0; p < RC; ++p) {
+            const int off = offs[p];
+            if (off < 0) continue;
+            const float4 tv = *reinterpret_cast<const float4 *>(st + (er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
+            float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
+            if (vec) {
+              v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
+              if (has_res && accum) {
+                const float4 q = *reinterpret_cast<const float4 *>(out + off);
+                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+              }
+              if (relu) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { const float d = v[e] - sK[e]; s1[e] += d; s2[e] += d * d; }
-            }
-          } else {
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+              }
+              if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+              if constexpr (EPI == 2) {
+                const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (co + e >= g.Cout) break;
-              float x = v[e];
-              if (has_res) x += residual[off + e];
-              if (accum) x += out[off + e];
-              if (relu) x = x > 0.f ? x : 0.f;
-              out[off + e] = x;
+                for (int e = 0; e < 4; ++e) {
+                  const float gd = (!g.bn_relu || xv[e] * bsc[e] + bsh[e] > 0.f) ? v[e] : 0.f;
+                  gs[e] += gd;
+                  gss[e] += gd * ((xv[e] - bmu[e]) * brs[e]);
+                }
+              }
+              if constexpr (EPI == 1) {
+                if (scnt == 0) { sK[0] = v[0]; sK[1] = v[1]; sK[2] = v[2]; sK[3] = v[3]; }
+                ++scnt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[e] - sK[e]; s1[e] += d; s2[e] += d * d; }
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (co + e >= g.Cout) break;
+                float x = v[e];
+                if (has_res) x += residual[off + e];
+                if (accum) x += out[off + e];
+                if (relu) x = x > 0.f ? x : 0.f;
+                out[off + e] = x;
+              }
             }
           }
         }
-        if (g.stats) {
+        if constexpr (EPI == 1) {
           // per-thread (mean, M2) of its rows -> LDS -> one thread per column merges the RPP row groups with
           // Chan's update in a fixed order -> stats[m tile][mean | M2][column]
           __syncthreads();               // every staged row has been read
@@ -474,6 +516,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
             const long long mt_ = m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
+          }
+        }
+        if constexpr (EPI == 2) {
+          // per-thread sums -> LDS -> one thread per column adds the RPP row groups in a fixed order
+          __syncthreads();               // every staged row has been read
+          float *red = smem;             // [RPP][BN][2]
+          if (vec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              red[((er0 * BN) + c4 * 4 + e) * 2] = gs[e];
+              red[((er0 * BN) + c4 * 4 + e) * 2 + 1] = gss[e];
+            }
+          }
+          __syncthreads();
+          if (tid < BN && n0 + tid < g.Cout) {
+            float a = 0.f, b = 0.f;
+            for (int er = 0; er < RPP; ++er) { a += red[(er * BN + tid) * 2]; b += red[(er * BN + tid) * 2 + 1]; }
+            const long long mt_ = g.bn_tile_base + m0 / BM;
+            g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + tid] = a;
+            g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + tid] = b;
           }
         }
       }
@@ -839,7 +901,7 @@ struct SplitWs { float *ptr; size_t bytes; };
 
 int g_math_bf16 = 0;   // dspn_conv2d_set_math
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
 int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -849,7 +911,7 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
   // mainloop buffers | staged output tile of the epilogue
   const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16, INTF>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
   static int slots = 0;
@@ -881,13 +943,13 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
               hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   const bool uni = ((g.Cin >> 2) & 7) == 0;
-#define DSPN_NT_(U, B, T) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
-  if (g.in_scale) {
-    if (g_math_bf16) return uni ? DSPN_NT_(true, true, true) : DSPN_NT_(false, true, true);
-    return uni ? DSPN_NT_(true, false, true) : DSPN_NT_(false, false, true);
-  }
-  if (g_math_bf16) return uni ? DSPN_NT_(true, true, false) : DSPN_NT_(false, true, false);
-  return uni ? DSPN_NT_(true, false, false) : DSPN_NT_(false, false, false);
+#define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+#define DSPN_NT_UB_(T, E) (g_math_bf16 ? (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E)) \
+                                       : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
+  if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
+  if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
+  return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
+#undef DSPN_NT_UB_
 #undef DSPN_NT_
 }
 
@@ -933,7 +995,11 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   int splits = 1, per = nk;
   if (g.stats && (!g.dense || !(g.flags & 16) || g.Cout % 4 != 0))
     return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: output statistics need a dense, 16-byte aligned output with Cout %% 4 == 0");
-  if (g.dense && nblk < 192 && nk >= 16 && ws.ptr && !g.stats) {
+  if (g.bn_sums && (g.in_scale || g.stats))
+    return dspn::fail(DSPN_ERR_ARG_, "conv: BatchNorm-backward sums cannot be combined with an input affine or output statistics");
+  if (g.bn_sums && (!(g.flags & 16) || g.Cout % 4 != 0))
+    return dspn::fail(DSPN_ERR_ARG_, "conv2d_dgrad: BatchNorm sums need a 16-byte aligned dx with Cin %% 4 == 0");
+  if (g.dense && nblk < 192 && nk >= 16 && ws.ptr && !g.stats && !g.bn_sums) {
     splits = (int)std::min<long long>((384 + nblk - 1) / nblk, nk / 8);
     splits = std::max(1, std::min(splits, 32));
     while (splits > 1 && sizeof(float) * (size_t)splits * M * g.Cout > ws.bytes) --splits;
@@ -1105,9 +1171,25 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
 
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
 // Also the forward of a transposed convolution (x := dy).
+struct BnBwd { const float *x, *scale, *shift, *mean, *rstd; int relu; float *sums; };
+
+// row tiles of the launches of one data gradient, in launch order (stride 2: up to 4 parity classes)
+static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class /* [4] or NULL */) {
+  int total = 0;
+  for (int ph = 0; ph < (stride == 1 ? 1 : 2); ++ph)
+    for (int pw = 0; pw < (stride == 1 ? 1 : 2); ++pw) {
+      const long long hg = stride == 1 ? H : (H - ph + 1) / 2, wg = stride == 1 ? W : (W - pw + 1) / 2;
+      const long long M = (long long)N * hg * wg;
+      const int t = M > 0 ? (int)((M + kNtBm[nt_config(M, Cin)] - 1) / kNtBm[nt_config(M, Cin)]) : 0;
+      if (per_class) per_class[ph * 2 + pw] = t;
+      total += t;
+    }
+  return total;
+}
+
 static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                          int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
+                          int Wo, int dx_ldc, int accumulate, BnBwd bn, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
   DSPN_REQUIRE(ldy % 4 == 0, "conv2d_dgrad: dy channel stride must be a multiple of 4");
@@ -1121,6 +1203,10 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
   g.obs = (long long)H * W * g.ldc;
   g.OW = W;
   g.flags = accumulate ? 4 : 0;
+  g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
+  g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
+  int class_tiles[4] = {0, 0, 0, 0};
+  if (bn.sums) dgrad_tiles(N, H, W, Cin, stride, class_tiles);
   hipStream_t s = (hipStream_t)stream;
   const SplitWs sws{static_cast<float *>(workspace), workspace ? workspace_bytes : 0};
   if (stride == 1) {
@@ -1133,13 +1219,14 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
     for (int pw = 0; pw < 2; ++pw) {
       ConvGeom c = g;
       c.Hg = (H - ph + 1) / 2; c.Wg = (W - pw + 1) / 2;
+      for (int q = 0; q < ph * 2 + pw; ++q) c.bn_tile_base += class_tiles[q];
       if (c.Hg <= 0 || c.Wg <= 0) continue;
       const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
       c.TR = r0 < R ? (R - r0 + 1) / 2 : 0;
       c.TS = s0 < S ? (S - s0 + 1) / 2 : 0;
       if (c.TR == 0 || c.TS == 0) {
         c.TR = 0; c.TS = 1;
-        if (accumulate) continue;   // nothing to add
+        if (accumulate && !bn.sums) continue;   // nothing to add (with BatchNorm sums the class still has to be read)
       }
       c.ish = 1; c.isw = 1; c.ioh = (ph + pad_h - r0) / 2; c.iow = (pw + pad_w - s0) / 2;
       c.idh = -1; c.idw = -1;
@@ -1151,21 +1238,45 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
   return 0;
 }
 
-int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
-                          int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                          int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
-                          void *stream) {
+int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 4 != 0 || (stride != 1 && stride != 2)) return 0;
+  return dgrad_tiles(N, H, W, Cin, stride, nullptr);
+}
+
+int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+                             int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                             int Wo, int dx_ldc, int accumulate,
+                             const float *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
+                             const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes,
+                             void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
   const int nb = batch_chunk(N, 4ll * Ho * Wo * ldy);
+  if (bn_sums) {
+    DSPN_REQUIRE(bn_x && bn_mean && bn_rstd && (!bn_relu || (bn_scale && bn_shift)), "conv2d_dgrad: BatchNorm operands missing");
+    DSPN_REQUIRE(ldc == Cin && nb == N, "conv2d_dgrad: BatchNorm sums need a dense dx and dy below 2 GiB");
+    const int tiles = dspn_conv2d_dgrad_bn_tiles(N, H, W, Cin, stride);
+    DSPN_REQUIRE(tiles > 0 && bn_sums_bytes >= sizeof(float) * 2 * (size_t)tiles * Cin,
+                 "conv2d_dgrad: bn_sums needs dspn_conv2d_dgrad_bn_tiles() x 2 x Cin floats");
+  }
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_dgrad_one(dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
-                                    W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate, workspace,
+                                    W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate,
+                                    BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums}, workspace,
                                     workspace_bytes, stream);
     if (rc) return rc;
   }
   return 0;
+}
+
+int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+                          int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                          int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  return dspn_conv2d_dgrad_bn_f32(dy, wt, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
+                                  accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, workspace,
+                                  workspace_bytes, stream);
 }
 
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {

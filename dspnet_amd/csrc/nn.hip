@@ -873,6 +873,30 @@ int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift,
   return dspn::check_launch("bn_backward");
 }
 
+// BatchNorm backward whose two reductions (sum dy', sum dy' xhat) were gathered per row tile by the data-gradient
+// kernel that produced dy (bn_sums of dspn_conv2d_dgrad_bn_f32): finalize + apply only
+int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
+                                   const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
+                                   int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
+                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
+  DSPN_REQUIRE(!relu || (scale && shift), "bn_backward_from_sums: relu needs the forward scale/shift");
+  DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward_from_sums: C must be a positive multiple of 4");
+  if (workspace_bytes < sizeof(float) * 3 * (size_t)C)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_from_sums: workspace too small (3*C floats)");
+  const int C4 = C / 4;
+  float *coef = static_cast<float *>(workspace);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), tile_sums, tiles, C,
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
+  const long long n4 = rows * C4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<const float4 *>(dy),
+                     reinterpret_cast<const float4 *>(coef), reinterpret_cast<float4 *>(dx), n4, C4, relu,
+                     accumulate);
+  return dspn::check_launch("bn_backward_from_sums");
+}
+
 int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream) {
   DSPN_REQUIRE(a && b && out && n >= 0, "add: bad argument");
   const long long n4 = n / 4;

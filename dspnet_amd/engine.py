@@ -113,8 +113,24 @@ class Graph:
         self.nodes.append(node)
         return node
 
+    def _plan_bn_backward_fusion(self):
+        """For every BatchNorm whose output only convolutions read: the convolution that runs LAST in backward (the
+        first in forward order) gathers the BatchNorm-backward reductions in its data-gradient epilogue."""
+        for n in self.nodes:
+            if not isinstance(n, BatchNorm) or not n.defer_apply or not n.conv_consumers or not n.out.requires_grad:
+                continue
+            last = min(n.conv_consumers, key=self.nodes.index)
+            if last.stride not in (1, 2) or (last.stride == 2 and last.dil != 1) or last.x.shape[3] % 4 != 0:
+                continue
+            tiles = fn.conv_dgrad_bn_tiles(last.x.shape, last.stride)
+            if tiles <= 0:
+                continue
+            n.bwd_sums = (fn.zeros(tiles, 2, last.x.shape[3], device=self.device), tiles)
+            last.bn_bwd_node = n
+
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
+        self._plan_bn_backward_fusion()
         off = 0
         for p in self.param_order:
             p.offset = off
@@ -239,6 +255,10 @@ class BatchNorm(Node):
                             virtual=defer_apply)
         if defer_apply:
             self.out.affine_src = (x, self.scale, self.shift, relu)
+        self.out.bn_node = self
+        self.conv_consumers = []     # convolutions reading self.out (deferred apply), in forward order
+        self.bwd_sums = None         # (buffer, tiles) written by the LAST data gradient into self.out.grad
+        self.bwd_sums_ready = False
 
     def forward(self):
         if self.tile_stats is not None:
@@ -260,6 +280,13 @@ class BatchNorm(Node):
             dx, acc = self.x.grad_target()
         else:  # parameters still need their gradients; dx goes to scratch
             dx, acc = self.out.grad, False
+        if self.bwd_sums_ready:      # the two reductions came out of the data-gradient kernel's epilogue
+            self.bwd_sums_ready = False
+            fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
+                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
+                                     relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
+                                     dbeta=self.beta.grad, accumulate=acc)
+            return
         fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
@@ -282,6 +309,7 @@ class Conv(Node):
             raw, sc, sh, arelu = x.affine_src
             self.x_raw, self.in_affine = raw, (sc, sh, arelu)
             assert not tap_expand
+            x.bn_node.conv_consumers.append(self)
         self.cout = num_filter
         # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
         self.input_sum_grad = input_sum_grad
@@ -357,7 +385,13 @@ class Conv(Node):
         if self.x.requires_grad:
             fn.weight_transpose(self.w.data, out=self.wt)
             dx, acc = self.x.grad_target()
-            fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc)
+            bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
+            bn_bwd = None
+            if bn is not None:
+                bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
+                bn.bwd_sums_ready = True
+            fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
+                            bn_bwd=bn_bwd)
 
 
 class Deconv4x4s2(Node):

@@ -31,6 +31,11 @@ _lib.register({
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
+    "dspn_conv2d_dgrad_bn_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
+                                            _vp, _sz, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                             _vp, _sz, _vp]),
@@ -175,8 +180,15 @@ def weight_transpose(w, out=None):
     return out
 
 
-def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
-    """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin)"""
+def conv_dgrad_bn_tiles(x_shape, stride):
+    N, H, W, C = x_shape
+    return L().dspn_conv2d_dgrad_bn_tiles(N, H, W, C, stride)
+
+
+def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None):
+    """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin).
+    bn_bwd = (bn_x, scale, shift, mean, rstd, relu, sums): dx is the complete gradient of a BatchNorm(+ReLU) output
+    whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin)"""
     N, H, W, Cx = x_shape
     Cin, R, S, ldy = wt.shape
     assert dy.shape[3] == ldy, (dy.shape, wt.shape)
@@ -185,9 +197,11 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
         out = zeros(N, H, W, Cx, device=dy.device) if Cx != Cin else empty(N, H, W, Cx, device=dy.device)
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
     ph, pw = _hw(pad)
-    check(L().dspn_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
-                                    Ho, Wo, out.shape[3], int(accumulate), ptr(ws), ws.numel(), stream()),
-          "conv2d_dgrad")
+    bx, bsc, bsh, bmu, brs, brelu, bsums = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False, None)
+    check(L().dspn_conv2d_dgrad_bn_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
+                                       Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
+                                       ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
+                                       ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
     return out
 
 
@@ -279,6 +293,22 @@ def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dga
     check(L().dspn_bn_backward_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
                                    ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(ws),
                                    ws.numel(), stream()), "bn_backward")
+    return dx, dgamma, dbeta
+
+
+def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=False, dx=None, dgamma=None,
+                          dbeta=None, accumulate=False):
+    """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...))"""
+    C = x.shape[-1]
+    rows = _rows(x)
+    dx = torch.empty_like(x) if dx is None else dx
+    dbeta = empty(C, device=x.device) if dbeta is None else dbeta
+    if gamma is not None and dgamma is None:
+        dgamma = empty(C, device=x.device)
+    ws = workspace(12 * C, x.device, "bn")
+    check(L().dspn_bn_backward_from_sums_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
+                                             ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
+                                             int(accumulate), ptr(ws), ws.numel(), stream()), "bn_backward_from_sums")
     return dx, dgamma, dbeta
 
 

@@ -21,8 +21,10 @@ def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottl
     q = int(num_filter * 0.25)
     # act1/act2/act3 feed convolutions only: their BN-apply + ReLU runs inside those convolutions' loaders
     act1 = g.add(E.BatchNorm(g, data, name + "_bn1", relu=True, defer_apply=True)).out
-    shortcut = data if dim_match else g.add(E.Conv(g, act1, name + "_sc", num_filter, 1, stride, 0)).out
+    # conv1 is created before the projection shortcut so that its (dense, stride-1) data gradient is the last
+    # writer of act1's gradient in backward and can gather bn1's backward reductions (engine._plan_bn_backward_fusion)
     conv1 = g.add(E.Conv(g, act1, name + "_conv1", q, 1, 1, 0)).out
+    shortcut = data if dim_match else g.add(E.Conv(g, act1, name + "_sc", num_filter, 1, stride, 0)).out
     act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True, defer_apply=True)).out
     conv2 = g.add(E.Conv(g, act2, name + "_conv2", q, 3, stride, 1)).out
     act3 = g.add(E.BatchNorm(g, conv2, name + "_bn3", relu=True, defer_apply=True)).out

@@ -89,6 +89,17 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
                           int N, int H, int W, int Cin, int ldy, int R, int S,
                           int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                           int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* The same data gradient, with the two reductions of the BatchNorm(+ReLU) backward that consumes dx gathered in the
+ * epilogue (dx must be the COMPLETE gradient of the BatchNorm output after this call, i.e. this is its last writer):
+ * bn_x = the BatchNorm's input (laid out like dx), bn_mean / bn_rstd (and bn_scale / bn_shift for the ReLU mask) its
+ * forward statistics.  bn_sums[(t*2 + 0)*Cin + c] = sum over row tile t of dy', [(t*2 + 1)*Cin + c] = sum of dy'*xhat,
+ * t < dspn_conv2d_dgrad_bn_tiles(); dspn_bn_backward_from_sums_f32 finishes the backward pass from them. */
+int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride);
+int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N, int H, int W, int Cin, int ldy,
+                             int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
+                             int accumulate, const float *bn_x, const float *bn_scale, const float *bn_shift,
+                             const float *bn_mean, const float *bn_rstd, int bn_relu, float *bn_sums,
+                             size_t bn_sums_bytes, void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
  * from per-tap sums of dy without forming the gradient (the first convolution's input only feeds the
@@ -142,6 +153,10 @@ int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift,
                          const float *mean, const float *rstd, const float *gamma, float *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
                          void *workspace, size_t workspace_bytes, void *stream);
+int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
+                                   const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
+                                   int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
+                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- element-wise / layout --------------------------------------------------------------- */
 int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream);      /* out = a + b */

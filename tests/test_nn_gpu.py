@@ -482,3 +482,34 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
     fn.bn_stats(y, 2e-5, gamma, beta, *ref)                      # the separate-pass kernel
     for a, r in zip(outs, ref):
         assert float((a - r).abs().max()) <= 5e-6 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 256, 64, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
+                                  (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, case, accumulate):
+    """dspn_conv2d_dgrad_bn_f32 + dspn_bn_backward_from_sums_f32 == dspn_conv2d_dgrad_f32 + dspn_bn_backward_f32
+    (stride 1 and the four parity classes of stride 2, with and without accumulation into dx)"""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 13)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()                  # BatchNorm input
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    gamma = (torch.rand(Cin, generator=g) + 0.5).cuda(); beta = torch.randn(Cin, generator=g).cuda()
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    wt = fn.weight_transpose(w)
+    base = torch.randn(N, H, W, Cin, generator=g).cuda() if accumulate else torch.zeros(N, H, W, Cin, device="cuda")
+    # reference: plain dgrad, then the three-kernel BatchNorm backward
+    d_ref = fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=base.clone(), accumulate=accumulate)
+    dx_ref, dg_ref, db_ref = fn.bn_backward(x, scale, shift, d_ref, mean, rstd, gamma, relu=True)
+    tiles = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    assert tiles > 0
+    sums = torch.full((tiles, 2, Cin), float("nan"), device="cuda")
+    d = fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=base.clone(), accumulate=accumulate,
+                        bn_bwd=(x, scale, shift, mean, rstd, True, sums))
+    assert float((d - d_ref).abs().max()) <= 1e-5 * float(d_ref.abs().max())
+    assert torch.isfinite(sums).all()
+    dx, dg, db = fn.bn_backward_from_sums(x, scale, shift, d, mean, rstd, gamma, sums, tiles, relu=True)
+    for a, r in ((dx, dx_ref), (dg, dg_ref), (db, db_ref)):
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), (float((a - r).abs().max()), float(r.abs().max()))
