@@ -143,6 +143,7 @@ def main():
     use_dist = world > 1 or os.environ.get("DSPN_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")       # no RCCL version banner on stdout next to the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -238,9 +239,16 @@ def main():
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out last, after anything a native library still holds in its stdio buffer
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
