@@ -233,3 +233,29 @@ def test_other_backbone_graphs_match_cpu_restatement(gpu_device, network, kind, 
     # make an element-wise bound meaningless below the heads).  inceptionv3: the float32 CPU
     # restatement is itself 3.6e-2 away from the float64 one on this input; the device measures 2.8e-2.
     assert (num / den) ** 0.5 < (6e-2 if network == "inceptionv3" else 2e-2)
+
+
+def test_bf16_mfma_graph_losses_close_to_fp32_restatement(gpu_device):
+    """BASELINE.json configs[3] runs its convolutions on bf16 MFMA (fp32 tensors, fp32 accumulate): the three loss
+    readouts of the resnet-50 multi-task graph stay within 2e-2 of the float64 CPU restatement (operand rounding
+    2^-9 per factor, averaged over K >= 64 products), and the step is still deterministic."""
+    from dspnet_amd import functional as fn
+    fn.set_conv_math("bf16")
+    try:
+        net, solver, data, lab, seg = make(2, 256, 256)
+        solver.forward(); solver.backward(); torch.cuda.synchronize()
+        dev_targets = [net.target.loc_target.cpu().numpy(), net.target.loc_mask.cpu().numpy(),
+                       net.target.cls_target.cpu().numpy()]
+        cfg = get_config("resnet-50", 256)
+        ref = ot.forward_loss(ot.export_params(net.g), data, lab, seg, cfg["sizes"][1:], cfg["ratios"][1:],
+                              dtype=torch.float64, targets=dev_targets)
+        m = MultiBoxMetric(); m.update(net)
+        names, vals = m.get()
+        for n, v in zip(names, vals):
+            if n in ref:
+                assert abs(v - ref[n]) <= 2e-2 * abs(ref[n]), (n, v, ref[n])
+        g1 = net.g.grad_arena.clone()
+        solver.forward(); solver.backward(); torch.cuda.synchronize()
+        assert torch.equal(g1, net.g.grad_arena)
+    finally:
+        fn.set_conv_math("fp32")
