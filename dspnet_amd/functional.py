@@ -60,6 +60,8 @@ _lib.register({
     "dspn_avgpool2d_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_set_math": (_i, [_i]),
     "dspn_conv2d_get_math": (_i, []),
+    "dspn_bilinear_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dspn_bilinear_backward_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -442,9 +444,15 @@ def bilinear_forward(x, out, coff):
     return out
 
 
-def bilinear_backward(dy, x_shape, coff, dx=None):
+def bilinear_backward(dy, x_shape, coff, dx=None, separable=True):
+    """separable: two passes (along W, then along H) through a scratch tensor; else the one-pass gather kernel"""
     N, Hin, Win, C = x_shape
     dx = empty(N, Hin, Win, C, device=dy.device) if dx is None else dx
+    if separable and (Hin, Win) != (dy.shape[1], dy.shape[2]):
+        ws = workspace(L().dspn_bilinear_backward_workspace_bytes(N, Win, C, dy.shape[1]), dy.device, "bilinear")
+        check(L().dspn_bilinear_backward_ws_f32(ptr(dy), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
+                                                dy.shape[3], coff, ptr(ws), ws.numel(), stream()), "bilinear_backward")
+        return dx
     check(L().dspn_bilinear_backward_f32(ptr(dy), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
                                          dy.shape[3], coff, stream()), "bilinear_backward")
     return dx

@@ -219,6 +219,11 @@ int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win,
                               int ldo, int coff, void *stream);
 int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                int ldo, int coff, void *stream);
+/* the same gradient computed separably (along W into a scratch tensor, then along H): ~2s loads per source pixel
+ * instead of ~(2s)^2 for an s-fold upsampling; the summation order differs from the one-pass kernel */
+size_t dspn_bilinear_backward_workspace_bytes(int N, int Win, int C, int Ho);
+int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
+                                  int ldo, int coff, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* SoftmaxOutput(multi_output, use_ignore) over the last (channel) axis of logits (rows, ld):

@@ -211,8 +211,10 @@ def test_bilinear_sampler_identity_grid(gpu_device, hin, win):
     assert float(out[..., :8].abs().max()) == 0 and float(out[..., 16:].abs().max()) == 0
     dyc = torch.zeros(2, Ho, Wo, 24, device="cuda")
     dyc[..., 8:16] = nhwc(dy)
-    dx = fn.bilinear_backward(dyc, (2, hin, win, 8), 8)
+    dx = fn.bilinear_backward(dyc, (2, hin, win, 8), 8)                       # separable two-pass kernels
     close(nchw(dx), x.grad, 1e-5)
+    dx1 = fn.bilinear_backward(dyc, (2, hin, win, 8), 8, separable=False)     # one-pass gather kernel
+    close(nchw(dx1), x.grad, 1e-5)
 
 
 def test_softmax_output_valid_normalisation(gpu_device):
