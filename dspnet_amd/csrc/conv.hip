@@ -898,6 +898,26 @@ __global__ void weight_transpose_kernel(const float *__restrict__ w, float *__re
   }
 }
 
+// all weight transposes of a step in ONE launch: table rows = {src, dst, K, T, C, Kp, first element of the row's
+// range in the concatenated index space}; a workgroup finds its row by binary search on the range starts
+struct WtDesc { const float *w; float *wt; int K, T, C, Kp; long long begin; };
+__global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int n, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const WtDesc e = d[lo];
+    const long long j = i - e.begin;
+    const int k = (int)(j % e.Kp);
+    const long long ct = j / e.Kp;
+    const int t = (int)(ct % e.T), c = (int)(ct / e.T);
+    e.wt[j] = k < e.K ? e.w[((long long)k * e.T + t) * e.C + c] : 0.f;
+  }
+}
+
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
 __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
                                        float *__restrict__ out, long long M, int Cout, int ldc, int splits,
@@ -1189,6 +1209,15 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
   hipLaunchKernelGGL(weight_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                      wt, Cout, taps, Cin, Cout_pad);
   return dspn::check_launch("weight_transpose");
+}
+
+int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_elements, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_elements > 0, "weight_transpose_batch: bad argument");
+  static_assert(sizeof(WtDesc) == 40, "table row layout: 2 pointers, 4 ints, 1 int64");
+  const int blocks = (int)std::min<long long>((total_elements + 255) / 256, 16384);
+  hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WtDesc *>(table), n, total_elements);
+  return dspn::check_launch("weight_transpose_batch");
 }
 
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].

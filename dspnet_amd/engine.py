@@ -92,6 +92,8 @@ class Graph:
         self.tensors = {}
         self.all_tensors = []
         self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
+        self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
+        self.wt_batched = False    # True while backward() runs after one batched transpose launch
         self.arena = self.grad_arena = self.mom_arena = None
 
     # -- construction ---------------------------------------------------------
@@ -131,6 +133,7 @@ class Graph:
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._plan_bn_backward_fusion()
+        self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and n.wt is not None]
         off = 0
         for p in self.param_order:
             p.offset = off
@@ -146,6 +149,8 @@ class Graph:
         for p in self.param_order:
             p.data = self.arena[p.offset:p.offset + p.size].view(p.shape)
             p.grad = self.grad_arena[p.offset:p.offset + p.size].view(p.shape)
+        if self._wt_pairs_nodes and self.device.type == "cuda":
+            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt) for n in self._wt_pairs_nodes], self.device)
         return self
 
     def load_params(self, values):
@@ -155,15 +160,23 @@ class Graph:
 
     # -- execution ------------------------------------------------------------
     def forward(self):
+        self.wt_batched = False        # the weights may have changed since the last batched transpose
         for f in self.pre_forward:
             f()
         for n in self.nodes:
             n.forward()
 
-    def backward(self):
+    def begin_backward(self):
+        """reset the gradient bookkeeping; all data-gradient operands (transposed weights) in one launch"""
         for t in self.all_tensors:
             t._gw = False
             t.grad = None
+        self.wt_batched = self.wt_table is not None
+        if self.wt_batched:
+            fn.weight_transpose_batch(*self.wt_table)
+
+    def backward(self):
+        self.begin_backward()
         for n in reversed(self.nodes):
             n.backward()
 
@@ -383,7 +396,8 @@ class Conv(Node):
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                      out=self.input_sum_grad.grad)
         if self.x.requires_grad:
-            fn.weight_transpose(self.w.data, out=self.wt)
+            if not self._g.wt_batched:
+                fn.weight_transpose(self.w.data, out=self.wt)
             dx, acc = self.x.grad_target()
             bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
             bn_bwd = None

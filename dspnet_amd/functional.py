@@ -28,6 +28,7 @@ _lib.register({
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _vp, _sz, _vp]),
+    "dspn_conv2d_weight_transpose_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
@@ -169,6 +170,26 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
                                          ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
+
+
+def weight_transpose_table(pairs, device):
+    """pairs: [(w [Cout,R,S,Cin], wt [Cin,R,S,Kp])] -> (device table, rows, total elements) for weight_transpose_batch"""
+    import numpy as np
+    rows = np.zeros(len(pairs), dtype=[("w", "<u8"), ("wt", "<u8"), ("K", "<i4"), ("T", "<i4"), ("C", "<i4"),
+                                       ("Kp", "<i4"), ("begin", "<i8")])
+    total = 0
+    for i, (w, wt) in enumerate(pairs):
+        Cout, R, S, Cin = w.shape
+        assert wt.shape[:3] == (Cin, R, S) and w.is_contiguous() and wt.is_contiguous()
+        rows[i] = (w.data_ptr(), wt.data_ptr(), Cout, R * S, Cin, wt.shape[3], total)
+        total += wt.numel()
+    assert rows.dtype.itemsize == 40
+    table = torch.from_numpy(rows.view(np.uint8).copy()).to(device)
+    return table, len(pairs), total
+
+
+def weight_transpose_batch(table, n, total):
+    check(L().dspn_conv2d_weight_transpose_batch_f32(ptr(table), n, total, stream()), "weight_transpose_batch")
 
 
 def weight_transpose(w, out=None):

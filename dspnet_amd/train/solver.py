@@ -94,9 +94,7 @@ class MultiTaskSolver:
 
     def backward(self):
         g = self.g
-        for t in g.all_tensors:
-            t._gw = False
-            t.grad = None
+        g.begin_backward()
         if self.reducer is not None:
             self.reducer.begin()
         for idx in range(len(g.nodes) - 1, -1, -1):

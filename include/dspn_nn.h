@@ -79,6 +79,10 @@ int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
                                      int Cout_pad, void *stream);
+/* every weight transpose of a training step in one launch.  table: n rows of 40 bytes in DEVICE memory,
+ * { const float *w; float *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin } where begin = the sum of
+ * Cin*taps*Cout_pad over the preceding rows (rows sorted by begin); total_elements = that sum over all rows. */
+int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_elements, void *stream);
 
 /* Data gradient of the convolution above: dx (N,H,W,dx_ldc) from dy (N,Ho,Wo,ldy) and the
  * transposed weights wt [Cin][R*S][ldy].  stride 1 (any dilation) or stride 2 (dilation 1; runs
