@@ -898,6 +898,29 @@ __global__ void weight_transpose_kernel(const float *__restrict__ w, float *__re
   }
 }
 
+// the split-K slab sums of many weight gradients in ONE launch (rows sorted by `begin`, found by binary search):
+// dw[i] (+)= sum_s slab[s][i], fixed order
+struct SlabDesc { const float4 *slab; float4 *dw; long long n4; int splits, accumulate; long long begin; };
+__global__ void slab_reduce_batch_kernel(const SlabDesc *__restrict__ d, int n, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const SlabDesc e = d[lo];
+    const long long j = i - e.begin;
+    float4 s = e.slab[j];
+    for (int k = 1; k < e.splits; ++k) {
+      const float4 v = e.slab[(long long)k * e.n4 + j];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (e.accumulate) { const float4 v = e.dw[j]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    e.dw[j] = s;
+  }
+}
+
 // all weight transposes of a step in ONE launch: table rows = {src, dst, K, T, C, Kp, first element of the row's
 // range in the concatenated index space}; a workgroup finds its row by binary search on the range starts
 struct WtDesc { const float *w; float *wt; int K, T, C, Kp; long long begin; };
@@ -1368,7 +1391,7 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
                           int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
-  DSPN_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
+  DSPN_REQUIRE(x && dy && workspace, "conv2d_wgrad: null pointer");   // dw == NULL: leave the partial slabs in workspace
   DSPN_REQUIRE(Cin % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: channel strides must be multiples of 4");
   WgradGeom g;
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
@@ -1422,7 +1445,7 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
 #undef DSPN_WGRAD_LAUNCH
 #undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");
-  if (rc) return rc;
+  if (rc || !dw) return rc;
   const long long n4 = (long long)Cout * J / 4;
   const int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s,
@@ -1448,6 +1471,40 @@ int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float 
     if (rc) return rc;
   }
   return 0;
+}
+
+/* number of split-K slabs ([splits][Cout][R*S*Cin] floats) the weight gradient of this geometry produces */
+int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, int S, int stride) {
+  const long long P = (long long)N * Ho * Wo;
+  const int J = R * S * Cin;
+  if (P <= 0 || J <= 0 || Cout <= 0) return 0;
+  return wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0).splits;
+}
+
+/* the weight-gradient GEMM alone: the split-K partial sums stay in `slabs` (dspn_conv2d_wgrad_splits() x Cout x
+ * R*S*Cin floats) for a later dspn_conv2d_slab_reduce_batch_f32 */
+int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                                const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
+                                int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                                int Wo, void *stream) {
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
+  DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+  DSPN_REQUIRE(std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy)) == N,
+               "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");
+  return conv2d_wgrad_one(x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
+                          pad_h, pad_w, dil, Ho, Wo, 0, slabs, slabs_bytes, stream);
+}
+
+/* table: n rows of 40 bytes in DEVICE memory, { const float *slabs; float *dw; int64 n4 (= Cout*R*S*Cin/4);
+ * int32 splits, accumulate; int64 begin (= sum of n4 over the preceding rows) }; total4 = sum of n4 */
+int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total4 > 0, "slab_reduce_batch: bad argument");
+  static_assert(sizeof(SlabDesc) == 40, "table row layout: 2 pointers, int64, 2 ints, int64");
+  const int blocks = (int)std::min<long long>((total4 + 255) / 256, 16384);
+  dspn::ProfScope prof(1, (hipStream_t)stream);   // part of the weight-gradient family's time
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const SlabDesc *>(table), n, total4);
+  return dspn::check_launch("slab_reduce_batch");
 }
 
 int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int H, int W, int Cin,

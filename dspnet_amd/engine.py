@@ -92,6 +92,7 @@ class Graph:
         self.tensors = {}
         self.all_tensors = []
         self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
+        self.slab_tables = {}      # key -> (conv nodes, device table) of deferred split-K slab reductions
         self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
         self.arena = self.grad_arena = self.mom_arena = None
@@ -151,7 +152,31 @@ class Graph:
             p.grad = self.grad_arena[p.offset:p.offset + p.size].view(p.shape)
         if self._wt_pairs_nodes and self.device.type == "cuda":
             self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt) for n in self._wt_pairs_nodes], self.device)
+        if self.device.type == "cuda":
+            # every Conv keeps the split-K partial sums of its weight gradient in a buffer of its own, so that the
+            # slab sums of many layers run as one launch (flush_slabs) instead of one small kernel per layer
+            for n in self.nodes:
+                if isinstance(n, Conv):
+                    n.alloc_slabs()
         return self
+
+    def flush_slabs(self, key="all", convs=None):
+        """sum the pending split-K slabs of `convs` (default: every Conv) into their weight gradients, one launch"""
+        if key not in self.slab_tables:
+            nodes = [n for n in (convs if convs is not None else self.nodes) if isinstance(n, Conv) and n.slabs is not None]
+            table = fn.slab_reduce_table([(n.slabs, n.w.grad, False) for n in nodes], self.device) if nodes else None
+            self.slab_tables[key] = (nodes, table)
+        nodes, table = self.slab_tables[key]
+        if not nodes:
+            return
+        if all(n.slabs_fresh for n in nodes):
+            fn.slab_reduce_batch(*table)
+        else:   # some convolution had no output gradient in this pass: reduce only the ones that ran
+            ran = [n for n in nodes if n.slabs_fresh]
+            if ran:
+                fn.slab_reduce_batch(*fn.slab_reduce_table([(n.slabs, n.w.grad, False) for n in ran], self.device))
+        for n in nodes:
+            n.slabs_fresh = False
 
     def load_params(self, values):
         """values: name -> numpy array in the param's (device-layout) shape"""
@@ -179,6 +204,7 @@ class Graph:
         self.begin_backward()
         for n in reversed(self.nodes):
             n.backward()
+        self.flush_slabs()
 
     def num_params(self):
         return sum(p.size for p in self.param_order)
@@ -333,6 +359,7 @@ class Conv(Node):
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), out_name or (name + "_out"))
         self.out.producer = self
+        self.slabs, self.slabs_fresh = None, False     # deferred split-K slab reduction (Graph.flush_slabs)
         self.out_stats = None      # (buffer, tiles, rows per tile) once a BatchNorm asked for them
         self._g = g
         # residual: a tensor of the output's shape added in the conv epilogue (`conv3 + shortcut`,
@@ -350,6 +377,15 @@ class Conv(Node):
         # algorithmic FLOPs per batch (direct-conv count, logical channels)
         self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
+
+    def alloc_slabs(self):
+        cout, kh, kw, cin = self.w.shape
+        wshape = (cout * kh * kw, 1, 1, cin) if self.tap_expand else self.w.shape
+        xs = self.x.shape
+        splits = fn.conv2d_wgrad_splits(xs, self.z.shape if self.tap_expand else self.out.shape, wshape,
+                                        1 if self.tap_expand else self.stride)
+        if splits > 0 and self.w.data.numel() % 4 == 0:
+            self.slabs = fn.zeros(splits, self.w.data.numel(), device=self._g.device)
 
     def enable_out_stats(self):
         """called by a BatchNorm on self.out: have the epilogue write per-tile statistics (None if unavailable)"""
@@ -387,11 +423,18 @@ class Conv(Node):
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
             fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
-            fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
-                            out=self.w.grad.view(cout * kh * kw, 1, 1, cin))
+            if self.slabs is not None:
+                fn.conv2d_wgrad_slabs(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), self.slabs, 1, 0, 1)
+            else:
+                fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
+                                out=self.w.grad.view(cout * kh * kw, 1, 1, cin))
+        elif self.slabs is not None:
+            fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
+                                  in_affine=self.in_affine)
         else:
             fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
                             in_affine=self.in_affine)
+        self.slabs_fresh = self.slabs is not None
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                      out=self.input_sum_grad.grad)

@@ -28,6 +28,10 @@ _lib.register({
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _vp, _sz, _vp]),
+    "dspn_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "dspn_conv2d_wgrad_slabs_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                         _i, _i, _vp]),
+    "dspn_conv2d_slab_reduce_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
@@ -262,6 +266,42 @@ def tap_spread(dy, cout, R, S, pad, out):
     check(L().dspn_tap_spread_f32(ptr(dy), ptr(out), N, H, W, cout, ldy, out.shape[3], R, S, ph, pw, stream()),
           "tap_spread")
     return out
+
+
+def conv2d_wgrad_splits(x_shape, dy_shape, w_shape, stride):
+    N, H, W, Cin = x_shape
+    Cout, R, S, _ = w_shape
+    return L().dspn_conv2d_wgrad_splits(N, dy_shape[1], dy_shape[2], Cin, Cout, R, S, stride)
+
+
+def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None):
+    """the weight-gradient GEMM alone: split-K partial sums -> slabs (splits, Cout, R, S, Cin); see slab_reduce_batch"""
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cw = w_shape
+    assert Cw == Cin
+    ph, pw = _hw(pad)
+    sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
+    check(L().dspn_conv2d_wgrad_slabs_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
+                                          N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
+                                          dy.shape[2], stream()), "conv2d_wgrad_slabs")
+
+
+def slab_reduce_table(entries, device):
+    """entries: [(slabs (splits, ...), dw, accumulate)] -> (device table, rows, total float4)"""
+    import numpy as np
+    rows = np.zeros(len(entries), dtype=[("slab", "<u8"), ("dw", "<u8"), ("n4", "<i8"), ("splits", "<i4"),
+                                         ("acc", "<i4"), ("begin", "<i8")])
+    total = 0
+    for i, (slabs, dw, acc) in enumerate(entries):
+        assert dw.numel() % 4 == 0 and slabs.numel() == slabs.shape[0] * dw.numel()
+        rows[i] = (slabs.data_ptr(), dw.data_ptr(), dw.numel() // 4, slabs.shape[0], int(acc), total)
+        total += dw.numel() // 4
+    assert rows.dtype.itemsize == 40
+    return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(entries), total
+
+
+def slab_reduce_batch(table, n, total4):
+    check(L().dspn_conv2d_slab_reduce_batch_f32(ptr(table), n, total4, stream()), "slab_reduce_batch")
 
 
 def conv2d_input_sum_grad(dy, w, x_shape, stride=1, pad=0, dil=1, out=None):

@@ -82,6 +82,12 @@ class MultiTaskSolver:
         self.buckets = plan_buckets(params, owner, g.arena.numel(), int(bucket_mb * (1 << 20) / 4))
         self.reducer = (GradBucketReducer(g.grad_arena, self.buckets, process_group)
                         if (world_size > 1 or force_reducer) else None)
+        # convolutions whose weight gradient lies in each bucket: their split-K slabs are summed in one launch
+        # right before the bucket is released to the all-reduce
+        self.bucket_convs = []
+        for lo, hi, first in self.buckets:
+            self.bucket_convs.append((first, [n for n in g.nodes if getattr(n, "slabs", None) is not None
+                                              and lo <= n.w.offset < hi]))
 
     def set_batch(self, data, label_det, label_seg):
         """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4)"""
@@ -97,10 +103,16 @@ class MultiTaskSolver:
         g.begin_backward()
         if self.reducer is not None:
             self.reducer.begin()
+        pending = list(range(len(self.bucket_convs)))      # buckets in release order
         for idx in range(len(g.nodes) - 1, -1, -1):
             g.nodes[idx].backward()
+            while pending and self.bucket_convs[pending[0]][0] >= idx:
+                b = pending.pop(0)
+                g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
             if self.reducer is not None:
                 self.reducer.node_done(idx)
+        for b in pending:
+            g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
         if self.reducer is not None:
             self.reducer.finish()
 

@@ -127,6 +127,18 @@ int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float 
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                              int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The two halves of the weight gradient separately, so that a training step can run ONE slab reduction for many
+ * layers (82 launches of a few microseconds each otherwise): dspn_conv2d_wgrad_slabs_f32 leaves the split-K partial
+ * sums [dspn_conv2d_wgrad_splits()][Cout][R*S*Cin] in `slabs`; dspn_conv2d_slab_reduce_batch_f32 sums the slabs of
+ * every row of a descriptor table (DEVICE memory, 40-byte rows { const float *slabs; float *dw; int64 n4 =
+ * Cout*R*S*Cin/4; int32 splits, accumulate; int64 begin = sum of n4 over the preceding rows }) in a fixed order. */
+int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, int S, int stride);
+int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
+                                const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
+                                int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                                int Wo, void *stream);
+int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream);
+
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
  * symbol/resnet.py:30-41,91,96; multitask_symbol_builder.py:545-585) ------------------ */
 
