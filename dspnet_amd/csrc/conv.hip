@@ -224,8 +224,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       const bool in_relu = g.flags & 32;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        float4 u = make_float4(ra[i].x * tf_sc.x + tf_sh.x, ra[i].y * tf_sc.y + tf_sh.y,
-                               ra[i].z * tf_sc.z + tf_sh.z, ra[i].w * tf_sc.w + tf_sh.w);
+        // fmaf, like every other place that evaluates this affine (nn.hip's apply / backward kernels, the
+        // EPI == 2 mask below): the ReLU mask must come out identical in forward and backward
+        float4 u = make_float4(fmaf(ra[i].x, tf_sc.x, tf_sh.x), fmaf(ra[i].y, tf_sc.y, tf_sh.y),
+                               fmaf(ra[i].z, tf_sc.z, tf_sh.z), fmaf(ra[i].w, tf_sc.w, tf_sh.w));
         if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
         const bool v = (tf_mask >> i) & 1u;
         ra[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
                 const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  const float gd = (!g.bn_relu || xv[e] * bsc[e] + bsh[e] > 0.f) ? v[e] : 0.f;
+                  const float gd = (!g.bn_relu || fmaf(xv[e], bsc[e], bsh[e]) > 0.f) ? v[e] : 0.f;
                   gs[e] += gd;
                   gss[e] += gd * ((xv[e] - bmu[e]) * brs[e]);
                 }
@@ -676,8 +678,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
     if constexpr (INTF) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
-        float4 u = make_float4(rb[i].x * tf_sc.x + tf_sh.x, rb[i].y * tf_sc.y + tf_sh.y,
-                               rb[i].z * tf_sc.z + tf_sh.z, rb[i].w * tf_sc.w + tf_sh.w);
+        float4 u = make_float4(fmaf(rb[i].x, tf_sc.x, tf_sh.x), fmaf(rb[i].y, tf_sc.y, tf_sh.y),
+                               fmaf(rb[i].z, tf_sc.z, tf_sh.z), fmaf(rb[i].w, tf_sc.w, tf_sh.w));
         if (g.in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
         const bool v = (tf_mask >> i) & 1u;
         rb[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);

@@ -133,6 +133,50 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
   }
 }
 
+// Pre-reduction of a long tile table (thousands of row tiles on the 128x128-pixel stages): groups of kTileGroup
+// consecutive tiles are merged into one entry of the SAME format, by hundreds of workgroups, so that the
+// single-workgroup-per-16-channels finalize kernels below read 32x fewer entries.
+//   MODE 0: (mean, M2) pairs  -> (mean_g, M2_g) by the one-sweep double formula;  MODE 1: plain sums
+constexpr int kTileGroup = 32;
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict__ ts, int tiles, int tile_rows,
+                                                         long long rows, int C, float *__restrict__ out) {
+  __shared__ double sA[4][64], sB[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const int t0 = blockIdx.x * kTileGroup, t1 = min(tiles, t0 + kTileGroup);
+  const long long last_n = rows - (long long)(tiles - 1) * tile_rows;
+  double A = 0, B = 0;
+  if (c < C) {
+#pragma unroll 8
+    for (int t = t0 + sl; t < t1; t += 4) {
+      const double a = ts[((long long)t * 2 + 0) * C + c], b = ts[((long long)t * 2 + 1) * C + c];
+      if (MODE == 0) {
+        const double nt = (double)(t == tiles - 1 ? last_n : (long long)tile_rows);
+        A += nt * a; B += b + nt * a * a;
+      } else {
+        A += a; B += b;
+      }
+    }
+  }
+  sA[sl][cl] = A; sB[sl][cl] = B;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 4; ++k) { A += sA[k][cl]; B += sB[k][cl]; }
+    if (MODE == 0) {
+      // rows of the whole group (every lane saw a different subset: recompute)
+      double ng = 0;
+      for (int t = t0; t < t1; ++t) ng += (double)(t == tiles - 1 ? last_n : (long long)tile_rows);
+      const double m = A / ng;
+      out[((long long)blockIdx.x * 2 + 0) * C + c] = (float)m;
+      out[((long long)blockIdx.x * 2 + 1) * C + c] = (float)fmax(B - ng * m * m, 0.0);
+    } else {
+      out[((long long)blockIdx.x * 2 + 0) * C + c] = (float)A;
+      out[((long long)blockIdx.x * 2 + 1) * C + c] = (float)B;
+    }
+  }
+}
+
 __global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
                                 const float4 *__restrict__ shift, float4 *__restrict__ y,
                                 long long n4, int C4, int relu) {
@@ -140,7 +184,7 @@ __global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__re
        i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
     const float4 v = x[i], a = scale[c4], b = shift[c4];
-    float4 o = make_float4(v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w);
+    float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
     if (relu) {
       o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
       o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
@@ -172,8 +216,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
       const float4 xv = x[r * C4 + c4];
       float4 g = dy[r * C4 + c4];
       if (relu) {
-        g.x = xv.x * sa.x + sb.x > 0.f ? g.x : 0.f; g.y = xv.y * sa.y + sb.y > 0.f ? g.y : 0.f;
-        g.z = xv.z * sa.z + sb.z > 0.f ? g.z : 0.f; g.w = xv.w * sa.w + sb.w > 0.f ? g.w : 0.f;
+        g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
       }
       s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
       ss.x += g.x * ((xv.x - m.x) * rs.x); ss.y += g.y * ((xv.y - m.y) * rs.y);
@@ -238,8 +282,8 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *
     float4 g = dy[i];
     if (relu) {
       const float4 sa = scale[c4], sb = shift[c4];
-      g.x = xv.x * sa.x + sb.x > 0.f ? g.x : 0.f; g.y = xv.y * sa.y + sb.y > 0.f ? g.y : 0.f;
-      g.z = xv.z * sa.z + sb.z > 0.f ? g.z : 0.f; g.w = xv.w * sa.w + sb.w > 0.f ? g.w : 0.f;
+      g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
     }
     const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
     float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
@@ -882,12 +926,23 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
   return dspn::check_launch("bn_stats");
 }
 
+size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) {
+  if (tiles <= 0 || C <= 0) return 0;
+  return sizeof(float) * 2 * (size_t)((tiles + kTileGroup - 1) / kTileGroup) * C;
+}
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, void *stream) {
+                                 float *shift, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
                "bn_stats_from_tiles: bad argument");
+  if (tiles >= 1024 && workspace && workspace_bytes >= dspn_bn_tiles_workspace_bytes(tiles, C)) {
+    const int groups = (tiles + kTileGroup - 1) / kTileGroup;
+    float *grouped = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(tile_group_kernel<0>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_stats, tiles,
+                       tile_rows, rows, C, grouped);
+    tile_stats = grouped; tiles = groups; tile_rows *= kTileGroup;
+  }
   hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
                      tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
   return dspn::check_launch("bn_stats_from_tiles");
@@ -944,6 +999,13 @@ int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const flo
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_from_sums: workspace too small (3*C floats)");
   const int C4 = C / 4;
   float *coef = static_cast<float *>(workspace);
+  if (tiles >= 1024 && workspace_bytes >= sizeof(float) * 3 * (size_t)C + dspn_bn_tiles_workspace_bytes(tiles, C)) {
+    const int groups = (tiles + kTileGroup - 1) / kTileGroup;
+    float *grouped = coef + 3 * (size_t)C;
+    hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
+                       (long long)tiles, C, grouped);
+    tile_sums = grouped; tiles = groups;
+  }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), tile_sums, tiles, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;

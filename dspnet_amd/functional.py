@@ -25,7 +25,8 @@ _lib.register({
     "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                         _i, _ll, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
-    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _vp, _sz, _vp]),
     "dspn_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
@@ -149,8 +150,10 @@ def conv_stats_layout(out_pixels, cout):
 
 
 def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift):
+    ws = workspace(L().dspn_bn_tiles_workspace_bytes(tiles, C), tile_stats.device, "bn")
     check(L().dspn_bn_stats_from_tiles_f32(ptr(tile_stats), tiles, tile_rows, rows, C, eps, ptr(gamma), ptr(beta), ptr(mean),
-                                           ptr(rstd), ptr(scale), ptr(shift), stream()), "bn_stats_from_tiles")
+                                           ptr(rstd), ptr(scale), ptr(shift), ptr(ws), ws.numel(), stream()),
+          "bn_stats_from_tiles")
 
 
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
@@ -368,7 +371,7 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     dbeta = empty(C, device=x.device) if dbeta is None else dbeta
     if gamma is not None and dgamma is None:
         dgamma = empty(C, device=x.device)
-    ws = workspace(12 * C, x.device, "bn")
+    ws = workspace(12 * C + L().dspn_bn_tiles_workspace_bytes(tiles, C), x.device, "bn")
     check(L().dspn_bn_backward_from_sums_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
                                              int(accumulate), ptr(ws), ws.numel(), stream()), "bn_backward_from_sums")

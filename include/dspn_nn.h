@@ -157,7 +157,10 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
  * double (Chan et al.), fixed order */
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, void *stream);
+                                 float *shift, void *workspace, size_t workspace_bytes, void *stream);
+/* optional scratch for long tile tables (>= 1024 tiles are first merged in groups of 32 by many workgroups);
+ * dspn_bn_backward_from_sums_f32 uses 3*C floats + this many bytes the same way */
+size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
                       int C, int relu, void *stream);
 

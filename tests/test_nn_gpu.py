@@ -452,7 +452,8 @@ def test_conv_with_input_affine(gpu_device, case, relu):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
-                                  (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0)])
+                                  (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0),
+                                  (8, 128, 128, 16, 64, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("with_res", [False, True])
 def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
     """out_stats of dspn_conv2d_forward_bn_f32 + dspn_bn_stats_from_tiles_f32 == dspn_bn_stats_f32 on the stored
@@ -487,7 +488,8 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 256, 64, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
-                                  (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0)])
+                                  (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0),
+                                  (8, 128, 128, 64, 16, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, case, accumulate):
     """dspn_conv2d_dgrad_bn_f32 + dspn_bn_backward_from_sums_f32 == dspn_conv2d_dgrad_f32 + dspn_bn_backward_f32
