@@ -79,10 +79,13 @@ def multitask_layer(g, from_layers, num_classes, sizes, ratios, normalization=-1
         from_name = from_layer.ssd_name              # symbol/common.py:367 `from_layer.name`
         size, ratio = sizes[k], ratios[k]
         num_anchors = len(size) - 1 + len(ratio)
+        # 20..54 output channels starve the 32-wide MFMA column dimension: on the large maps the 3x3 head
+        # convolutions run tap-expanded (a 1x1 convolution to Cout*9 channels + a shifted sum, engine.Conv)
+        big = from_layer.shape[0] * from_layer.shape[1] * from_layer.shape[2] >= 4096
         loc = g.add(E.Conv(g, from_layer, "{}_loc_pred_conv".format(from_name), num_anchors * 5, 3, 1, 1,
-                           no_bias=False, init="maxdim")).out
+                           no_bias=False, init="maxdim", tap_expand=big)).out
         cls = g.add(E.Conv(g, from_layer, "{}_cls_pred_conv".format(from_name), num_anchors * num_classes, 3,
-                           1, 1, no_bias=False, init="maxdim")).out
+                           1, 1, no_bias=False, init="maxdim", tap_expand=big)).out
         loc_maps.append(loc); loc_w.append(num_anchors * 5)
         cls_maps.append(cls); cls_w.append(num_anchors * num_classes)
         step = (steps[k], steps[k]) if steps else (-1.0, -1.0)
