@@ -1,0 +1,39 @@
+/*
+ * dspn_nms.h -- C ABI of the pixel-coordinate (Fast R-CNN, "+1" convention) non-maximum suppression of
+ * liangfu/dspnet: detect/nms.py:24-58 (`nms`, the one the video demo calls at
+ * detect/multitask_detector.py:450), cython/cpu_nms.pyx:17-68 (`cpu_nms`) and cython/nms_kernel.cu:24-144 +
+ * cython/gpu_nms.pyx (`gpu_nms`).  SURVEY.md section 8f rank 4.
+ *
+ * All three compute, for boxes [x1, y1, x2, y2, score] taken in descending score order,
+ *     area = (x2 - x1 + 1) * (y2 - y1 + 1),  inter = max(0, xx2 - xx1 + 1) * max(0, yy2 - yy1 + 1),
+ *     ovr  = inter / (area_i + area_j - inter)
+ * in float32 and keep a box unless an already kept one overlaps it; they differ in the comparison:
+ *     nms() keeps `ovr <= thresh` (detect/nms.py:55) and nms_kernel suppresses `> thresh` (nms_kernel.cu:68): suppress_ge = 0
+ *     cpu_nms suppresses `ovr >= thresh` (cpu_nms.pyx:65):                                                suppress_ge = 1
+ * Equal scores: the reference sorts with numpy's unstable argsort()[::-1]; here ties go to the HIGHER index first
+ * (the reverse of a stable ascending sort), which is what numpy returns for short arrays.
+ *
+ * Conventions as in dspn_multibox.h: device pointers, caller-owned buffers and workspace, explicit stream, status
+ * return + dspn_last_error().
+ */
+#ifndef DSPN_NMS_H_
+#define DSPN_NMS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* n <= 8192 boxes */
+size_t dspn_nms_pixel_workspace_bytes(int n);
+
+/* dets_dev: (n, 5) float32.  keep_dev: n int32 slots receiving the ORIGINAL indices of the kept boxes in
+ * descending score order (the reference's `keep` list); num_keep_dev: one int32. */
+int dspn_nms_pixel_f32(const float *dets_dev, int n, float thresh, int suppress_ge, int *keep_dev,
+                       int *num_keep_dev, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DSPN_NMS_H_ */

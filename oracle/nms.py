@@ -1,0 +1,58 @@
+"""CPU restatement of the reference's pixel-coordinate NMS.  TEST INFRASTRUCTURE ONLY.
+
+PARITY STATUS: "parity unpinned" -- the reference has no tests or vectors for it; detect/nms.py cannot be imported
+here (it imports the compiled cython modules at line 2-3), so its pure-numpy `nms` (detect/nms.py:24-58) and the loop
+of cython/cpu_nms.pyx:17-68 are restated below in float32, operation for operation.  Ties in score: the reference
+uses numpy's unstable argsort()[::-1]; a stable ascending sort reversed is used here (higher index first)."""
+import numpy as np
+
+
+def _order(scores):
+    return np.argsort(scores, kind="stable")[::-1]
+
+
+def nms(dets, thresh):
+    """detect/nms.py:24-58"""
+    dets = np.asarray(dets, np.float32)
+    x1, y1, x2, y2, scores = (dets[:, i] for i in range(5))
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = _order(scores)
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        xx1 = np.maximum(x1[i], x1[order[1:]]); yy1 = np.maximum(y1[i], y1[order[1:]])
+        xx2 = np.minimum(x2[i], x2[order[1:]]); yy2 = np.minimum(y2[i], y2[order[1:]])
+        w = np.maximum(np.float32(0), xx2 - xx1 + one)
+        h = np.maximum(np.float32(0), yy2 - yy1 + one)
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[order[1:]] - inter)
+        order = order[np.where(ovr <= np.float32(thresh))[0] + 1]
+    return keep
+
+
+def cpu_nms(dets, thresh):
+    """cython/cpu_nms.pyx:17-68 (suppress when ovr >= thresh)"""
+    dets = np.asarray(dets, np.float32)
+    x1, y1, x2, y2, scores = (dets[:, i] for i in range(5))
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = _order(scores)
+    n = dets.shape[0]
+    suppressed = np.zeros(n, bool)
+    keep = []
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(int(i))
+        rest = order[_i + 1:]
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + one)
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + one)
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[rest] - inter)
+        suppressed[rest[ovr >= np.float32(thresh)]] = True
+    return keep
