@@ -22,6 +22,10 @@ inline int grid_for(long long n, int per_block = kT, int cap = 8192) {
   return (int)std::max<long long>(1, std::min<long long>(b, cap));
 }
 
+// bias gradients are column sums of small, narrow tensors (20..54 channels): slabs of 64 rows keep a few
+// hundred workgroups busy instead of rows/512
+inline int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64, (rows + 4095) / 4096); }
+
 // ------------------------------------------------------------------ BN statistics
 // partial[slab][0][c] = sum (x - K[c]), partial[slab][1][c] = sum (x - K[c])^2, K = row 0
 __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__restrict__ x,
@@ -343,13 +347,60 @@ __global__ __launch_bounds__(kT) void colsum_partial_kernel(const float *__restr
     __syncthreads();
   }
 }
-__global__ void colsum_final_kernel(const float *partial, int nslabs, int C, float *out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dx = (y > 0) ? dy : 0 in place of a separate ReLU-backward pass, AND the per-slab column sums of dx (the bias
+// gradient of a convolution with a fused ReLU epilogue): one read of y and dy instead of three passes.
+// Layout: rows x ld floats, channels [0, C) summed; ld % 4 == 0; blocks of 256 threads = CL channel quads x RL rows.
+__global__ __launch_bounds__(kT) void relu_bwd_colsum_partial_kernel(const float4 *__restrict__ y,
+                                                                   const float4 *__restrict__ dy,
+                                                                   float4 *__restrict__ dx, long long rows, int ld4,
+                                                                   int CL, float *__restrict__ partial, int C,
+                                                                   int slab_rows) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm4[];
+  const int RL = kT / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c4 = blockIdx.y * CL + cl;
+  const long long r0 = (long long)blockIdx.x * slab_rows, r1 = min(rows, r0 + slab_rows);
+  float4 s = make_float4(0, 0, 0, 0);
+  if (rl < RL && c4 < ld4) {
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const float4 yv = y[r * ld4 + c4];
+      float4 g = dy[r * ld4 + c4];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      dx[r * ld4 + c4] = g;
+      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+    }
+  }
+  sm4[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c4 < ld4) {
+    for (int k = 1; k < RL; ++k) {
+      const float4 a = sm4[k * CL + cl];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    float *p = partial + (long long)blockIdx.x * C;
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c4 * 4 + e < C) p[c4 * 4 + e] = v[e];
+  }
+}
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float *partial, int nslabs, int C, float *out) {
+  __shared__ double sm[64][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0;
+  if (c < C) {
 #pragma unroll 8
-  for (int k = 0; k < nslabs; ++k) s += partial[(long long)k * C + c];
-  out[c] = (float)s;
+    for (int k = sl; k < nslabs; k += 64) s += partial[(long long)k * C + c];
+  }
+  sm[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 64; ++k) s += sm[k][cl];
+    out[c] = (float)s;
+  }
 }
 
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
@@ -395,6 +446,7 @@ __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__res
     dst[i] = src[(b * N + n) * C + c];
   }
 }
+
 
 // ------------------------------------------------------------------ tap-expanded convolution
 // A stride-1 RxS convolution with very few output channels (score3_conv: 3328 -> 19) starves the
@@ -1037,6 +1089,24 @@ int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long
   return dspn::check_launch("relu_backward");
 }
 
+/* dx = (y > 0) ? dy : 0 (dx may alias dy) and out[c] = sum over rows of dx[:, c], c < C, in one pass */
+int dspn_relu_backward_colsum_f32(const float *y, const float *dy, float *dx, long long rows, int C, int ld, float *out,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(y && dy && dx && out && workspace && rows > 0 && C > 0 && ld >= C && ld % 4 == 0,
+               "relu_backward_colsum: bad argument");
+  const int sr = colsum_slab_rows(rows);
+  const int ns = (int)((rows + sr - 1) / sr);
+  if (workspace_bytes < sizeof(float) * (size_t)ns * C)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "relu_backward_colsum: workspace too small (dspn_colsum_workspace_bytes)");
+  const int ld4 = ld / 4, CL = std::min(ld4, 64);
+  float *partial = static_cast<float *>(workspace);
+  hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(ns, (ld4 + CL - 1) / CL), dim3(kT), sizeof(float4) * kT,
+                     S_(stream), reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy),
+                     reinterpret_cast<float4 *>(dx), rows, ld4, CL, partial, C, sr);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), partial, ns, C, out);
+  return dspn::check_launch("relu_backward_colsum");
+}
+
 int dspn_fill_f32(float *p, float v, long long n, void *stream) {
   DSPN_REQUIRE(p && n >= 0, "fill: bad argument");
   if (n == 0) return 0;
@@ -1044,9 +1114,6 @@ int dspn_fill_f32(float *p, float v, long long n, void *stream) {
   return dspn::check_launch("fill");
 }
 
-// bias gradients are column sums of small, narrow tensors (20..54 channels): slabs of 64 rows keep a few
-// hundred workgroups busy instead of rows/512
-static int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64, (rows + 4095) / 4096); }
 size_t dspn_colsum_workspace_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   const int sr = colsum_slab_rows(rows);
@@ -1061,7 +1128,7 @@ int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out, v
     return dspn::fail(DSPN_ERR_WORKSPACE_, "colsum: workspace too small");
   float *partial = static_cast<float *>(workspace);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), a, rows, C, ld, partial, sr);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), partial, ns, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), partial, ns, C, out);
   return dspn::check_launch("colsum");
 }
 

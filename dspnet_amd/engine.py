@@ -414,11 +414,13 @@ class Conv(Node):
         if not self.out._gw:
             return
         dy = self.out.grad
-        if self.relu:
+        if self.relu and self.b is not None:     # ReLU mask and bias gradient in one pass over dy
+            fn.relu_backward_colsum(self.out.data, dy, self.cout, dx=dy, out=self.b.grad)
+        elif self.relu:
             fn.relu_backward(self.out.data, dy, dx=dy)
         if self.residual is not None and self.residual.requires_grad:
             self.residual.give_grad(dy)
-        if self.b is not None:
+        if self.b is not None and not self.relu:
             fn.colsum(dy, self.cout, out=self.b.grad)
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape

@@ -56,6 +56,7 @@ _lib.register({
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "dspn_fill_f32": (_i, [_vp, _f, _ll, _vp]),
+    "dspn_relu_backward_colsum_f32": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
     "dspn_colsum_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_colsum_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
     "dspn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -390,6 +391,18 @@ def relu_backward(y, dy, dx=None, accumulate=False):
     check(L().dspn_relu_backward_f32(ptr(y), ptr(dy), ptr(dx), y.numel(), int(accumulate), stream()),
           "relu_backward")
     return dx
+
+
+def relu_backward_colsum(y, dy, C, dx=None, out=None):
+    """dx = (y > 0) * dy (in place by default) and the column sums of dx over all rows, in one pass"""
+    dx = dy if dx is None else dx
+    ld = y.shape[-1]
+    rows = _rows(y)
+    out = empty(C, device=y.device) if out is None else out
+    ws = workspace(L().dspn_colsum_workspace_bytes(rows, C), y.device, "colsum")
+    check(L().dspn_relu_backward_colsum_f32(ptr(y), ptr(dy), ptr(dx), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()),
+          "relu_backward_colsum")
+    return dx, out
 
 
 def fill(t, v):

@@ -180,6 +180,11 @@ int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const flo
 /* ---- element-wise / layout --------------------------------------------------------------- */
 int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream);      /* out = a + b */
 int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long n, int accumulate, void *stream);
+/* ReLU backward and the bias gradient of the convolution whose epilogue applied the ReLU, in one pass:
+ * dx = (y > 0) ? dy : 0 (dx may alias dy), out[c] = sum_rows dx[:, c] for c < C; rows of ld floats (ld % 4 == 0);
+ * workspace: dspn_colsum_workspace_bytes(rows, C) */
+int dspn_relu_backward_colsum_f32(const float *y, const float *dy, float *dx, long long rows, int C, int ld,
+                                  float *out, void *workspace, size_t workspace_bytes, void *stream);
 int dspn_fill_f32(float *p, float v, long long n, void *stream);
 /* per-column sum of a (rows, ld) matrix over its first C columns: out[c] = sum_r a[r, c] (bias grads) */
 size_t dspn_colsum_workspace_bytes(long long rows, int C);

@@ -517,3 +517,17 @@ def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, case, accumulate):
     dx, dg, db = fn.bn_backward_from_sums(x, scale, shift, d, mean, rstd, gamma, sums, tiles, relu=True)
     for a, r in ((dx, dx_ref), (dg, dg_ref), (db, db_ref)):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), (float((a - r).abs().max()), float(r.abs().max()))
+
+
+@pytest.mark.parametrize("rows,C,ld", [(1000, 64, 64), (70000, 30, 32), (5, 8, 8), (300000, 128, 128)])
+def test_relu_backward_colsum(gpu_device, rows, C, ld):
+    g = torch.Generator().manual_seed(rows + C)
+    y = torch.randn(rows, ld, generator=g).clamp(min=0).cuda()
+    dy = torch.randn(rows, ld, generator=g).cuda()
+    ref_dx = torch.where(y > 0, dy, torch.zeros_like(dy))
+    ref_sum = ref_dx.double().sum(0)[:C]
+    dx, out = fn.relu_backward_colsum(y, dy.clone(), C, out=torch.empty(C, device="cuda"))
+    assert torch.equal(dx, ref_dx)
+    assert float((out.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
+    out2 = fn.colsum(ref_dx, C)
+    assert float((out2.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
