@@ -116,6 +116,32 @@ class Graph:
         self.nodes.append(node)
         return node
 
+    def _resolve_auto_deferred(self):
+        """BatchNorm(defer_apply="auto"): keep the output virtual only if every reader is a plain convolution input;
+        otherwise (a concat, a pooling layer, a residual operand ...) materialise it and unhook the convolutions."""
+        readers = {}
+        for n in self.nodes:
+            for k, v in vars(n).items():
+                if k in ("out", "x_raw"):
+                    continue
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, Tensor) and t.affine_src is not None:
+                        ok = isinstance(n, Conv) and k == "x" and not n.tap_expand
+                        readers.setdefault(id(t), []).append((n, ok))
+        for n in self.nodes:
+            if not isinstance(n, BatchNorm) or n.defer_apply != "auto":
+                continue
+            rs = readers.get(id(n.out), [])
+            if rs and all(ok for _, ok in rs):
+                n.defer_apply = True
+                continue
+            n.defer_apply = False
+            n.out.affine_src = None
+            n.out.data = fn.zeros(*n.out.shape, device=self.device)
+            for c in n.conv_consumers:
+                c.x_raw, c.in_affine = c.x, None
+            n.conv_consumers = []
+
     def _plan_bn_backward_fusion(self):
         """For every BatchNorm whose output only convolutions read: the convolution that runs LAST in backward (the
         first in forward order) gathers the BatchNorm-backward reductions in its data-gradient epilogue."""
@@ -133,6 +159,7 @@ class Graph:
 
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
+        self._resolve_auto_deferred()
         self._plan_bn_backward_fusion()
         self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and n.wt is not None]
         off = 0
@@ -291,7 +318,7 @@ class BatchNorm(Node):
         # separate pass over x
         self.tile_stats = x.producer.enable_out_stats() if getattr(x, "producer", None) is not None else None
         self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer,
-                            virtual=defer_apply)
+                            virtual=bool(defer_apply))
         if defer_apply:
             self.out.affine_src = (x, self.scale, self.shift, relu)
         self.out.bn_node = self

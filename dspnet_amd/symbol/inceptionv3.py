@@ -15,7 +15,10 @@ def get_symbol(g, data, **kwargs):
     def Conv(x, num_filter, kernel=(1, 1), stride=1, pad=(0, 0), name=None, suffix='', cin_logical=None):
         c = g.add(E.Conv(g, x, '%s%s_conv2d' % (name, suffix), num_filter, kernel, stride, pad,
                          cin_logical=cin_logical)).out
-        return g.add(E.BatchNorm(g, c, '%s%s_batchnorm' % (name, suffix), fix_gamma=True, eps=0.001, relu=True)).out
+        # "auto": the BN-apply + ReLU runs inside the next convolution's loader when convolutions are the only readers
+        # (tower interiors); outputs that feed a concat or a pooling layer are materialised
+        return g.add(E.BatchNorm(g, c, '%s%s_batchnorm' % (name, suffix), fix_gamma=True, eps=0.001, relu=True,
+                                 defer_apply="auto")).out
 
     def pool(x, kind, kernel, stride, pad, name):
         if kind == "max":
