@@ -25,6 +25,11 @@ import torch
 from . import functional as fn
 
 
+# Test switch: with FUSE_BATCHNORM = False every BatchNorm runs its own statistics / apply / backward kernels and
+# convolutions never read raw pre-BN tensors (the graph is then built from the plain kernels only).
+FUSE_BATCHNORM = True
+
+
 class Tensor:
     """An activation: NHWC (or any) float32 device buffer + its gradient slot."""
 
@@ -305,6 +310,8 @@ class BatchNorm(Node):
         tile loaders (dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32): forward is the statistics pass alone and
         the normalised tensor is never written"""
         C = x.shape[-1]
+        if not FUSE_BATCHNORM:
+            defer_apply = False
         self.x, self.eps, self.relu = x, eps, relu
         self.gamma = None if fix_gamma else g.param(name + "_gamma", (C,), init_ones)
         self.beta = g.param(name + "_beta", (C,), init_zeros)
@@ -316,7 +323,8 @@ class BatchNorm(Node):
         self.defer_apply = defer_apply
         # statistics gathered by the producing convolution's epilogue (one (mean, M2) pair per row tile) instead of a
         # separate pass over x
-        self.tile_stats = x.producer.enable_out_stats() if getattr(x, "producer", None) is not None else None
+        self.tile_stats = (x.producer.enable_out_stats()
+                           if FUSE_BATCHNORM and getattr(x, "producer", None) is not None else None)
         self.out = g.tensor(x.shape, name + ("_relu" if relu else "_out"), requires_grad=not beta_grad_from_consumer,
                             virtual=bool(defer_apply))
         if defer_apply:
