@@ -840,6 +840,36 @@ __global__ void bilinear_bwd_h_kernel(const float4 *__restrict__ tmp, float4 *__
   }
 }
 
+// ------------------------------------------------------------------ segmentation readouts
+// Counts behind CustomAccuracyMetric (train/metric.py:100-133) and IoUMetric (evaluate/eval_metric.py:359-384):
+// pred = argmax over the class axis (first maximum), counts[0*C + c] = #(label == c & pred == c),
+// counts[1*C + c] = #(pred == c), counts[2*C + c] = #(label == c), counts[3*C] = #(pred == label) -- integer
+// atomics (order independent).  scores: rows x ld floats, classes [0, C); label: rows floats (any value, e.g. 255).
+constexpr int kMaxSegC = 64;
+__global__ __launch_bounds__(kT) void seg_counts_kernel(const float *__restrict__ scores, const float *__restrict__ label,
+                                                       long long rows, int C, int ld,
+                                                       unsigned long long *__restrict__ counts) {
+  __shared__ unsigned int h[3 * kMaxSegC + 1];
+  for (int i = threadIdx.x; i < 3 * C + 1; i += kT) h[i] = 0;
+  __syncthreads();
+  for (long long r = blockIdx.x * (long long)kT + threadIdx.x; r < rows; r += (long long)gridDim.x * kT) {
+    const float *p = scores + r * ld;
+    int best = 0;
+    float bv = p[0];
+    for (int c = 1; c < C; ++c) {
+      const float v = p[c];
+      if (v > bv) { bv = v; best = c; }
+    }
+    const int lab = (int)label[r];
+    atomicAdd(&h[C + best], 1u);
+    if (lab >= 0 && lab < C) atomicAdd(&h[2 * C + lab], 1u);
+    if (lab == best) { atomicAdd(&h[best], 1u); atomicAdd(&h[3 * C], 1u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C + 1; i += kT)
+    if (h[i]) atomicAdd(&counts[i < 3 * C ? i : 3 * C], (unsigned long long)h[i]);
+}
+
 // ------------------------------------------------------------------ losses
 constexpr int kMaxSoftmaxC = 64;
 __global__ void softmax_output_kernel(const float *__restrict__ logits, const float *__restrict__ label,
@@ -1289,6 +1319,15 @@ int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, in
   hipLaunchKernelGGL(bilinear_bwd_h_kernel, dim3(grid_for(t2, kT, 65535)), dim3(kT), 0, S_(stream),
                      static_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, t2);
   return dspn::check_launch("bilinear_backward_ws");
+}
+
+int dspn_seg_counts_f32(const float *scores, const float *label, long long rows, int C, int ld,
+                        unsigned long long *counts, void *stream) {
+  DSPN_REQUIRE(scores && label && counts && rows > 0 && C > 0 && C <= kMaxSegC && ld >= C, "seg_counts: bad argument (C <= 64)");
+  (void)hipMemsetAsync(counts, 0, sizeof(unsigned long long) * (3 * C + 1), S_(stream));
+  hipLaunchKernelGGL(seg_counts_kernel, dim3(grid_for(rows, kT, 2048)), dim3(kT), 0, S_(stream), scores, label, rows, C, ld,
+                     counts);
+  return dspn::check_launch("seg_counts");
 }
 
 int dspn_softmax_output_f32(const float *logits, const float *label, float *prob, float *grad,

@@ -69,6 +69,7 @@ _lib.register({
     "dspn_conv2d_get_math": (_i, []),
     "dspn_bilinear_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dspn_bilinear_backward_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "dspn_seg_counts_f32": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -533,6 +534,17 @@ def bilinear_backward(dy, x_shape, coff, dx=None, separable=True):
     check(L().dspn_bilinear_backward_f32(ptr(dy), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
                                          dy.shape[3], coff, stream()), "bilinear_backward")
     return dx
+
+
+def seg_counts(scores, label, C):
+    """scores (..., ld >= C) class scores per pixel, label (...) -> int64 tensor [3C+1]: per class intersection,
+    predicted count, label count, then the number of pixels with pred == label"""
+    ld = scores.shape[-1]
+    rows = _rows(scores)
+    assert label.numel() == rows
+    out = torch.zeros(3 * C + 1, dtype=torch.int64, device=scores.device)
+    check(L().dspn_seg_counts_f32(ptr(scores), ptr(label), rows, C, ld, ptr(out), stream()), "seg_counts")
+    return out
 
 
 # ------------------------------------------------------------------ losses / optimizer

@@ -39,3 +39,75 @@ class MultiBoxMetric:
         names = ["CrossEntropy", "SmoothL1", "SegCrossEntropy"]
         vals = [s / n if n > 0 else float("nan") for s, n in zip(self.sum_metric, self.num_inst)]
         return names, vals
+
+
+def _seg_inputs(labels, preds, num_classes):
+    """(scores (rows, ld) NHWC-style device tensor, labels) from either this build's NHWC probabilities
+    (B, H, W, ld) or the reference's layout (B, C, H, W)"""
+    import torch
+    from .. import functional as fn
+    if preds.dim() == 4 and tuple(preds.shape[2:]) == tuple(labels.shape[1:]) and preds.shape[1] >= num_classes:
+        preds = fn.nchw_to_nhwc(preds.contiguous(), Cp=fn.pad4(preds.shape[1]))      # (B, C, H, W) -> (B, H, W, Cp)
+    return preds.contiguous(), labels.contiguous().to(torch.float32)
+
+
+class CustomAccuracyMetric:
+    """Pixel accuracy of the segmentation output (train/metric.py:71-133): pred = argmax over the class axis,
+    sum_metric += #(pred == label), num_inst += #pixels (ignore-labelled pixels count as misses, as in the reference).
+    The counting runs on the device (dspn_seg_counts_f32)."""
+
+    def __init__(self, axis=1, name="accuracy", num_classes=19):
+        self.axis, self.name, self.num_classes = axis, name, num_classes
+        self.reset()
+
+    def reset(self):
+        self.sum_metric, self.num_inst = 0.0, 0
+
+    def update(self, labels, preds):
+        from .. import functional as fn
+        for label, pred in zip(labels, preds):
+            scores, lab = _seg_inputs(label, pred, self.num_classes)
+            c = fn.seg_counts(scores, lab, self.num_classes).cpu()
+            self.sum_metric += float(c[3 * self.num_classes])
+            self.num_inst += lab.numel()
+
+    def get(self):
+        return self.name, (self.sum_metric / self.num_inst if self.num_inst else float("nan"))
+
+
+class IoUMetric:
+    """Per-class intersection / union counts and their mean (evaluate/eval_metric.py:278-388):
+    sum_metric[c] += #(label == c & pred == c), num_inst[c] += #(label == c | pred == c);
+    get(): mIoU = mean(sum_metric[:-1] / (num_inst[:-1] + 1e-5)) (:386-388)."""
+
+    def __init__(self, axis=1, name="mIoU", class_names=None):
+        assert isinstance(class_names, (list, tuple)) and all(isinstance(n, str) for n in class_names)
+        self.axis = axis
+        self.class_names = list(class_names)
+        self.name = self.class_names + [name]
+        self.num = len(self.class_names) + 1
+        self.reset()
+
+    def reset(self):
+        import numpy as np
+        self.num_inst = np.zeros(self.num)
+        self.sum_metric = np.zeros(self.num)
+
+    def update(self, labels, preds):
+        from .. import functional as fn
+        C = self.num - 1
+        for label, pred in zip(labels, preds):
+            scores, lab = _seg_inputs(label, pred, C)
+            c = fn.seg_counts(scores, lab, C).cpu().numpy().astype("float64")
+            inter, npred, nlab = c[:C], c[C:2 * C], c[2 * C:3 * C]
+            self.sum_metric[:C] += inter
+            self.num_inst[:C] += npred + nlab - inter
+            # the reference also loops idx == C (the mIoU slot): no pixel carries that id, both sums stay 0
+
+    def get(self):
+        import numpy as np
+        self.sum_metric[-1] = np.mean(self.sum_metric[:-1] / (self.num_inst[:-1] + 1e-5))
+        self.num_inst[-1] = 1.0
+        names = ["%s" % n for n in self.name]
+        values = [x / y if y != 0 else float("nan") for x, y in zip(self.sum_metric, self.num_inst)]
+        return names, values

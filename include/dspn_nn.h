@@ -250,6 +250,13 @@ int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, in
                                   int ldo, int coff, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- losses ---------------------------------------------------------------------------------- */
+/* ---- Segmentation readouts (train/metric.py:100-133 CustomAccuracyMetric, evaluate/eval_metric.py:278-388
+ * IoUMetric): pred = argmax over the C classes of each row (first maximum, like mx.nd.argmax);
+ * counts[c] = #(label == c and pred == c), counts[C + c] = #(pred == c), counts[2C + c] = #(label == c),
+ * counts[3C] = #(pred == label); counts: 3C+1 unsigned 64-bit DEVICE words, overwritten.  C <= 64. ---- */
+int dspn_seg_counts_f32(const float *scores, const float *label, long long rows, int C, int ld,
+                        unsigned long long *counts, void *stream);
+
 /* SoftmaxOutput(multi_output, use_ignore) over the last (channel) axis of logits (rows, ld):
  * prob (rows, ld) = softmax over the first C channels (pad channels -> 0);
  * grad (rows, ld) = (prob - onehot(label)) * scale, 0 for rows whose label == ignore_label.
