@@ -10,7 +10,7 @@ def timeit(f, reps=10):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-shapes = [(32, 128, 128, 64, 256, 1), (32, 64, 64, 128, 512, 1), (32, 128, 128, 256, 64, 1), (32, 32, 32, 256, 1024, 1)]
+shapes = [(32, 32, 32, 256, 256, 3), (32, 16, 16, 512, 512, 3), (32, 32, 32, 1024, 1024, 1), (32, 128, 128, 64, 256, 1), (32, 64, 64, 128, 512, 1)]
 for (N, H, W, Cin, Cout, k) in shapes:
     x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
     out = torch.empty(N, H, W, Cout, device=dev)
