@@ -251,13 +251,9 @@ def init_ones(rng, shape):
     return np.ones(shape, np.float32)
 
 
-def init_uniform_maxdim(rng, shape):
-    """multi_init.py:74-76: U(-1/sqrt(max(shape)), 1/sqrt(max(shape))) on the MXNet shape
-    (Cout, Cin, kh, kw); device layout is (Cout, kh, kw, Cin_phys), pad channels stay 0."""
-    return None  # replaced by conv_weight_init below
-
-
 def conv_weight_init(kind, cin_logical):
+    """"maxdim": multi_init.py:74-76, U(+-1/sqrt(max(shape))) on the MXNet shape (Cout, Cin, kh, kw); "xavier":
+    mx.init.Xavier(uniform, avg, magnitude 3).  Device layout (Cout, kh, kw, Cin_phys); pad channels stay 0."""
     def f(rng, shape):
         cout, r, s, cin_p = shape
         w = np.zeros(shape, np.float32)

@@ -12,8 +12,6 @@ buckets of the flat gradient arena, launched as soon as backward has produced ev
 bucket so the reduction overlaps the remaining dgrad/wgrad kernels, then scaled by 1/world_size
 inside the SGD kernel (`rescale_grad = 1/len(ctx)` convention of train/train_multitask.py:248).
 """
-import torch
-
 from .. import functional as fn
 
 
