@@ -23,6 +23,7 @@
 //
 // fp32 MFMA is an exact fmaf chain (no reduced precision); peak 157 TFLOP/s.
 #include "dspn_common.h"
+#include <cstdlib>
 #include "../../include/dspn_nn.h"
 
 namespace {
@@ -266,6 +267,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
   const int nk1 = max(nk, 1);   // a K range without taps (parity class of a strided data gradient) runs one all-zero k-step
   int t = blockIdx.x;
   if (t >= ntiles) return;
+  // diagnostic build path (dspn_debug_set bit 2048, results WRONG): shader clock held under load =
+  // delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+  const unsigned long long stamp_c0 = (dbg & 2048) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long stamp_r0 = (dbg & 2048) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   f32x16 acc[TM][TN];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -541,7 +546,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
           }
         }
       }
-      if (!has_next) break;
+      if (!has_next) {
+        if ((dbg & 2048) && tid == 0 && blockIdx.y == 0) {
+          const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+          // 4 words per workgroup: cycles, real-time ticks (100 MHz), start tick and end tick (low 32 bits, raw)
+          out[4 * blockIdx.x] = (float)(c1 - stamp_c0);
+          out[4 * blockIdx.x + 1] = (float)(r1 - stamp_r0);
+          out[4 * blockIdx.x + 2] = __uint_as_float((unsigned)stamp_r0);
+          out[4 * blockIdx.x + 3] = __uint_as_float((unsigned)r1);
+        }
+        break;
+      }
       zero_acc();
       t = tn; tn += gridDim.x;
       m0 = ld_m0; n0 = ld_n0;
@@ -990,6 +1005,9 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
+    if (getenv("DSPN_DEBUG_PRINT"))
+      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
+              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, (int)BF16, (int)INTF, EPI, lds, per_cu, cus, slots);
   }
   const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
