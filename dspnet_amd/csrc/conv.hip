@@ -10,7 +10,8 @@
 // pixels into slabs that a reduce kernel sums in a fixed order (bitwise
 // reproducible; no float atomics).
 //
-// Tiling (wave64, 4 waves / 256 threads per workgroup): block tile
+// Tiling (wave64, 4 waves per workgroup -- 8 for the 128x128 weight gradient and the plain-epilogue 128x128
+// forward, where two workgroups then keep 4 waves on every SIMD): block tile
 // (WAVES_M*TM*32) x (WAVES_N*TN*32), BK = 32 floats.  Tiles are staged
 // global -> registers -> LDS (16 B per lane, coalesced along C of NHWC) and
 // double buffered: the loads of k-step t+1 are issued before the MFMAs of step
@@ -43,7 +44,6 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
 
 constexpr int kBK = 32;        // floats per k-step
 constexpr int kLdsRow = 36;    // padded LDS row (floats)
-constexpr int kThreads = 256;
 
 struct ConvGeom {
   int N, Hin, Win, Cin;            // gathered tensor (Cin % 4 == 0)
@@ -83,12 +83,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
     const int ksteps_per_split, float *__restrict__ slab, const float *__restrict__ residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per k-step
+  constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
+  constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
+  constexpr int A_LD = BM / RSTEP, B_LD = BN / RSTEP;   // 16-B loads per thread per k-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     ld_m0 = mt * BM; ld_n0 = nt * BN;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      const int m = ld_m0 + row0 + 32 * i;
+      const int m = ld_m0 + row0 + RSTEP * i;
       const int hw = g.Hg * g.Wg;
       const int n = m / hw, rem = m - n * hw;
       const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      const int k = ld_n0 + row0 + 32 * i;
+      const int k = ld_n0 + row0 + RSTEP * i;
       b_eoff[i] = k < g.Cout ? k * g.WTAPS * g.Cin : -1;
     }
     ld_kt = 0;
@@ -238,18 +240,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
-        *reinterpret_cast<bf16x4 *>(a + (row0 + 32 * i) * kLdsRowH + chunk * 4) = to_bf16x4(ra[i]);
+        *reinterpret_cast<bf16x4 *>(a + (row0 + RSTEP * i) * kLdsRowH + chunk * 4) = to_bf16x4(ra[i]);
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
-        *reinterpret_cast<bf16x4 *>(b + (row0 + 32 * i) * kLdsRowH + chunk * 4) = to_bf16x4(rb[i]);
+        *reinterpret_cast<bf16x4 *>(b + (row0 + RSTEP * i) * kLdsRowH + chunk * 4) = to_bf16x4(rb[i]);
     } else {
       float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
-        *reinterpret_cast<float4 *>(a + (row0 + 32 * i) * kLdsRow + chunk * 4) = ra[i];
+        *reinterpret_cast<float4 *>(a + (row0 + RSTEP * i) * kLdsRow + chunk * 4) = ra[i];
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
-        *reinterpret_cast<float4 *>(b + (row0 + 32 * i) * kLdsRow + chunk * 4) = rb[i];
+        *reinterpret_cast<float4 *>(b + (row0 + RSTEP * i) * kLdsRow + chunk * 4) = rb[i];
     }
   };
 
@@ -380,10 +382,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_nt_kernel(
         // their HBM latency overlaps the LDS round trip instead of serialising with the stores (4 loads in
         // flight per thread held the residual convolutions to ~3 TB/s).
         constexpr int SLD = BN + 4;
-        constexpr int C4 = BN / 4, RPP = kThreads / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
+        constexpr int C4 = BN / 4, RPP = NTHR / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
         // rows are handled RC at a time: all of them, or half of them when the BatchNorm-backward sums hold a second
         // operand row in registers
-        constexpr int RC = (EPI == 2 && NP > 8) ? NP / 2 : NP;
+        constexpr int RC8 = (EPI == 1 && INTF) ? 2 : 4;   // 8 waves: the kernel has to fit in 128 VGPRs
+        constexpr int RC = NTHR == 512 ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
         float *st = smem;
         const int c4 = tid % C4, er0 = tid / C4;
         const int co = n0 + c4 * 4;
@@ -591,11 +594,12 @@ struct WgradGeom {
 constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16, bool INTF>
-__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;   // BM over cout, BN over (tap,c)
-  constexpr int A_LD = BM * kBK / 4 / kThreads, B_LD = BN * kBK / 4 / kThreads;
+  constexpr int NTHR = WAVES_M * WAVES_N * 64;                     // 4 waves, or 8 (4 waves per SIMD with two workgroups per CU)
+  constexpr int A_LD = BM * kBK / 4 / NTHR, B_LD = BN * kBK / 4 / NTHR;
   constexpr int A_CH = BM / 4, B_CH = BN / 4;                      // 16-B chunks per tile row
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                      // [2][kBK][BM]
@@ -613,8 +617,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   const int nk = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
 
   // fixed per-thread column chunk of the B (x) tile -> fixed tap and channel
-  const int b_chunk = tid % B_CH, b_row0 = tid / B_CH;   // rows step by kThreads / B_CH
-  constexpr int B_RSTEP = kThreads / B_CH;
+  const int b_chunk = tid % B_CH, b_row0 = tid / B_CH;   // rows step by NTHR / B_CH
+  constexpr int B_RSTEP = NTHR / B_CH;
   const int jq = (j0 >> 2) + b_chunk;
   const int CQ = g.Cin >> 2;
   const bool jv = jq * 4 < J;
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
   const int tr = tap / g.S, ts = tap - tr * g.S;
   const int tdh = tr * g.dh - g.ph, tdw = ts * g.dw - g.pw;
   const int a_chunk = tid % A_CH, a_row0 = tid / A_CH;
-  constexpr int A_RSTEP = kThreads / A_CH;
+  constexpr int A_RSTEP = NTHR / A_CH;
   const bool kv = k0 + a_chunk * 4 < g.Cout;
 
   const __amdgpu_buffer_rsrc_t rsrc_x =
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(
       for (int r = 0; r < 16; ++r)
         st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
   __syncthreads();
-  constexpr int C4 = BN / 4, RPP = kThreads / C4;
+  constexpr int C4 = BN / 4, RPP = NTHR / C4;
   const int c4 = tid % C4, er0 = tid / C4;
   const int jj = j0 + c4 * 4;
   if (jj >= J) return;
@@ -1001,10 +1005,11 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int per_cu = 0, dev = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), kThreads, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
+    if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
       fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
               WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, (int)BF16, (int)INTF, EPI, lds, per_cu, cus, slots);
@@ -1012,7 +1017,7 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
   const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
     dspn::ProfScope prof(0, s);
-    hipLaunchKernelGGL(kern, dim3(grid_x, splits), dim3(kThreads), lds, s, in, w, bias, out, g, mt, nt,
+    hipLaunchKernelGGL(kern, dim3(grid_x, splits), dim3(WAVES_M * WAVES_N * 64), lds, s, in, w, bias, out, g, mt, nt,
                        ksteps_per_split, splits > 1 ? slab : nullptr, residual);
     if (splits > 1) {
       const long long total = M * g.Cout;
@@ -1091,6 +1096,13 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
     per = (nk + splits - 1) / splits;
     splits = (nk + per - 1) / per;
   }
+  // The 128x128 tile on 8 waves (4 x 2 of 32 x 64; two workgroups put 4 waves on every SIMD instead of 2): one wave
+  // per SIMD reaches 67 % of the MFMA rate in this loop, two 81 %, four 93 % on a plain 1x1 layer (in-kernel stamps,
+  // scratch/clock_probe.py) -- but the 128-VGPR budget leaves no room for the fused-BatchNorm epilogues, which lose
+  // more than the main loop gains.  Used for the plain epilogue only (measured +4..6 %); DSPN_NT_8WAVE=1|0 forces it.
+  static const char *eight_env = getenv("DSPN_NT_8WAVE");
+  const bool eight = eight_env ? atoi(eight_env) != 0 : (!g.stats && !g.bn_sums);
+  if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
     case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
@@ -1456,12 +1468,12 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
       attr = true;                                                                                       \
     }                                                                                                    \
-    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(kThreads), lds, s, x, dy, slab, g, kt, jt); \
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64
-  else DSPN_WGRAD_LAUNCH(2, 2, 2, 2)                              // 128 x 128
+  else DSPN_WGRAD_LAUNCH(4, 2, 1, 2)   // 128 x 128 on 8 waves: two workgroups = 4 waves per SIMD (+3..6 % over <2,2,2,2>)
 #undef DSPN_WGRAD_LAUNCH
 #undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");
