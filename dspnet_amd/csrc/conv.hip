@@ -1101,7 +1101,10 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   // scratch/clock_probe.py) -- but the 128-VGPR budget leaves no room for the fused-BatchNorm epilogues, which lose
   // more than the main loop gains.  Used for the plain epilogue only (measured +4..6 %); DSPN_NT_8WAVE=1|0 forces it.
   static const char *eight_env = getenv("DSPN_NT_8WAVE");
-  const bool eight = eight_env ? atoi(eight_env) != 0 : (!g.stats && !g.bn_sums);
+  const int eight_mode = eight_env ? atoi(eight_env) : -1;   // -1 default, 0 never, 1 always, 2 default + 1x1 dgrads, 3 default + every 1x1
+  const bool one_tap = g.TR * g.TS == 1;
+  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true
+                     : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
