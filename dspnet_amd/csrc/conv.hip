@@ -511,18 +511,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           }
           __syncthreads();
           if (tid < BN && n0 + tid < g.Cout) {
+            // merge of the RPP row groups about the first group's mean (no division inside the loop):
+            //   mean = m_0 + sum n_e d_e / n,  M2 = sum (M2_e + n_e d_e^2) - n (mean - m_0)^2,  d_e = mean_e - m_0
             const int lim = min(M - m0, BM);
-            float n = 0.f, mean = 0.f, m2 = 0.f;
+            const float mref = red[tid * 2];            // row group 0 is never empty
+            float n = 0.f, sd = 0.f, sq = 0.f;
+#pragma unroll 4
             for (int er = 0; er < RPP; ++er) {
               const int ne_i = lim > er ? (lim - er + RPP - 1) / RPP : 0;   // rows er, er + RPP, ... of this tile below M
-              if (ne_i <= 0) continue;
               const float ne = (float)ne_i;
-              const float me = red[(er * BN + tid) * 2], m2e = red[(er * BN + tid) * 2 + 1];
-              const float tot = n + ne, delta = me - mean;
-              mean += delta * (ne / tot);
-              m2 += m2e + delta * delta * (n * ne / tot);
-              n = tot;
+              const float d = ne_i > 0 ? red[(er * BN + tid) * 2] - mref : 0.f;
+              const float m2e = ne_i > 0 ? red[(er * BN + tid) * 2 + 1] : 0.f;
+              n += ne; sd += ne * d; sq += m2e + ne * d * d;
             }
+            const float dm = sd / n;
+            const float mean = mref + dm;
+            const float m2 = fmaxf(sq - n * dm * dm, 0.f);
             const long long mt_ = m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
