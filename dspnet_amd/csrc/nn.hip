@@ -870,6 +870,66 @@ __global__ __launch_bounds__(kT) void seg_counts_kernel(const float *__restrict_
     if (h[i]) atomicAdd(&counts[i < 3 * C ? i : 3 * C], (unsigned long long)h[i]);
 }
 
+// Segmentation read-out at full resolution (multi_eval.py:28-34, prob_upsampling): BilinearSampler of the class
+// probabilities onto an identity-affine grid of Ho x Wo followed by argmax over classes -- fused, the (C, Ho, Wo)
+// probability volume (19 x 1024 x 2048 floats per image) is never written.  Each thread produces 4 neighbouring
+// output pixels (one 4-byte store); the <= 4 x 2 source pixels they touch are L1/L2 hits for the whole 8x8 patch.
+// Arithmetic order per class follows the sampler: tl*wy*wx + tr*wy*(1-wx) + bl*(1-wy)*wx + br*(1-wy)*(1-wx),
+// corners outside the map contribute 0; ties keep the lowest class (argmax).
+// (separate, uncontracted multiplies and adds: the class map is compared bit for bit with the CPU restatement)
+__device__ __forceinline__ float src_coord_exact(int o, int O, int I) {
+#pragma clang fp contract(off)
+  const float step = 2.f / (float)(O - 1);
+  const float prod = (float)o * step;
+  const float g = O > 1 ? -1.f + prod : 0.f;
+  return (g + 1.f) * (float)(I - 1) / 2.f;
+}
+__global__ __launch_bounds__(kT) void seg_upsample_argmax_kernel(const float *__restrict__ prob, unsigned char *__restrict__ out,
+                                                                int Hin, int Win, int C, int ld, int Ho, int Wo,
+                                                                long long total) {
+#pragma clang fp contract(off)
+  const int Wq = (Wo + 3) / 4;
+  for (long long i = blockIdx.x * (long long)kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+    const int wq = (int)(i % Wq);
+    long long t = i / Wq;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const float ys = src_coord_exact(ho, Ho, Hin);
+    const int y0 = (int)floorf(ys);
+    const float wy = 1.f - (ys - (float)y0);
+    const bool vy0 = (unsigned)y0 < (unsigned)Hin, vy1 = (unsigned)(y0 + 1) < (unsigned)Hin;
+    const float *r0 = prob + ((n * Hin + (vy0 ? y0 : 0)) * Win) * (long long)ld;
+    const float *r1 = prob + ((n * Hin + (vy1 ? y0 + 1 : 0)) * Win) * (long long)ld;
+    unsigned char res[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int wo = wq * 4 + e;
+      if (wo >= Wo) break;
+      const float xs = src_coord_exact(wo, Wo, Win);
+      const int x0 = (int)floorf(xs);
+      const float wx = 1.f - (xs - (float)x0);
+      const bool vx0 = (unsigned)x0 < (unsigned)Win, vx1 = (unsigned)(x0 + 1) < (unsigned)Win;
+      const float *tl = r0 + (long long)(vx0 ? x0 : 0) * ld, *tr = r0 + (long long)(vx1 ? x0 + 1 : 0) * ld;
+      const float *bl = r1 + (long long)(vx0 ? x0 : 0) * ld, *br = r1 + (long long)(vx1 ? x0 + 1 : 0) * ld;
+      const bool mtl = vy0 && vx0, mtr = vy0 && vx1, mbl = vy1 && vx0, mbr = vy1 && vx1;
+      float bv = -INFINITY;
+      int best = 0;
+      for (int c = 0; c < C; ++c) {
+        const float a = mtl ? tl[c] : 0.f, b = mtr ? tr[c] : 0.f, d = mbl ? bl[c] : 0.f, f = mbr ? br[c] : 0.f;
+        const float v = a * wy * wx + b * wy * (1.f - wx) + d * (1.f - wy) * wx + f * (1.f - wy) * (1.f - wx);
+        if (v > bv || c == 0) { bv = v; best = c; }
+      }
+      res[e] = (unsigned char)best;
+    }
+    unsigned char *o = out + (n * Ho + ho) * (long long)Wo + wq * 4;
+    if (wq * 4 + 3 < Wo && (Wo & 3) == 0) {
+      *reinterpret_cast<uchar4 *>(o) = make_uchar4(res[0], res[1], res[2], res[3]);
+    } else {
+      for (int e = 0; e < 4 && wq * 4 + e < Wo; ++e) o[e] = res[e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ losses
 constexpr int kMaxSoftmaxC = 64;
 __global__ void softmax_output_kernel(const float *__restrict__ logits, const float *__restrict__ label,
@@ -1328,6 +1388,16 @@ int dspn_seg_counts_f32(const float *scores, const float *label, long long rows,
   hipLaunchKernelGGL(seg_counts_kernel, dim3(grid_for(rows, kT, 2048)), dim3(kT), 0, S_(stream), scores, label, rows, C, ld,
                      counts);
   return dspn::check_launch("seg_counts");
+}
+
+int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, int Hin, int Win, int C, int ld,
+                                 int Ho, int Wo, void *stream) {
+  DSPN_REQUIRE(prob && out && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C <= 256 && ld >= C,
+               "seg_upsample_argmax: bad argument (0 < C <= 256, ld >= C)");
+  const long long total = (long long)N * Ho * ((Wo + 3) / 4);
+  hipLaunchKernelGGL(seg_upsample_argmax_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), prob, out, Hin,
+                     Win, C, ld, Ho, Wo, total);
+  return dspn::check_launch("seg_upsample_argmax");
 }
 
 int dspn_softmax_output_f32(const float *logits, const float *label, float *prob, float *grad,

@@ -70,6 +70,7 @@ _lib.register({
     "dspn_bilinear_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dspn_bilinear_backward_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_seg_counts_f32": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
+    "dspn_seg_upsample_argmax_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -544,6 +545,17 @@ def seg_counts(scores, label, C):
     assert label.numel() == rows
     out = torch.zeros(3 * C + 1, dtype=torch.int64, device=scores.device)
     check(L().dspn_seg_counts_f32(ptr(scores), ptr(label), rows, C, ld, ptr(out), stream()), "seg_counts")
+    return out
+
+
+def seg_upsample_argmax(prob, C, Ho, Wo):
+    """prob (N, Hin, Win, ld >= C) NHWC class probabilities -> uint8 (N, Ho, Wo): bilinear sampling on the identity
+    grid fused with the argmax over classes (multi_eval.py:28-34)"""
+    assert prob.dim() == 4 and prob.is_contiguous() and prob.dtype == torch.float32
+    N, Hin, Win, ld = prob.shape
+    out = torch.empty(N, Ho, Wo, dtype=torch.uint8, device=prob.device)
+    check(L().dspn_seg_upsample_argmax_f32(ptr(prob), ptr(out), N, Hin, Win, C, ld, Ho, Wo, stream()),
+          "seg_upsample_argmax")
     return out
 
 

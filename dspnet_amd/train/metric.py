@@ -111,3 +111,80 @@ class IoUMetric:
         names = ["%s" % n for n in self.name]
         values = [x / y if y != 0 else float("nan") for x, y in zip(self.sum_metric, self.num_inst)]
         return names, values
+
+
+class DistanceAccuracyMetric:
+    """Relative error of the predicted object distance against the disparity map (train/metric.py:135-260).
+
+    update(labels, preds): labels (B, hh, ww) disparity maps (host array or tensor), preds = list of detection
+    tensors (n, N, 7) rows [id, score, xmin, ymin, xmax, ymax, dist], paired sample-wise with the disparity maps
+    exactly as the reference's `zip(labels, preds)` pairs them.  For every detection up to the first id < 0:
+    pixel box (truncating int(), xmin / ymin clamped at 0, an empty column range widened to 1 pixel), reference
+    distance = 2200 * 75 / (q + 1e-3) with q the element of rank n // 2 of the sorted disparities in the box
+    (`int(math.ceil(n / 2))` under Python 2 integer division), > 1000 -> 200, > 199 -> skipped; the error
+    |dist_pred * 255 - dist| / dist is collected per class.  get(): per-class mean and the overall mean ('derror').
+
+    Host code, as in the reference (a few boxes per image).  Differences from the reference, both deliberate:
+    a one-pixel box is evaluated (np.squeeze makes it 0-d there and np.sort raises), and get() only writes
+    "dist_errors.txt" when dump_errors is given."""
+
+    def __init__(self, class_names, name="derror", dump_errors=None):
+        self.name = list(class_names) + [name]
+        self.num = len(class_names) + 1
+        self.dump_errors = dump_errors
+        self.reset()
+
+    def reset(self):
+        self.num_inst = [0] * self.num
+        self.sum_metric = [0.0] * self.num
+        self.errors = []
+
+    @staticmethod
+    def _host(a):
+        import numpy as np
+        if hasattr(a, "detach"):
+            a = a.detach().cpu().numpy()
+        return np.asarray(a)
+
+    def update(self, labels, preds):
+        import math
+        import numpy as np
+        labels = self._host(labels)
+        _, hh, ww = labels.shape
+        error = [[] for _ in range(self.num - 1)]
+        for disparity, dets in zip(labels, preds):
+            dets = self._host(dets).astype(np.float32, copy=False)
+            for img in dets.reshape((-1,) + dets.shape[-2:]):
+                for bbox in img:
+                    if bbox[0] < 0:
+                        break
+                    xmin, xmax = int(bbox[2] * np.float32(ww)), int(bbox[4] * np.float32(ww))
+                    ymin, ymax = int(bbox[3] * np.float32(hh)), int(bbox[5] * np.float32(hh))
+                    xmin, ymin = max(0, xmin), max(0, ymin)
+                    if xmin == xmax:
+                        xmax = xmin + 1
+                    roi = disparity[ymin:ymax, xmin:xmax].reshape(-1).astype(np.float32)
+                    if roi.shape[0] == 0:
+                        continue
+                    k = roi.shape[0] // 2
+                    q = float(np.partition(roi, k)[k])      # rank-k element == np.sort(roi)[k]
+                    dist = 2200. * 75. / (q + 1e-3)
+                    if dist > 1000:
+                        dist = 200
+                    if dist > 199:
+                        continue
+                    error[int(bbox[0])].append(math.fabs(float(bbox[6]) * 255. - dist) / dist)
+        for i in range(self.num - 1):
+            self.sum_metric[i] += math.fsum(error[i])
+            self.num_inst[i] += len(error[i])
+            self.errors += error[i]
+        self.sum_metric[self.num - 1] += math.fsum([math.fsum(e) for e in error])
+        self.num_inst[self.num - 1] += math.fsum([len(e) for e in error])
+
+    def get(self):
+        names = ["%s" % n for n in self.name]
+        values = [x / y if y != 0 else float("nan") for x, y in zip(self.sum_metric, self.num_inst)]
+        if self.dump_errors:
+            import numpy as np
+            np.savetxt(self.dump_errors, np.array(self.errors) * 100., fmt="%.1f")
+        return names, values

@@ -257,6 +257,15 @@ int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, in
 int dspn_seg_counts_f32(const float *scores, const float *label, long long rows, int C, int ld,
                         unsigned long long *counts, void *stream);
 
+/* Full-resolution segmentation read-out (multi_eval.py:28-34 prob_upsampling: mx.nd.BilinearSampler of the class
+ * probabilities on the identity-affine grid GridGenerator(target_shape=(Ho, Wo)) then mx.nd.argmax(axis=1) -> uint8),
+ * fused: prob is the NHWC probability tensor (N, Hin, Win, ld >= C), out (N, Ho, Wo) unsigned bytes, fully
+ * overwritten.  Source coordinate (g + 1) * (I - 1) / 2 with g = -1 + o * 2 / (O - 1); corners outside the map
+ * contribute 0; per class tl*wy*wx + tr*wy*(1-wx) + bl*(1-wy)*wx + br*(1-wy)*(1-wx) in that order; ties keep the
+ * lowest class.  0 < C <= 256. */
+int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, int Hin, int Win, int C, int ld,
+                                 int Ho, int Wo, void *stream);
+
 /* SoftmaxOutput(multi_output, use_ignore) over the last (channel) axis of logits (rows, ld):
  * prob (rows, ld) = softmax over the first C channels (pad channels -> 0);
  * grad (rows, ld) = (prob - onehot(label)) * scale, 0 for rows whose label == ignore_label.
