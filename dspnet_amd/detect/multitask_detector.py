@@ -16,13 +16,18 @@ MEAN_RGB = (123.0, 117.0, 104.0)
 
 class Detector:
     def __init__(self, network="resnet-50", data_shape=512, num_classes=8, batch_size=1, mean_pixels=MEAN_RGB,
-                 nms_thresh=0.5, force_suppress=False, nms_topk=400, device=None, params=None, seed=0):
+                 nms_thresh=0.5, force_suppress=False, nms_topk=400, device=None, params=None, seed=0,
+                 model_prefix=None, epoch=0):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.net = get_multi_symbol(network, data_shape, num_classes=num_classes, batch_size=batch_size,
                                     nms_thresh=nms_thresh, force_suppress=force_suppress, nms_topk=nms_topk,
                                     device=self.device, seed=seed)
         if params:
             self.net.g.load_params(params)
+        if model_prefix is not None:   # mx.model.load_checkpoint(model_prefix, epoch) (detect/multitask_detector.py:105)
+            from ..model import load_checkpoint
+            _, args, _ = load_checkpoint(model_prefix, epoch)
+            self.net.g.set_params(args)
         self.mean = torch.tensor(mean_pixels, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
 
     def forward(self, data=None):

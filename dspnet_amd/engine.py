@@ -42,6 +42,7 @@ class Tensor:
         # their tile loaders, see BatchNorm(defer_apply=True)); .data stays None so any other consumer fails loudly
         self.affine_src = None
         self.producer = None       # the Conv node that writes this tensor (it can emit BatchNorm tile statistics)
+        self.channels = None       # logical channel count when the last axis is padded (19 -> 20, 3 -> 4)
         self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device))
         self.grad = None
         self._own_grad = None
@@ -74,6 +75,10 @@ class Param:
         self.name, self.shape, self.init, self.wd_mult = name, tuple(shape), init, wd_mult
         self.data = self.grad = None
         self.offset = 0
+        # shape of the same parameter in the reference's checkpoint: (Cout, Cin, kh, kw) for a Convolution weight,
+        # (in, out, kh, kw) for a Deconvolution weight, (C,) otherwise -- without the channel padding of `shape`
+        self.logical = None
+        self.kind = "vec"          # "conv" | "deconv" | "vec"
 
     @property
     def size(self):
@@ -94,6 +99,7 @@ class Graph:
         self.nodes = []
         self.params = {}
         self.param_order = []
+        self.bn_names = []         # (name, channels, fix_gamma) of every BatchNorm, for checkpoint files
         self.tensors = {}
         self.all_tensors = []
         self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
@@ -241,6 +247,50 @@ class Graph:
     def num_params(self):
         return sum(p.size for p in self.param_order)
 
+    # -- checkpoint exchange in the reference's shapes (mx.model.load_checkpoint -> arg_params) ----------------
+    def set_params(self, arg_params, allow_missing=False, allow_extra=True):
+        """arg_params: name -> numpy array in the reference's shape (Convolution weight (Cout, Cin, kh, kw),
+        Deconvolution weight (in, out, kh, kw), vectors (C,)).  Converted to the device layout ([Cout][kh][kw][Cin
+        padded to the input tensor's physical channels], pad channels zero) and copied into the arena.
+        Shape mismatches raise; names the graph has no parameter for (the `*_gamma` of fix_gamma BatchNorms,
+        `affine_matrix`, ...) are ignored unless allow_extra=False; graph parameters without a value keep their
+        current contents if allow_missing else raise (Module.set_params semantics)."""
+        missing = [p.name for p in self.param_order if p.name not in arg_params]
+        if missing and not allow_missing:
+            raise KeyError("set_params: no value for " + ", ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
+        extra = [k for k in arg_params if k not in self.params]
+        if extra and not allow_extra:
+            raise KeyError("set_params: graph has no parameter " + ", ".join(extra[:8]))
+        for p in self.param_order:
+            if p.name not in arg_params:
+                continue
+            v = np.asarray(arg_params[p.name], np.float32)
+            logical = tuple(p.logical or p.shape)
+            if tuple(v.shape) != logical:
+                raise ValueError("set_params: %s has shape %s, the graph expects %s" % (p.name, tuple(v.shape), logical))
+            dev = np.zeros(p.shape, np.float32)
+            if p.kind in ("conv", "deconv"):
+                t = v.transpose(0, 2, 3, 1)                       # -> [rows][kh][kw][cols]
+                dev[:t.shape[0], :, :, :t.shape[3]] = t
+            else:
+                if v.shape[0] < p.shape[0]:                       # padded vector: keep the pad lanes as they are
+                    dev[:] = p.data.detach().cpu().numpy()
+                dev[:v.shape[0]] = v
+            p.data.copy_(torch.from_numpy(dev))
+
+    def get_params(self):
+        """-> name -> numpy array in the reference's shapes (inverse of set_params; pad channels dropped)"""
+        out = {}
+        for p in self.param_order:
+            v = p.data.detach().cpu().numpy()
+            logical = tuple(p.logical or p.shape)
+            if p.kind in ("conv", "deconv"):
+                v = v[:logical[0], :, :, :logical[1]].transpose(0, 3, 1, 2)
+            else:
+                v = v[:logical[0]]
+            out[p.name] = np.ascontiguousarray(v)
+        return out
+
 
 # ------------------------------------------------------------------ initialisers
 def init_zeros(rng, shape):
@@ -291,6 +341,7 @@ class InputNCHW(Node):
         self.src = src
         N, C, H, W = src.shape
         self.out = g.tensor((N, H, W, fn.pad4(C)), name, requires_grad=False)
+        self.out.channels = C
 
     def forward(self):
         fn.nchw_to_nhwc(self.src.data, out=self.out.data)
@@ -311,6 +362,10 @@ class BatchNorm(Node):
         self.x, self.eps, self.relu = x, eps, relu
         self.gamma = None if fix_gamma else g.param(name + "_gamma", (C,), init_ones)
         self.beta = g.param(name + "_beta", (C,), init_zeros)
+        for p in (self.gamma, self.beta):
+            if p is not None:
+                p.logical = (x.channels or C,)
+        g.bn_names.append((name, x.channels or C, bool(fix_gamma)))   # gamma / moving_* entries of a checkpoint
         self.mean = fn.zeros(C, device=g.device)
         self.rstd = fn.zeros(C, device=g.device)
         self.scale = fn.zeros(C, device=g.device)
@@ -383,12 +438,17 @@ class Conv(Node):
         self.cout = num_filter
         # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
         self.input_sum_grad = input_sum_grad
+        cin_meta = cin_logical if cin_logical is not None else (x.channels or Cin)   # channels a checkpoint holds
         cin_logical = Cin if cin_logical is None else cin_logical
         self.w = g.param(name + "_weight", (num_filter, kh, kw, Cin), conv_weight_init(init, cin_logical))
         self.b = None if no_bias else g.param(name + "_bias", (num_filter,), init_zeros)
+        self.w.logical, self.w.kind = (num_filter, cin_meta, kh, kw), "conv"
+        if self.b is not None:
+            self.b.logical = (num_filter,)
         Ho, Wo = fn.conv_out_size(H, kh, stride, ph, dilate), fn.conv_out_size(W, kw, stride, pw, dilate)
         ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), out_name or (name + "_out"))
+        self.out.channels = num_filter
         self.out.producer = self
         self.slabs, self.slabs_fresh = None, False     # deferred split-K slab reduction (Graph.flush_slabs)
         self.out_stats = None      # (buffer, tiles, rows per tile) once a BatchNorm asked for them
@@ -492,8 +552,10 @@ class Deconv4x4s2(Node):
         N, H, W, Cp = x.shape
         self.x = x
         self.w = g.param(name + "_weight", (Cp, 4, 4, Cp), deconv_bilinear_init(channels))
+        self.w.logical, self.w.kind = (channels, channels, 4, 4), "deconv"
         self.wt = fn.zeros(Cp, 4, 4, Cp, device=g.device)
         self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
+        self.out.channels = channels
         self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
