@@ -36,14 +36,14 @@ _CMAP_BGR = (_c.c_int * 3)(2, 1, 0)                             # BGR source -> 
 _CMAP_RGB = (_c.c_int * 3)(0, 1, 2)                             # Pillow decodes to RGB: identity
 
 
+_lib.register({"dspn_augment_batch_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.c_void_p,
+                                                     _c.c_void_p, _c.c_void_p, _c.c_void_p])})
+
+
 def _entry():
-    """dspn_augment_batch_u8 with its ctypes signature (fails loudly when the HIP library is missing)"""
-    fn = _lib.lib().dspn_augment_batch_u8
-    if fn.argtypes is None:
-        fn.restype = _c.c_int
-        fn.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int),
-                       _c.POINTER(_c.c_double), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]
-    return fn
+    """dspn_augment_batch_u8 (fails loudly when the HIP library is missing)"""
+    return _lib.lib().dspn_augment_batch_u8
 
 
 def seg_lut():

@@ -9,6 +9,7 @@ import pytest
 from dspnet_amd import _lib
 from dspnet_amd import functional  # noqa: F401  (registers the include/dspn_nn.h signatures)
 from dspnet_amd.detect import nms as _nms_front  # noqa: F401  (registers include/dspn_nms.h)
+from dspnet_amd.dataset import iterator as _iter_front  # noqa: F401  (registers include/dspn_augment.h)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
