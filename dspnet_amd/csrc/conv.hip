@@ -385,7 +385,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         constexpr int C4 = BN / 4, RPP = NTHR / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
         // rows are handled RC at a time: all of them, or half of them when the BatchNorm-backward sums hold a second
         // operand row in registers
-        constexpr int RC8 = (EPI == 1 && INTF) ? 2 : 4;   // 8 waves: the kernel has to fit in 128 VGPRs
+        // 8 waves: the kernel has to fit in 128 VGPRs.  Rows in flight per thread and the unrolling of the chunk loop
+        // are the settings that compile without scratch (hipcc 7.2): INTF + statistics 1 row / unrolled, the other
+        // fused epilogues 2 rows / rolled, the plain epilogue 4 rows / unrolled
+        constexpr int RC8 = (EPI == 1 && INTF) ? 1 : (EPI != 0) ? 2 : 4;
         constexpr int RC = NTHR == 512 ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
         float *st = smem;
         const int c4 = tid % C4, er0 = tid / C4;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         // BatchNorm statistics of the stored values (g.stats): shifted sums about the thread's first row
         float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         int scnt = 0;
-#pragma unroll
+#pragma unroll (NTHR == 512 && EPI != 0 && !(EPI == 1 && INTF) ? 1 : NP / RC)
         for (int ch = 0; ch < NP / RC; ++ch) {
           if (ch > 0) { rows_begin(ch); rows_bn_x(); }
 #pragma unroll
