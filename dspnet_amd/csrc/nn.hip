@@ -884,6 +884,7 @@ __device__ __forceinline__ float src_coord_exact(int o, int O, int I) {
   const float g = O > 1 ? -1.f + prod : 0.f;
   return (g + 1.f) * (float)(I - 1) / 2.f;
 }
+template <bool VEC>   // VEC: ld % 4 == 0, the class vectors of the four corners are read as float4
 __global__ __launch_bounds__(kT) void seg_upsample_argmax_kernel(const float *__restrict__ prob, unsigned char *__restrict__ out,
                                                                 int Hin, int Win, int C, int ld, int Ho, int Wo,
                                                                 long long total) {
@@ -911,13 +912,28 @@ __global__ __launch_bounds__(kT) void seg_upsample_argmax_kernel(const float *__
       const bool vx0 = (unsigned)x0 < (unsigned)Win, vx1 = (unsigned)(x0 + 1) < (unsigned)Win;
       const float *tl = r0 + (long long)(vx0 ? x0 : 0) * ld, *tr = r0 + (long long)(vx1 ? x0 + 1 : 0) * ld;
       const float *bl = r1 + (long long)(vx0 ? x0 : 0) * ld, *br = r1 + (long long)(vx1 ? x0 + 1 : 0) * ld;
-      const bool mtl = vy0 && vx0, mtr = vy0 && vx1, mbl = vy1 && vx0, mbr = vy1 && vx1;
+      // a corner outside the map contributes 0: its weight product is applied to a zero value
+      const float mtl = (vy0 && vx0) ? 1.f : 0.f, mtr = (vy0 && vx1) ? 1.f : 0.f;
+      const float mbl = (vy1 && vx0) ? 1.f : 0.f, mbr = (vy1 && vx1) ? 1.f : 0.f;
+      const float wx1 = 1.f - wx, wy1 = 1.f - wy;
       float bv = -INFINITY;
       int best = 0;
-      for (int c = 0; c < C; ++c) {
-        const float a = mtl ? tl[c] : 0.f, b = mtr ? tr[c] : 0.f, d = mbl ? bl[c] : 0.f, f = mbr ? br[c] : 0.f;
-        const float v = a * wy * wx + b * wy * (1.f - wx) + d * (1.f - wy) * wx + f * (1.f - wy) * (1.f - wx);
-        if (v > bv || c == 0) { bv = v; best = c; }
+      auto consider = [&](const int c, float a, float b, float d, float f) __attribute__((always_inline)) {
+        a = mtl != 0.f ? a : 0.f; b = mtr != 0.f ? b : 0.f; d = mbl != 0.f ? d : 0.f; f = mbr != 0.f ? f : 0.f;
+        const float v = a * wy * wx + b * wy * wx1 + d * wy1 * wx + f * wy1 * wx1;
+        if (c < C && (v > bv || c == 0)) { bv = v; best = c; }
+      };
+      if constexpr (VEC) {
+        for (int c = 0; c < C; c += 4) {
+          const float4 a = *reinterpret_cast<const float4 *>(tl + c), b = *reinterpret_cast<const float4 *>(tr + c);
+          const float4 d = *reinterpret_cast<const float4 *>(bl + c), f = *reinterpret_cast<const float4 *>(br + c);
+          consider(c, a.x, b.x, d.x, f.x);
+          consider(c + 1, a.y, b.y, d.y, f.y);
+          consider(c + 2, a.z, b.z, d.z, f.z);
+          consider(c + 3, a.w, b.w, d.w, f.w);
+        }
+      } else {
+        for (int c = 0; c < C; ++c) consider(c, tl[c], tr[c], bl[c], br[c]);
       }
       res[e] = (unsigned char)best;
     }
@@ -1395,8 +1411,14 @@ int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, i
   DSPN_REQUIRE(prob && out && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C <= 256 && ld >= C,
                "seg_upsample_argmax: bad argument (0 < C <= 256, ld >= C)");
   const long long total = (long long)N * Ho * ((Wo + 3) / 4);
-  hipLaunchKernelGGL(seg_upsample_argmax_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), prob, out, Hin,
-                     Win, C, ld, Ho, Wo, total);
+  // float4 reads of the class vectors need 16-byte aligned rows that hold the rounded-up channel count
+  const bool vec = ld % 4 == 0 && (C + 3) / 4 * 4 <= ld && reinterpret_cast<uintptr_t>(prob) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL(seg_upsample_argmax_kernel<true>, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), prob, out,
+                       Hin, Win, C, ld, Ho, Wo, total);
+  else
+    hipLaunchKernelGGL(seg_upsample_argmax_kernel<false>, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), prob, out,
+                       Hin, Win, C, ld, Ho, Wo, total);
   return dspn::check_launch("seg_upsample_argmax");
 }
 
