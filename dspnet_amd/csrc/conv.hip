@@ -903,7 +903,15 @@ __global__ void slab_reduce_kernel(const float4 *__restrict__ slab, float4 *__re
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     float4 s = slab[i];
-    for (int k = 1; k < splits; ++k) {
+    int k = 1;
+    for (; k + 16 <= splits; k += 16) {   // 16 rows in flight, added in order (see slab_reduce_batch_kernel)
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = slab[(long long)(k + u) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < splits; ++k) {
       const float4 v = slab[(long long)k * n4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -940,7 +948,17 @@ __global__ void slab_reduce_batch_kernel(const SlabDesc *__restrict__ d, int n, 
     const SlabDesc e = d[lo];
     const long long j = i - e.begin;
     float4 s = e.slab[j];
-    for (int k = 1; k < e.splits; ++k) {
+    // 16 slab rows requested per batch, added in order: a small matrix cut into hundreds of slabs (64 x 64 weights,
+    // 745 splits) is one long latency chain per thread otherwise
+    int k = 1;
+    for (; k + 16 <= e.splits; k += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = e.slab[(long long)(k + u) * e.n4 + j];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < e.splits; ++k) {
       const float4 v = e.slab[(long long)k * e.n4 + j];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -1134,6 +1152,11 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   // J = taps x channels <= 64 (the 1x1 convolutions on 64 channels of stage 1): a 128-wide column tile would be
   // half padding
   p.bn = (J <= 64 && p.bm == 128) ? 64 : 128;   // (64 x 64 tiles measured slower than 64 x 128 for Cout <= 64)
+  if (const char *e = getenv("DSPN_WG_TILE")) {   // experiments: 0 32x128, 1 64x128, 2 128x64, 3 128x128
+    const int t = atoi(e);
+    p.bm = t == 0 ? 32 : (t == 1 ? 64 : 128);
+    p.bn = t == 2 ? 64 : 128;
+  }
   const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + p.bn - 1) / p.bn);
   const long long lds = 4ll * std::max(2 * kBK * (p.bm + p.bn), p.bm * (p.bn + 4));
   const long long slots = 256 * std::min<long long>(8, (160ll << 10) / lds);
@@ -1155,6 +1178,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
     if (t < best * 0.999) { best = t; splits = sp; }
     if (tiles * sp > 8 * slots) break;
   }
+  if (const char *e = getenv("DSPN_WG_SPLITS")) splits = std::max<long long>(1, std::min<long long>(atoll(e), s_max));   // experiments
   long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
   p.splits = (int)((P + pps - 1) / pps);
   p.pps = (int)pps;
