@@ -123,3 +123,74 @@ class MultiTaskSolver:
         self.forward()
         self.backward()
         self.update()
+
+
+class BatchEndParam(object):
+    """what the reference hands to batch_end_callback (mx.model.BatchEndParam: epoch, nbatch, eval_metric)"""
+
+    def __init__(self, epoch, nbatch, eval_metric):
+        self.epoch, self.nbatch, self.eval_metric = epoch, nbatch, eval_metric
+
+
+def do_checkpoint(prefix):
+    """mx.callback.do_checkpoint(prefix) (multi_train.py:370): epoch_end_callback that writes prefix-%04d.params
+    for epoch + 1"""
+    from ..model import save_checkpoint
+
+    def _callback(epoch, net, aux_params=None):
+        save_checkpoint(prefix, epoch + 1, net, aux_params=aux_params)
+    return _callback
+
+
+def fit(solver, train_data, begin_epoch=0, num_epoch=1, batch_end_callback=None, epoch_end_callback=None,
+        eval_data=None, class_names=None, seg_class_names=None, logger=None):
+    """The epoch loop of MultiTaskSolver.fit (multi_solver.py:229-345 + the evaluation pass :353-436): per epoch
+    train_data.reset(), metric reset, one solver.step() per batch with the MultiBoxMetric / CustomAccuracyMetric
+    read-outs, batch_end_callback(BatchEndParam), epoch_end_callback(epoch, net), the 'Train-<name>' log lines, and
+    -- when eval_data is given -- evaluate.multi_eval.evaluate_net over it.
+    train_data / eval_data: dspnet_amd.dataset.iterator.MultiTaskRecordIter (or any iterator of (batch, fnames) with
+    batch.data[0], batch.label[0], batch.label[1] device tensors).  -> list of per-epoch dicts of metric values."""
+    import logging
+    from .metric import CustomAccuracyMetric, MultiBoxMetric
+    logger = logger or logging
+    net = solver.net
+    multibox_metric = MultiBoxMetric()
+    acc_metric = CustomAccuracyMetric(num_classes=net.seg_out.C)
+    history = []
+    for epoch in range(begin_epoch, num_epoch):
+        nbatch = 0
+        train_data.reset()
+        multibox_metric.reset(); acc_metric.reset()
+        while train_data.iter_next():
+            batch, _ = train_data.next()
+            nbatch += 1
+            solver.set_batch(batch.data[0], batch.label[0], batch.label[1])
+            solver.step()
+            multibox_metric.update(net)
+            acc_metric.update([net.label_seg.data], [net.seg_out.prob.data])
+            if batch_end_callback is not None:
+                batch_end_callback(BatchEndParam(epoch, nbatch, (multibox_metric, acc_metric)))
+        if epoch_end_callback is not None:
+            epoch_end_callback(epoch, net)
+        names, values = multibox_metric.get()
+        out = dict(zip(names, values))
+        name, value = acc_metric.get()
+        out[name] = value
+        for k, v in out.items():
+            logger.info("                     --->Epoch[%d] Train-%s=%f", epoch, k, v)
+        if eval_data is not None:
+            from ..evaluate.multi_eval import evaluate_net
+
+            def batches():
+                eval_data.reset()
+                while eval_data.iter_next():
+                    b, _ = eval_data.next()
+                    yield {"data": b.data[0], "label_det": b.label[0], "label_seg": b.label[1]}
+            ev = evaluate_net(net, batches(), class_names, seg_class_names)
+            for k, v in ev.items():
+                if not isinstance(v, list):
+                    logger.info("                     --->Epoch[%d] Validation-%s=%f", epoch, k, v)
+            out["validation"] = ev
+        out["nbatch"] = nbatch
+        history.append(out)
+    return history

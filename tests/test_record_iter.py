@@ -258,3 +258,31 @@ def test_augment_kernel_random_affines(gpu_device):
     # argument checks
     assert it._entry()(ipool.data_ptr(), spool.data_ptr(), desc.data_ptr(), B, 50, W, it._CMAP_BGR, (c.c_double * 3)(*mean),
                        0, data.data_ptr(), seg_out.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
+def test_fit_from_records_and_checkpoint(gpu_device, tmp_path):
+    """iterator -> solver epoch loop -> checkpoint -> evaluation, the chain multi_train.py / multi_solver.fit drive"""
+    import math
+    from dspnet_amd import model
+    from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
+    from dspnet_amd.train.solver import MultiTaskSolver, do_checkpoint, fit
+    g = np.random.Generator(np.random.PCG64(21))
+    path = _write_dataset(str(tmp_path), 6, g, hw=(128, 128))
+    B, S = 2, 128
+    train_iter = it.MultiTaskRecordIter(path, B, (3, S, S), enable_aug=True, device=gpu_device)
+    eval_iter = it.MultiTaskRecordIter(path, B, (3, S, S), enable_aug=False, device=gpu_device)
+    net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=gpu_device)
+    solver = MultiTaskSolver(net, learning_rate=0.0005)
+    seen = []
+    hist = fit(solver, train_iter, num_epoch=2, batch_end_callback=lambda p: seen.append((p.epoch, p.nbatch)),
+               epoch_end_callback=do_checkpoint(str(tmp_path / "dspnet")), eval_data=eval_iter,
+               class_names=["c%d" % i for i in range(8)], seg_class_names=["s%d" % i for i in range(19)])
+    assert seen == [(0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3)] and len(hist) == 2
+    for h in hist:
+        assert all(math.isfinite(h[k]) for k in ("CrossEntropy", "SmoothL1", "SegCrossEntropy", "accuracy"))
+        assert math.isfinite(h["validation"]["mIoU"]) and "mAP" in h["validation"]
+    _, args, _ = model.load_checkpoint(str(tmp_path / "dspnet"), 2)
+    now = net.g.get_params()
+    for k, v in now.items():
+        np.testing.assert_array_equal(args[k], v)
