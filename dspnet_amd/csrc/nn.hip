@@ -713,6 +713,7 @@ __device__ __forceinline__ float src_coord(int o, int O, int I) {
   const float g = O > 1 ? -1.f + (float)o * (2.f / (float)(O - 1)) : 0.f;
   return (g + 1.f) * (float)(I - 1) / 2.f;
 }
+template <bool ACC>   // ACC: y += resize(x) (sum of several resized maps in a fixed order)
 __global__ void bilinear_fwd_kernel(const float4 *__restrict__ x, float *__restrict__ y, int Hin,
                                     int Win, int C4, int Ho, int Wo, int ldo, int coff, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -736,7 +737,9 @@ __global__ void bilinear_fwd_kernel(const float4 *__restrict__ x, float *__restr
         const float4 v = x[((n * Hin + yy) * Win + xx) * C4 + c4];
         acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
       }
-    *reinterpret_cast<float4 *>(y + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4) = acc;
+    float4 *o = reinterpret_cast<float4 *>(y + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4);
+    if (ACC) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+    *o = acc;
   }
 }
 // gather form of the backward: every source pixel collects from the target pixels that touch it
@@ -1365,9 +1368,17 @@ int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win,
                               int ldo, int coff, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_forward: bad argument");
   const long long total = (long long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+  hipLaunchKernelGGL(bilinear_fwd_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
                      reinterpret_cast<const float4 *>(x), y, Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
   return dspn::check_launch("bilinear_forward");
+}
+int dspn_bilinear_forward_acc_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
+                                  int ldo, int coff, void *stream) {
+  DSPN_REQUIRE(x && y && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_forward_acc: bad argument");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bilinear_fwd_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), y, Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
+  return dspn::check_launch("bilinear_forward_acc");
 }
 int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                int ldo, int coff, void *stream) {

@@ -28,6 +28,9 @@ from . import functional as fn
 # Test switch: with FUSE_BATCHNORM = False every BatchNorm runs its own statistics / apply / backward kernels and
 # convolutions never read raw pre-BN tensors (the graph is then built from the plain kernels only).
 FUSE_BATCHNORM = True
+# Test switch: False builds score3_conv in the direct form (BilinearConcat + tap-expanded Conv) instead of
+# BilinearConcatConv.
+COMMUTE_RESIZE_CONV = True
 
 
 class Tensor:
@@ -542,6 +545,90 @@ class Conv(Node):
                 bn.bwd_sums_ready = True
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
                             bn_bwd=bn_bwd)
+
+
+class BilinearConcatConv(Node):
+    """Convolution(kernel k x k, stride 1, 'same', no bias) of the channel concatenation of bilinearly resized maps
+    -- `score3_conv` over `score3_concat` (multitask_symbol_builder.py:574-585) -- evaluated WITHOUT the
+    concatenation.
+
+    With the k x k taps expanded (dspn_tap_sum_f32) the convolution is a per-pixel linear map W (Cout*k*k x Cin)
+    followed by a shifted sum, and a per-pixel linear map commutes with the resize U_c of each component (both are
+    linear; U_c acts on pixels, W on channels):
+        z = W . concat_c U_c(x_c) = sum_c U_c(W_c . x_c),          W_c = the columns of W that face component c.
+    So each component is multiplied at ITS OWN resolution (4x4 ... 64x64 instead of 64x64 for all 3328 channels:
+    9.3x fewer multiply-adds at 512x512), the small Cout*k*k-channel results are resized and added, and the
+    3328-channel concatenation (1.7 GB per batch of 32, written once and read three times) never exists.  Backward
+    is the transpose of the same chain: dz_c = U_c^T dz, dx_c = W_c^T dz_c, dW_c = dz_c^T x_c.
+    Exact in real arithmetic; in fp32 the result differs from the direct form by rounding only (the graph-level
+    parity tests against the direct-form oracle cover it).  The parameter keeps the reference's name and shape."""
+
+    def __init__(self, g, inputs, name, num_filter, kernel, pad, target_hw, init="maxdim"):
+        N = inputs[0].shape[0]
+        kh, kw = fn._hw(kernel)
+        self.pad = fn._hw(pad)
+        assert (kh - 1) // 2 == self.pad[0] and (kw - 1) // 2 == self.pad[1], "needs a 'same' convolution"
+        Ht, Wt = target_hw
+        self.inputs = inputs
+        self.offsets = np.cumsum([0] + [t.shape[3] for t in inputs]).tolist()
+        Cin = self.offsets[-1]
+        self.cout, self.kh, self.kw = num_filter, kh, kw
+        self.w = g.param(name + "_weight", (num_filter, kh, kw, Cin), conv_weight_init(init, Cin))
+        self.w.logical, self.w.kind = (num_filter, Cin, kh, kw), "conv"
+        T = num_filter * kh * kw
+        Tp = fn.pad4(T)
+        self.T = T
+        self.z = fn.zeros(N, Ht, Wt, Tp, device=g.device)            # tap-expanded map at the target size (dz in backward)
+        self.zc, self.wc, self.wct, self.dwc = [], [], [], []
+        for t in inputs:
+            native = (t.shape[1], t.shape[2]) == (Ht, Wt)
+            self.zc.append(None if native else fn.zeros(N, t.shape[1], t.shape[2], Tp, device=g.device))
+            self.wc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))      # W_c, contiguous
+            self.wct.append(fn.zeros(t.shape[3], 1, 1, Tp, device=g.device))    # its transpose (data-gradient operand)
+            self.dwc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))
+        # native-size components first: their product is written, the resized ones are added to it
+        self.order = sorted(range(len(inputs)), key=lambda c: self.zc[c] is not None)
+        self.out = g.tensor((N, Ht, Wt, fn.pad4(num_filter)), name + "_out")
+        self.out.channels = num_filter
+        # multiply-adds actually executed (the direct form would be 2 * Cin * Cout * k * k * Ht * Wt * N)
+        self.flops_fwd = sum(2.0 * t.shape[3] * T * t.shape[1] * t.shape[2] * N for t in inputs)
+        self.flops_bwd = self.flops_fwd + sum(2.0 * t.shape[3] * T * t.shape[1] * t.shape[2] * N
+                                              for t in inputs if t.requires_grad)
+        self.flops_direct = 2.0 * Cin * T * Ht * Wt * N
+
+    def _gather_weights(self):
+        w2d = self.w.data
+        Cin = self.offsets[-1]
+        for c, t in enumerate(self.inputs):
+            fn.copy_block(w2d, self.wc[c], 1, self.T, t.shape[3], 0, Cin, self.offsets[c], 0, t.shape[3], 0)
+
+    def forward(self):
+        self._gather_weights()
+        first = True
+        for c in self.order:
+            t = self.inputs[c]
+            if self.zc[c] is None:
+                fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.z, accumulate=not first)
+            else:
+                fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.zc[c])
+                fn.bilinear_forward(self.zc[c], self.z, 0, accumulate=not first)
+            first = False
+        fn.tap_sum(self.z, None, self.cout, self.kh, self.kw, self.pad, out=self.out.data)
+
+    def backward(self):
+        if not self.out._gw:
+            return
+        fn.tap_spread(self.out.grad, self.cout, self.kh, self.kw, self.pad, out=self.z)
+        Cin = self.offsets[-1]
+        for c in self.order:
+            t = self.inputs[c]
+            dz = self.z if self.zc[c] is None else fn.bilinear_backward(self.z, self.zc[c].shape, 0, dx=self.zc[c])
+            fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c])
+            fn.copy_block(self.dwc[c], self.w.grad, 1, self.T, t.shape[3], 0, t.shape[3], 0, 0, Cin, self.offsets[c])
+            if t.requires_grad:
+                fn.weight_transpose(self.wc[c], out=self.wct[c])
+                dx, acc = t.grad_target()
+                fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc)
 
 
 class Deconv4x4s2(Node):

@@ -79,6 +79,7 @@ _lib.register({
     "dspn_avgpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_bilinear_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_bilinear_forward_acc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_bilinear_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_softmax_output_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
     "dspn_count_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp]),
@@ -515,11 +516,12 @@ def avgpool_backward(dy, x_shape, k, dx=None, accumulate=False):
     return dx
 
 
-def bilinear_forward(x, out, coff):
-    """resize x (N,Hin,Win,C) into channels [coff, coff+C) of out (N,Ho,Wo,ldo)"""
+def bilinear_forward(x, out, coff, accumulate=False):
+    """resize x (N,Hin,Win,C) into (accumulate: onto) channels [coff, coff+C) of out (N,Ho,Wo,ldo)"""
     N, Hin, Win, C = x.shape
-    check(L().dspn_bilinear_forward_f32(ptr(x), ptr(out), N, Hin, Win, C, out.shape[1], out.shape[2],
-                                        out.shape[3], coff, stream()), "bilinear_forward")
+    f = L().dspn_bilinear_forward_acc_f32 if accumulate else L().dspn_bilinear_forward_f32
+    check(f(ptr(x), ptr(out), N, Hin, Win, C, out.shape[1], out.shape[2], out.shape[3], coff, stream()),
+          "bilinear_forward")
     return out
 
 

@@ -312,10 +312,14 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     score2_pool2_bn = conv_bn(score_pool2, "score2_pool2", 256, 1, 0)
     score2_pool1_bn = conv_bn(score_pool1, "score2_pool1", 512, 1, 0)
     target_hw = (H // 8, W // 8)   # (64,128) at 512x1024 (:575)
-    score3_concat = g.add(E.BilinearConcat(
-        g, [score2_pool4_bn, score2_pool2_bn, score2_pool1_bn, res5_reduced_bn, res4_reduced2_bn,
-            res3_reduced2_bn], "score3_concat", target_hw)).out
-    score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1, tap_expand=True)
+    pyramid = [score2_pool4_bn, score2_pool2_bn, score2_pool1_bn, res5_reduced_bn, res4_reduced2_bn, res3_reduced2_bn]
+    if E.COMMUTE_RESIZE_CONV:
+        # score3_conv over score3_concat without the 3328-channel concatenation (engine.BilinearConcatConv)
+        c = g.add(E.BilinearConcatConv(g, pyramid, "score3_conv", seg_classes, 3, 1, target_hw)).out
+        score3_conv_bn = g.add(E.BatchNorm(g, c, "score3_conv_bn", fix_gamma=True, eps=eps)).out
+    else:
+        score3_concat = g.add(E.BilinearConcat(g, pyramid, "score3_concat", target_hw)).out
+        score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1, tap_expand=True)
     score4_conv = g.add(E.Deconv4x4s2(g, score3_conv_bn, "score4_conv", seg_classes)).out
     if train:
         seg_out = g.add(SegSoftmaxOutput(g, score4_conv, seg_label, seg_classes))

@@ -241,6 +241,9 @@ int dspn_avgpool2d_backward_f32(const float *dy, float *dx, int N, int H, int W,
  * channel slice [coff, coff+C) of a (N,Ho,Wo,ldo) concat buffer. ------------------------------ */
 int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
                               int ldo, int coff, void *stream);
+/* the same resize ADDED to the destination channels (a sum of several resized maps, accumulated in call order) */
+int dspn_bilinear_forward_acc_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
+                                  int ldo, int coff, void *stream);
 int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                int ldo, int coff, void *stream);
 /* the same gradient computed separably (along W into a scratch tensor, then along H): ~2s loads per source pixel
