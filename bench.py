@@ -206,7 +206,7 @@ def main():
         ach = flops_step / conv_s / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
         try:
-            traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_conv_family.json")))["hbm_bytes_per_launch"])
+            traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_j_pmc_conv_family.json")))["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         peak = FP32_MATRIX_PEAK_TFLOPS if args.math == "fp32" else BF16_MATRIX_PEAK_TFLOPS
