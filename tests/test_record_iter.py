@@ -286,3 +286,36 @@ def test_fit_from_records_and_checkpoint(gpu_device, tmp_path):
     now = net.g.get_params()
     for k, v in now.items():
         np.testing.assert_array_equal(args[k], v)
+
+
+@pytest.mark.gpu
+def test_record_iter_missing_label_map_and_grey_record(gpu_device, tmp_path):
+    """enable_aug=False tolerates a missing label PNG (cv2.imread returns None there: the label map stays 0,
+    dataset/iterator.py:571-575); a single-channel JPEG record decodes to three equal planes like cv2.imdecode(..., 1)"""
+    from PIL import Image
+    import io
+    g = np.random.Generator(np.random.PCG64(8))
+    path = _write_dataset(str(tmp_path), 4, g, hw=(64, 96))
+    os.remove(os.path.join(str(tmp_path), "cityscapes", "SegmentationClass", "city_000001_gtFine_labelTrainIds.png"))
+    # rewrite record 2 as a greyscale JPEG
+    rd = recordio.MXIndexedRecordIO(path.replace(".rec", ".idx"), path, "r")
+    items = [rd.read_idx(i) for i in range(4)]
+    rd.close()
+    h2, img2 = recordio.unpack_img(items[2])
+    buf = io.BytesIO()
+    Image.fromarray(img2[:, :, 1]).save(buf, format="JPEG", quality=90)
+    items[2] = recordio.pack(recordio.IRHeader(0, h2.label, h2.id, 0), buf.getvalue())
+    w = recordio.MXIndexedRecordIO(path.replace(".rec", ".idx"), path, "w")
+    for i, it_ in enumerate(items):
+        w.write_idx(i, it_)
+    w.close()
+    itr = it.MultiTaskRecordIter(path, 4, (3, 32, 64), enable_aug=False, device=gpu_device, prefetch=False)
+    batch, fnames = itr.next()
+    order = [int(k) for k in itr.index_table[:4]]
+    seg = batch.label[1].cpu().numpy()
+    data = batch.data[0].cpu().numpy()
+    assert (seg[order.index(1)] == 0).all() and (seg[order.index(0)] != 0).any()
+    grey = np.rint(data[order.index(2)].astype(np.float64) + np.asarray(itr.mean_pixels)[:, None, None])
+    np.testing.assert_array_equal(grey[0], grey[1]); np.testing.assert_array_equal(grey[1], grey[2])
+    with pytest.raises(AssertionError, match="not found"):
+        it.MultiTaskRecordIter(path, 4, (3, 32, 64), enable_aug=True, device=gpu_device, prefetch=False)
