@@ -292,3 +292,45 @@ def test_fused_and_unfused_batchnorm_graphs_agree(gpu_device):
         a, b = gf[p.name].double(), p.grad.double()
         num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
     assert (num / den) ** 0.5 < 2e-2
+
+
+@pytest.mark.gpu
+def test_score3_conv_per_level_matches_direct_form(gpu_device):
+    """engine.BilinearConcatConv (each pyramid level multiplied at its own resolution, results resized and summed)
+    against the direct form it replaces (3328-channel concatenation + tap-expanded convolution) on the same weights
+    and inputs: the segmentation output, the three losses and every parameter gradient.  The two are equal in real
+    arithmetic; in fp32 they differ by summation order only.  Tolerances: outputs / losses 1e-5 relative; gradients
+    2e-2 in global relative L2 for the same reason as the fused / unfused BatchNorm builds (ReLU pre-activations that
+    lie within rounding of zero flip once the decoder's gradient into the backbone moves in its last bits) and
+    1e-4 for the parameters of the block itself and of everything downstream of it, where no ReLU intervenes."""
+    from dspnet_amd import engine as E
+
+    def run(commute):
+        E.COMMUTE_RESIZE_CONV = commute
+        try:
+            net, solver, data, lab, seg = make(2, 256, 256)
+        finally:
+            E.COMMUTE_RESIZE_CONV = True
+        solver.forward(); solver.backward(); torch.cuda.synchronize()
+        m = MultiBoxMetric(); m.update(net)
+        return net, dict(zip(*m.get()))
+
+    net_c, loss_c = run(True)
+    net_d, loss_d = run(False)
+    assert any(isinstance(n, E.BilinearConcatConv) for n in net_c.g.nodes)
+    assert not any(isinstance(n, E.BilinearConcatConv) for n in net_d.g.nodes)
+    assert [p.name for p in net_c.g.param_order] == [p.name for p in net_d.g.param_order]
+    torch.testing.assert_close(net_c.g.arena, net_d.g.arena, rtol=0, atol=0)       # same initial parameters
+    a, b = net_c.seg_out.prob.data, net_d.seg_out.prob.data
+    assert float((a - b).abs().max()) <= 1e-5
+    for k in loss_c:
+        assert abs(loss_c[k] - loss_d[k]) <= 1e-5 * abs(loss_d[k]) + 1e-9, (k, loss_c[k], loss_d[k])
+    gc = {p.name: p.grad for p in net_c.g.param_order}
+    num = den = 0.0
+    for p in net_d.g.param_order:
+        x, y = gc[p.name].double(), p.grad.double()
+        num += float(((x - y) ** 2).sum()); den += float((y ** 2).sum())
+        if p.name.startswith(("score3_conv", "score4_conv")):
+            rel = float(((x - y) ** 2).sum() ** 0.5 / max(float((y ** 2).sum() ** 0.5), 1e-30))
+            assert rel < 1e-4, (p.name, rel)
+    assert (num / den) ** 0.5 < 2e-2
