@@ -355,7 +355,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     const bool has_next = tn < ntiles;
     if (last && has_next) setup_tile(tn);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
-    if (nk > 0) mma_step(buf);   // nk == 0: a parity class without taps only writes zeros (or is skipped by the host)
+    // nk == 0 (a parity class of a strided data gradient without taps): the loads return zeros, so the k-step may run
+    // (accumulators stay 0) or be skipped.  The 8-wave build must NOT branch here: with the branch hipcc keeps the
+    // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
+    // (32 v_mov + a full MFMA drain per k-step, seen in the ISA of the non-INTF 8-wave variants)
+    if (NTHR == 512 || nk > 0) mma_step(buf);
     if (last) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
