@@ -108,6 +108,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int nk = slab ? max(0, min(nk_all - k_begin, ksteps_per_split)) : nk_all;
 
   const int chunk = tid & 7, row0 = tid >> 3;
+  // 8-wave kernels only (measured: +3..4 % there; on 4 waves the doubled store count costs more than the reads gain)
+  constexpr bool LDS_SHIFT = NTHR == 512;
+  const int lds_shift_w = LDS_SHIFT ? ((row0 >> 3) & 1) * 2 : 0;
+  const int lds_shift_r = LDS_SHIFT ? ((tid >> 3) & 1) * 2 : 0;   // (lane & 31) >> 3 & 1 == tid >> 3 & 1
 
   // Buffer descriptors over the gathered tensor and the weights: a tap outside the image (or a row
   // past M / Cout, or a chunk past K) is given an out-of-range offset and the hardware bounds check
@@ -245,13 +249,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int i = 0; i < B_LD; ++i)
         *reinterpret_cast<bf16x4 *>(b + (row0 + RSTEP * i) * kLdsRowH + chunk * 4) = to_bf16x4(rb[i]);
     } else {
-      float *a = sA + buf * BM * kLdsRow, *b = sB + buf * BN * kLdsRow;
+      // rows whose bit 3 is set start 2 floats later (inside the 4-float pad): the 16 rows one ds_read_b64 pass
+      // fetches then touch all 32 banks instead of 16 (row stride 36 = 4 mod 32 alone is a 2-way conflict on every
+      // fragment read: SQ_LDS_BANK_CONFLICT was 42 % of the LDS-active cycles).  The shifted rows are only 8-byte
+      // aligned, so the tile is stored as float2 pairs.
+      float *a = sA + buf * BM * kLdsRow + lds_shift_w, *b = sB + buf * BN * kLdsRow + lds_shift_w;
+      auto put = [&](float *d, const float4 v) __attribute__((always_inline)) {
+        if constexpr (LDS_SHIFT) {
+          reinterpret_cast<float2 *>(d)[0] = make_float2(v.x, v.y);
+          reinterpret_cast<float2 *>(d)[1] = make_float2(v.z, v.w);
+        } else {
+          *reinterpret_cast<float4 *>(d) = v;
+        }
+      };
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i)
-        *reinterpret_cast<float4 *>(a + (row0 + RSTEP * i) * kLdsRow + chunk * 4) = ra[i];
+      for (int i = 0; i < A_LD; ++i) put(a + (row0 + RSTEP * i) * kLdsRow + chunk * 4, ra[i]);
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i)
-        *reinterpret_cast<float4 *>(b + (row0 + RSTEP * i) * kLdsRow + chunk * 4) = rb[i];
+      for (int i = 0; i < B_LD; ++i) put(b + (row0 + RSTEP * i) * kLdsRow + chunk * 4, rb[i]);
     }
   };
 
@@ -304,8 +318,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     } else {
-      const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk;
-      const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk;
+      const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk + lds_shift_r;
+      const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk + lds_shift_r;
       // fragments of group gq+1 are fetched from LDS before the MFMAs of group gq are issued
       float2 fa[2][TM], fb[2][TN];
 #pragma unroll
