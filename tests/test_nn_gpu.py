@@ -531,3 +531,57 @@ def test_relu_backward_colsum(gpu_device, rows, C, ld):
     assert float((out.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
     out2 = fn.colsum(ref_dx, C)
     assert float((out2.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
+
+
+# BASELINE.json's full sizes (batch 32 at 512x512): where the fp64 CPU reference of the cases above would take minutes,
+# the three kernels are tied to each other by size-independent properties and to an independent GPU implementation
+FULL_SIZE_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (32, 128, 128, 64, 64, 3, 1, 1),      # stage1 conv2
+    (32, 128, 128, 256, 64, 1, 1, 0),     # stage1 conv1
+    (32, 128, 128, 256, 128, 3, 2, 1),    # stage2 entry (strided data gradient: 4 parity classes)
+    (32, 64, 64, 256, 512, 1, 2, 0),      # stage2 shortcut (3 of 4 parity classes empty)
+    (32, 32, 32, 256, 256, 3, 1, 1),      # stage3 conv2
+    (32, 16, 16, 512, 512, 3, 1, 1),      # stage4 conv2
+    (32, 512, 512, 4, 64, 7, 2, 3),       # conv0 (3 channels padded to 4)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FULL_SIZE_CASES)
+def test_conv_full_size_properties(gpu_device, case):
+    """<conv(x; w), y> = <x, dgrad(y; w)> = <w, wgrad(x, y)> (the three kernels are adjoint views of one trilinear
+    form), linearity of the forward, and agreement with torch's own ROCm convolution (MIOpen) on the same operands.
+    Tolerances: 2e-5 relative on the inner products (fp64 reductions of fp32 results), 1e-4 of the output's max on the
+    element-wise comparisons (different summation orders over K up to 4608)."""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    if Cin == 4:
+        x[..., 3] = 0                                     # the pad channel of conv0's input is zero
+    w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    y = fn.conv2d_forward(x, w, None, stride=stride, pad=pad, dil=1)
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    wt = fn.weight_transpose(w)
+    dx = fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride=stride, pad=pad, dil=1)
+    dw = fn.conv2d_wgrad(x, dy, tuple(w.shape), stride=stride, pad=pad, dil=1)
+    a = float((y.double() * dy.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((w.double() * dw.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(a - b) <= 2e-5 * scale and abs(a - c) <= 2e-5 * scale, (a, b, c, scale)
+    # linearity in x
+    x2 = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    if Cin == 4:
+        x2[..., 3] = 0
+    y2 = fn.conv2d_forward(x2, w, None, stride=stride, pad=pad, dil=1)
+    y12 = fn.conv2d_forward(0.5 * x + x2, w, None, stride=stride, pad=pad, dil=1)
+    assert float((y12 - (0.5 * y + y2)).abs().max()) <= 1e-4 * float(y.abs().max())
+    # an independent implementation on the same device
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, stride=stride, padding=pad)
+    assert float((y.permute(0, 3, 1, 2) - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    xr = x.permute(0, 3, 1, 2).detach().requires_grad_()
+    wr = w.permute(0, 3, 1, 2).detach().requires_grad_()
+    F.conv2d(xr, wr, None, stride=stride, padding=pad).backward(dy.permute(0, 3, 1, 2))
+    assert float((dx.permute(0, 3, 1, 2) - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    assert float((dw.permute(0, 3, 1, 2) - wr.grad).abs().max()) <= 2e-4 * float(wr.grad.abs().max())
