@@ -319,3 +319,16 @@ def test_record_iter_missing_label_map_and_grey_record(gpu_device, tmp_path):
     np.testing.assert_array_equal(grey[0], grey[1]); np.testing.assert_array_equal(grey[1], grey[2])
     with pytest.raises(AssertionError, match="not found"):
         it.MultiTaskRecordIter(path, 4, (3, 32, 64), enable_aug=True, device=gpu_device, prefetch=False)
+
+
+def test_augment_restatement_against_committed_vectors():
+    """regression pin of oracle/augment.py itself: tests/golden/augment_warp.npz (generator: make_augment_golden.py)"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_warp.npz"))
+    np.testing.assert_array_equal(oa.warp_affine(z["img"], z["M"], (32, 16), True, 128), z["linear_border128"])
+    np.testing.assert_array_equal(oa.warp_affine(z["seg"], z["M"], (32, 16), False, 255), z["nearest_border255"])
+    h = z["hdr_in"].copy()
+    oa.get_augmented(np.zeros((24, 40, 3), np.uint8), h, np.zeros((24, 40), np.uint8), (3, 16, 32), list(z["aug"]))
+    np.testing.assert_array_equal(h, z["hdr_out"])
+    rows = z["hdr_in"].copy()
+    it.augmented_boxes(rows[3:].reshape(-1, 6), (3, 16, 32), list(z["aug"]))
+    np.testing.assert_allclose(rows, z["hdr_out"], rtol=1e-12, atol=1e-12)
