@@ -122,6 +122,14 @@ def augmented_boxes(rows, data_shape, aug):
     return True
 
 
+class _Decoded(object):
+    """decoded pixels of a cached record, with the two attributes _prepare reads from a PIL image"""
+
+    def __init__(self, a):
+        self.a = a
+        self.size = (a.shape[1], a.shape[0])
+
+
 class DataBatch(object):
     def __init__(self, data, label):
         self.data, self.label = data, label
@@ -132,7 +140,7 @@ class MultiTaskRecordIter(object):
 
     def __init__(self, path_imgrec, batch_size, data_shape, path_imglist="", label_width=-1, label_pad_width=-1,
                  label_pad_value=-1, resize_mode="force", mean_pixels=(123.68, 116.779, 103.939), enable_aug=True,
-                 device=None, decode_threads=8, prefetch=True, **kwargs):
+                 device=None, decode_threads=8, prefetch=True, cache_decoded=False, **kwargs):
         path_imgidx = path_imgrec.replace(".rec", ".idx")
         path_imglst = path_imgrec.replace(".rec", ".lst")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -169,6 +177,9 @@ class MultiTaskRecordIter(object):
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(decode_threads)))
         self._producer = ThreadPoolExecutor(max_workers=1)
         self.prefetch, self._ahead = bool(prefetch), None
+        # cache_decoded: keep the decoded uint8 pixels of every record in host memory (Cityscapes train: 2975 x 8.4 MB =
+        # 25 GB); from the second epoch on the host phase is a memcpy instead of a JPEG + PNG decode
+        self._cache = {} if cache_decoded else None
         self._get_batch()
         if not self.provide_label:
             raise RuntimeError("Invalid ImageDetRecordIter: " + path_imgrec)
@@ -210,29 +221,39 @@ class MultiTaskRecordIter(object):
     # host phase (_prepare: records, decode straight into a pinned pool, boxes, descriptors; may run ahead of the
     # consumer on the producer thread) and device phase (_finish: one upload, one launch pair, on the caller's stream)
     def _peek(self, item):
-        """header, label row and the lazily opened image(s) of one record: sizes are known before any pixel is decoded"""
+        """header, label row and the lazily opened image(s) of one record: sizes are known before any pixel is decoded.
+        With cache_decoded the images come back as arrays from the second time a record is seen."""
         import io
         from PIL import Image
         header, payload = recordio.unpack(item)
         hdr = np.array([header.label.shape[0]] + header.label.tolist())
-        im = Image.open(io.BytesIO(payload))
         seg_path = self.imglst[str(header.id)]
+        hit = self._cache.get(header.id) if self._cache is not None else None
+        if hit is not None:
+            return hdr, _Decoded(hit[0]), (None if hit[1] is None else _Decoded(hit[1])), seg_path, header.id
+        im = Image.open(io.BytesIO(payload))
         seg_im = Image.open(seg_path) if os.path.exists(seg_path) else None
         if self.enable_aug:
             assert seg_im is not None, seg_path + " not found."
         if seg_im is not None:
             assert seg_im.size == im.size, "label map and image differ in size: " + seg_path
-        return hdr, im, seg_im, seg_path
+        return hdr, im, seg_im, seg_path, header.id
 
-    @staticmethod
-    def _decode_into(args):
+    def _decode_into(self, args):
         """decode one image / label map into its slice of the pinned pools (worker thread; Pillow's decoders and
         numpy's copy loops release the GIL)"""
-        im, seg_im, img_dst, seg_dst = args
+        im, seg_im, img_dst, seg_dst, rec_id = args
+        if isinstance(im, _Decoded):                           # cached pixels: one memcpy each
+            img_dst[...] = im.a
+            if seg_im is not None:
+                seg_dst[...] = seg_im.a
+            return True
         img_dst[...] = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))   # the kernel's channel map is the identity
         if seg_im is not None:
             a = np.asarray(seg_im if seg_im.mode in ("L", "P") else seg_im.convert("L"))
             seg_dst[...] = a
+        if self._cache is not None:
+            self._cache[rec_id] = (img_dst.copy(), None if seg_im is None else seg_dst.copy())
         return True
 
     def _pool_set(self, k, img_bytes, seg_bytes):
@@ -253,8 +274,8 @@ class MultiTaskRecordIter(object):
         B, (C, H, W) = self.batch_size, self.data_shape
         items = [self.rec.read_idx(self.rec.key_type(self.index_table[s])) for s in range(start, start + B)]
         peeked = [self._peek(item) for item in items]
-        img_sizes = [im.size[0] * im.size[1] * 3 for _, im, _, _ in peeked]
-        seg_sizes = [(sm.size[0] * sm.size[1] if sm is not None else 0) for _, _, sm, _ in peeked]
+        img_sizes = [im.size[0] * im.size[1] * 3 for _, im, _, _, _ in peeked]
+        seg_sizes = [(sm.size[0] * sm.size[1] if sm is not None else 0) for _, _, sm, _, _ in peeked]
         pool = self._pool_set(serial % 2, sum(img_sizes), sum(seg_sizes))
         ip, sp = pool[0].numpy(), pool[1].numpy()
         label = np.ones((B, 1206)) * -1
@@ -262,7 +283,7 @@ class MultiTaskRecordIter(object):
         samples = np.zeros(B, _SAMPLE)
         jobs, fnames = [], []
         io_ = so = 0
-        for b, (hdr, im, seg_im, seg_path) in enumerate(peeked):
+        for b, (hdr, im, seg_im, seg_path, rec_id) in enumerate(peeked):
             ww, hh = im.size
             slot = start + b
             rows = hdr[3:].reshape((-1, 6))                     # view: the edits land in hdr
@@ -282,7 +303,7 @@ class MultiTaskRecordIter(object):
             s["flip"], s["img_border"], s["seg_border"] = int(flip_img), ib, sb
             s["minv"] = invert_affine(M)
             jobs.append((im, seg_im, ip[io_:io_ + img_sizes[b]].reshape(hh, ww, 3),
-                         sp[so:so + seg_sizes[b]].reshape(hh, ww) if seg_im is not None else None))
+                         sp[so:so + seg_sizes[b]].reshape(hh, ww) if seg_im is not None else None, rec_id))
             io_ += img_sizes[b]
             so += seg_sizes[b]
             label[b, 3:3 + hdr.shape[0]] = hdr

@@ -89,6 +89,15 @@ def main():
             torch.cuda.synchronize()
             print("iterator end to end (decode 1024x2048 JPEG + PNG on %d host threads, %d cores): %.0f img/s"
                   % (threads, os.cpu_count(), cnt / (time.time() - t0)))
+        itr = it.MultiTaskRecordIter(os.path.join(root, "t.rec"), 32, (3, 512, 512), device=dev, decode_threads=8, cache_decoded=True)
+        for epoch in range(3):
+            t0 = time.time()
+            cnt = 0
+            while itr.iter_next():
+                itr.next(); cnt += 32
+            torch.cuda.synchronize()
+            print("   cache_decoded, 8 threads, epoch %d: %.0f img/s" % (epoch, cnt / (time.time() - t0)))
+            itr.reset()
 
 
 if __name__ == "__main__":

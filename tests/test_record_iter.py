@@ -332,3 +332,21 @@ def test_augment_restatement_against_committed_vectors():
     rows = z["hdr_in"].copy()
     it.augmented_boxes(rows[3:].reshape(-1, 6), (3, 16, 32), list(z["aug"]))
     np.testing.assert_allclose(rows, z["hdr_out"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_record_iter_decoded_cache_is_transparent(gpu_device, tmp_path):
+    """cache_decoded=True (pixels kept in host memory after the first decode) yields the same batches"""
+    import torch
+    g = np.random.Generator(np.random.PCG64(13))
+    path = _write_dataset(str(tmp_path), 8, g, hw=(64, 96))
+    a = it.MultiTaskRecordIter(path, 4, (3, 32, 64), device=gpu_device)
+    b = it.MultiTaskRecordIter(path, 4, (3, 32, 64), device=gpu_device, cache_decoded=True)
+    for epoch in range(3):
+        while a.iter_next():
+            (ba, fa), (bb, fb) = a.next(), b.next()
+            assert fa == fb
+            assert torch.equal(ba.data[0], bb.data[0]) and torch.equal(ba.label[0], bb.label[0])
+            assert torch.equal(ba.label[1], bb.label[1])
+        a.reset(); b.reset()
+    assert len(b._cache) == 8
