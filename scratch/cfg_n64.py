@@ -11,7 +11,7 @@ def timeit(f, reps=20):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-shapes = [(32, 128, 128, 256, 64, 1), (32, 128, 128, 64, 64, 3), (32, 128, 128, 64, 64, 1), (32, 64, 64, 512, 128, 1), (32, 64, 64, 128, 128, 3)]
+shapes = [(32, 16, 16, 2048, 512, 1), (32, 16, 16, 512, 2048, 1), (32, 16, 16, 512, 512, 3), (32, 32, 32, 1024, 256, 1), (32, 32, 32, 256, 1024, 1), (32, 32, 32, 256, 256, 3)] if len(sys.argv) > 1 else [(32, 128, 128, 256, 64, 1), (32, 128, 128, 64, 64, 3), (32, 128, 128, 64, 64, 1), (32, 64, 64, 512, 128, 1), (32, 64, 64, 128, 128, 3)]
 for (N, H, W, Cin, Cout, k) in shapes:
     x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
     o = torch.empty(N, H, W, Cout, device=dev)
