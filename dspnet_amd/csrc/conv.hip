@@ -762,6 +762,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     load_tiles(kt + 1);   // past the last k-step: every offset out of range, zero-cost
+    // keep the requests HERE: without the fence hipcc sinks the four buffer loads below the 32 MFMAs (to shorten their
+    // live ranges) and waits for them at once -- the whole global-memory latency of every k-step was exposed
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (BF16) {
       // transposed-read addressing: 16-lane group gl = lane >> 4 covers channels 16*(gl&1) .. +15 of a 32-channel
       // block and pixels 8*(gl>>1) .. +7 of a 16-pixel MFMA k block; lane 4q+p of the group supplies the address
@@ -814,7 +817,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    // unconditional (the last iteration stores the zeros its out-of-range loads returned into the idle buffer): behind
+    // `if (kt + 1 < nk)` hipcc sinks the loads of load_tiles into the branch, i.e. below the MFMAs
+    store_tiles(buf ^ 1);
     __syncthreads();
   }
   // slab[split][k][J]: the tile goes through LDS (free after the mainloop's last barrier) and leaves as

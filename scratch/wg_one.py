@@ -18,8 +18,8 @@ if sys.argv[1] == "child":
     t = a.elapsed_time(b) / 10
     print("%.3f ms  %.1f TF  (%d splits)" % (t, 2.0 * N * H * W * Cin * Cout * k * k / t / 1e9, nsp))
 else:
-    for tile in ("", "1", "3"):
-        for sp in ("", "8", "16", "32", "64"):
+    for tile in ("",):
+        for sp in ("", "4", "7", "14", "28", "56", "112"):
             env = dict(os.environ)
             if tile: env["DSPN_WG_TILE"] = tile
             if sp: env["DSPN_WG_SPLITS"] = sp
