@@ -718,7 +718,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
   char *hA = reinterpret_cast<char *>(smem);            // [2][kBK][RAB]
   char *hB = hA + 2 * kBK * RAB;                        // [2][kBK][RBB]
-  auto store_tiles = [&](int buf) {
+  // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
+  auto transform_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (INTF) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
@@ -729,6 +730,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         rb[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
       }
     }
+  };
+  auto store_tiles = [&](int buf, bool transformed = false) __attribute__((always_inline)) {
+    if (!transformed) transform_tiles();
     if constexpr (BF16) {
       char *a = hA + buf * kBK * RAB, *b = hB + buf * kBK * RBB;
 #pragma unroll
@@ -815,11 +819,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       if (ks + 1 < kBK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      if constexpr (INTF) {
+        // half way through the k-step the x rows requested above have arrived: their affine runs on the vector ALU
+        // while the matrix pipe works through the MFMAs already issued, instead of after the last one
+        if (ks == kBK / 4 - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          transform_tiles();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     }
     // unconditional (the last iteration stores the zeros its out-of-range loads returned into the idle buffer): behind
     // `if (kt + 1 < nk)` hipcc sinks the loads of load_tiles into the branch, i.e. below the MFMAs
-    store_tiles(buf ^ 1);
+    store_tiles(buf ^ 1, INTF && !BF16);
     __syncthreads();
   }
   // slab[split][k][J]: the tile goes through LDS (free after the mainloop's last barrier) and leaves as
