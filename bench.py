@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
+# committed rocprofv3 --pmc passes of the headline workload, newest first (roofline.traffic is read from these)
+TRAFFIC_PROFILES = ["r02_pmc_conv_family.json", "r01_j_pmc_conv_family.json"]
 
 
 def parse():
@@ -45,8 +47,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the short side measurement of BASELINE.json configs[1] (vgg16_reduced, bs 16) at N=1")
+                    help="skip the short side measurements of BASELINE.json configs[1] (vgg16_reduced, bs 16), configs[3] "
+                         "(inceptionv3 1024x512, bs 8, bf16) and configs[4] (inference p50, bs 64) at N=1")
     ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher plumbing only (gloo, no GPU): every rank joins, rank 0 prints {dry_run, n_gpus}")
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="infer = BASELINE.json configs[4]: forward-only test graph + MultiBoxDetection/NMS, p50 latency")
     return ap.parse_args()
@@ -131,13 +136,174 @@ def cpu_baseline(size, images, cfg, width=None):
                       "ops + C multibox oracle; no optimizer step)" % (reps, cfg["network"], images, size, width)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run and
+    pass their exit status on.  Runs BEFORE anything in this process touches the GPU (no torch.cuda call, no HIP
+    library loaded): the children are ordinary child processes, never an exec of a process that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                       # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, traffic=None, traffic_source=None):
+    """roofline block of the implicit-GEMM convolution family from the HIP events the library recorded on the launch
+    stream around every conv launch since dspn_profile_enable(1).  `frac` = executed multiply-adds / conv kernel time /
+    peak; `frac_end_to_end_3x` = SURVEY.md 8(d)'s own definition, images/s x (3 x direct-conv forward FLOPs) / peak,
+    i.e. the whole step (every non-conv kernel and launch gap included) priced against the matrix peak."""
+    tot, cnt = ctypes.c_double(), ctypes.c_longlong()
+    lib.dspn_profile_collect(0, ctypes.byref(tot), ctypes.byref(cnt))
+    nt_ms, nt_n = tot.value, cnt.value
+    lib.dspn_profile_collect(1, ctypes.byref(tot), ctypes.byref(cnt))
+    wg_ms, wg_n = tot.value, cnt.value
+    conv_s = (nt_ms + wg_ms) / 1e3 / steps
+    if conv_s <= 0:
+        return None
+    ach = flops_step / conv_s / 1e12
+    peak = FP32_MATRIX_PEAK_TFLOPS if math == "fp32" else BF16_MATRIX_PEAK_TFLOPS
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "frac_end_to_end_3x": round(flops_3x_step / step_s / 1e12 / peak, 4),
+            "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: %s implicit-GEMM family" % math,
+            "launches_per_step": (nt_n + wg_n) // steps,
+            "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
+            "conv_ms_per_step": round(conv_s * 1e3, 3),
+            "nt_ms_per_step": round(nt_ms / steps, 3), "wgrad_ms_per_step": round(wg_ms / steps, 3),
+            "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
+            "share_of_step_time": round(conv_s / step_s, 3)}
+
+
+def conv_nodes(net):
+    from dspnet_amd import engine as E
+    return [n for n in net.g.nodes if isinstance(n, (E.Conv, E.Deconv4x4s2, E.BilinearConcatConv))]
+
+
+def side_train(network, H, W, B, math, steps, warmup, dev):
+    """a short side measurement of another BASELINE.json training config on this GPU (never part of `value`)"""
+    import torch
+    from dspnet_amd import _lib, functional as fn, synthetic
+    from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
+    from dspnet_amd.train.solver import MultiTaskSolver
+    lib = _lib.lib()
+    fn.set_conv_math(math)
+    try:
+        net = get_multi_symbol_train(network, (3, H, W), num_classes=8, batch_size=B, device=dev, seed=0)
+        solver = MultiTaskSolver(net)
+        g = synthetic.rng(233)
+        solver.set_batch(torch.from_numpy(synthetic.images(B, H, W, g)).to(dev),
+                         torch.from_numpy(synthetic.det_labels(B, gen=g, height=H, width=W)).to(dev),
+                         torch.from_numpy(synthetic.seg_labels(B, H, W, gen=g)).to(dev))
+        convs = conv_nodes(net)
+        flops_step = sum(n.flops_fwd + n.flops_bwd for n in convs)
+        flops_3x = 3.0 * sum(getattr(n, "flops_direct", n.flops_fwd) for n in convs)
+        for _ in range(warmup):
+            solver.step()
+        torch.cuda.synchronize()
+        lib.dspn_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lib.dspn_profile_enable(0)
+        return {"workload": "%s multitask (det+depth+seg) %dx%d (HxW), bs %d, %s, forward+backward+SGD, N=%d anchors"
+                            % (network, H, W, B, "fp32" if math == "fp32" else "bf16 MFMA convs", net.anchors.shape[1]),
+                "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+                "steps": steps, "warmup": warmup, "dtype": "f32" if math == "fp32" else "bf16",
+                "roofline": conv_family_roofline(lib, steps, flops_step, flops_3x, math, dt / steps)}
+    finally:
+        fn.set_conv_math("fp32")
+
+
+def side_infer(B, size, iters, warmup, dev):
+    """BASELINE.json configs[4]: inference-only detector path, p50 latency of forward + MultiBoxDetection/NMS"""
+    import numpy as np
+    import torch
+    from dspnet_amd import _lib, synthetic
+    from dspnet_amd.detect.multitask_detector import Detector
+    lib = _lib.lib()
+    det = Detector("resnet-50", size, num_classes=8, batch_size=B, device=dev)
+    det.net.data.data.copy_(torch.from_numpy(synthetic.images(B, size, size, synthetic.rng(233))).to(dev))
+    convs = conv_nodes(det.net)
+    flops_fwd = sum(n.flops_fwd for n in convs)
+    flops_direct = sum(getattr(n, "flops_direct", n.flops_fwd) for n in convs)
+    for _ in range(warmup):
+        det.forward()
+    torch.cuda.synchronize()
+    lib.dspn_profile_enable(1)
+    lat = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        det.forward()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lib.dspn_profile_enable(0)
+    lat = np.sort(np.asarray(lat))
+    p50 = float(np.percentile(lat, 50))
+    return {"workload": "resnet-50 multitask test graph %dx%d, batch %d, fp32, forward + MultiBoxDetection/NMS, random-init "
+                        "weights (nearly all 6132 rows valid: worst case for sort + NMS)" % (size, size, B),
+            "p50_ms_per_batch": round(p50, 3), "p90_ms_per_batch": round(float(np.percentile(lat, 90)), 3),
+            "images_per_s": round(B / p50 * 1e3, 1), "iterations": iters, "warmup": warmup, "dtype": "f32",
+            "roofline": conv_family_roofline(lib, iters, flops_fwd, flops_direct, "fp32", float(lat.mean()) / 1e3)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run and
+    pass their exit status on.  Runs BEFORE anything in this process touches the GPU (no torch.cuda call, no HIP
+    library loaded): the children are ordinary child processes, never an exec of a process that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                       # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """--dry-run: the launcher / rendezvous / one-JSON-line plumbing of an N-rank run without a GPU (gloo): every rank
+    joins the group, a sum all-reduce of (rank + 1) must give N (N + 1) / 2, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        assert float(t.item()) == world * (world + 1) / 2
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.dry_run:
+        return dry_run(args)
     if args.mode == "infer":
         return run_infer(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and os.environ.get("DSPN_FORCE_DIST") != "1":
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # DSPN_FORCE_DIST=1 runs the RCCL code path (init, bucketed async all-reduce, barrier) even at
@@ -149,11 +315,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from dspnet_amd import _lib, engine as E, synthetic
+    from dspnet_amd import _lib, synthetic
     from dspnet_amd.symbol.multitask_symbol_factory import get_config, get_multi_symbol_train
     from dspnet_amd.train.solver import MultiTaskSolver
 
@@ -167,7 +334,7 @@ def main():
     solver.set_batch(torch.from_numpy(synthetic.images(B, S, Wd, gen)).to(dev),
                      torch.from_numpy(synthetic.det_labels(B, gen=gen, height=S, width=Wd)).to(dev),
                      torch.from_numpy(synthetic.seg_labels(B, S, Wd, gen=gen)).to(dev))
-    convs = [n for n in net.g.nodes if isinstance(n, (E.Conv, E.Deconv4x4s2, E.BilinearConcatConv))]
+    convs = conv_nodes(net)
     # executed multiply-adds: score3_conv is evaluated per pyramid level before the resize (engine.BilinearConcatConv,
     # an exact linear identity) and is counted with what it executes, NOT with the 9.3x larger direct-form count, so
     # the MFMA fraction below is not inflated by the saving; the 3x convention uses the direct count of every layer
@@ -199,58 +366,35 @@ def main():
 
     roofline = None
     if prof:
-        tot, cnt = ctypes.c_double(), ctypes.c_longlong()
-        lib.dspn_profile_collect(0, ctypes.byref(tot), ctypes.byref(cnt))
-        nt_ms, nt_n = tot.value, cnt.value
-        lib.dspn_profile_collect(1, ctypes.byref(tot), ctypes.byref(cnt))
-        wg_ms, wg_n = tot.value, cnt.value
-        conv_s = (nt_ms + wg_ms) / 1e3 / args.steps
-        ach = flops_step / conv_s / 1e12
-        traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
-        try:
-            traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_j_pmc_conv_family.json")))["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
-        peak = FP32_MATRIX_PEAK_TFLOPS if args.math == "fp32" else BF16_MATRIX_PEAK_TFLOPS
-        if args.math != "fp32" or args.network != "resnet-50" or (S, Wd, B) != (512, 512, 32):
-            traffic = None          # the committed PMC passes are of the headline workload only
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
-                    "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: %s implicit-GEMM family" % args.math,
-                    "launches_per_step": (nt_n + wg_n) // args.steps,
-                    "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
-                    "conv_ms_per_step": round(conv_s * 1e3, 3),
-                    "nt_ms_per_step": round(nt_ms / args.steps, 3), "wgrad_ms_per_step": round(wg_ms / args.steps, 3),
-                    "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
-                    "share_of_step_time": round(conv_s / (dt / args.steps), 3)}
+        # HBM bytes per conv launch: rocprofv3 --pmc cannot run inside bench.py, so this figure is OFFLINE -- read from
+        # the committed PMC passes of the headline workload named in traffic_source -- not a measurement of this run
+        traffic = tsrc = None
+        headline = (args.network, S, Wd, B, args.math) == ("resnet-50", 512, 512, 32, "fp32")
+        if headline:
+            for name in TRAFFIC_PROFILES:
+                try:
+                    traffic = round(json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"])
+                    tsrc = "offline: profiles/" + name
+                    break
+                except (OSError, KeyError, ValueError):
+                    pass
+        roofline = conv_family_roofline(lib, args.steps, flops_step, flops_3x, args.math, dt / args.steps, traffic, tsrc)
 
-    # BASELINE.json configs[1] (vgg16_reduced multitask 512x512, bs 16, fp32, one GPU) beside the headline workload:
-    # a short side measurement OUTSIDE the timed region above (never part of `value`), N=1 only
+    # the other BASELINE.json configs beside the headline workload: short side measurements OUTSIDE the timed region
+    # above (never part of `value`), N=1 only, each with its own roofline block
     other = None
     headline = (args.network, S, Wd, B, args.math) == ("resnet-50", 512, 512, 32, "fp32")
     if rank == 0 and world == 1 and headline and not args.no_other_configs and not args.no_cpu_baseline:
-        try:
-            net2 = get_multi_symbol_train("vgg16_reduced", (3, 512, 512), num_classes=8, batch_size=16, device=dev, seed=0)
-            solver2 = MultiTaskSolver(net2)
-            g2 = synthetic.rng(233)
-            solver2.set_batch(torch.from_numpy(synthetic.images(16, 512, 512, g2)).to(dev),
-                              torch.from_numpy(synthetic.det_labels(16, gen=g2, height=512, width=512)).to(dev),
-                              torch.from_numpy(synthetic.seg_labels(16, 512, 512, gen=g2)).to(dev))
-            for _ in range(2):
-                solver2.step()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(5):
-                solver2.step()
-            torch.cuda.synchronize()
-            d2 = time.perf_counter() - t2
-            other = {"configs[1]": {"workload": "vgg16_reduced multitask (det+depth+seg) 512x512, bs 16, fp32, "
-                                                "forward+backward+SGD, N=%d anchors" % net2.anchors.shape[1],
-                                    "images_per_s": round(16 * 5 / d2, 2), "ms_per_step": round(d2 / 5 * 1e3, 3),
-                                    "steps": 5, "warmup": 2}}
-            del net2, solver2
-        except Exception as e:          # the side measurement must never cost the headline line
-            other = {"configs[1]": {"error": str(e)[:200]}}
+        del solver
+        other = {}
+        for key, f in (("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "fp32", 5, 2, dev)),
+                       ("configs[3]", lambda: side_train("inceptionv3", 512, 1024, 8, "bf16", 8, 3, dev)),
+                       ("configs[4]", lambda: side_infer(64, 512, 100, 10, dev))):
+            try:
+                other[key] = f()
+            except Exception as e:          # a side measurement must never cost the headline line
+                other[key] = {"error": str(e)[:200]}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         cfg = get_config(args.network, S)

@@ -1,0 +1,318 @@
+// GridGenerator(transform_type='affine') + BilinearSampler with a LEARNABLE affine_matrix
+// (symbol/multitask_symbol_builder.py:574-581, multi_init.py:72; the optimizer updates it like any other
+// argument, multi_solver.py:291-293).  C ABI in include/dspn_nn.h.
+//
+// Semantics restated from MXNet's operators (not vendored by the reference):
+//   grid_dst(ho, wo) = (x_t, y_t, 1),  x_t = -1 + wo * 2/(Wo-1),  y_t = -1 + ho * 2/(Ho-1)
+//   grid_src = theta(2x3) . grid_dst                        (one grid, shared by the whole batch)
+//   x_real = (x_src + 1) * (Win-1) / 2,  y_real likewise;  the four neighbours are weighted
+//   bilinearly and a neighbour outside the image contributes 0.
+//   d out / d x_real = (1-fy) (v01 - v00) + fy (v11 - v10)   (out-of-image neighbours are 0),
+//   d L / d theta = sum over target pixels of [dL/dx_src * (x_t, y_t, 1), dL/dy_src * (x_t, y_t, 1)].
+// With theta = (1,0,0,0,1,0) every product above is exact, so the identity case reproduces the plain
+// align-corners resize of nn.hip bit for bit.
+//
+// Forward: one thread per (pixel, float4 column) of the destination sums every source that covers the
+// column (a concat writes disjoint slices, the per-level evaluation of score3_conv sums six maps in one
+// pass).  Data gradient: gather form -- a workgroup per source pixel walks the pre-image of its 2x2
+// footprint under the affine map (bounding box from the inverse map, exact membership test with the
+// forward's own coordinate function), rows of the box split over the workgroup's slices and summed in a
+// fixed order: no atomics, bitwise reproducible.  theta gradient: one wave per target pixel (lanes over
+// channels, butterfly reduction), per-wave double accumulators, fixed-order final sum.
+#include "dspn_common.h"
+#include "../../include/dspn_nn.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxSrc = DSPN_SAMPLER_MAX_SOURCES;
+
+struct Src { const float *x; int Hin, Win, C4, coff4; };
+struct SrcTable { Src s[kMaxSrc]; int n; };
+
+struct Theta { float t[6]; };
+__device__ __forceinline__ Theta load_theta(const float *theta) {
+  Theta r;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.t[i] = theta[i];
+  return r;
+}
+__device__ __forceinline__ float tgt_coord(int o, int O) {
+  return O > 1 ? -1.f + (float)o * (2.f / (float)(O - 1)) : 0.f;
+}
+// source coordinates of target pixel (ho, wo); clamped to a band around the image so that the int conversion is
+// defined for any theta (inside the band nothing changes; outside every neighbour is out of the image anyway)
+__device__ __forceinline__ void src_xy(const Theta &th, float xt, float yt, int Hin, int Win, float &xs, float &ys) {
+  const float gx = th.t[0] * xt + th.t[1] * yt + th.t[2];
+  const float gy = th.t[3] * xt + th.t[4] * yt + th.t[5];
+  xs = (gx + 1.f) * (float)(Win - 1) / 2.f;
+  ys = (gy + 1.f) * (float)(Hin - 1) / 2.f;
+  xs = fminf(fmaxf(xs, -2.f), (float)Win + 1.f);
+  ys = fminf(fmaxf(ys, -2.f), (float)Hin + 1.f);
+}
+
+__global__ void sampler_fwd_kernel(const SrcTable tab, const float *__restrict__ theta, float4 *__restrict__ y,
+                                   int Ho, int Wo, int ld4, long long total) {
+  const Theta th = load_theta(theta);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % ld4);
+    long long t = i / ld4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const float xt = tgt_coord(wo, Wo), yt = tgt_coord(ho, Ho);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int si = 0; si < tab.n; ++si) {
+      const Src s = tab.s[si];
+      const int c = c4 - s.coff4;
+      if (c < 0 || c >= s.C4) continue;
+      float xs, ys;
+      src_xy(th, xt, yt, s.Hin, s.Win, xs, ys);
+      const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+      const float wy0 = 1.f - (ys - (float)y0), wx0 = 1.f - (xs - (float)x0);
+      const float4 *x = reinterpret_cast<const float4 *>(s.x);
+#pragma unroll
+      for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+          const int yy = y0 + dyy, xx = x0 + dxx;
+          if ((unsigned)yy >= (unsigned)s.Hin || (unsigned)xx >= (unsigned)s.Win) continue;
+          const float wgt = (dyy ? 1.f - wy0 : wy0) * (dxx ? 1.f - wx0 : wx0);
+          const float4 v = x[((n * s.Hin + yy) * s.Win + xx) * s.C4 + c];
+          acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+        }
+    }
+    y[i] = acc;
+  }
+}
+
+// one workgroup (64 channel lanes x SL slices) per source pixel
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const float *__restrict__ dy,
+                                                                   const float *__restrict__ theta,
+                                                                   float4 *__restrict__ dx, int Hin, int Win, int C4,
+                                                                   int Ho, int Wo, int ldo, int coff, int accumulate) {
+  __shared__ float4 red[SL > 1 ? SL : 1][64];
+  const Theta th = load_theta(theta);
+  const int lane = threadIdx.x, sl = threadIdx.y;
+  const long long pix = blockIdx.x;
+  const int w = (int)(pix % Win);
+  const int h = (int)((pix / Win) % Hin);
+  const long long n = pix / ((long long)Win * Hin);
+  // pixel-space affine map: xs = axw*wo + axh*ho + ax0, ys = ayw*wo + ayh*ho + ay0 (for the bounding box only)
+  const float kx = Wo > 1 ? 2.f / (float)(Wo - 1) : 0.f, ky = Ho > 1 ? 2.f / (float)(Ho - 1) : 0.f;
+  const float hw = (float)(Win - 1) / 2.f, hh = (float)(Hin - 1) / 2.f;
+  const float x0t = Wo > 1 ? -1.f : 0.f, y0t = Ho > 1 ? -1.f : 0.f;
+  const float axw = th.t[0] * kx * hw, axh = th.t[1] * ky * hw, ax0 = (th.t[0] * x0t + th.t[1] * y0t + th.t[2] + 1.f) * hw;
+  const float ayw = th.t[3] * kx * hh, ayh = th.t[4] * ky * hh, ay0 = (th.t[3] * x0t + th.t[4] * y0t + th.t[5] + 1.f) * hh;
+  const float det = axw * ayh - axh * ayw;
+  int wo_lo = 0, wo_hi = Wo - 1, ho_lo = 0, ho_hi = Ho - 1;
+  if (fabsf(det) > 1e-20f && isfinite(det)) {
+    float fw_lo = 3e38f, fw_hi = -3e38f, fh_lo = 3e38f, fh_hi = -3e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sx = (float)w + ((k & 1) ? 1.f : -1.f) - ax0, sy = (float)h + ((k & 2) ? 1.f : -1.f) - ay0;
+      const float fw = (ayh * sx - axh * sy) / det, fh = (axw * sy - ayw * sx) / det;
+      fw_lo = fminf(fw_lo, fw); fw_hi = fmaxf(fw_hi, fw); fh_lo = fminf(fh_lo, fh); fh_hi = fmaxf(fh_hi, fh);
+    }
+    if (isfinite(fw_lo) && isfinite(fw_hi) && isfinite(fh_lo) && isfinite(fh_hi)) {
+      // two pixels of slack for the rounding of the inverse; membership is tested exactly below
+      wo_lo = (int)fmaxf(floorf(fw_lo) - 2.f, 0.f); wo_hi = (int)fminf(ceilf(fw_hi) + 2.f, (float)(Wo - 1));
+      ho_lo = (int)fmaxf(floorf(fh_lo) - 2.f, 0.f); ho_hi = (int)fminf(ceilf(fh_hi) + 2.f, (float)(Ho - 1));
+    }
+  }
+  for (int cb = 0; cb < C4; cb += 64) {
+    const int c4 = cb + lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ho = ho_lo + sl; ho <= ho_hi; ho += SL) {
+      const float yt = tgt_coord(ho, Ho);
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        float xs, ys;
+        src_xy(th, tgt_coord(wo, Wo), yt, Hin, Win, xs, ys);
+        const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+        float wy, wx;
+        if (y0 == h) wy = 1.f - (ys - (float)y0);
+        else if (y0 + 1 == h) wy = 1.f - (1.f - (ys - (float)y0));
+        else continue;
+        if (x0 == w) wx = 1.f - (xs - (float)x0);
+        else if (x0 + 1 == w) wx = 1.f - (1.f - (xs - (float)x0));
+        else continue;
+        if (c4 >= C4) continue;
+        const float wgt = wy * wx;
+        const float4 v = *reinterpret_cast<const float4 *>(dy + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4);
+        acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+      }
+    }
+    if (SL > 1) {
+      red[sl][lane] = acc;
+      __syncthreads();
+      if (sl == 0) {
+#pragma unroll
+        for (int k = 1; k < SL; ++k) {
+          const float4 v = red[k][lane];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    }
+    if (sl == 0 && c4 < C4) {
+      float4 *o = dx + pix * C4 + c4;
+      if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+      *o = acc;
+    }
+    if (SL > 1) __syncthreads();
+  }
+}
+
+// partial[wave][6] (double): this wave's target pixels, all sources
+constexpr int kThetaWavesPerBlock = 4;
+__global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_kernel(
+    const SrcTable tab, const float *__restrict__ theta, const float *__restrict__ dy, double *__restrict__ partial,
+    int Ho, int Wo, int ldo, long long pixels) {
+  const Theta th = load_theta(theta);
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * kThetaWavesPerBlock + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * kThetaWavesPerBlock;
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (long long p = gw; p < pixels; p += nw) {
+    const int wo = (int)(p % Wo);
+    const int ho = (int)((p / Wo) % Ho);
+    const long long n = p / ((long long)Wo * Ho);
+    const float xt = tgt_coord(wo, Wo), yt = tgt_coord(ho, Ho);
+    const float *g = dy + p * (long long)ldo;
+    for (int si = 0; si < tab.n; ++si) {
+      const Src s = tab.s[si];
+      float xs, ys;
+      src_xy(th, xt, yt, s.Hin, s.Win, xs, ys);
+      const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+      const float fy = ys - (float)y0, fx = xs - (float)x0;
+      const bool vy0 = (unsigned)y0 < (unsigned)s.Hin, vy1 = (unsigned)(y0 + 1) < (unsigned)s.Hin;
+      const bool vx0 = (unsigned)x0 < (unsigned)s.Win, vx1 = (unsigned)(x0 + 1) < (unsigned)s.Win;
+      float gx = 0.f, gy = 0.f;
+      if ((vy0 || vy1) && (vx0 || vx1)) {
+        const float4 *x = reinterpret_cast<const float4 *>(s.x);
+        const long long base = ((n * s.Hin + y0) * s.Win + x0) * s.C4;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = lane; c < s.C4; c += 64) {
+          const float4 v00 = (vy0 && vx0) ? x[base + c] : z;
+          const float4 v01 = (vy0 && vx1) ? x[base + s.C4 + c] : z;
+          const float4 v10 = (vy1 && vx0) ? x[base + (long long)s.Win * s.C4 + c] : z;
+          const float4 v11 = (vy1 && vx1) ? x[base + (long long)(s.Win + 1) * s.C4 + c] : z;
+          const float4 d = *reinterpret_cast<const float4 *>(g + (s.coff4 + c) * 4);
+          const float ax_[4] = {v01.x - v00.x, v01.y - v00.y, v01.z - v00.z, v01.w - v00.w};
+          const float bx_[4] = {v11.x - v10.x, v11.y - v10.y, v11.z - v10.z, v11.w - v10.w};
+          const float ay_[4] = {v10.x - v00.x, v10.y - v00.y, v10.z - v00.z, v10.w - v00.w};
+          const float by_[4] = {v11.x - v01.x, v11.y - v01.y, v11.z - v01.z, v11.w - v01.w};
+          const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            gx += dd[e] * ((1.f - fy) * ax_[e] + fy * bx_[e]);
+            gy += dd[e] * ((1.f - fx) * ay_[e] + fx * by_[e]);
+          }
+        }
+      }
+      // fixed butterfly over the 64 lanes
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { gx += __shfl_xor(gx, o, 64); gy += __shfl_xor(gy, o, 64); }
+      const double cx = (double)gx * (double)(s.Win - 1) * 0.5, cy = (double)gy * (double)(s.Hin - 1) * 0.5;
+      a[0] += cx * xt; a[1] += cx * yt; a[2] += cx;
+      a[3] += cy * xt; a[4] += cy * yt; a[5] += cy;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) partial[gw * 6 + k] = a[k];
+  }
+}
+
+__global__ __launch_bounds__(384) void sampler_theta_final_kernel(const double *__restrict__ partial, long long rows,
+                                                                  float *__restrict__ dtheta, int accumulate) {
+  __shared__ double sm[64][6];
+  const int k = threadIdx.x % 6, j = threadIdx.x / 6;      // 64 row groups x 6 components, fixed assignment
+  double s = 0;
+  for (long long r = j; r < rows; r += 64) s += partial[r * 6 + k];
+  sm[j][k] = s;
+  __syncthreads();
+  if (j == 0) {
+    for (int q = 1; q < 64; ++q) s += sm[q][k];
+    dtheta[k] = (float)(accumulate ? (double)dtheta[k] + s : s);
+  }
+}
+
+int theta_blocks(long long pixels) {
+  return (int)std::max<long long>(1, std::min<long long>((pixels + 4 * kThetaWavesPerBlock - 1) / (4 * kThetaWavesPerBlock), 1024));
+}
+
+int make_table(SrcTable &tab, const float *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+               int nsrc, int ldo, const char *what) {
+  DSPN_REQUIRE(x && Hin && Win && C && coff && nsrc >= 1 && nsrc <= kMaxSrc, "%s: 1..%d sources", what, kMaxSrc);
+  tab.n = nsrc;
+  for (int i = 0; i < nsrc; ++i) {
+    DSPN_REQUIRE(x[i] && Hin[i] > 0 && Win[i] > 0 && C[i] > 0 && C[i] % 4 == 0 && coff[i] >= 0 && coff[i] % 4 == 0 &&
+                     coff[i] + C[i] <= ldo, "%s: bad source %d", what, i);
+    tab.s[i] = Src{x[i], Hin[i], Win[i], C[i] / 4, coff[i] / 4};
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspn_affine_sampler_forward_f32(const float *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+                                    int nsrc, const float *theta, float *y, int N, int Ho, int Wo, int ldo, void *stream) {
+  DSPN_REQUIRE(theta && y && N > 0 && Ho > 0 && Wo > 0 && ldo > 0 && ldo % 4 == 0, "affine_sampler_forward: bad argument");
+  SrcTable tab;
+  if (int rc = make_table(tab, x, Hin, Win, C, coff, nsrc, ldo, "affine_sampler_forward")) return rc;
+  const long long total = (long long)N * Ho * Wo * (ldo / 4);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 16384));
+  hipLaunchKernelGGL(sampler_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, theta,
+                     reinterpret_cast<float4 *>(y), Ho, Wo, ldo / 4, total);
+  return dspn::check_launch("affine_sampler_forward");
+}
+
+int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, float *dx, int N, int Hin, int Win, int C,
+                                          int Ho, int Wo, int ldo, int coff, int accumulate, void *stream) {
+  DSPN_REQUIRE(dy && theta && dx && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 &&
+                   ldo % 4 == 0 && coff >= 0 && coff % 4 == 0 && coff + C <= ldo, "affine_sampler_backward_data: bad argument");
+  const long long pix = (long long)N * Hin * Win;
+  DSPN_REQUIRE(pix < (1ll << 31), "affine_sampler_backward_data: too many source pixels");
+  // slices by the nominal footprint (the grid is near the identity map): rows of the pre-image box per source pixel
+  const int rows = 2 * ((Ho + Hin - 1) / Hin) + 4;
+  hipStream_t s = (hipStream_t)stream;
+#define DSPN_SBD_(SL) hipLaunchKernelGGL(sampler_bwd_data_kernel<SL>, dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
+                                         reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate)
+  if (rows >= 32) DSPN_SBD_(16);
+  else if (rows >= 10) DSPN_SBD_(4);
+  else DSPN_SBD_(1);
+#undef DSPN_SBD_
+  return dspn::check_launch("affine_sampler_backward_data");
+}
+
+size_t dspn_affine_sampler_theta_workspace_bytes(int N, int Ho, int Wo) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  return sizeof(double) * 6 * (size_t)theta_blocks((long long)N * Ho * Wo) * kThetaWavesPerBlock;
+}
+
+int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin, const int *Win, const int *C,
+                                           const int *coff, int nsrc, const float *theta, const float *dy, int N, int Ho,
+                                           int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(theta && dy && dtheta && workspace && N > 0 && Ho > 0 && Wo > 0 && ldo > 0 && ldo % 4 == 0,
+               "affine_sampler_backward_theta: bad argument");
+  SrcTable tab;
+  if (int rc = make_table(tab, x, Hin, Win, C, coff, nsrc, ldo, "affine_sampler_backward_theta")) return rc;
+  if (workspace_bytes < dspn_affine_sampler_theta_workspace_bytes(N, Ho, Wo))
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "affine_sampler_backward_theta: workspace too small");
+  const long long pixels = (long long)N * Ho * Wo;
+  const int blocks = theta_blocks(pixels);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sampler_bwd_theta_kernel, dim3(blocks), dim3(64 * kThetaWavesPerBlock), 0, s, tab, theta, dy,
+                     static_cast<double *>(workspace), Ho, Wo, ldo, pixels);
+  hipLaunchKernelGGL(sampler_theta_final_kernel, dim3(1), dim3(384), 0, s, static_cast<const double *>(workspace),
+                     (long long)blocks * kThetaWavesPerBlock, dtheta, accumulate);
+  return dspn::check_launch("affine_sampler_backward_theta");
+}
+
+}  // extern "C"

@@ -255,8 +255,8 @@ class Graph:
         """arg_params: name -> numpy array in the reference's shape (Convolution weight (Cout, Cin, kh, kw),
         Deconvolution weight (in, out, kh, kw), vectors (C,)).  Converted to the device layout ([Cout][kh][kw][Cin
         padded to the input tensor's physical channels], pad channels zero) and copied into the arena.
-        Shape mismatches raise; names the graph has no parameter for (the `*_gamma` of fix_gamma BatchNorms,
-        `affine_matrix`, ...) are ignored unless allow_extra=False; graph parameters without a value keep their
+        Shape mismatches raise; names the graph has no parameter for (the `*_gamma` of fix_gamma BatchNorms, the moving
+        statistics, ...) are ignored unless allow_extra=False; graph parameters without a value keep their
         current contents if allow_missing else raise (Module.set_params semantics)."""
         missing = [p.name for p in self.param_order if p.name not in arg_params]
         if missing and not allow_missing:
@@ -272,7 +272,9 @@ class Graph:
             if tuple(v.shape) != logical:
                 raise ValueError("set_params: %s has shape %s, the graph expects %s" % (p.name, tuple(v.shape), logical))
             dev = np.zeros(p.shape, np.float32)
-            if p.kind in ("conv", "deconv"):
+            if p.kind == "raw":                                   # same values, only the shape differs ((1,6) <-> (6,))
+                dev[:] = v.reshape(p.shape)
+            elif p.kind in ("conv", "deconv"):
                 t = v.transpose(0, 2, 3, 1)                       # -> [rows][kh][kw][cols]
                 dev[:t.shape[0], :, :, :t.shape[3]] = t
             else:
@@ -287,7 +289,9 @@ class Graph:
         for p in self.param_order:
             v = p.data.detach().cpu().numpy()
             logical = tuple(p.logical or p.shape)
-            if p.kind in ("conv", "deconv"):
+            if p.kind == "raw":
+                v = v.reshape(logical)
+            elif p.kind in ("conv", "deconv"):
                 v = v[:logical[0], :, :, :logical[1]].transpose(0, 3, 1, 2)
             else:
                 v = v[:logical[0]]
@@ -334,6 +338,20 @@ def deconv_bilinear_init(channels):
             w[i, :, :, i] = filt
         return w
     return f
+
+
+def init_affine_identity(rng, shape):
+    """multi_init.py:72: affine_matrix = [[1, 0, 0, 0, 1, 0]]"""
+    return np.array([1, 0, 0, 0, 1, 0], np.float32)
+
+
+def affine_matrix_param(g, name="affine_matrix"):
+    """mx.sym.var("affine_matrix", shape=(1,6)) (multitask_symbol_builder.py:574): an ordinary argument -- it gets
+    a gradient through GridGenerator / BilinearSampler and the optimizer updates it (multi_solver.py:205-208,
+    291-293), weight decay included.  Device shape (6,), checkpoint shape (1, 6)."""
+    p = g.param(name, (6,), init_affine_identity)
+    p.logical, p.kind = (1, 6), "raw"
+    return p
 
 
 # ------------------------------------------------------------------ nodes
@@ -563,13 +581,14 @@ class BilinearConcatConv(Node):
     Exact in real arithmetic; in fp32 the result differs from the direct form by rounding only (the graph-level
     parity tests against the direct-form oracle cover it).  The parameter keeps the reference's name and shape."""
 
-    def __init__(self, g, inputs, name, num_filter, kernel, pad, target_hw, init="maxdim"):
+    def __init__(self, g, inputs, name, num_filter, kernel, pad, target_hw, theta, init="maxdim"):
         N = inputs[0].shape[0]
         kh, kw = fn._hw(kernel)
         self.pad = fn._hw(pad)
         assert (kh - 1) // 2 == self.pad[0] and (kw - 1) // 2 == self.pad[1], "needs a 'same' convolution"
         Ht, Wt = target_hw
         self.inputs = inputs
+        self.theta = theta            # Param "affine_matrix": the sampling grid of every component
         self.offsets = np.cumsum([0] + [t.shape[3] for t in inputs]).tolist()
         Cin = self.offsets[-1]
         self.cout, self.kh, self.kw = num_filter, kh, kw
@@ -581,13 +600,14 @@ class BilinearConcatConv(Node):
         self.z = fn.zeros(N, Ht, Wt, Tp, device=g.device)            # tap-expanded map at the target size (dz in backward)
         self.zc, self.wc, self.wct, self.dwc = [], [], [], []
         for t in inputs:
-            native = (t.shape[1], t.shape[2]) == (Ht, Wt)
-            self.zc.append(None if native else fn.zeros(N, t.shape[1], t.shape[2], Tp, device=g.device))
+            # W_c . x_c at the component's own resolution (its gradient in backward).  Every component goes through
+            # the sampler, also the ones that already have the target size: once the optimizer has moved
+            # affine_matrix off the identity they are resampled too, and their grid gradient is not zero
+            self.zc.append(fn.zeros(N, t.shape[1], t.shape[2], Tp, device=g.device))
             self.wc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))      # W_c, contiguous
             self.wct.append(fn.zeros(t.shape[3], 1, 1, Tp, device=g.device))    # its transpose (data-gradient operand)
             self.dwc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))
-        # native-size components first: their product is written, the resized ones are added to it
-        self.order = sorted(range(len(inputs)), key=lambda c: self.zc[c] is not None)
+        self.sources = None           # fn.SamplerSources over zc, made at the first forward
         self.out = g.tensor((N, Ht, Wt, fn.pad4(num_filter)), name + "_out")
         self.out.channels = num_filter
         # multiply-adds actually executed (the direct form would be 2 * Cin * Cout * k * k * Ht * Wt * N)
@@ -604,25 +624,22 @@ class BilinearConcatConv(Node):
 
     def forward(self):
         self._gather_weights()
-        first = True
-        for c in self.order:
-            t = self.inputs[c]
-            if self.zc[c] is None:
-                fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.z, accumulate=not first)
-            else:
-                fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.zc[c])
-                fn.bilinear_forward(self.zc[c], self.z, 0, accumulate=not first)
-            first = False
+        for c, t in enumerate(self.inputs):
+            fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.zc[c])
+        if self.sources is None:
+            self.sources = fn.SamplerSources([(z, 0) for z in self.zc])
+        fn.affine_sampler_forward(self.sources, self.theta.data, self.z)       # z = sum_c U_c(theta)(W_c x_c), one pass
         fn.tap_sum(self.z, None, self.cout, self.kh, self.kw, self.pad, out=self.out.data)
 
     def backward(self):
         if not self.out._gw:
             return
         fn.tap_spread(self.out.grad, self.cout, self.kh, self.kw, self.pad, out=self.z)
+        # d L / d affine_matrix needs the forward values W_c x_c: taken before zc is reused for the gradients
+        fn.affine_sampler_backward_theta(self.sources, self.theta.data, self.z, self.theta.grad)
         Cin = self.offsets[-1]
-        for c in self.order:
-            t = self.inputs[c]
-            dz = self.z if self.zc[c] is None else fn.bilinear_backward(self.z, self.zc[c].shape, 0, dx=self.zc[c])
+        for c, t in enumerate(self.inputs):
+            dz = fn.affine_sampler_backward_data(self.z, self.theta.data, self.zc[c].shape, 0, dx=self.zc[c])
             fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c])
             fn.copy_block(self.dwc[c], self.w.grad, 1, self.T, t.shape[3], 0, t.shape[3], 0, 0, Cin, self.offsets[c])
             if t.requires_grad:
@@ -792,28 +809,28 @@ class Concat(Node):
 
 
 class BilinearConcat(Node):
-    """GridGenerator(identity affine, target) + BilinearSampler on each input, concatenated along
+    """GridGenerator(affine_matrix, target) + BilinearSampler on each input, concatenated along
     channels (multitask_symbol_builder.py:574-582)."""
 
-    def __init__(self, g, inputs, name, target_hw):
+    def __init__(self, g, inputs, name, target_hw, theta):
         N = inputs[0].shape[0]
         self.inputs = inputs
+        self.theta = theta
         self.offsets = np.cumsum([0] + [t.shape[3] for t in inputs]).tolist()
         self.out = g.tensor((N, target_hw[0], target_hw[1], self.offsets[-1]), name)
+        self.sources = None           # made at the first forward (Graph.finalize may still re-allocate an input)
 
     def forward(self):
-        for t, off in zip(self.inputs, self.offsets):
-            fn.bilinear_forward(t.data, self.out.data, off)
+        if self.sources is None:
+            self.sources = fn.SamplerSources([(t.data, off) for t, off in zip(self.inputs, self.offsets)])
+        fn.affine_sampler_forward(self.sources, self.theta.data, self.out.data)
 
     def backward(self):
         if not self.out._gw:
             return
+        fn.affine_sampler_backward_theta(self.sources, self.theta.data, self.out.grad, self.theta.grad)
         for t, off in zip(self.inputs, self.offsets):
             if not t.requires_grad:
                 continue
-            if t._gw:
-                tmp = fn.bilinear_backward(self.out.grad, t.shape, off)
-                fn.add(t.grad, tmp, out=t.grad)
-            else:
-                dx, _ = t.grad_target()
-                fn.bilinear_backward(self.out.grad, t.shape, off, dx=dx)
+            dx, acc = t.grad_target()
+            fn.affine_sampler_backward_data(self.out.grad, self.theta.data, t.shape, off, dx=dx, accumulate=acc)

@@ -81,6 +81,11 @@ _lib.register({
     "dspn_bilinear_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_bilinear_forward_acc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_bilinear_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_affine_sampler_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dspn_affine_sampler_backward_data_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_affine_sampler_theta_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dspn_affine_sampler_backward_theta_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i,
+                                                    _vp, _sz, _vp]),
     "dspn_softmax_output_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
     "dspn_count_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp]),
     "dspn_smooth_l1_forward_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
@@ -537,6 +542,48 @@ def bilinear_backward(dy, x_shape, coff, dx=None, separable=True):
     check(L().dspn_bilinear_backward_f32(ptr(dy), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
                                          dy.shape[3], coff, stream()), "bilinear_backward")
     return dx
+
+
+class SamplerSources:
+    """host-side table of the source maps of one affine-sampler call: [(x (N,Hin,Win,C), channel offset)]"""
+
+    def __init__(self, entries):
+        n = len(entries)
+        self.n = n
+        self.tensors = [x for x, _ in entries]                  # keep the buffers alive
+        self.x = (_c.c_void_p * n)(*[x.data_ptr() for x, _ in entries])
+        self.Hin = (_c.c_int * n)(*[x.shape[1] for x, _ in entries])
+        self.Win = (_c.c_int * n)(*[x.shape[2] for x, _ in entries])
+        self.C = (_c.c_int * n)(*[x.shape[3] for x, _ in entries])
+        self.coff = (_c.c_int * n)(*[int(o) for _, o in entries])
+
+
+def affine_sampler_forward(sources, theta, out):
+    """GridGenerator(affine theta, target out.shape[1:3]) + BilinearSampler of every source into its channel slice
+    of out (N,Ho,Wo,ldo); coinciding slices are summed, uncovered channels zeroed"""
+    N, Ho, Wo, ldo = out.shape
+    check(L().dspn_affine_sampler_forward_f32(sources.x, sources.Hin, sources.Win, sources.C, sources.coff, sources.n,
+                                              ptr(theta), ptr(out), N, Ho, Wo, ldo, stream()), "affine_sampler_forward")
+    return out
+
+
+def affine_sampler_backward_data(dy, theta, x_shape, coff, dx=None, accumulate=False):
+    N, Hin, Win, C = x_shape
+    dx = empty(N, Hin, Win, C, device=dy.device) if dx is None else dx
+    check(L().dspn_affine_sampler_backward_data_f32(ptr(dy), ptr(theta), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
+                                                    dy.shape[3], coff, int(accumulate), stream()),
+          "affine_sampler_backward_data")
+    return dx
+
+
+def affine_sampler_backward_theta(sources, theta, dy, dtheta, accumulate=False):
+    N, Ho, Wo, ldo = dy.shape
+    ws = workspace(L().dspn_affine_sampler_theta_workspace_bytes(N, Ho, Wo), dy.device, "theta")
+    check(L().dspn_affine_sampler_backward_theta_f32(sources.x, sources.Hin, sources.Win, sources.C, sources.coff,
+                                                     sources.n, ptr(theta), ptr(dy), N, Ho, Wo, ldo, ptr(dtheta),
+                                                     int(accumulate), ptr(ws), ws.numel(), stream()),
+          "affine_sampler_backward_theta")
+    return dtheta
 
 
 def seg_counts(scores, label, C):

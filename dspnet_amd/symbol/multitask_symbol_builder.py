@@ -9,8 +9,10 @@ Outputs, in the reference's order (:592): cls_prob (B,C+1,N), loc_loss (B,N*5), 
 det_out (B,N,7), seg_out (B,19,H/4,W/4).
 
 Generalisations that are this build's own: the sampling grid is (H/8, W/8)
-instead of the hard-coded (64,128) (equal at the reference's only consistent shape 512x1024), and
-`affine_matrix` is the constant identity (the reference lets SGD perturb it).
+instead of the hard-coded (64,128) (equal at the reference's only consistent shape 512x1024), and the
+(1,6) `affine_matrix` argument -- learnable, as in the reference (:574, multi_init.py:72) -- drives ONE
+grid that is shared by every sample of the batch (MXNet's BilinearSampler wants one grid per sample, which
+only binds at the reference's batch size 1); its gradient is summed over the batch.
 """
 import torch
 
@@ -312,13 +314,14 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     score2_pool2_bn = conv_bn(score_pool2, "score2_pool2", 256, 1, 0)
     score2_pool1_bn = conv_bn(score_pool1, "score2_pool1", 512, 1, 0)
     target_hw = (H // 8, W // 8)   # (64,128) at 512x1024 (:575)
+    affine_matrix = E.affine_matrix_param(g)        # mx.sym.var("affine_matrix", shape=(1,6)) (:574)
     pyramid = [score2_pool4_bn, score2_pool2_bn, score2_pool1_bn, res5_reduced_bn, res4_reduced2_bn, res3_reduced2_bn]
     if E.COMMUTE_RESIZE_CONV:
         # score3_conv over score3_concat without the 3328-channel concatenation (engine.BilinearConcatConv)
-        c = g.add(E.BilinearConcatConv(g, pyramid, "score3_conv", seg_classes, 3, 1, target_hw)).out
+        c = g.add(E.BilinearConcatConv(g, pyramid, "score3_conv", seg_classes, 3, 1, target_hw, affine_matrix)).out
         score3_conv_bn = g.add(E.BatchNorm(g, c, "score3_conv_bn", fix_gamma=True, eps=eps)).out
     else:
-        score3_concat = g.add(E.BilinearConcat(g, pyramid, "score3_concat", target_hw)).out
+        score3_concat = g.add(E.BilinearConcat(g, pyramid, "score3_concat", target_hw, affine_matrix)).out
         score3_conv_bn = conv_bn(score3_concat, "score3_conv", seg_classes, 3, 1, tap_expand=True)
     score4_conv = g.add(E.Deconv4x4s2(g, score3_conv_bn, "score4_conv", seg_classes)).out
     if train:

@@ -8,7 +8,7 @@
  * symbol/resnet.py, symbol/common.py and symbol/multitask_symbol_builder.py;
  * each entry cites the call site whose arithmetic it provides.  MXNet itself is
  * not vendored by the reference, so the semantics followed are the documented
- * MXNet 0.11-1.0 ones, restated in oracle/nn_oracle.py ("parity unpinned").
+ * MXNet 0.11-1.0 ones, restated in oracle/dspnet_torch.py ("parity unpinned").
  *
  * Conventions
  *   - activations are NHWC float32, dense, with a physical channel count that is
@@ -251,6 +251,30 @@ int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int W
 size_t dspn_bilinear_backward_workspace_bytes(int N, int Win, int C, int Ho);
 int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                   int ldo, int coff, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- GridGenerator(transform_type='affine', target_shape=(Ho,Wo)) + BilinearSampler with the LEARNABLE
+ * `affine_matrix` argument (symbol/multitask_symbol_builder.py:574-581; initialised to (1,0,0,0,1,0) by
+ * multi_init.py:72 and updated by the optimizer like every other argument, multi_solver.py:291-293).
+ * theta: 6 floats in DEVICE memory (row-major 2x3), one grid shared by the whole batch.  With the identity theta
+ * the result equals dspn_bilinear_forward_f32 bit for bit.  Up to DSPN_SAMPLER_MAX_SOURCES source maps per call:
+ * source i (N,Hin[i],Win[i],C[i]) is sampled into channels [coff[i], coff[i]+C[i]) of y (N,Ho,Wo,ldo); sources
+ * whose channel ranges coincide are summed (in table order), channels no source covers are written as 0.
+ * x / Hin / Win / C / coff are HOST arrays of nsrc entries (x[i] are device pointers). */
+#define DSPN_SAMPLER_MAX_SOURCES 8
+int dspn_affine_sampler_forward_f32(const float *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+                                    int nsrc, const float *theta, float *y, int N, int Ho, int Wo, int ldo, void *stream);
+/* gradient with respect to ONE source map: dx (N,Hin,Win,C) (+)= sum over the target pixels that sample it of
+ * weight * dy[..., coff:coff+C]; gather form, fixed summation order (no atomics) */
+int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, float *dx, int N, int Hin, int Win, int C,
+                                          int Ho, int Wo, int ldo, int coff, int accumulate, void *stream);
+/* gradient with respect to theta, all sources of a forward call at once: dtheta[6] (+)= sum over batch, target
+ * pixels, sources and channels (BilinearSampler's grid gradient contracted with GridGenerator's backward);
+ * two-stage fixed-order reduction in double */
+size_t dspn_affine_sampler_theta_workspace_bytes(int N, int Ho, int Wo);
+int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin, const int *Win, const int *C,
+                                           const int *coff, int nsrc, const float *theta, const float *dy, int N, int Ho,
+                                           int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
+                                           size_t workspace_bytes, void *stream);
 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* ---- Segmentation readouts (train/metric.py:100-133 CustomAccuracyMetric, evaluate/eval_metric.py:278-388

@@ -9,7 +9,9 @@ documented MXNet 0.11-1.0 semantics:
   * Convolution / Deconvolution(no bias) / Pooling(max: pad ignored, avg) -> torch conv2d /
     conv_transpose2d / max_pool2d / avg_pool2d;
   * BatchNorm(is_train): biased batch variance, eps 2e-5, fix_gamma => gamma == 1;
-  * GridGenerator(affine identity) + BilinearSampler -> bilinear resize with align_corners=True;
+  * GridGenerator(transform_type='affine') on the learnable (1,6) `affine_matrix` + BilinearSampler ->
+    affine_grid(align_corners=True) + grid_sample(bilinear, zeros padding, align_corners=True); one grid
+    for the whole batch (the reference binds at batch size 1); autograd supplies d/d affine_matrix;
   * SoftmaxOutput(multi_output, use_ignore): backward (p - onehot) * grad_scale, zero on ignored
     labels, divided by #valid for normalization='valid', by the number of positions per sample for
     the default normalization; expressed here as the scalar whose autograd gradient is that;
@@ -249,7 +251,10 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
     p2 = conv_bn(P, F.avg_pool2d(r5, 2, 2), "score2_pool2", 0)
     p1 = conv_bn(P, r5, "score2_pool1", 0)
     th, tw = H // 8, W // 8
-    samp = [F.interpolate(t, size=(th, tw), mode="bilinear", align_corners=True) for t in (p4, p2, p1, r5, r4, r3)]
+    theta = P["affine_matrix"].reshape(1, 2, 3).expand(B, 2, 3)
+    grid = F.affine_grid(theta, (B, 1, th, tw), align_corners=True)
+    samp = [F.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+            for t in (p4, p2, p1, r5, r4, r3)]
     cat = torch.cat(samp, dim=1)
     s3 = conv_bn(P, cat, "score3_conv", 1)
     s4 = F.conv_transpose2d(s3, P["score4_conv_weight"], stride=2, padding=1)
@@ -290,6 +295,8 @@ def export_params(graph):
 def import_grad(name, g):
     """oracle gradient (torch, logical shape) -> device layout numpy for comparison (pads dropped)"""
     g = g.detach().cpu().numpy()
+    if name == "affine_matrix":
+        return g.reshape(-1)
     if name == "score4_conv_weight":
         return g.transpose(0, 2, 3, 1)               # (in,out,4,4) -> [in][R][S][out]
     if g.ndim == 4:

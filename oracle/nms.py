@@ -1,9 +1,16 @@
 """CPU restatement of the reference's pixel-coordinate NMS.  TEST INFRASTRUCTURE ONLY.
 
-PARITY STATUS: "parity unpinned" -- the reference has no tests or vectors for it; detect/nms.py cannot be imported
-here (it imports the compiled cython modules at line 2-3), so its pure-numpy `nms` (detect/nms.py:24-58) and the loop
-of cython/cpu_nms.pyx:17-68 are restated below in float32, operation for operation.  Ties in score: the reference
-uses numpy's unstable argsort()[::-1]; a stable ascending sort reversed is used here (higher index first)."""
+PARITY STATUS: PINNED against the reference's own code run in the build container.  cython/cpu_nms.pyx:17-68 is
+compiled unmodified (oracle/build_ref_cpu_nms.sh -> oracle/_ref/, Anaconda python3.9 + Cython 0.29 + numpy 1.26 of
+this image) and the `nms` function of detect/nms.py:24-58 is executed from the file where it lies
+(tests/golden/make_nms_golden.py); their keep lists on 27 cases -- n = 1..1000, thresholds 0.3 / 0.5 / 0.95, dense
+clusters, overlaps exactly at the threshold, degenerate boxes, tied scores -- are committed as
+tests/golden/nms_pixel.npz and this file reproduces all of them (tests/test_nms_pixel.py).
+Both functions are restated in float32, operation for operation.  Ties in score: the reference uses numpy's unstable
+argsort()[::-1], whose order among equal scores depends on the numpy build; a stable ascending sort reversed is used
+here (higher index first), and `order=` takes an explicit permutation (the golden file records the one numpy 1.26.4
+produced).  One behaviour is NOT reproduced: cpu_nms.pyx raises ZeroDivisionError for a pair whose union is exactly 0
+(Cython's checked division); here, as in the numpy `nms`, the quotient is nan and the pair is not suppressed."""
 import numpy as np
 
 
@@ -11,13 +18,13 @@ def _order(scores):
     return np.argsort(scores, kind="stable")[::-1]
 
 
-def nms(dets, thresh):
+def nms(dets, thresh, order=None):
     """detect/nms.py:24-58"""
     dets = np.asarray(dets, np.float32)
     x1, y1, x2, y2, scores = (dets[:, i] for i in range(5))
     one = np.float32(1)
     areas = (x2 - x1 + one) * (y2 - y1 + one)
-    order = _order(scores)
+    order = _order(scores) if order is None else np.asarray(order)
     keep = []
     while order.size > 0:
         i = order[0]
@@ -33,13 +40,13 @@ def nms(dets, thresh):
     return keep
 
 
-def cpu_nms(dets, thresh):
+def cpu_nms(dets, thresh, order=None):
     """cython/cpu_nms.pyx:17-68 (suppress when ovr >= thresh)"""
     dets = np.asarray(dets, np.float32)
     x1, y1, x2, y2, scores = (dets[:, i] for i in range(5))
     one = np.float32(1)
     areas = (x2 - x1 + one) * (y2 - y1 + one)
-    order = _order(scores)
+    order = _order(scores) if order is None else np.asarray(order)
     n = dets.shape[0]
     suppressed = np.zeros(n, bool)
     keep = []

@@ -2,7 +2,7 @@
 against plain PyTorch CPU references of the same ops in float64.
 
 These ops are MXNet built-ins in the reference (not vendored: "parity unpinned"); the semantics
-checked here are the documented MXNet ones restated in oracle/nn_oracle.py.  Tolerance: the fp32
+checked here are the documented MXNet ones restated in oracle/dspnet_torch.py.  Tolerance: the fp32
 MFMA path is an exact fmaf chain, so |err| <= 2e-6 * sum|a*b| is expected; tests use 1e-4 relative to
 the output scale (BASELINE.json: fp32 losses within 1e-4)."""
 import numpy as np
@@ -215,6 +215,65 @@ def test_bilinear_sampler_identity_grid(gpu_device, hin, win):
     close(nchw(dx), x.grad, 1e-5)
     dx1 = fn.bilinear_backward(dyc, (2, hin, win, 8), 8, separable=False)     # one-pass gather kernel
     close(nchw(dx1), x.grad, 1e-5)
+
+
+THETAS = [(1, 0, 0, 0, 1, 0),                                    # multi_init.py:72
+          (0.98, 0.03, -0.02, -0.04, 1.05, 0.01),                 # a few SGD steps away from it
+          (0.7, 0.3, 0.2, -0.25, 0.8, -0.1),                      # rotation + shear + shift: parts of the grid leave the image
+          (1.3, 0.0, 0.0, 0.0, 1.3, 0.0)]                         # zoom out: a border of zero padding
+
+
+@pytest.mark.parametrize("theta", THETAS)
+@pytest.mark.parametrize("shapes", [[(4, 4), (8, 8), (16, 16)], [(16, 16)], [(5, 9), (16, 12)]])
+def test_affine_sampler_matches_torch_grid_sample(gpu_device, theta, shapes):
+    """GridGenerator(affine_matrix) + BilinearSampler (multitask_symbol_builder.py:574-581) with a learnable
+    affine_matrix: forward, data gradients and d/d affine_matrix against affine_grid + grid_sample autograd in
+    float64 (align_corners=True, zeros padding); concat mode (disjoint slices) and sum mode (one slice)."""
+    Ho, Wo, B, C = 16, 12, 2, 8
+    g = torch.Generator().manual_seed(11)
+    th = torch.tensor(theta, dtype=torch.float64).requires_grad_()
+    xs = [torch.randn(B, C, h, w, generator=g, dtype=torch.float64, requires_grad=True) for h, w in shapes]
+    grid = F.affine_grid(th.view(1, 2, 3).expand(B, 2, 3), (B, 1, Ho, Wo), align_corners=True)
+    samp = [F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True) for x in xs]
+    th_dev = torch.tensor(theta, dtype=torch.float32, device="cuda")
+    for mode in ("concat", "sum"):
+        for t in xs + [th]:
+            t.grad = None
+        y_ref = torch.cat(samp, dim=1) if mode == "concat" else sum(samp)
+        dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+        y_ref.backward(dy, retain_graph=True)
+        offs = [C * i if mode == "concat" else 0 for i in range(len(xs))]
+        xd = [nhwc(x.detach()) for x in xs]
+        src = fn.SamplerSources(list(zip(xd, offs)))
+        out = torch.full((B, Ho, Wo, y_ref.shape[1] + 4), 7.0, device="cuda")        # 4 uncovered channels
+        fn.affine_sampler_forward(src, th_dev, out)
+        close(nchw(out)[:, :y_ref.shape[1]], y_ref.detach(), 1e-5)
+        assert float(out[..., y_ref.shape[1]:].abs().max()) == 0
+        dyc = torch.zeros_like(out)
+        dyc[..., :y_ref.shape[1]] = nhwc(dy)[..., :y_ref.shape[1]]
+        for x, xdev, off in zip(xs, xd, offs):
+            dx = fn.affine_sampler_backward_data(dyc, th_dev, xdev.shape, off)
+            close(nchw(dx), x.grad, 1e-5)
+            acc = fn.affine_sampler_backward_data(dyc, th_dev, xdev.shape, off, dx=dx.clone(), accumulate=True)
+            close(nchw(acc), 2 * x.grad, 1e-5)
+        dth = torch.zeros(6, device="cuda")
+        fn.affine_sampler_backward_theta(src, th_dev, dyc, dth)
+        close(dth.cpu().double(), th.grad, 1e-4)
+        again = torch.zeros(6, device="cuda")
+        fn.affine_sampler_backward_theta(src, th_dev, dyc, again)
+        assert torch.equal(dth, again)                                   # fixed-order reductions
+
+
+@pytest.mark.parametrize("hin,win", [(4, 4), (16, 16), (64, 64), (5, 9)])
+def test_affine_sampler_identity_equals_plain_resize(gpu_device, hin, win):
+    """with affine_matrix = (1,0,0,0,1,0) the general sampler reproduces dspn_bilinear_forward_f32 bit for bit"""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, hin, win, 8, generator=g).cuda()
+    a = torch.zeros(2, 64, 64, 8, device="cuda")
+    b = torch.zeros_like(a)
+    fn.bilinear_forward(x, a, 0)
+    fn.affine_sampler_forward(fn.SamplerSources([(x, 0)]), torch.tensor([1., 0, 0, 0, 1, 0], device="cuda"), b)
+    assert torch.equal(a, b)
 
 
 def test_softmax_output_valid_normalisation(gpu_device):
