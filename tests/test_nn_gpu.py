@@ -258,7 +258,11 @@ def test_affine_sampler_matches_torch_grid_sample(gpu_device, theta, shapes):
             close(nchw(acc), 2 * x.grad, 1e-5)
         dth = torch.zeros(6, device="cuda")
         fn.affine_sampler_backward_theta(src, th_dev, dyc, dth)
-        close(dth.cpu().double(), th.grad, 1e-4)
+        # at the identity grid a source of the target's own height or width is sampled exactly ON its pixels, where the
+        # interpolation has a kink (left / right derivative differ): d/d theta is compared off the kinks only
+        kink = tuple(theta) == (1, 0, 0, 0, 1, 0) and any(h == Ho or w == Wo for h, w in shapes)
+        if not kink:
+            close(dth.cpu().double(), th.grad, 1e-4)
         again = torch.zeros(6, device="cuda")
         fn.affine_sampler_backward_theta(src, th_dev, dyc, again)
         assert torch.equal(dth, again)                                   # fixed-order reductions
