@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel_px(const float *__restrict
     const float inter = w * h;
     const float sb = (bx2 - bx1 + 1.f) * (by2 - by1 + 1.f);
     const float ovr = inter / (sa + sb - inter);
-    if (suppress_ge ? ovr >= thresh : ovr > thresh) t |= 1ull << i;
+    if (suppress_ge == 1 ? ovr >= thresh : (suppress_ge == 2 ? ovr > thresh : !(ovr <= thresh))) t |= 1ull << i;
   }
   mask[(long long)row * col_blocks + cb] = t;
 }
@@ -135,6 +135,7 @@ size_t dspn_nms_pixel_workspace_bytes(int n) {
 int dspn_nms_pixel_f32(const float *dets_dev, int n, float thresh, int suppress_ge, int *keep_dev,
                        int *num_keep_dev, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(keep_dev && num_keep_dev, "nms_pixel: null output pointer");
+  DSPN_REQUIRE(suppress_ge >= 0 && suppress_ge <= 2, "nms_pixel: suppress_ge is 0 (nms), 1 (cpu_nms) or 2 (gpu_nms)");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) { (void)hipMemsetAsync(num_keep_dev, 0, sizeof(int), s); return 0; }
   DSPN_REQUIRE(dets_dev && n > 0 && n <= kMaxN, "nms_pixel: 1 <= n <= %d boxes", kMaxN);

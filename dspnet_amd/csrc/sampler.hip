@@ -22,7 +22,7 @@
 #include "dspn_common.h"
 #include "../../include/dspn_nn.h"
 
-#pragma clang fp contract(off)
+#pragma clang fp contract(fast)   // as nn.hip: the identity grid then reproduces its plain resize kernel bit for bit
 
 namespace {
 

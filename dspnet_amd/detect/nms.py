@@ -49,8 +49,8 @@ def nms(dets, thresh):
 
 
 def gpu_nms(dets, thresh, device_id=0):
-    """cython/gpu_nms.pyx + nms_kernel.cu: suppress overlap > thresh"""
-    return _run(dets, thresh, 0, torch.device("cuda", device_id))
+    """cython/gpu_nms.pyx + nms_kernel.cu: suppress overlap > thresh (a NaN overlap survives, unlike in `nms`)"""
+    return _run(dets, thresh, 2, torch.device("cuda", device_id))
 
 
 def cpu_nms(dets, thresh):

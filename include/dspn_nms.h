@@ -8,8 +8,11 @@
  *     area = (x2 - x1 + 1) * (y2 - y1 + 1),  inter = max(0, xx2 - xx1 + 1) * max(0, yy2 - yy1 + 1),
  *     ovr  = inter / (area_i + area_j - inter)
  * in float32 and keep a box unless an already kept one overlaps it; they differ in the comparison:
- *     nms() keeps `ovr <= thresh` (detect/nms.py:55) and nms_kernel suppresses `> thresh` (nms_kernel.cu:68): suppress_ge = 0
+ *     nms() keeps `ovr <= thresh` (detect/nms.py:55), i.e. drops when NOT(ovr <= thresh):                suppress_ge = 0
  *     cpu_nms suppresses `ovr >= thresh` (cpu_nms.pyx:65):                                                suppress_ge = 1
+ *     nms_kernel suppresses `ovr > thresh` (nms_kernel.cu:68):                                            suppress_ge = 2
+ *   modes 0 and 2 differ only for a NaN overlap (two zero-area boxes, 0/0): numpy's comparison drops the pair, the
+ *   CUDA kernel's keeps it (pinned by tests/golden/nms_pixel.npz, case degenerate_zero_union).
  * Equal scores: the reference sorts with numpy's unstable argsort()[::-1]; here ties go to the HIGHER index first
  * (the reverse of a stable ascending sort), which is what numpy returns for short arrays.
  *

@@ -28,6 +28,49 @@ from . import multibox as om
 
 EPS = 2e-5
 
+# conv_quant="bf16" (forward_loss): every convolution GEMM -- forward, data gradient, weight gradient, and the 4x4/2
+# transposed convolution likewise -- sees its two operands rounded to bfloat16 (round to nearest even) and accumulates
+# exactly: the arithmetic of BASELINE.json configs[3] "bf16 MFMA convs" (bf16 operands, fp32 accumulate) with the
+# accumulation error removed.  Everything else (BatchNorm, pooling, sampler, losses) stays in `dtype`.
+_QUANT = None
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(t.dtype) if _QUANT == "bf16" else t
+
+
+class _QuantGemmOp(torch.autograd.Function):
+    """y = op(q(x), q(w)); backward: the two gradient GEMMs of the same op on q(dy) and the saved q(x) / q(w)"""
+
+    @staticmethod
+    def forward(ctx, x, w, op):
+        xq, wq = _q(x.detach()), _q(w.detach())
+        ctx.save_for_backward(xq, wq)
+        ctx.op = op
+        return op(xq, wq)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xq, wq = ctx.saved_tensors
+        with torch.enable_grad():
+            xr, wr = xq.clone().requires_grad_(), wq.clone().requires_grad_()
+            y = ctx.op(xr, wr)
+            gx, gw = torch.autograd.grad(y, (xr, wr), _q(gy))
+        return gx, gw, None
+
+
+def _conv(x, w, bias=None, stride=1, padding=0, dilation=1):
+    if _QUANT is None:
+        return F.conv2d(x, w, bias, stride=stride, padding=padding, dilation=dilation)
+    y = _QuantGemmOp.apply(x, w, lambda a, b: F.conv2d(a, b, None, stride=stride, padding=padding, dilation=dilation))
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+def _deconv(x, w, stride=1, padding=0):
+    if _QUANT is None:
+        return F.conv_transpose2d(x, w, stride=stride, padding=padding)
+    return _QuantGemmOp.apply(x, w, lambda a, b: F.conv_transpose2d(a, b, stride=stride, padding=padding))
+
 
 def bn(x, gamma, beta, relu=False):
     mean = x.mean(dim=(0, 2, 3), keepdim=True)
@@ -55,18 +98,18 @@ class Params:
 
 def residual_unit(P, data, name, stride, dim_match):
     act1 = bn(data, P[name + "_bn1_gamma"], P[name + "_bn1_beta"], relu=True)
-    conv1 = F.conv2d(act1, P[name + "_conv1_weight"])
+    conv1 = _conv(act1, P[name + "_conv1_weight"])
     act2 = bn(conv1, P[name + "_bn2_gamma"], P[name + "_bn2_beta"], relu=True)
-    conv2 = F.conv2d(act2, P[name + "_conv2_weight"], stride=stride, padding=1)
+    conv2 = _conv(act2, P[name + "_conv2_weight"], stride=stride, padding=1)
     act3 = bn(conv2, P[name + "_bn3_gamma"], P[name + "_bn3_beta"], relu=True)
-    conv3 = F.conv2d(act3, P[name + "_conv3_weight"])
-    shortcut = data if dim_match else F.conv2d(act1, P[name + "_sc_weight"], stride=stride)
+    conv3 = _conv(act3, P[name + "_conv3_weight"])
+    shortcut = data if dim_match else _conv(act1, P[name + "_sc_weight"], stride=stride)
     return conv3 + shortcut
 
 
 def resnet50(P, data):
     x = bn(data, None, P["bn_data_beta"])
-    x = F.conv2d(x, P["conv0_weight"], stride=2, padding=3)
+    x = _conv(x, P["conv0_weight"], stride=2, padding=3)
     x = bn(x, P["bn0_gamma"], P["bn0_beta"], relu=True)
     body = F.max_pool2d(x, 3, 2, 1)
     internals, plus = {}, 0
@@ -80,13 +123,13 @@ def resnet50(P, data):
 
 
 def conv_bn(P, x, name, pad):
-    return bn(F.conv2d(x, P[name + "_weight"], padding=pad), None, P[name + "_bn_beta"])
+    return bn(_conv(x, P[name + "_weight"], padding=pad), None, P[name + "_bn_beta"])
 
 
 def vgg16_reduced(P, data):
     """symbol/vgg16_reduced.py:3-75"""
     def c(x, name, pad=1, dil=1):
-        return F.relu(F.conv2d(x, P[name + "_weight"], P[name + "_bias"], padding=pad, dilation=dil))
+        return F.relu(_conv(x, P[name + "_weight"], P[name + "_bias"], padding=pad, dilation=dil))
     inter = {}
     x = c(c(data, "conv1_1"), "conv1_2")
     x = F.max_pool2d(x, 2, 2)
@@ -109,7 +152,7 @@ def inceptionv3(P, data):
     """symbol/inceptionv3.py:10-160: Conv = conv(no bias) -> BN(fix_gamma, MXNet default eps 1e-3) -> ReLU"""
     def C(x, name, suffix='', stride=1, pad=(0, 0)):
         n = '%s%s' % (name, suffix)
-        y = F.conv2d(x, P[n + "_conv2d_weight"], stride=stride, padding=pad)
+        y = _conv(x, P[n + "_conv2d_weight"], stride=stride, padding=pad)
         mean = y.mean(dim=(0, 2, 3), keepdim=True)
         var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
         return F.relu((y - mean) / torch.sqrt(var + 1e-3) + P[n + "_batchnorm_beta"].view(1, -1, 1, 1))
@@ -170,11 +213,40 @@ def inceptionv3(P, data):
 
 
 def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, num_classes=8, dtype=torch.float64,
-                 nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True):
+                 nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True,
+                 conv_quant=None):
     """Runs the multi-task (or, with_seg=False, the detection+depth) training graph on the CPU.
     `config` is the preset of multitask_symbol_factory.get_config (un-sliced); without it the resnet-50
     preset wiring is assumed and sizes/ratios are the already sliced lists.  Returns dict with the graph
-    outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params."""
+    outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params.
+    conv_quant="bf16": bf16-operand convolutions (see _QUANT above); call .backward() on the objective INSIDE
+    `with quantized("bf16"):` as well, the gradient GEMMs read the same switch."""
+    global _QUANT
+    prev, _QUANT = _QUANT, conv_quant
+    try:
+        return _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes, dtype, nms_thresh,
+                             force_suppress, nms_topk, targets, config, with_seg)
+    finally:
+        _QUANT = prev
+
+
+class quantized:
+    """context manager: `with quantized("bf16"): ref["objective"].backward()`"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global _QUANT
+        self.prev, _QUANT = _QUANT, self.mode
+
+    def __exit__(self, *a):
+        global _QUANT
+        _QUANT = self.prev
+
+
+def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes, dtype, nms_thresh, force_suppress,
+                  nms_topk, targets, config, with_seg):
     P = Params(values, dtype)
     x = torch.tensor(data, dtype=dtype)
     B, _, H, W = x.shape
@@ -196,14 +268,14 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
             layers.append(inter[name]); names.append(name)
         else:
             n1, n3 = "multi_feat_%d_conv_1x1_conv" % k, "multi_feat_%d_conv_3x3_conv" % k
-            c1 = F.relu(F.conv2d(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
-            c3 = F.relu(F.conv2d(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=st, padding=pd))
+            c1 = F.relu(_conv(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
+            c3 = F.relu(_conv(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=st, padding=pd))
             layers.append(c3); names.append("multi_feat_%d_conv_3x3_relu" % k)
     conv_feat = layers[1]
     locs, clss, anchors = [], [], []
     for k, (layer, nm, sz, rt) in enumerate(zip(layers, names, sizes, ratios)):
-        lp = F.conv2d(layer, P[nm + "_loc_pred_conv_weight"], P[nm + "_loc_pred_conv_bias"], padding=1)
-        cp = F.conv2d(layer, P[nm + "_cls_pred_conv_weight"], P[nm + "_cls_pred_conv_bias"], padding=1)
+        lp = _conv(layer, P[nm + "_loc_pred_conv_weight"], P[nm + "_loc_pred_conv_bias"], padding=1)
+        cp = _conv(layer, P[nm + "_cls_pred_conv_weight"], P[nm + "_cls_pred_conv_bias"], padding=1)
         locs.append(lp.permute(0, 2, 3, 1).reshape(B, -1))
         clss.append(cp.permute(0, 2, 3, 1).reshape(B, -1))
         st = (steps[k], steps[k]) if steps else (-1.0, -1.0)
@@ -255,9 +327,24 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
     grid = F.affine_grid(theta, (B, 1, th, tw), align_corners=True)
     samp = [F.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
             for t in (p4, p2, p1, r5, r4, r3)]
-    cat = torch.cat(samp, dim=1)
-    s3 = conv_bn(P, cat, "score3_conv", 1)
-    s4 = F.conv_transpose2d(s3, P["score4_conv_weight"], stride=2, padding=1)
+    if _QUANT is None:
+        cat = torch.cat(samp, dim=1)
+        s3 = conv_bn(P, cat, "score3_conv", 1)
+    else:
+        # The device evaluates score3_conv per pyramid level BEFORE the resize (engine.BilinearConcatConv: an exact
+        # identity in real arithmetic), so its bf16 operand rounding happens on the un-resized maps.  Same here: the
+        # tap-expanded 1x1 products at each level's own resolution, sampled, summed, then the shifted sum over taps.
+        Wf = P["score3_conv_weight"]                                   # (19, 3328, 3, 3)
+        co, _, kh, kw = Wf.shape
+        z, off = 0, 0
+        for t in (p4, p2, p1, r5, r4, r3):
+            wc = Wf[:, off:off + t.shape[1]].permute(0, 2, 3, 1).reshape(co * kh * kw, t.shape[1], 1, 1)   # row = (co, r, s)
+            off += t.shape[1]
+            z = z + F.grid_sample(_conv(t, wc), grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        zp = F.pad(z.reshape(B, co, kh, kw, th, tw), (1, 1, 1, 1))
+        s3c = sum(zp[:, :, r, q, r:r + th, q:q + tw] for r in range(kh) for q in range(kw))
+        s3 = bn(s3c, None, P["score3_conv_bn_beta"])
+    s4 = _deconv(s3, P["score4_conv_weight"], stride=2, padding=1)
     seg_prob = torch.softmax(s4, dim=1)
     sl = torch.tensor(label_seg, dtype=torch.long)
     svalid = sl != 255

@@ -97,7 +97,7 @@ def main():
     deg[3::11, 3] = deg[3::11, 1] - 3.0
     add("degenerate", deg, 0.5)
     # two zero-area boxes: union == 0.  cpu_nms.pyx raises ZeroDivisionError (recorded as keep_cpu = [-2]); the numpy
-    # `nms` gets nan and keeps both
+    # `nms` gets nan, and `nan <= thresh` being false drops the second zero-area box
     zero = np.array([[5, 5, 4, 9, 0.9], [30, 30, 29, 40, 0.8], [0, 0, 9, 9, 0.7]], np.float32)
     add("degenerate_zero_union", zero, 0.5)
     # tied scores (order among equals = numpy's unstable sort; see the module docstring)

@@ -97,7 +97,8 @@ def test_forward_backward_matches_cpu_restatement(gpu_device):
         else:
             gdev = gdev[:gref.shape[0]]
         emax[p.name], el2[p.name] = rel(gdev, gref), l2(gdev, gref)
-        num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
+        if p.name != "affine_matrix":
+            num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
     print("largest gradient L2 errs", sorted(el2.items(), key=lambda kv: -kv[1])[:5], "global", (num / den) ** 0.5)
     # Parameters with no ReLU between them and the losses (the SSD head convs and the whole ReLU-free seg
     # decoder) must agree element-wise.  Everywhere else an fp32 and an fp64 forward disagree on the sign of
@@ -315,6 +316,8 @@ def test_other_backbone_graphs_match_cpu_restatement(gpu_device, network, kind, 
         gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
         if p.name.endswith(("pred_conv_weight", "pred_conv_bias")):      # nothing but the loss below them
             assert rel(gdev, gref) < 10 * ttol, p.name
+        if p.name == "affine_matrix":      # identity grid: d/d affine_matrix sits on the interpolation kinks (see above)
+            continue
         num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
     # global relative L2 over all parameter gradients (ReLU sign flips of pre-activations within rounding of zero
     # make an element-wise bound meaningless below the heads).  inceptionv3: the float32 CPU
@@ -341,6 +344,13 @@ def test_bf16_mfma_graph_losses_close_to_fp32_restatement(gpu_device):
         for n, v in zip(names, vals):
             if n in ref:
                 assert abs(v - ref[n]) <= 2e-2 * abs(ref[n]), (n, v, ref[n])
+        # ... and against the oracle that rounds the conv operands to bf16 as well (same arithmetic, exact accumulation)
+        refq = ot.forward_loss(ot.export_params(net.g), data, lab, seg, cfg["sizes"][1:], cfg["ratios"][1:],
+                               dtype=torch.float64, targets=dev_targets, conv_quant="bf16")
+        qerr = {n: abs(v - refq[n]) / abs(refq[n]) for n, v in zip(names, vals) if n in refq}
+        print("bf16 resnet-50 256x256 vs bf16-operand oracle: losses", qerr)
+        for n, e in qerr.items():
+            assert e <= 2e-3, (n, e)
         g1 = net.g.grad_arena.clone()
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)
@@ -350,16 +360,18 @@ def test_bf16_mfma_graph_losses_close_to_fp32_restatement(gpu_device):
 
 def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
     """BASELINE.json configs[3] in its own precision and at its own shape: inceptionv3 multi-task graph, 1024x512
-    (H 512, W 1024), convolutions on bf16 MFMA (operands rounded to bf16, fp32 accumulate), against the float64 CPU
-    restatement on the same parameters and inputs, matching pinned to the device's.
+    (H 512, W 1024), convolutions on bf16 MFMA (operands rounded to bf16, fp32 accumulate).
 
-    Tolerances (stated, not tuned to pass): a bf16 operand carries a relative rounding error of at most 2^-9 = 2e-3;
-    a K-term dot product of independently rounded factors is off by ~2^-9 * sqrt(2/K) of its scale per layer, and the
-    94 batch-normalised layers of inceptionv3 re-normalise the error at every layer instead of letting it grow with
-    depth, so activations stay within a few 1e-3 .. 1e-2 of their scale.  Bounds: loss readouts 2e-2 relative (the
-    same bound the resnet-50 bf16 test uses); prediction tensors 5e-2 of their max; gradients of the SSD head
-    convolutions (nothing but the loss below them) 1e-1 in relative L2; all parameter gradients together 0.3 in
-    relative L2 (ReLU sign flips, as in fp32, plus the operand rounding of both backward GEMMs)."""
+    The oracle runs THE SAME ARITHMETIC: oracle/dspnet_torch.py with conv_quant="bf16" rounds both operands of every
+    convolution GEMM (forward, data gradient, weight gradient, transposed convolution) to bfloat16 and accumulates in
+    float64, so what is compared is the device's bf16 path against its specification, not bf16 against fp64.  (Against
+    the UNQUANTISED float64 restatement this 94-layer stack of batch-statistics BatchNorms with random weights is not a
+    usable yardstick: it amplifies rounding noise ~1e4-fold -- fp32 vs fp64 already differ by 2e-4 .. 9e-4, DESIGN.md
+    section 3 -- and the bf16 run measures 0.7 .. 0.8 of the tensor scale away, 15 % on the cross-entropy.)
+    What remains between device and oracle: fp32 accumulation order, and activations that the device computes in fp32
+    and the oracle in fp64 before the SAME rounding to bf16 -- a value within fp32 noise of a bf16 rounding boundary
+    lands on the neighbouring bf16 number (one 2^-9 step on a small fraction of elements per layer), which the same
+    amplification carries to the outputs.  Bounds below = measured x ~3 (printed by the test)."""
     from dspnet_amd import functional as fn
     fn.set_conv_math("bf16")
     try:
@@ -382,7 +394,7 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
         mc.assert_target_equal(dev_targets, om.multibox_target(anchors, lab, net.target.cls_preds.data.cpu().numpy(),
                                                                negative_mining_ratio=3))
         ref = ot.forward_loss(ot.export_params(net.g), data, lab, seg, num_classes=8, dtype=torch.float64,
-                              targets=dev_targets, config=cfg)
+                              targets=dev_targets, config=cfg, conv_quant="bf16")
 
         def rel(a, b):
             return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
@@ -392,24 +404,27 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
                 "cls_prob": rel(outs[0], ref["cls_prob"].numpy()), "seg_out": rel(outs[4], ref["seg_out"].numpy())}
         m = MultiBoxMetric(); m.update(net)
         lerr = {n: abs(v - ref[n]) / abs(ref[n]) for n, v in zip(*m.get()) if n in ref}
-        ref["objective"].backward()
+        with ot.quantized("bf16"):
+            ref["objective"].backward()
         num = den = 0.0
         herr = {}
         for p in net.g.param_order:
             gref = ot.import_grad(p.name, ref["params"][p.name].grad)
             gdev = p.grad.cpu().numpy()
             gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
+            if p.name == "affine_matrix":          # identity grid: on the interpolation kinks, see the resnet-50 test
+                continue
             if p.name.endswith("pred_conv_weight"):
                 herr[p.name] = float(np.linalg.norm((gdev - gref).ravel()) / (np.linalg.norm(gref.ravel()) + 1e-30))
             num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
-        print("bf16 inceptionv3 512x1024: tensors", errs, "losses", lerr, "head grads max", max(herr.values()),
-              "global grad L2", (num / den) ** 0.5)
+        print("bf16 inceptionv3 512x1024 vs bf16-operand oracle: tensors", errs, "losses", lerr, "head grads max",
+              max(herr.values()), "global grad L2", (num / den) ** 0.5)
         for k, e in lerr.items():
-            assert e <= 2e-2, (k, e)
+            assert e <= 2e-3, (k, e)
         for k, e in errs.items():
-            assert e <= 5e-2, (k, e)
-        assert max(herr.values()) <= 1e-1, herr
-        assert (num / den) ** 0.5 <= 0.3
+            assert e <= 2e-2, (k, e)
+        assert max(herr.values()) <= 5e-2, herr
+        assert (num / den) ** 0.5 <= 0.15
         g1 = net.g.grad_arena.clone()
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)              # deterministic in bf16 mode as well
