@@ -28,6 +28,65 @@ def make(batch, h, w, seed=233):
     return net, solver, data, lab, seg
 
 
+def bf16_parity_report(net, data, lab, seg, cfg, num_classes=8, legacy=None):
+    """Device (bf16 MFMA convolutions) against the oracle evaluating THE SAME ARITHMETIC (conv_quant="bf16": both operands
+    of every convolution GEMM rounded to bfloat16, exact accumulation) in float64 -- and, as the yardstick, the same
+    oracle evaluated in float32 against its float64 self.  Both comparisons see the same two effects: float32
+    accumulation order, and activations computed in float32 landing on the other side of a bf16 rounding boundary
+    than their float64 counterparts (one 2^-9 step on a small fraction of elements per layer, then amplified by the
+    batch-statistics BatchNorm stack like any other perturbation).  -> (dev, ref32): dicts of relative errors."""
+    dev_targets = [net.target.loc_target.cpu().numpy(), net.target.loc_mask.cpu().numpy(),
+                   net.target.cls_target.cpu().numpy()]
+    values = ot.export_params(net.g)
+    kw = dict(num_classes=num_classes, targets=dev_targets, conv_quant="bf16")
+    if legacy is not None:
+        args = (values, data, lab, seg) + tuple(legacy)
+    else:
+        args, kw = (values, data, lab, seg), dict(kw, config=cfg)
+    r64 = ot.forward_loss(*args, dtype=torch.float64, **kw)
+    r32 = ot.forward_loss(*args, dtype=torch.float32, **kw)
+    with ot.quantized("bf16"):
+        r64["objective"].backward()
+        r32["objective"].backward()
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+    outs = [o.cpu().numpy() for o in net.outputs()]
+    m = MultiBoxMetric(); m.update(net)
+    losses = dict(zip(*m.get()))
+    dev, c32 = {}, {}
+    for key, dv in (("loc_preds", net.loc_preds.data.cpu().numpy()), ("cls_prob", outs[0]), ("seg_out", outs[4])):
+        dev[key], c32[key] = rel(dv, r64[key].numpy()), rel(r32[key].numpy(), r64[key].numpy())
+    for n, v in losses.items():
+        if n in r64:
+            dev["loss:" + n], c32["loss:" + n] = abs(v - r64[n]) / abs(r64[n]), abs(r32[n] - r64[n]) / abs(r64[n])
+    nd = dd = n3 = 0.0
+    hd = h3 = hh = 0.0
+    for p in net.g.param_order:
+        if p.name == "affine_matrix":          # identity grid: on the interpolation kinks (see the fp32 resnet-50 test)
+            continue
+        g64 = ot.import_grad(p.name, r64["params"][p.name].grad).astype(np.float64)
+        g32 = ot.import_grad(p.name, r32["params"][p.name].grad).astype(np.float64)
+        gdev = p.grad.cpu().numpy().astype(np.float64)
+        gdev = gdev[:g64.shape[0], :, :, :g64.shape[3]] if gdev.ndim == 4 else gdev[:g64.shape[0]]
+        e_d, e_3, sq = float(((gdev - g64) ** 2).sum()), float(((g32 - g64) ** 2).sum()), float((g64 ** 2).sum())
+        nd += e_d; n3 += e_3; dd += sq
+        if p.name.endswith("pred_conv_weight"):
+            hd += e_d; h3 += e_3; hh += sq
+    dev["grad_L2:all"], c32["grad_L2:all"] = (nd / dd) ** 0.5, (n3 / dd) ** 0.5
+    dev["grad_L2:heads"], c32["grad_L2:heads"] = (hd / hh) ** 0.5, (h3 / hh) ** 0.5
+    return dev, c32
+
+
+def assert_within_yardstick(dev, c32, factor=4.0, floor=2e-4):
+    """the device may be `factor` x as far from the float64 evaluation as the CPU's own float32 evaluation of the same
+    bf16-operand arithmetic is (floor: the plain fp32-accumulation level where that yardstick happens to be tiny)"""
+    for k in dev:
+        assert dev[k] <= max(factor * c32[k], floor), (k, dev[k], c32[k])
+
+
 def test_recorded_shapes_512x1024(gpu_device):
     """utils.py:38 internal_out_shapes_512 (1x3x512x1024, 10 det classes)"""
     net = get_multi_symbol_train("resnet-50", (3, 512, 1024), num_classes=10, batch_size=1)
@@ -344,13 +403,11 @@ def test_bf16_mfma_graph_losses_close_to_fp32_restatement(gpu_device):
         for n, v in zip(names, vals):
             if n in ref:
                 assert abs(v - ref[n]) <= 2e-2 * abs(ref[n]), (n, v, ref[n])
-        # ... and against the oracle that rounds the conv operands to bf16 as well (same arithmetic, exact accumulation)
-        refq = ot.forward_loss(ot.export_params(net.g), data, lab, seg, cfg["sizes"][1:], cfg["ratios"][1:],
-                               dtype=torch.float64, targets=dev_targets, conv_quant="bf16")
-        qerr = {n: abs(v - refq[n]) / abs(refq[n]) for n, v in zip(names, vals) if n in refq}
-        print("bf16 resnet-50 256x256 vs bf16-operand oracle: losses", qerr)
-        for n, e in qerr.items():
-            assert e <= 2e-3, (n, e)
+        # ... and against the oracle that rounds the conv operands to bf16 as well (same arithmetic), with the CPU's own
+        # float32 evaluation of that arithmetic as the yardstick
+        devq, c32 = bf16_parity_report(net, data, lab, seg, None, legacy=(cfg["sizes"][1:], cfg["ratios"][1:]))
+        print("bf16 resnet-50 256x256 vs bf16-operand oracle: device", devq, "| oracle fp32 vs fp64", c32)
+        assert_within_yardstick(devq, c32)
         g1 = net.g.grad_arena.clone()
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)
@@ -371,7 +428,10 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
     What remains between device and oracle: fp32 accumulation order, and activations that the device computes in fp32
     and the oracle in fp64 before the SAME rounding to bf16 -- a value within fp32 noise of a bf16 rounding boundary
     lands on the neighbouring bf16 number (one 2^-9 step on a small fraction of elements per layer), which the same
-    amplification carries to the outputs.  Bounds below = measured x ~3 (printed by the test)."""
+    amplification carries to the outputs.  The tolerance is therefore not a constant but a yardstick measured in the
+    test: the SAME oracle evaluated in float32 on the CPU shows both effects against its float64 self; the device has
+    to stay within 4x of that on every tensor, loss and gradient norm (bf16_parity_report / assert_within_yardstick).
+    A wrong tap, a wrong tile or a missing rounding would be orders of magnitude outside."""
     from dspnet_amd import functional as fn
     fn.set_conv_math("bf16")
     try:
@@ -393,38 +453,13 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
         # the operators inside the graph stay bit-exact against the C oracle on the device's own (bf16-produced) inputs
         mc.assert_target_equal(dev_targets, om.multibox_target(anchors, lab, net.target.cls_preds.data.cpu().numpy(),
                                                                negative_mining_ratio=3))
-        ref = ot.forward_loss(ot.export_params(net.g), data, lab, seg, num_classes=8, dtype=torch.float64,
-                              targets=dev_targets, config=cfg, conv_quant="bf16")
-
-        def rel(a, b):
-            return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-        outs = [o.cpu().numpy() for o in net.outputs()]
-        errs = {"loc_preds": rel(net.loc_preds.data.cpu().numpy(), ref["loc_preds"].numpy()),
-                "cls_prob": rel(outs[0], ref["cls_prob"].numpy()), "seg_out": rel(outs[4], ref["seg_out"].numpy())}
-        m = MultiBoxMetric(); m.update(net)
-        lerr = {n: abs(v - ref[n]) / abs(ref[n]) for n, v in zip(*m.get()) if n in ref}
-        with ot.quantized("bf16"):
-            ref["objective"].backward()
-        num = den = 0.0
-        herr = {}
-        for p in net.g.param_order:
-            gref = ot.import_grad(p.name, ref["params"][p.name].grad)
-            gdev = p.grad.cpu().numpy()
-            gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
-            if p.name == "affine_matrix":          # identity grid: on the interpolation kinks, see the resnet-50 test
-                continue
-            if p.name.endswith("pred_conv_weight"):
-                herr[p.name] = float(np.linalg.norm((gdev - gref).ravel()) / (np.linalg.norm(gref.ravel()) + 1e-30))
-            num += float(((gdev - gref) ** 2).sum()); den += float((gref ** 2).sum())
-        print("bf16 inceptionv3 512x1024 vs bf16-operand oracle: tensors", errs, "losses", lerr, "head grads max",
-              max(herr.values()), "global grad L2", (num / den) ** 0.5)
-        for k, e in lerr.items():
-            assert e <= 2e-3, (k, e)
-        for k, e in errs.items():
-            assert e <= 2e-2, (k, e)
-        assert max(herr.values()) <= 5e-2, herr
-        assert (num / den) ** 0.5 <= 0.15
+        devq, c32 = bf16_parity_report(net, data, lab, seg, cfg)
+        print("bf16 inceptionv3 512x1024 vs bf16-operand oracle: device", devq, "| oracle fp32 vs fp64", c32)
+        assert_within_yardstick(devq, c32)
+        # absolute backstops on the quantities BASELINE.json names (losses), whatever the yardstick says
+        for k in devq:
+            if k.startswith("loss:"):
+                assert devq[k] <= 5e-2, (k, devq[k])
         g1 = net.g.grad_arena.clone()
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)              # deterministic in bf16 mode as well

@@ -390,23 +390,32 @@ def test_conv_input_sum_grad(gpu_device, case):
     close(got[:Cin].cpu().double(), x.grad.sum(dim=(0, 2, 3)), 1e-4)
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin", [32, 48])
 @pytest.mark.parametrize("kh,kw,ph,pw,stride", [(1, 7, 0, 3, 1), (7, 1, 3, 0, 1), (1, 3, 0, 1, 1), (3, 1, 1, 0, 1),
                                                 (5, 5, 2, 2, 1), (3, 3, 0, 0, 2)])
-def test_conv_inception_kernel_classes(gpu_device, kh, kw, ph, pw, stride):
-    """asymmetric kernels / pads of symbol/inceptionv3.py (1x7, 7x1, 1x3, 3x1, 5x5 p2, 3x3 s2 p0)"""
+def test_conv_inception_kernel_classes(gpu_device, kh, kw, ph, pw, stride, cin, math):
+    """asymmetric kernels / pads of symbol/inceptionv3.py (1x7, 7x1, 1x3, 3x1, 5x5 p2, 3x3 s2 p0), with a channel count
+    whose 32-channel k-steps stay inside one tap (32) and one where they straddle taps (48: the 5x5 tower's input);
+    fp32 MFMA, and bf16 MFMA on bf16-representable operands (every product exact, fp32 accumulate: same bound)"""
     g = torch.Generator().manual_seed(kh * 10 + kw)
-    N, H, W, Cin, Cout = 2, 17, 17, 32, 48
-    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
-    w = (torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) / np.sqrt(Cin * kh * kw)).requires_grad_()
+    N, H, W, Cin, Cout = 2, 17, 17, cin, 48
+    rb = (lambda t: t.float().bfloat16().double()) if math == "bf16" else (lambda t: t)
+    x = rb(torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)).requires_grad_()
+    w = rb(torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) / np.sqrt(Cin * kh * kw)).requires_grad_()
     y_ref = F.conv2d(x, w, stride=stride, padding=(ph, pw))
-    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    dy = rb(torch.randn(y_ref.shape, generator=g, dtype=torch.float64))
     y_ref.backward(dy)
     xd, wd_, dyd = nhwc(x.detach()), wdev(w.detach()), nhwc(dy)
-    y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=(ph, pw))
+    fn.set_conv_math(math)
+    try:
+        y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=(ph, pw))
+        dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=(ph, pw))
+        dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=(ph, pw))
+    finally:
+        fn.set_conv_math("fp32")
     close(nchw(y, Cout), y_ref.detach())
-    dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=(ph, pw))
     close(nchw(dx, Cin), x.grad)
-    dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=(ph, pw))
     close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad)
 
 
