@@ -1,5 +1,7 @@
 // Library-wide C ABI helpers (error string, version).
 #include "dspn_common.h"
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "../../include/dspn_multibox.h"
 
@@ -14,22 +16,30 @@ namespace dspn {
 // Optional per-family kernel timing with HIP events recorded on the launch stream
 // (bench.py's live roofline measurement).  Off by default: zero cost.
 struct ProfRec { hipEvent_t a, b; int family; };
-static bool g_prof_on = false;
+// The one piece of process-wide state in the library: an opt-in measurement aid (bench.py), never touched by a compute
+// entry point unless enabled.  Guarded by a mutex so that callers on several threads stay safe while it is on; each
+// thread's open scope is tracked separately (prof_begin / prof_end pairs never interleave within a thread).
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
-bool prof_enabled() { return g_prof_on; }
+static thread_local hipEvent_t t_prof_end = nullptr;
+bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed); }
 void prof_begin(int family, hipStream_t s) {
   ProfRec r; r.family = family;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, s);
+  t_prof_end = r.b;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(r);
 }
-void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
+void prof_end(hipStream_t s) { if (t_prof_end) (void)hipEventRecord(t_prof_end, s); t_prof_end = nullptr; }
 }  // namespace dspn
 
 extern "C" {
-int dspn_profile_enable(int on) { dspn::g_prof_on = on != 0; return 0; }
+int dspn_profile_enable(int on) { dspn::g_prof_on.store(on != 0); return 0; }
 int dspn_profile_collect(int family, double *total_ms, long long *launches) {
   double t = 0; long long n = 0;
+  std::lock_guard<std::mutex> lk(dspn::g_prof_mu);
   std::vector<dspn::ProfRec> keep;
   for (auto &r : dspn::g_prof) {
     if (r.family != family) { keep.push_back(r); continue; }

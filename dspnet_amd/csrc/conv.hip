@@ -34,7 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-// bf16-MFMA math mode (dspn_conv2d_set_math): tensors stay fp32 in HBM, the loaders round to bf16 (RNE,
+// bf16-MFMA math mode (per call: the `math` argument of the *_bn_f32 entry points): tensors stay fp32 in HBM, the loaders round to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on the way into LDS, v_mfma_f32_32x32x16_bf16 accumulates in fp32.
 constexpr int kLdsRowH = 40;   // padded LDS row of the bf16 NT tiles, in bf16 (80 B: conflict-free ds_read_b128)
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
@@ -56,7 +56,8 @@ struct ConvGeom {
   int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
   int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal, 32 ReLU after the input affine
   int dense;                       // output address = m*ldc (no decomposition needed)
-  int dbg;                         // timing-only ablation bits (dspn_debug_set), 0 in production
+  int dbg;                         // timing-only ablation bits (DSPN_ABLATE builds), 0 in production
+  int bf16;                        // host side only: 1 = bf16 MFMA math (per call, DSPN_MATH_BF16), 0 = fp32 MFMA
   unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
   // optional per-input-channel affine (+ReLU when flags & 32) applied to the gathered tensor on its way into
   // LDS: the BatchNorm(+ReLU) in front of a convolution (symbol/resnet.py:30-45) without materialising its output
@@ -271,7 +272,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 
   const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
   const int frow = lane & 31, fk = (lane >> 5) * 2;
-  const int dbg = g.dbg;
+#ifdef DSPN_ABLATE
+  const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
+#else
+  constexpr int dbg = 0;   // production build: every ablation branch below is compiled out
+#endif
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
 
   // ---- persistent loop over output tiles ----------------------------------------------------------
@@ -611,6 +616,7 @@ struct WgradGeom {
   unsigned x_bytes, dy_bytes;
   const float *in_scale, *in_shift;   // optional affine (+ReLU) on x, as in ConvGeom
   int in_relu;
+  int bf16;                           // host side only: math mode of this call
 };
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
@@ -1046,8 +1052,6 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-int g_math_bf16 = 0;   // dspn_conv2d_set_math
-
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
 int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
@@ -1095,7 +1099,7 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
               hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
   const bool uni = ((g.Cin >> 2) & 7) == 0;
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
-#define DSPN_NT_UB_(T, E) (g_math_bf16 ? (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E)) \
+#define DSPN_NT_UB_(T, E) (g.bf16 ? (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E)) \
                                        : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
@@ -1106,7 +1110,11 @@ int launch_nt(const float *in, const float *w, const float *bias, float *out, co
 
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
 // leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
-int g_debug_bits = 0;
+#ifdef DSPN_ABLATE
+int g_debug_bits = 0;       // timing experiments only (dspn_debug_set, csrc/dspn_debug.h); absent from the production library
+#else
+constexpr int g_debug_bits = 0;
+#endif
 static const int kNtBm[4] = {128, 128, 64, 256}, kNtBn[4] = {128, 64, 64, 32};
 // Tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32) for an M x Cout output
 int nt_config(long long M, int Cout) {
@@ -1225,14 +1233,9 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
 
 extern "C" {
 
+#ifdef DSPN_ABLATE
 int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
-
-int dspn_conv2d_set_math(int mode) {
-  DSPN_REQUIRE(mode == 0 || mode == 1, "conv2d_set_math: 0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulate");
-  g_math_bf16 = mode;
-  return 0;
-}
-int dspn_conv2d_get_math(void) { return g_math_bf16; }
+#endif
 
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   if (out_pixels <= 0 || Cout <= 0) return 0;
@@ -1243,7 +1246,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 
 struct InAffine { const float *scale, *shift; int relu; };
 
-static int conv2d_forward_one(const float *x, InAffine tf, float *stats, const float *w, const float *bias, const float *residual, float *y, int N,
+static int conv2d_forward_one(int math, const float *x, InAffine tf, float *stats, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -1268,6 +1271,7 @@ static int conv2d_forward_one(const float *x, InAffine tf, float *stats, const f
   g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0) | ((tf.scale && tf.relu) ? 32 : 0);
   g.in_scale = tf.scale; g.in_shift = tf.shift;
   g.stats = stats;
+  g.bf16 = math;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -1290,9 +1294,10 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                const float *w, const float *bias, const float *residual, float *y, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                                int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
-                               int relu, int accumulate, float *out_stats, size_t out_stats_bytes,
+                               int relu, int accumulate, float *out_stats, size_t out_stats_bytes, int math,
                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_forward: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   if (out_stats) {
     int tile_rows = 0;
@@ -1306,7 +1311,7 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
   const int nb = batch_chunk(N, 4ll * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, bias,
+    const int rc = conv2d_forward_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
@@ -1321,8 +1326,8 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
   return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
-                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, workspace,
-                                    workspace_bytes, stream);
+                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, DSPN_MATH_FP32,
+                                    workspace, workspace_bytes, stream);
 }
 
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -1363,7 +1368,7 @@ static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class 
   return total;
 }
 
-static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, int H, int W,
+static int conv2d_dgrad_one(int math, const float *dy, const float *wt, float *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, BnBwd bn, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -1379,6 +1384,7 @@ static int conv2d_dgrad_one(const float *dy, const float *wt, float *dx, int N, 
   g.obs = (long long)H * W * g.ldc;
   g.OW = W;
   g.flags = accumulate ? 4 : 0;
+  g.bf16 = math;
   g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
   g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
   int class_tiles[4] = {0, 0, 0, 0};
@@ -1423,9 +1429,10 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N,
                              int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                              int Wo, int dx_ldc, int accumulate,
                              const float *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
-                             const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes,
+                             const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, int math,
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_dgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
   const int nb = batch_chunk(N, 4ll * Ho * Wo * ldy);
   if (bn_sums) {
@@ -1437,7 +1444,7 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N,
   }
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_dgrad_one(dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
+    const int rc = conv2d_dgrad_one(math, dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
                                     W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate,
                                     BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums}, workspace,
                                     workspace_bytes, stream);
@@ -1451,8 +1458,8 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   return dspn_conv2d_dgrad_bn_f32(dy, wt, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
-                                  accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, workspace,
-                                  workspace_bytes, stream);
+                                  accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, DSPN_MATH_FP32,
+                                  workspace, workspace_bytes, stream);
 }
 
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {
@@ -1489,7 +1496,7 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
   return sizeof(float) * m * Cout * J;
 }
 
-static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float *dw, int N, int H, int W, int Cin,
+static int conv2d_wgrad_one(int math, const float *x, InAffine tf, const float *dy, float *dw, int N, int H, int W, int Cin,
                           int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -1499,6 +1506,7 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
   g.sh = stride; g.sw = stride; g.ph = pad_h; g.pw = pad_w; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
   g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
+  g.bf16 = math;
   {
     const long long xb = 4ll * N * H * W * Cin, yb = 4ll * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -1522,10 +1530,10 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
     if (g.in_scale) {                                                                                    \
-      if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                  \
+      if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                       \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, true)                                             \
     } else {                                                                                             \
-      if (g_math_bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                 \
+      if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                      \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, false)                                            \
     }                                                                                                    \
   }
@@ -1559,14 +1567,15 @@ static int conv2d_wgrad_one(const float *x, InAffine tf, const float *dy, float 
 int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                              const float *dy, float *dw, int N, int H, int W, int Cin,
                              int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                             int Wo, int accumulate, void *workspace, size_t workspace_bytes,
+                             int Wo, int accumulate, int math, void *workspace, size_t workspace_bytes,
                              void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
   const int nb = std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_wgrad_one(x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
+    const int rc = conv2d_wgrad_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
                                     dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
                                     Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, accumulate || n0 > 0,
                                     workspace, workspace_bytes, stream);
@@ -1588,12 +1597,13 @@ int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, in
 int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                                 const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                                int Wo, void *stream) {
+                                int Wo, int math, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
   DSPN_REQUIRE(std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");
-  return conv2d_wgrad_one(x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
+  return conv2d_wgrad_one(math, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
                           pad_h, pad_w, dil, Ho, Wo, 0, slabs, slabs_bytes, stream);
 }
 
@@ -1614,7 +1624,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   return dspn_conv2d_wgrad_bn_f32(x, nullptr, nullptr, 0, dy, dw, N, H, W, Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil,
-                                  Ho, Wo, accumulate, workspace, workspace_bytes, stream);
+                                  Ho, Wo, accumulate, DSPN_MATH_FP32, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,8 @@
+// PRIVATE to dspnet_amd/csrc (not part of the C ABI in include/): timing-only ablation switches of conv_nt_kernel.
+// They exist only in a library built with `make ABLATE=1` (-DDSPN_ABLATE -> ../libdspn_hip_ablate.so), which the
+// experiment scripts under scratch/ load with DSPN_LIB=...; the production library has neither the symbol nor the
+// branches.  Results are WRONG when any bit is set.
+//   bit 1 (2): skip the LDS stores   bit 2 (4): skip the per-k-step barrier   bit 4 (16): skip the output stores
+//   bit 5 (32): skip the epilogue    bits 8-10: force a tile configuration    bit 11 (2048): in-kernel clock stamps
+#pragma once
+extern "C" int dspn_debug_set(int bits);

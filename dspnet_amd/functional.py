@@ -19,19 +19,18 @@ _sz = _c.c_size_t
 
 _lib.register({
     "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
-    "dspn_debug_set": (_i, [_i]),
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                        _i, _ll, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+                                        _i, _ll, _i, _i, _i, _vp, _sz, _i, _vp, _sz, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      _i, _vp, _sz, _vp]),
+                                      _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dspn_conv2d_wgrad_slabs_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                         _i, _i, _vp]),
+                                         _i, _i, _i, _vp]),
     "dspn_conv2d_slab_reduce_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -39,7 +38,7 @@ _lib.register({
                                    _sz, _vp]),
     "dspn_conv2d_dgrad_bn_tiles": (_i, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp]),
     "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
                                             _vp, _sz, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -65,8 +64,6 @@ _lib.register({
     "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dspn_avgpool2d_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool2d_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "dspn_conv2d_set_math": (_i, [_i]),
-    "dspn_conv2d_get_math": (_i, []),
     "dspn_bilinear_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dspn_bilinear_backward_ws_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_seg_counts_f32": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
@@ -142,13 +139,19 @@ def zeros(*shape, device=None):
 
 
 # ------------------------------------------------------------------ convolution
+_MATH = 0      # DSPN_MATH_FP32 | DSPN_MATH_BF16: this module's default for the `math` argument it passes on every call
+
+
 def set_conv_math(mode):
-    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA, fp32 accumulate) for every conv kernel"""
-    check(L().dspn_conv2d_set_math({"fp32": 0, "f32": 0, "bf16": 1}[mode]), "conv2d_set_math")
+    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA, fp32 accumulate) for the convolution calls made through
+    this module from now on.  Host-side default only: the C ABI takes the mode per call (include/dspn_nn.h,
+    DSPN_MATH_*), the library itself has no state."""
+    global _MATH
+    _MATH = {"fp32": 0, "f32": 0, "bf16": 1}[mode]
 
 
 def get_conv_math():
-    return "bf16" if L().dspn_conv2d_get_math() else "fp32"
+    return "bf16" if _MATH else "fp32"
 
 
 def conv_stats_layout(out_pixels, cout):
@@ -184,7 +187,7 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     check(L().dspn_conv2d_forward_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
-                                         ptr(ws), ws.numel(), stream()), "conv2d_forward")
+                                         _MATH, ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
 
 
@@ -240,7 +243,7 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     check(L().dspn_conv2d_dgrad_bn_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
                                        Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
                                        ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
-                                       ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
+                                       _MATH, ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
     return out
 
 
@@ -257,8 +260,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     ph, pw = _hw(pad)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     check(L().dspn_conv2d_wgrad_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
-                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), ptr(ws), ws.numel(), stream()),
-          "conv2d_wgrad")
+                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), _MATH, ptr(ws), ws.numel(),
+                                       stream()), "conv2d_wgrad")
     return out
 
 
@@ -295,7 +298,7 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     check(L().dspn_conv2d_wgrad_slabs_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
-                                          dy.shape[2], stream()), "conv2d_wgrad_slabs")
+                                          dy.shape[2], _MATH, stream()), "conv2d_wgrad_slabs")
 
 
 def slab_reduce_table(entries, device):

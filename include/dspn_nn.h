@@ -42,15 +42,14 @@ extern "C" {
  * too small to fill the chip (SSD heads / extras); any size, dspn_conv2d_split_workspace_bytes() is
  * always enough.  Partials are summed in a fixed order (deterministic). */
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
-/* Math mode of the convolution family (forward, dgrad, wgrad; process-wide, like cudnnSetConvolutionMathType):
- *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fmaf chains (default)
- *   1  bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: tensors stay fp32 in HBM and are rounded to bf16
- *      (round-to-nearest-even) on the way into LDS -- BASELINE.json configs[3] "bf16 MFMA convs" */
-int dspn_conv2d_set_math(int mode);
-int dspn_conv2d_get_math(void);
+/* Math mode of one convolution call -- the `math` argument of the *_bn_f32 / *_slabs_f32 entry points (the plain
+ * *_f32 entries are always DSPN_MATH_FP32).  A per-call argument, not library state: the library keeps no globals.
+ *   DSPN_MATH_FP32  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fmaf chains
+ *   DSPN_MATH_BF16  bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: tensors stay fp32 in HBM and are rounded
+ *                   to bf16 (round-to-nearest-even) on the way into LDS -- BASELINE.json configs[3] "bf16 MFMA convs" */
+#define DSPN_MATH_FP32 0
+#define DSPN_MATH_BF16 1
 
-/* timing-only ablation switches of the conv kernel (results are WRONG when non-zero); 0 = production */
-int dspn_debug_set(int bits);
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
                             int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
@@ -67,7 +66,7 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                long long y_batch_stride, int y_ldc, int relu, int accumulate,
-                               float *out_stats, size_t out_stats_bytes,
+                               float *out_stats, size_t out_stats_bytes, int math,
                                void *workspace, size_t workspace_bytes, void *stream);
 /* out_stats (optional): BatchNorm statistics of y gathered in the convolution's epilogue, one (mean, M2) pair per
  * channel and row tile: out_stats[(t*2 + 0)*Cout + c] = mean of tile t's rows, [(t*2 + 1)*Cout + c] = their sum of
@@ -103,7 +102,7 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N,
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                              int accumulate, const float *bn_x, const float *bn_scale, const float *bn_shift,
                              const float *bn_mean, const float *bn_rstd, int bn_relu, float *bn_sums,
-                             size_t bn_sums_bytes, void *workspace, size_t workspace_bytes, void *stream);
+                             size_t bn_sums_bytes, int math, void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
  * from per-tap sums of dy without forming the gradient (the first convolution's input only feeds the
@@ -125,7 +124,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
 int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                              const float *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
-                             int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+                             int accumulate, int math, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The two halves of the weight gradient separately, so that a training step can run ONE slab reduction for many
  * layers (82 launches of a few microseconds each otherwise): dspn_conv2d_wgrad_slabs_f32 leaves the split-K partial
@@ -136,7 +135,7 @@ int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, in
 int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                                 const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                                int Wo, void *stream);
+                                int Wo, int math, void *stream);
 int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream);
 
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
