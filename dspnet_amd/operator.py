@@ -136,6 +136,19 @@ def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=
     return [loc_target, loc_mask, cls_target]
 
 
+def MultiBoxTarget_check(batch, device):
+    """Deferred form of check_errors=True: reads the per-sample abort codes the LAST MultiBoxTarget call on `device`
+    left in its workspace (synchronises) and raises DspnError with the reference's message if a label row after the
+    terminator was not all -1 (multibox_target.cc:98-101) or hard-negative mining ran out of candidates (:236).  A
+    training loop calls this once per step where it synchronises anyway (solver.fit does, at the metric read-out)."""
+    ws = _ws_cache.get(("target", device))
+    if ws is None:
+        return
+    L = _lib.lib()
+    codes = (ctypes.c_int * int(batch))()
+    check(L.dspn_multibox_target_errors(ws.data_ptr(), int(batch), codes, _stream_ptr()), "MultiBoxTarget")
+
+
 def MultiBoxDetection(cls_prob, loc_pred, anchor, clip=True, threshold=0.01, background_id=0,
                       nms_threshold=0.5, force_suppress=False, variances=(0.1, 0.1, 0.2, 0.2),
                       nms_topk=-1, out=None):

@@ -46,6 +46,11 @@ class MultiBoxTargetNode(E.Node):
             negative_mining_ratio=3, minimum_negative_samples=0, negative_mining_thresh=.5,
             variances=(0.1, 0.1, 0.2, 0.2))
 
+    def raise_on_errors(self):
+        """the reference's data-dependent CHECKs (multibox_target.cc:98-101, :236) for the last forward: synchronises;
+        the kernel itself only records the codes so that the step never waits on the host"""
+        op.MultiBoxTarget_check(self.cls_preds.shape[0], self.cls_preds.data.device)
+
 
 class ClsSoftmaxOutput(E.Node):
     """SoftmaxOutput(cls_preds, cls_target, ignore_label=-1, use_ignore, multi_output,

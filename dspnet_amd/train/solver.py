@@ -143,13 +143,17 @@ def do_checkpoint(prefix):
 
 
 def fit(solver, train_data, begin_epoch=0, num_epoch=1, batch_end_callback=None, epoch_end_callback=None,
-        eval_data=None, class_names=None, seg_class_names=None, logger=None):
+        eval_data=None, class_names=None, seg_class_names=None, logger=None, eval_score_thresh=0.25,
+        check_label_errors=True):
     """The epoch loop of MultiTaskSolver.fit (multi_solver.py:229-345 + the evaluation pass :353-436): per epoch
     train_data.reset(), metric reset, one solver.step() per batch with the MultiBoxMetric / CustomAccuracyMetric
     read-outs, batch_end_callback(BatchEndParam), epoch_end_callback(epoch, net), the 'Train-<name>' log lines, and
     -- when eval_data is given -- evaluate.multi_eval.evaluate_net over it.
     train_data / eval_data: dspnet_amd.dataset.iterator.MultiTaskRecordIter (or any iterator of (batch, fnames) with
-    batch.data[0], batch.label[0], batch.label[1] device tensors).  -> list of per-epoch dicts of metric values."""
+    batch.data[0], batch.label[0], batch.label[1] device tensors).  -> list of per-epoch dicts of metric values.
+    eval_score_thresh: the in-training evaluation keeps detections with score > .25 (multi_solver.py:428; multi_eval.py
+    uses .1).  check_label_errors: after every step (at the metric read-out, which synchronises anyway) raise DspnError
+    where the reference's MultiBoxTarget would have CHECK-failed on the batch (multibox_target.cc:98-101, :236)."""
     import logging
     from .metric import CustomAccuracyMetric, MultiBoxMetric
     logger = logger or logging
@@ -168,6 +172,8 @@ def fit(solver, train_data, begin_epoch=0, num_epoch=1, batch_end_callback=None,
             solver.step()
             multibox_metric.update(net)
             acc_metric.update([net.label_seg.data], [net.seg_out.prob.data])
+            if check_label_errors and net.target is not None:
+                net.target.raise_on_errors()
             if batch_end_callback is not None:
                 batch_end_callback(BatchEndParam(epoch, nbatch, (multibox_metric, acc_metric)))
         if epoch_end_callback is not None:
@@ -186,7 +192,7 @@ def fit(solver, train_data, begin_epoch=0, num_epoch=1, batch_end_callback=None,
                 while eval_data.iter_next():
                     b, _ = eval_data.next()
                     yield {"data": b.data[0], "label_det": b.label[0], "label_seg": b.label[1]}
-            ev = evaluate_net(net, batches(), class_names, seg_class_names)
+            ev = evaluate_net(net, batches(), class_names, seg_class_names, score_thresh=eval_score_thresh)
             for k, v in ev.items():
                 if not isinstance(v, list):
                     logger.info("                     --->Epoch[%d] Validation-%s=%f", epoch, k, v)

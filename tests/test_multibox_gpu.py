@@ -129,8 +129,13 @@ def test_target_reference_aborts_become_codes(gpu_device):
     lab[1, 1] = [-1, .2, -1, -1, -1, -1]
     pred = np.zeros((2, 3, anc.shape[1]), np.float32)
     op.MultiBoxTarget(dev(anc), dev(lab), dev(pred), negative_mining_ratio=3)   # async: no raise
+    with pytest.raises(DspnError, match="padded label row"):                     # ... until the deferred check
+        op.MultiBoxTarget_check(2, dev(anc).device)
     with pytest.raises(DspnError, match="padded label row"):
         op.MultiBoxTarget(dev(anc), dev(lab), dev(pred), negative_mining_ratio=3, check_errors=True)
+    lab[1, 1] = -1                                                               # a clean batch clears the codes
+    op.MultiBoxTarget(dev(anc), dev(lab), dev(pred), negative_mining_ratio=3)
+    op.MultiBoxTarget_check(2, dev(anc).device)
     _, rc = om.multibox_target(anc, lab, pred, negative_mining_ratio=3, return_code=True)
     assert rc == -2
 
