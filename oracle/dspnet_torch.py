@@ -72,14 +72,48 @@ def _deconv(x, w, stride=1, padding=0):
     return _QuantGemmOp.apply(x, w, lambda a, b: F.conv_transpose2d(a, b, stride=stride, padding=padding))
 
 
-def bn(x, gamma, beta, relu=False):
+# Pinned decisions (forward_loss(decisions=...)): the discrete choices of a forward pass -- which ReLU inputs are
+# positive, which window element a max-pool takes -- as some OTHER evaluation of the same graph made them (the device,
+# in the graph parity tests).  A float32 and a float64 forward disagree on the sign of the ~1e-4 of pre-activations that
+# lie within rounding of zero, and every such flip moves single gradient entries by O(1); with the decisions pinned the
+# two backward passes differentiate the SAME piecewise-linear function and can be compared element by element.
+#   "relu:<layer>"  bool (N,C,H,W): the layer's ReLU passes the element       (<layer> = BatchNorm / Convolution name)
+#   "pool:<i>"      int64 (N,C,Ho,Wo): window position r*k+s of the maximum of the i-th max-pool in forward order
+_DECISIONS = None
+_POOL_CALLS = [0]
+
+
+def _relu(y, name):
+    if _DECISIONS is not None and name is not None and ("relu:" + name) in _DECISIONS:
+        return y * _DECISIONS["relu:" + name].to(y.dtype)
+    return F.relu(y)
+
+
+def _max_pool(x, k, s, p=0, ceil_mode=False):
+    i = _POOL_CALLS[0]
+    _POOL_CALLS[0] += 1
+    key = "pool:%d" % i
+    if _DECISIONS is None or key not in _DECISIONS:
+        return F.max_pool2d(x, k, s, p, ceil_mode=ceil_mode)
+    pos = _DECISIONS[key]
+    N, C, Ho, Wo = pos.shape
+    H, W = x.shape[2], x.shape[3]
+    oh = torch.arange(Ho).view(1, 1, Ho, 1)
+    ow = torch.arange(Wo).view(1, 1, 1, Wo)
+    ih = oh * s - p + torch.div(pos, k, rounding_mode="floor")
+    iw = ow * s - p + pos % k
+    assert int(ih.min()) >= 0 and int(ih.max()) < H and int(iw.min()) >= 0 and int(iw.max()) < W
+    return x.flatten(2).gather(2, (ih * W + iw).flatten(2)).view(N, C, Ho, Wo)
+
+
+def bn(x, gamma, beta, relu=False, name=None):
     mean = x.mean(dim=(0, 2, 3), keepdim=True)
     var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
     y = (x - mean) / torch.sqrt(var + EPS)
     if gamma is not None:
         y = y * gamma.view(1, -1, 1, 1)
     y = y + beta.view(1, -1, 1, 1)
-    return F.relu(y) if relu else y
+    return _relu(y, name) if relu else y
 
 
 class Params:
@@ -97,11 +131,11 @@ class Params:
 
 
 def residual_unit(P, data, name, stride, dim_match):
-    act1 = bn(data, P[name + "_bn1_gamma"], P[name + "_bn1_beta"], relu=True)
+    act1 = bn(data, P[name + "_bn1_gamma"], P[name + "_bn1_beta"], relu=True, name=name + "_bn1")
     conv1 = _conv(act1, P[name + "_conv1_weight"])
-    act2 = bn(conv1, P[name + "_bn2_gamma"], P[name + "_bn2_beta"], relu=True)
+    act2 = bn(conv1, P[name + "_bn2_gamma"], P[name + "_bn2_beta"], relu=True, name=name + "_bn2")
     conv2 = _conv(act2, P[name + "_conv2_weight"], stride=stride, padding=1)
-    act3 = bn(conv2, P[name + "_bn3_gamma"], P[name + "_bn3_beta"], relu=True)
+    act3 = bn(conv2, P[name + "_bn3_gamma"], P[name + "_bn3_beta"], relu=True, name=name + "_bn3")
     conv3 = _conv(act3, P[name + "_conv3_weight"])
     shortcut = data if dim_match else _conv(act1, P[name + "_sc_weight"], stride=stride)
     return conv3 + shortcut
@@ -110,8 +144,8 @@ def residual_unit(P, data, name, stride, dim_match):
 def resnet50(P, data):
     x = bn(data, None, P["bn_data_beta"])
     x = _conv(x, P["conv0_weight"], stride=2, padding=3)
-    x = bn(x, P["bn0_gamma"], P["bn0_beta"], relu=True)
-    body = F.max_pool2d(x, 3, 2, 1)
+    x = bn(x, P["bn0_gamma"], P["bn0_beta"], relu=True, name="bn0")
+    body = _max_pool(x, 3, 2, 1)
     internals, plus = {}, 0
     for i, n in enumerate([3, 4, 6, 3]):
         for j in range(n):
@@ -129,19 +163,19 @@ def conv_bn(P, x, name, pad):
 def vgg16_reduced(P, data):
     """symbol/vgg16_reduced.py:3-75"""
     def c(x, name, pad=1, dil=1):
-        return F.relu(_conv(x, P[name + "_weight"], P[name + "_bias"], padding=pad, dilation=dil))
+        return _relu(_conv(x, P[name + "_weight"], P[name + "_bias"], padding=pad, dilation=dil), name)
     inter = {}
     x = c(c(data, "conv1_1"), "conv1_2")
-    x = F.max_pool2d(x, 2, 2)
+    x = _max_pool(x, 2, 2)
     x = c(c(x, "conv2_1"), "conv2_2")
-    x = F.max_pool2d(x, 2, 2)
+    x = _max_pool(x, 2, 2)
     x = c(c(c(x, "conv3_1"), "conv3_2"), "conv3_3")
-    x = F.max_pool2d(x, 2, 2, ceil_mode=True)          # pooling_convention="full"
+    x = _max_pool(x, 2, 2, ceil_mode=True)          # pooling_convention="full"
     x = c(c(c(x, "conv4_1"), "conv4_2"), "conv4_3")
     inter["relu4_3"] = x
-    x = F.max_pool2d(x, 2, 2)
+    x = _max_pool(x, 2, 2)
     x = c(c(c(x, "conv5_1"), "conv5_2"), "conv5_3")
-    x = F.max_pool2d(x, 3, 1, 1)
+    x = _max_pool(x, 3, 1, 1)
     x = c(x, "fc6", pad=6, dil=6)
     x = c(x, "fc7", pad=0)
     inter["relu7"] = x
@@ -214,20 +248,23 @@ def inceptionv3(P, data):
 
 def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, num_classes=8, dtype=torch.float64,
                  nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True,
-                 conv_quant=None):
+                 conv_quant=None, decisions=None):
     """Runs the multi-task (or, with_seg=False, the detection+depth) training graph on the CPU.
     `config` is the preset of multitask_symbol_factory.get_config (un-sliced); without it the resnet-50
     preset wiring is assumed and sizes/ratios are the already sliced lists.  Returns dict with the graph
     outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params.
     conv_quant="bf16": bf16-operand convolutions (see _QUANT above); call .backward() on the objective INSIDE
-    `with quantized("bf16"):` as well, the gradient GEMMs read the same switch."""
-    global _QUANT
+    `with quantized("bf16"):` as well, the gradient GEMMs read the same switch.
+    decisions: pinned ReLU / max-pool choices (see _DECISIONS above; resnet and vgg16_reduced wiring)."""
+    global _QUANT, _DECISIONS
     prev, _QUANT = _QUANT, conv_quant
+    prev_d, _DECISIONS = _DECISIONS, decisions
+    _POOL_CALLS[0] = 0
     try:
         return _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes, dtype, nms_thresh,
                              force_suppress, nms_topk, targets, config, with_seg)
     finally:
-        _QUANT = prev
+        _QUANT, _DECISIONS = prev, prev_d
 
 
 class quantized:
@@ -268,8 +305,8 @@ def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes
             layers.append(inter[name]); names.append(name)
         else:
             n1, n3 = "multi_feat_%d_conv_1x1_conv" % k, "multi_feat_%d_conv_3x3_conv" % k
-            c1 = F.relu(_conv(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]))
-            c3 = F.relu(_conv(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=st, padding=pd))
+            c1 = _relu(_conv(layers[-1], P[n1 + "_weight"], P[n1 + "_bias"]), n1)
+            c3 = _relu(_conv(c1, P[n3 + "_weight"], P[n3 + "_bias"], stride=st, padding=pd), n3)
             layers.append(c3); names.append("multi_feat_%d_conv_3x3_relu" % k)
     conv_feat = layers[1]
     locs, clss, anchors = [], [], []
