@@ -24,8 +24,19 @@
 //
 // fp32 MFMA is an exact fmaf chain (no reduced precision); peak 157 TFLOP/s.
 #include "dspn_common.h"
+#include "dspn_store.h"
 #include <cstdlib>
 #include "../../include/dspn_nn.h"
+
+// This file is compiled twice (dspn_store.h): float tensors -> the `*_f32` entry points, and through conv_h.hip with
+// DSPN_HALF -> bfloat16 activations, bfloat16 weight copies and the `*_bf16` entry points.  In the bf16 build a 16-byte
+// chunk holds 8 channels, a k-step 64 of them, tiles go global -> registers -> LDS without conversion (the folded
+// BatchNorm-apply loader widens, applies and rounds), the MFMA is always v_mfma_f32_32x32x16_bf16 and the epilogue
+// rounds the fp32 accumulators to bf16 on the way out (BatchNorm statistics are taken of the ROUNDED values, i.e. of the
+// tensor the consumers read).
+using dspn::st_t;
+using dspn::kHalf;
+using dspn::u32x4_t;
 
 namespace {
 
@@ -36,17 +47,34 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // bf16-MFMA math mode (per call: the `math` argument of the *_bn_f32 entry points): tensors stay fp32 in HBM, the loaders round to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on the way into LDS, v_mfma_f32_32x32x16_bf16 accumulates in fp32.
-constexpr int kLdsRowH = 40;   // padded LDS row of the bf16 NT tiles, in bf16 (80 B: conflict-free ds_read_b128)
+// padded LDS row of the bf16 NT tiles, in bf16: 32 + 8 (80 B) for float tensors rounded on the way in, 64 + 8 (144 B) for
+// bf16 tensors; both strides are conflict-free for ds_read_b128
+constexpr int kLdsRowH = kHalf ? 72 : 40;
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
   bf16x4 r = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
   return r;
 }
 
-constexpr int kBK = 32;        // floats per k-step
+constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
+constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
+constexpr int kBKF = 32;                       // ... of its fp32-MFMA path
+constexpr int kPK = 32;                        // pixels per k-step of the weight-gradient kernel
+__device__ __forceinline__ float4 ld4(const st_t *p) { return dspn::CA1Ptr(p).vec4()[0]; }
+__device__ __forceinline__ void st4(st_t *p, const float4 v) { dspn::A1Ptr(p).vec4()[0] = v; }
+// 8 bf16 of one 16-byte chunk <-> 8 floats
+__device__ __forceinline__ void widen8(const u32x4_t w, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = dspn::bf16_lo(w[e]); f[2 * e + 1] = dspn::bf16_hi(w[e]); }
+}
+__device__ __forceinline__ u32x4_t narrow8(const float (&f)[8]) {
+  u32x4_t r = {dspn::pack_bf16x2(f[0], f[1]), dspn::pack_bf16x2(f[2], f[3]), dspn::pack_bf16x2(f[4], f[5]),
+               dspn::pack_bf16x2(f[6], f[7])};
+  return r;
+}
 constexpr int kLdsRow = 36;    // padded LDS row (floats)
 
 struct ConvGeom {
-  int N, Hin, Win, Cin;            // gathered tensor (Cin % 4 == 0)
+  int N, Hin, Win, Cin;            // gathered tensor (Cin % kEPC == 0)
   int Hg, Wg;                      // grid of output points per image
   int ish, isw, ioh, iow, idh, idw;  // ih = i*ish + ioh + tr*idh
   int TR, TS;                      // taps enumerated
@@ -69,7 +97,8 @@ struct ConvGeom {
   // bn_x, same layout as out): per row tile t, bn_sums[((tile_base + t)*2 + 0)*Cout + c] = sum of dy' and
   // [... + 1 ...] = sum of dy' * xhat, with dy' = dy where (bn_x*bn_scale + bn_shift > 0 or no ReLU) else 0 and
   // xhat = (bn_x - bn_mean) * bn_rstd: the layout dspn_bn_backward_from_sums_f32 reads
-  const float *bn_x, *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
+  const st_t *bn_x;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   float *bn_sums;
   int bn_relu, bn_tile_base;
 };
@@ -85,9 +114,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
-    const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
-    const int ksteps_per_split, float *__restrict__ slab, const float *__restrict__ residual) {
+    const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
+    st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
+    const int ksteps_per_split, float *__restrict__ slab, const st_t *__restrict__ residual) {
+  static_assert(!kHalf || BF16, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
@@ -101,7 +131,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = m_tiles * n_tiles;
   const int M = g.N * g.Hg * g.Wg;
-  const int CQ = g.Cin >> 2;
+  const int CQ = g.Cin / kEPC;
   const int total_q = g.TR * g.TS * CQ;
   const int nk_all = (total_q + 7) >> 3;
   // split-K: this workgroup handles k-steps [k_begin, k_begin + nk)
@@ -118,15 +148,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // past M / Cout, or a chunk past K) is given an out-of-range offset and the hardware bounds check
   // returns zeros -- no branch, no select, and all loads of a k-step sit in one basic block.
   const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(in), 0, g.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(wgt), 0, g.w_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(g.in_scale), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(g.in_shift), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
   float4 tf_sc = make_float4(0.f, 0.f, 0.f, 0.f), tf_sh = tf_sc;   // affine of this thread's 4 channels (INTF)
+  float4 tf_sc2 = tf_sc, tf_sh2 = tf_sc;                           // ... channels 4..7 of its chunk (bf16 tensors)
   unsigned tf_mask = 0;                                            // bit i: A row i of the k-step is inside the image
 
   // ---- loader state of ONE output tile (re-initialised by setup_tile) -----------------------------
@@ -176,6 +207,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
 
   float4 ra[A_LD], rb[B_LD];
+  u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
   auto load_tiles = [&]() __attribute__((always_inline)) {     // issues the global loads of k-step ld_kt of the tile set up last
     int tr, ts, cq;
     bool qv;
@@ -196,13 +228,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
     ++ld_kt;
     const int dh = tr * g.idh, dw = ts * g.idw;
-    const int a_off = (dh * g.Win + dw) * g.Cin + cq * 4;
+    const int a_off = (dh * g.Win + dw) * g.Cin + cq * kEPC;
     if constexpr (INTF) {
-      const unsigned coff = qv ? (unsigned)cq * 16u : kOOB;
+      const unsigned coff = qv ? (unsigned)cq * (4u * kEPC) : kOOB;
       const auto s4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)coff, 0, 0);
       const auto h4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)coff, 0, 0);
       tf_sc = make_float4(__uint_as_float(s4[0]), __uint_as_float(s4[1]), __uint_as_float(s4[2]), __uint_as_float(s4[3]));
       tf_sh = make_float4(__uint_as_float(h4[0]), __uint_as_float(h4[1]), __uint_as_float(h4[2]), __uint_as_float(h4[3]));
+      if constexpr (kHalf) {
+        const auto s8 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)(coff + (qv ? 16u : 0u)), 0, 0);
+        const auto h8 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)(coff + (qv ? 16u : 0u)), 0, 0);
+        tf_sc2 = make_float4(__uint_as_float(s8[0]), __uint_as_float(s8[1]), __uint_as_float(s8[2]), __uint_as_float(s8[3]));
+        tf_sh2 = make_float4(__uint_as_float(h8[0]), __uint_as_float(h8[1]), __uint_as_float(h8[2]), __uint_as_float(h8[3]));
+      }
       tf_mask = 0;
     }
 #pragma unroll
@@ -211,23 +249,53 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       const bool v = qv && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
       if constexpr (INTF) tf_mask |= v ? (1u << i) : 0u;
       // valid offsets are < 2^31; setting bit 31 pushes an invalid one past num_records
-      const unsigned off = ((unsigned)(a_eoff[i] + a_off) * 4u) | (v ? 0u : kOOB);
+      const unsigned off = ((unsigned)(a_eoff[i] + a_off) * (unsigned)sizeof(st_t)) | (v ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
-      ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
-                          __uint_as_float(t[3]));
+      if constexpr (kHalf) ha[i] = t;
+      else ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                               __uint_as_float(t[3]));
     }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
-    const int b_off = wtap * g.Cin + cq * 4;
+    const int b_off = wtap * g.Cin + cq * kEPC;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const bool v = qv && b_eoff[i] >= 0;
-      const unsigned off = ((unsigned)(b_eoff[i] + b_off) * 4u) | (v ? 0u : kOOB);
+      const unsigned off = ((unsigned)(b_eoff[i] + b_off) * (unsigned)sizeof(st_t)) | (v ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off, 0, 0);
-      rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
-                          __uint_as_float(t[3]));
+      if constexpr (kHalf) hb[i] = t;
+      else rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                               __uint_as_float(t[3]));
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (kHalf) {
+      if constexpr (INTF) {   // widen, u = x * scale[c] + shift[c] (ReLU), zero outside the image, round back to bf16
+        const bool in_relu = g.flags & 32;
+        const float sc[8] = {tf_sc.x, tf_sc.y, tf_sc.z, tf_sc.w, tf_sc2.x, tf_sc2.y, tf_sc2.z, tf_sc2.w};
+        const float sh[8] = {tf_sh.x, tf_sh.y, tf_sh.z, tf_sh.w, tf_sh2.x, tf_sh2.y, tf_sh2.z, tf_sh2.w};
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          float f[8];
+          widen8(ha[i], f);
+          const bool v = (tf_mask >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float u = fmaf(f[e], sc[e], sh[e]);      // the same fmaf as every other evaluation of this affine
+            if (in_relu) u = fmaxf(u, 0.f);
+            f[e] = v ? u : 0.f;
+          }
+          ha[i] = narrow8(f);
+        }
+      }
+      __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        *reinterpret_cast<u32x4_t *>(a + (row0 + RSTEP * i) * kLdsRowH + chunk * 8) = ha[i];
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        *reinterpret_cast<u32x4_t *>(b + (row0 + RSTEP * i) * kLdsRowH + chunk * 8) = hb[i];
+      return;
+    }
     if constexpr (INTF) {   // u = x * scale[c] + shift[c] (ReLU), zero where the tap is outside the image
       const bool in_relu = g.flags & 32;
 #pragma unroll
@@ -307,21 +375,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
       const __bf16 *a = hA + buf * BM * kLdsRowH + (wm + frow) * kLdsRowH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * kLdsRowH + (wn + frow) * kLdsRowH + (lane >> 5) * 8;
-      bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int hk = 0; hk < kBK / 32; ++hk) {     // 32 k values (two 16-deep MFMA blocks) at a time
+        bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * kLdsRowH + kk * 16);
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * kLdsRowH + kk * 16);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
+            fa[kk][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * kLdsRowH + hk * 32 + kk * 16);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            fb[kk][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * kLdsRowH + hk * 32 + kk * 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+      }
     } else {
       const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk + lds_shift_r;
       const float *b = sB + buf * BN * kLdsRow + (wn + frow) * kLdsRow + fk + lds_shift_r;
@@ -332,9 +405,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float2 *>(b + j * 32 * kLdsRow);
 #pragma unroll
-      for (int gq = 0; gq < kBK / 4; ++gq) {
+      for (int gq = 0; gq < kBKF / 4; ++gq) {
         const int cur = gq & 1, nxt = cur ^ 1;
-        if (gq + 1 < kBK / 4) {
+        if (gq + 1 < kBKF / 4) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
             fa[nxt][i] = *reinterpret_cast<const float2 *>(a + i * 32 * kLdsRow + (gq + 1) * 4);
@@ -351,7 +424,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           }
         // pin the order: the LDS reads of the NEXT group are issued ahead of this group's MFMAs, so their
         // latency hides under 2*TM*TN MFMAs instead of one (hipcc otherwise sinks them next to their use)
-        if (gq + 1 < kBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        if (gq + 1 < kBKF / 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
         // ... and the next tile's global loads (with their address arithmetic) are spread over the
         // groups instead of delaying the first MFMA of the k-step
         __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
@@ -397,7 +470,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             }
         }
       } else if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
-        if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5];
+        if (acc[0][0][0] == 1.2345e33f) out[0] = (st_t)acc[TM - 1][TN - 1][5];
       } else {
         // Output tile -> LDS (the barrier above has retired every fragment read) -> rows of float4: a
         // 128-wide row leaves as one 512-B contiguous store per 32 lanes.  The residual / accumulate operand
@@ -418,7 +491,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         const int co = n0 + c4 * 4;
         const bool cvalid = co < g.Cout;
         const bool vec = (g.flags & 16) && co + 3 < g.Cout;
-        const float *addsrc = has_res ? residual : (accum ? out : nullptr);   // first additive operand
+        const st_t *addsrc = has_res ? residual : (accum ? out : nullptr);   // first additive operand
         int offs[RC];   // element offsets (the host checks that the output holds < 2^31 elements)
         float4 rq[RC], xq[EPI == 2 ? RC : 1];
         auto rows_begin = [&](const int ch) __attribute__((always_inline)) {   // addresses + additive operand of chunk ch
@@ -435,7 +508,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             }
             if (m >= M || !cvalid) offs[p] = -1;
             rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (addsrc && vec && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
+            if (addsrc && vec && offs[p] >= 0) rq[p] = ld4(addsrc + offs[p]);
           }
         };
         auto rows_bn_x = [&]() __attribute__((always_inline)) {   // the BatchNorm input rows of the current chunk
@@ -443,7 +516,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
             for (int p = 0; p < RC; ++p) {
               xq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (vec && offs[p] >= 0) xq[p] = *reinterpret_cast<const float4 *>(g.bn_x + offs[p]);
+              if (vec && offs[p] >= 0) xq[p] = ld4(g.bn_x + offs[p]);
             }
           }
         };
@@ -486,14 +559,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             if (vec) {
               v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
               if (has_res && accum) {
-                const float4 q = *reinterpret_cast<const float4 *>(out + off);
+                const float4 q = ld4(out + off);
                 v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
               }
               if (relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
               }
-              if (!(dbg & 16) || v[0] == 1.2345e33f) *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+              if constexpr (kHalf) {   // what is stored (and what the statistics / sums below describe) is the bf16 value
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dspn::round_bf16(v[e]);
+              }
+              if (!(dbg & 16) || v[0] == 1.2345e33f) st4(out + off, make_float4(v[0], v[1], v[2], v[3]));
               if constexpr (EPI == 2) {
                 const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
 #pragma unroll
@@ -514,10 +591,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
               for (int e = 0; e < 4; ++e) {
                 if (co + e >= g.Cout) break;
                 float x = v[e];
-                if (has_res) x += residual[off + e];
-                if (accum) x += out[off + e];
+                if (has_res) x += (float)residual[off + e];
+                if (accum) x += (float)out[off + e];
                 if (relu) x = x > 0.f ? x : 0.f;
-                out[off + e] = x;
+                out[off + e] = (st_t)x;
               }
             }
           }
@@ -583,10 +660,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         if ((dbg & 2048) && tid == 0 && blockIdx.y == 0) {
           const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
           // 4 words per workgroup: cycles, real-time ticks (100 MHz), start tick and end tick (low 32 bits, raw)
-          out[4 * blockIdx.x] = (float)(c1 - stamp_c0);
-          out[4 * blockIdx.x + 1] = (float)(r1 - stamp_r0);
-          out[4 * blockIdx.x + 2] = __uint_as_float((unsigned)stamp_r0);
-          out[4 * blockIdx.x + 3] = __uint_as_float((unsigned)r1);
+          float *po = reinterpret_cast<float *>(out);
+          po[4 * blockIdx.x] = (float)(c1 - stamp_c0);
+          po[4 * blockIdx.x + 1] = (float)(r1 - stamp_r0);
+          po[4 * blockIdx.x + 2] = __uint_as_float((unsigned)stamp_r0);
+          po[4 * blockIdx.x + 3] = __uint_as_float((unsigned)r1);
         }
         break;
       }
@@ -612,7 +690,7 @@ struct WgradGeom {
   int ldy;                   // dY pixel stride (floats)
   int sh, sw, ph, pw, dh, dw;  // ih = ho*sh - ph + r*dh
   int R, S;
-  int pix_per_split;         // multiple of kBK
+  int pix_per_split;         // multiple of kPK
   unsigned x_bytes, dy_bytes;
   const float *in_scale, *in_shift;   // optional affine (+ReLU) on x, as in ConvGeom
   int in_relu;
@@ -626,15 +704,18 @@ constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16, bool INTF>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
-    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slab,
+    const st_t *__restrict__ x, const st_t *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
+  static_assert(!kHalf || BF16, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;   // BM over cout, BN over (tap,c)
   constexpr int NTHR = WAVES_M * WAVES_N * 64;                     // 4 waves, or 8 (4 waves per SIMD with two workgroups per CU)
-  constexpr int A_LD = BM * kBK / 4 / NTHR, B_LD = BN * kBK / 4 / NTHR;
-  constexpr int A_CH = BM / 4, B_CH = BN / 4;                      // 16-B chunks per tile row
+  constexpr int A_CH = BM / kEPC, B_CH = BN / kEPC;                // 16-B chunks per tile row
+  // 16-B chunks per thread and k-step; a small tile of bf16 tensors has fewer chunks than threads (32 channels x 32 pixels
+  // = 128 chunks on 256 threads): the surplus threads address past the pixel block, fetch nothing and store nothing
+  constexpr int A_LD = (A_CH * kPK + NTHR - 1) / NTHR, B_LD = (B_CH * kPK + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *sA = smem;                      // [2][kBK][BM]
-  float *sB = smem + 2 * kBK * BM;       // [2][kBK][BN]
+  float *sA = smem;                      // [2][kPK][BM]
+  float *sB = smem + 2 * kPK * BM;       // [2][kPK][BN]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
@@ -645,36 +726,40 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int J = g.R * g.S * g.Cin;
   const int p_begin = split * g.pix_per_split;
   const int p_end = min(P, p_begin + g.pix_per_split);
-  const int nk = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+  const int nk = p_end > p_begin ? (p_end - p_begin + kPK - 1) / kPK : 0;
 
   // fixed per-thread column chunk of the B (x) tile -> fixed tap and channel
   const int b_chunk = tid % B_CH, b_row0 = tid / B_CH;   // rows step by NTHR / B_CH
   constexpr int B_RSTEP = NTHR / B_CH;
-  const int jq = (j0 >> 2) + b_chunk;
-  const int CQ = g.Cin >> 2;
-  const bool jv = jq * 4 < J;
+  const int jq = j0 / kEPC + b_chunk;
+  const int CQ = g.Cin / kEPC;
+  const bool jv = jq * kEPC < J;
   const int tap = jq / CQ, cq = jq - tap * CQ;
   const int tr = tap / g.S, ts = tap - tr * g.S;
   const int tdh = tr * g.dh - g.ph, tdw = ts * g.dw - g.pw;
   const int a_chunk = tid % A_CH, a_row0 = tid / A_CH;
   constexpr int A_RSTEP = NTHR / A_CH;
-  const bool kv = k0 + a_chunk * 4 < g.Cout;
+  const bool kv = k0 + a_chunk * kEPC < g.Cout;
 
   const __amdgpu_buffer_rsrc_t rsrc_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, g.x_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(x), 0, g.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_dy =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy), 0, g.dy_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(dy), 0, g.dy_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
   // this thread's x chunk is a fixed (tap, 4 channels): its affine is loaded once
-  float4 tf_sc = make_float4(0.f, 0.f, 0.f, 0.f), tf_sh = tf_sc;
+  float4 tf_sc = make_float4(0.f, 0.f, 0.f, 0.f), tf_sh = tf_sc, tf_sc2 = tf_sc, tf_sh2 = tf_sc;
   unsigned tf_mask = 0;
   if constexpr (INTF) {
     if (jv) {
-      tf_sc = *reinterpret_cast<const float4 *>(g.in_scale + cq * 4);
-      tf_sh = *reinterpret_cast<const float4 *>(g.in_shift + cq * 4);
+      tf_sc = *reinterpret_cast<const float4 *>(g.in_scale + cq * kEPC);
+      tf_sh = *reinterpret_cast<const float4 *>(g.in_shift + cq * kEPC);
+      if constexpr (kHalf) {
+        tf_sc2 = *reinterpret_cast<const float4 *>(g.in_scale + cq * kEPC + 4);
+        tf_sh2 = *reinterpret_cast<const float4 *>(g.in_shift + cq * kEPC + 4);
+      }
     }
   }
-  // (image, row, column) of this thread's x rows, advanced by kBK pixels per k-step with carries instead of two
+  // (image, row, column) of this thread's x rows, advanced by kPK pixels per k-step with carries instead of two
   // integer divisions per load (the divisions were ~120 of the ~270 VALU instructions beside the 64 MFMAs)
   typedef int ivec8 __attribute__((ext_vector_type(8)));
   static_assert(B_LD <= 8, "x-row state holds 8 rows");
@@ -688,18 +773,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       b_n[i] = n; b_ho[i] = rem / g.Wo; b_wo[i] = rem - (rem / g.Wo) * g.Wo;
     }
   }
-  const int adv_n = kBK / (g.Ho * g.Wo), adv_rem = kBK - adv_n * (g.Ho * g.Wo);
+  const int adv_n = kPK / (g.Ho * g.Wo), adv_rem = kPK - adv_n * (g.Ho * g.Wo);
   const int adv_h = adv_rem / g.Wo, adv_w = adv_rem - adv_h * g.Wo;
   float4 ra[A_LD], rb[B_LD];
+  u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
   auto load_tiles = [&](int kt) {
-    const int pb = p_begin + kt * kBK;
+    const int pb = p_begin + kt * kPK;
     if constexpr (INTF) tf_mask = 0;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int p = pb + a_row0 + i * A_RSTEP;
-      const unsigned off = ((unsigned)(p * g.ldy + k0 + a_chunk * 4) * 4u) | ((kv && p < p_end) ? 0u : kOOB);
+      const bool in_blk = a_row0 + i * A_RSTEP < kPK;
+      const unsigned off = ((unsigned)(p * g.ldy + k0 + a_chunk * kEPC) * (unsigned)sizeof(st_t)) |
+                           ((kv && in_blk && p < p_end) ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)off, 0, 0);
-      ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+      if constexpr (kHalf) ha[i] = t;
+      else ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -714,19 +803,38 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         b_wo[i] = w2; b_ho[i] = h2; b_n[i] = n2;
       }
       const int ih = ho * g.sh + tdh, iw = wo * g.sw + tdw;
-      const bool v = jv && p < p_end && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      const bool v = jv && p < p_end && (b_row0 + i * B_RSTEP < kPK) && (unsigned)ih < (unsigned)g.Hin &&
+                     (unsigned)iw < (unsigned)g.Win;
       if constexpr (INTF) tf_mask |= v ? (1u << i) : 0u;
-      const unsigned off = ((unsigned)(((n * g.Hin + ih) * g.Win + iw) * g.Cin + cq * 4) * 4u) | (v ? 0u : kOOB);
+      const unsigned off = ((unsigned)(((n * g.Hin + ih) * g.Win + iw) * g.Cin + cq * kEPC) * (unsigned)sizeof(st_t)) |
+                           (v ? 0u : kOOB);
       const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)off, 0, 0);
-      rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+      if constexpr (kHalf) hb[i] = t;
+      else rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
     }
   };
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
-  char *hA = reinterpret_cast<char *>(smem);            // [2][kBK][RAB]
-  char *hB = hA + 2 * kBK * RAB;                        // [2][kBK][RBB]
+  char *hA = reinterpret_cast<char *>(smem);            // [2][kPK][RAB]
+  char *hB = hA + 2 * kPK * RAB;                        // [2][kPK][RBB]
   // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
   auto transform_tiles = [&]() __attribute__((always_inline)) {
-    if constexpr (INTF) {
+    if constexpr (INTF && kHalf) {
+      const float sc[8] = {tf_sc.x, tf_sc.y, tf_sc.z, tf_sc.w, tf_sc2.x, tf_sc2.y, tf_sc2.z, tf_sc2.w};
+      const float sh[8] = {tf_sh.x, tf_sh.y, tf_sh.z, tf_sh.w, tf_sh2.x, tf_sh2.y, tf_sh2.z, tf_sh2.w};
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        float f[8];
+        widen8(hb[i], f);
+        const bool v = (tf_mask >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float u = fmaf(f[e], sc[e], sh[e]);
+          if (g.in_relu) u = fmaxf(u, 0.f);
+          f[e] = v ? u : 0.f;
+        }
+        hb[i] = narrow8(f);
+      }
+    } else if constexpr (INTF) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         float4 u = make_float4(fmaf(rb[i].x, tf_sc.x, tf_sh.x), fmaf(rb[i].y, tf_sc.y, tf_sh.y),
@@ -739,8 +847,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   auto store_tiles = [&](int buf, bool transformed = false) __attribute__((always_inline)) {
     if (!transformed) transform_tiles();
-    if constexpr (BF16) {
-      char *a = hA + buf * kBK * RAB, *b = hB + buf * kBK * RBB;
+    if constexpr (kHalf) {       // [pixel][channel] images, as loaded: 16 bytes = this pixel's 8 channels
+      char *a = hA + buf * kPK * RAB, *b = hB + buf * kPK * RBB;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        if (a_row0 + i * A_RSTEP < kPK)
+          *reinterpret_cast<u32x4_t *>(a + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 16) = ha[i];
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        if (b_row0 + i * B_RSTEP < kPK)
+          *reinterpret_cast<u32x4_t *>(b + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 16) = hb[i];
+    } else if constexpr (BF16) {
+      char *a = hA + buf * kPK * RAB, *b = hB + buf * kPK * RBB;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
         *reinterpret_cast<bf16x4 *>(a + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8) = to_bf16x4(ra[i]);
@@ -748,7 +866,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int i = 0; i < B_LD; ++i)
         *reinterpret_cast<bf16x4 *>(b + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8) = to_bf16x4(rb[i]);
     } else {
-      float *a = sA + buf * kBK * BM, *b = sB + buf * kBK * BN;
+      float *a = sA + buf * kPK * BM, *b = sB + buf * kPK * BN;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
         *reinterpret_cast<float4 *>(a + (a_row0 + i * A_RSTEP) * BM + a_chunk * 4) = ra[i];
@@ -780,8 +898,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // block and pixels 8*(gl>>1) .. +7 of a 16-pixel MFMA k block; lane 4q+p of the group supplies the address
       // of pixel row q, channels 4p .. 4p+3, and receives its own channel's 4 pixels.
       const int gl = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-      const char *a = hA + buf * kBK * RAB + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
-      const char *b = hB + buf * kBK * RBB + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *a = hA + buf * kPK * RAB + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *b = hB + buf * kPK * RBB + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
       auto frag = [](const char *base, int row_bytes) {
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base + 4 * row_bytes));
@@ -802,17 +920,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     } else {
-    const float *a = sA + buf * kBK * BM + (lane >> 5) * BM + wm + (lane & 31);
-    const float *b = sB + buf * kBK * BN + (lane >> 5) * BN + wn + (lane & 31);
+    const float *a = sA + buf * kPK * BM + (lane >> 5) * BM + wm + (lane & 31);
+    const float *b = sB + buf * kPK * BN + (lane >> 5) * BN + wn + (lane & 31);
     float fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = a[i * 32];
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[0][j] = b[j * 32];
 #pragma unroll
-    for (int ks = 0; ks < kBK / 2; ++ks) {
+    for (int ks = 0; ks < kPK / 2; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < kBK / 2) {
+      if (ks + 1 < kPK / 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[nxt][i] = a[(ks + 1) * 2 * BM + i * 32];
 #pragma unroll
@@ -823,12 +941,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-      if (ks + 1 < kBK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      if (ks + 1 < kPK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
       if constexpr (INTF) {
         // half way through the k-step the x rows requested above have arrived: their affine runs on the vector ALU
         // while the matrix pipe works through the MFMAs already issued, instead of after the last one
-        if (ks == kBK / 4 - 1) {
+        if (ks == kPK / 4 - 1) {
           __builtin_amdgcn_sched_barrier(0);
           transform_tiles();
           __builtin_amdgcn_sched_barrier(0);
@@ -874,7 +992,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 // Used for the first convolution, whose input only feeds the beta of bn_data (symbol/resnet.py:91):
 // the full data gradient there would be a GEMM with N = 3 useful columns.
 // ---------------------------------------------------------------------------
-__global__ void batch_sum_kernel(const float4 *__restrict__ dy, float4 *__restrict__ p2, int N,
+__global__ void batch_sum_kernel(const dspn::CA4Ptr dy, float4 *__restrict__ p2, int N,
                                  long long per_image4) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < per_image4;
        i += (long long)gridDim.x * blockDim.x) {
@@ -962,17 +1080,21 @@ __global__ void slab_reduce_kernel(const float4 *__restrict__ slab, float4 *__re
   }
 }
 
-// W[k][t][c] -> Wt[c][t][k]   (data-gradient operand)
-__global__ void weight_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt,
+// W[k][t][c] (float master) -> Wt[c][t][k] in the storage type (data-gradient operand); bf16 build: also the
+// storage-type copy Wh[k][t][c] of W itself (forward operand) when wh != NULL
+__global__ void weight_transpose_kernel(const float *__restrict__ w, st_t *__restrict__ wt, st_t *__restrict__ wh,
                                         int K, int T, int C, int Kp) {
-  // wt has row length Kp >= K (Kp % 4 == 0), zero padded
+  // wt has row length Kp >= K (Kp % kEPC == 0), zero padded
   const long long total = (long long)C * T * Kp;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kp);
     const long long ct = i / Kp;
     const int t = (int)(ct % T), c = (int)(ct / T);
-    wt[i] = k < K ? w[((long long)k * T + t) * C + c] : 0.f;
+    const long long src = ((long long)k * T + t) * C + c;
+    const float v = k < K ? w[src] : 0.f;
+    wt[i] = (st_t)v;
+    if (wh && k < K) wh[src] = (st_t)v;
   }
 }
 
@@ -1011,7 +1133,7 @@ __global__ void slab_reduce_batch_kernel(const SlabDesc *__restrict__ d, int n, 
 
 // all weight transposes of a step in ONE launch: table rows = {src, dst, K, T, C, Kp, first element of the row's
 // range in the concatenated index space}; a workgroup finds its row by binary search on the range starts
-struct WtDesc { const float *w; float *wt; int K, T, C, Kp; long long begin; };
+struct WtDesc { const float *w; st_t *wt; int K, T, C, Kp; long long begin; st_t *wh; };
 __global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int n, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -1025,14 +1147,17 @@ __global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int 
     const int k = (int)(j % e.Kp);
     const long long ct = j / e.Kp;
     const int t = (int)(ct % e.T), c = (int)(ct / e.T);
-    e.wt[j] = k < e.K ? e.w[((long long)k * e.T + t) * e.C + c] : 0.f;
+    const long long src = ((long long)k * e.T + t) * e.C + c;
+    const float v = k < e.K ? e.w[src] : 0.f;
+    e.wt[j] = (st_t)v;
+    if (e.wh && k < e.K) e.wh[src] = (st_t)v;
   }
 }
 
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
 __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
-                                       float *__restrict__ out, long long M, int Cout, int ldc, int splits,
-                                       int flags, const float *__restrict__ residual) {
+                                       st_t *__restrict__ out, long long M, int Cout, int ldc, int splits,
+                                       int flags, const st_t *__restrict__ residual) {
   const long long total = M * Cout;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -1041,11 +1166,11 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
     float v = slab[i];
     for (int k = 1; k < splits; ++k) v += slab[(long long)k * total + i];
     if (flags & 1) v += bias[co];
-    if (flags & 8) v += residual[m * ldc + co];
-    float *o = out + m * ldc + co;
-    if (flags & 4) v += *o;
+    if (flags & 8) v += (float)residual[m * ldc + co];
+    st_t *o = out + m * ldc + co;
+    if (flags & 4) v += (float)*o;
     if (flags & 2) v = v > 0.f ? v : 0.f;
-    *o = v;
+    *o = (st_t)v;
   }
 }
 
@@ -1053,8 +1178,8 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 struct SplitWs { float *ptr; size_t bytes; };
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
-int launch_nt_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-                   hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
+int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
+                   hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
@@ -1095,12 +1220,16 @@ int launch_nt_impl(const float *in, const float *w, const float *bias, float *ou
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g,
-              hipStream_t s, int splits, int ksteps_per_split, float *slab, const float *residual) {
-  const bool uni = ((g.Cin >> 2) & 7) == 0;
+int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
+              hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
+  const bool uni = ((g.Cin / kEPC) & 7) == 0;
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+#ifdef DSPN_HALF
+#define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E))
+#else
 #define DSPN_NT_UB_(T, E) (g.bf16 ? (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E)) \
-                                       : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
+                                  : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
+#endif
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
   return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
@@ -1130,16 +1259,18 @@ int nt_config(long long M, int Cout) {
   if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
   return cfg;
 }
-int dispatch_nt(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g_in,
-                hipStream_t s, SplitWs ws, const float *residual = nullptr) {
+int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g_in,
+                hipStream_t s, SplitWs ws, const st_t *residual = nullptr) {
   ConvGeom g = g_in;
   g.dbg = g_debug_bits;
-  // float4 epilogue needs 16-byte aligned rows in every operand it touches
-  if (g.ldc % 4 == 0 && g.obs % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0))
+  // the 4-element-vector epilogue needs aligned rows (16 bytes float, 8 bytes bf16) in every operand it touches
+  constexpr uintptr_t amask = 4 * sizeof(st_t) - 1;
+  if (g.ldc % 4 == 0 && g.obs % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & amask) == 0 &&
+      (!residual || (reinterpret_cast<uintptr_t>(residual) & amask) == 0))
     g.flags |= 16;
   {
-    const long long ib = 4ll * g.N * g.Hin * g.Win * g.Cin, wb = 4ll * g.Cout * g.WTAPS * g.Cin;
+    const long long ib = (long long)sizeof(st_t) * g.N * g.Hin * g.Win * g.Cin,
+                    wb = (long long)sizeof(st_t) * g.Cout * g.WTAPS * g.Cin;
     if (ib >= (1ll << 31) || wb >= (1ll << 31))
       return dspn::fail(DSPN_ERR_ARG_, "conv: tensors of 2 GiB or more are not supported by the buffer-addressed kernel");
     g.in_bytes = (unsigned)ib; g.w_bytes = (unsigned)wb;
@@ -1150,7 +1281,7 @@ int dispatch_nt(const float *in, const float *w, const float *bias, float *out, 
   const int cfg = nt_config(M, g.Cout);
   const int *bm_ = kNtBm, *bn_ = kNtBn;
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
-  const int nk = (g.TR * g.TS * (g.Cin >> 2) + 7) >> 3;
+  const int nk = (g.TR * g.TS * (g.Cin / kEPC) + 7) >> 3;
   int splits = 1, per = nk;
   if (g.stats && (!g.dense || !(g.flags & 16) || g.Cout % 4 != 0))
     return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: output statistics need a dense, 16-byte aligned output with Cout %% 4 == 0");
@@ -1202,7 +1333,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
     p.bn = t == 2 ? 64 : 128;
   }
   const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((J + p.bn - 1) / p.bn);
-  const long long lds = 4ll * std::max(2 * kBK * (p.bm + p.bn), p.bm * (p.bn + 4));
+  const long long lds = 4ll * std::max(2 * kPK * (p.bm + p.bn), p.bm * (p.bn + 4));
   const long long slots = 256 * std::min<long long>(8, (160ll << 10) / lds);
   // every tap re-reads the same pixels of x: keep one split's share of x within the Infinity Cache /
   // L2 so that only the first tap's workgroups fetch it from HBM
@@ -1214,7 +1345,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   double best = 1e30;
   long long splits = s_min;
   for (long long sp = s_min; sp <= s_max; ++sp) {
-    const long long pps = ((P + sp - 1) / sp + kBK - 1) / kBK * kBK;
+    const long long pps = ((P + sp - 1) / sp + kPK - 1) / kPK * kPK;
     const long long real = (P + pps - 1) / pps;
     const long long rounds = (tiles * real + slots - 1) / slots;
     const double t = (double)rounds * ((double)pps + ovh_pix) * flop_per_pix / slot_rate +
@@ -1223,7 +1354,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
     if (tiles * sp > 8 * slots) break;
   }
   if (const char *e = getenv("DSPN_WG_SPLITS")) splits = std::max<long long>(1, std::min<long long>(atoll(e), s_max));   // experiments
-  long long pps = ((P + splits - 1) / splits + kBK - 1) / kBK * kBK;
+  long long pps = ((P + splits - 1) / splits + kPK - 1) / kPK * kPK;
   p.splits = (int)((P + pps - 1) / pps);
   p.pps = (int)pps;
   return p;
@@ -1237,22 +1368,24 @@ extern "C" {
 int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
 #endif
 
+#ifndef DSPN_HALF
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
   if (out_pixels <= 0 || Cout <= 0) return 0;
   // split-K is only taken below 192 workgroups (<= 192*64 x 192*64 outputs) with <= 32 splits
   const long long capped = std::min<long long>(out_pixels * Cout, 192ll * 64 * 64 * 4);
   return sizeof(float) * 32 * (size_t)capped;
 }
+#endif
 
 struct InAffine { const float *scale, *shift; int relu; };
 
-static int conv2d_forward_one(int math, const float *x, InAffine tf, float *stats, const float *w, const float *bias, const float *residual, float *y, int N,
+static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats, const st_t *w, const float *bias, const st_t *residual, st_t *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
   DSPN_REQUIRE(x && w && y, "conv2d_forward: null pointer");
-  DSPN_REQUIRE(Cin % 4 == 0, "conv2d_forward: Cin must be a multiple of 4 (pad channels), got %d", Cin);
+  DSPN_REQUIRE(Cin % kEPC == 0, "conv2d_forward: Cin must be a multiple of %d (pad channels), got %d", kEPC, Cin);
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0,
                "conv2d_forward: bad geometry");
   DSPN_REQUIRE(Ho == (H + 2 * pad_h - dil * (R - 1) - 1) / stride + 1 &&
@@ -1271,7 +1404,7 @@ static int conv2d_forward_one(int math, const float *x, InAffine tf, float *stat
   g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0) | ((tf.scale && tf.relu) ? 32 : 0);
   g.in_scale = tf.scale; g.in_shift = tf.shift;
   g.stats = stats;
-  g.bf16 = math;
+  g.bf16 = kHalf ? 1 : math;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -1283,15 +1416,19 @@ static int batch_chunk(int N, long long bytes_per_image) {
   return (int)std::max<long long>(1, lim / bytes_per_image);
 }
 
-int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows) {
+static int stats_layout(long long out_pixels, int Cout, int *tile_rows) {
   if (out_pixels <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
   const int bm = kNtBm[nt_config(out_pixels, Cout)];
   if (tile_rows) *tile_rows = bm;
   return (int)((out_pixels + bm - 1) / bm);
 }
+#ifndef DSPN_HALF
+/* the same tiling for both storage types */
+int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows) { return stats_layout(out_pixels, Cout, tile_rows); }
+#endif
 
-int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
-                               const float *w, const float *bias, const float *residual, float *y, int N,
+int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
+                               const st_t *w, const float *bias, const st_t *residual, st_t *y, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                                int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                                int relu, int accumulate, float *out_stats, size_t out_stats_bytes, int math,
@@ -1301,14 +1438,14 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   if (out_stats) {
     int tile_rows = 0;
-    const int mt = dspn_conv2d_stats_layout((long long)N * Ho * Wo, Cout, &tile_rows);
+    const int mt = stats_layout((long long)N * Ho * Wo, Cout, &tile_rows);
     DSPN_REQUIRE(mt > 0 && out_stats_bytes >= sizeof(float) * 2 * (size_t)mt * Cout,
                  "conv2d_forward: out_stats needs dspn_conv2d_stats_layout() tiles x 2 x Cout floats and Cout %% 4 == 0");
-    DSPN_REQUIRE(batch_chunk(N, 4ll * H * W * Cin) == N, "conv2d_forward: out_stats is not available for inputs of 2 GiB or more");
+    DSPN_REQUIRE(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin) == N, "conv2d_forward: out_stats is not available for inputs of 2 GiB or more");
   }
   const int ldc = y_ldc > 0 ? y_ldc : Cout;
   const long long ybs = y_batch_stride > 0 ? y_batch_stride : (long long)Ho * Wo * ldc;
-  const int nb = batch_chunk(N, 4ll * H * W * Cin);
+  const int nb = batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_forward_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, bias,
@@ -1320,6 +1457,7 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
   return 0;
 }
 
+#ifndef DSPN_HALF
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
@@ -1337,22 +1475,45 @@ int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int ta
   const long long total = (long long)Cin * taps * Cout_pad;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(weight_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     wt, Cout, taps, Cin, Cout_pad);
+                     wt, static_cast<float *>(nullptr), Cout, taps, Cin, Cout_pad);
   return dspn::check_launch("weight_transpose");
 }
 
 int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_elements, void *stream) {
   DSPN_REQUIRE(table && n > 0 && total_elements > 0, "weight_transpose_batch: bad argument");
-  static_assert(sizeof(WtDesc) == 40, "table row layout: 2 pointers, 4 ints, 1 int64");
+  static_assert(sizeof(WtDesc) == 48, "table row layout: 2 pointers, 4 ints, 1 int64, 1 pointer (NULL here)");
   const int blocks = (int)std::min<long long>((total_elements + 255) / 256, 16384);
   hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WtDesc *>(table), n, total_elements);
   return dspn::check_launch("weight_transpose_batch");
 }
+#else
+/* bf16 operands of a float master weight w [Cout][taps][Cin]: wt [Cin][taps][Cout_pad] (data gradient) and, when
+ * wh != NULL, the copy wh [Cout][taps][Cin] (forward).  Cout_pad % 8 == 0. */
+int dspn_conv2d_weight_prepare_bf16(const float *w, st_t *wh, st_t *wt, int Cout, int taps, int Cin,
+                                    int Cout_pad, void *stream) {
+  DSPN_REQUIRE(w && wt && Cout > 0 && taps > 0 && Cin > 0 && Cout_pad >= Cout && Cout_pad % kEPC == 0,
+               "weight_prepare: bad argument");
+  const long long total = (long long)Cin * taps * Cout_pad;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     wt, wh, Cout, taps, Cin, Cout_pad);
+  return dspn::check_launch("weight_prepare");
+}
+
+int dspn_conv2d_weight_prepare_batch_bf16(const void *table, int n, long long total_elements, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_elements > 0, "weight_prepare_batch: bad argument");
+  static_assert(sizeof(WtDesc) == 48, "table row layout: 2 pointers, 4 ints, 1 int64, 1 pointer");
+  const int blocks = (int)std::min<long long>((total_elements + 255) / 256, 16384);
+  hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WtDesc *>(table), n, total_elements);
+  return dspn::check_launch("weight_prepare_batch");
+}
+#endif
 
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
 // Also the forward of a transposed convolution (x := dy).
-struct BnBwd { const float *x, *scale, *shift, *mean, *rstd; int relu; float *sums; };
+struct BnBwd { const st_t *x; const float *scale, *shift, *mean, *rstd; int relu; float *sums; };
 
 // row tiles of the launches of one data gradient, in launch order (stride 2: up to 4 parity classes)
 static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class /* [4] or NULL */) {
@@ -1368,12 +1529,12 @@ static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class 
   return total;
 }
 
-static int conv2d_dgrad_one(int math, const float *dy, const float *wt, float *dx, int N, int H, int W,
+static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, st_t *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, BnBwd bn, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
-  DSPN_REQUIRE(ldy % 4 == 0, "conv2d_dgrad: dy channel stride must be a multiple of 4");
+  DSPN_REQUIRE(ldy % kEPC == 0, "conv2d_dgrad: dy channel stride must be a multiple of %d", kEPC);
   DSPN_REQUIRE(stride == 1 || (stride == 2 && dil == 1), "conv2d_dgrad: stride 1, or stride 2 with dilation 1");
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && R > 0 && S > 0, "conv2d_dgrad: bad geometry");
   ConvGeom g;
@@ -1384,7 +1545,7 @@ static int conv2d_dgrad_one(int math, const float *dy, const float *wt, float *d
   g.obs = (long long)H * W * g.ldc;
   g.OW = W;
   g.flags = accumulate ? 4 : 0;
-  g.bf16 = math;
+  g.bf16 = kHalf ? 1 : math;
   g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
   g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
   int class_tiles[4] = {0, 0, 0, 0};
@@ -1420,25 +1581,28 @@ static int conv2d_dgrad_one(int math, const float *dy, const float *wt, float *d
   return 0;
 }
 
-int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) {
+static int dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 4 != 0 || (stride != 1 && stride != 2)) return 0;
   return dgrad_tiles(N, H, W, Cin, stride, nullptr);
 }
+#ifndef DSPN_HALF
+int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) { return dgrad_bn_tiles(N, H, W, Cin, stride); }
+#endif
 
-int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
+int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, st_t *dx, int N, int H, int W,
                              int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                              int Wo, int dx_ldc, int accumulate,
-                             const float *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
+                             const st_t *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
                              const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, int math,
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
   DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_dgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
-  const int nb = batch_chunk(N, 4ll * Ho * Wo * ldy);
+  const int nb = batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy);
   if (bn_sums) {
     DSPN_REQUIRE(bn_x && bn_mean && bn_rstd && (!bn_relu || (bn_scale && bn_shift)), "conv2d_dgrad: BatchNorm operands missing");
     DSPN_REQUIRE(ldc == Cin && nb == N, "conv2d_dgrad: BatchNorm sums need a dense dx and dy below 2 GiB");
-    const int tiles = dspn_conv2d_dgrad_bn_tiles(N, H, W, Cin, stride);
+    const int tiles = dgrad_bn_tiles(N, H, W, Cin, stride);
     DSPN_REQUIRE(tiles > 0 && bn_sums_bytes >= sizeof(float) * 2 * (size_t)tiles * Cin,
                  "conv2d_dgrad: bn_sums needs dspn_conv2d_dgrad_bn_tiles() x 2 x Cin floats");
   }
@@ -1453,6 +1617,7 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N,
   return 0;
 }
 
+#ifndef DSPN_HALF
 int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
@@ -1465,26 +1630,28 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {
   return sizeof(float) * ((size_t)Ho * Wo * ldy + (size_t)R * S * 32 * ldy);
 }
+#endif
 
-int dspn_conv2d_input_sum_grad_f32(const float *dy, const float *w, float *out, int N, int H, int W,
+int DSPN_FN(dspn_conv2d_input_sum_grad)(const st_t *dy, const float *w, float *out, int N, int H, int W,
                                    int Cin, int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil,
                                    int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(dy && w && out && workspace, "conv2d_input_sum_grad: null pointer");
   DSPN_REQUIRE(ldy % 4 == 0 && Cin >= 1 && Cin <= 8, "conv2d_input_sum_grad: Cin <= 8, ldy % 4 == 0");
-  if (workspace_bytes < dspn_conv2d_input_sum_grad_workspace_bytes(Ho, Wo, ldy, R, S))
+  if (workspace_bytes < sizeof(float) * ((size_t)Ho * Wo * ldy + (size_t)R * S * 32 * ldy))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_input_sum_grad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float *p2 = static_cast<float *>(workspace);
   float *partial = p2 + (size_t)Ho * Wo * ldy;
   const long long per4 = (long long)Ho * Wo * ldy / 4;
   hipLaunchKernelGGL(batch_sum_kernel, dim3((int)std::min<long long>((per4 + 255) / 256, 8192)), dim3(256), 0, s,
-                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(p2), N, per4);
+                     dspn::CA4Ptr(dy), reinterpret_cast<float4 *>(p2), N, per4);
   SumGradGeom g{H, W, Ho, Wo, ldy, R, S, stride, stride, pad_h, pad_w, dil, dil, 32};
   hipLaunchKernelGGL(tap_sum_kernel, dim3(R * S, 32), dim3(256), 0, s, p2, partial, g);
   hipLaunchKernelGGL(sum_grad_final_kernel, dim3(1), dim3(1024), 0, s, partial, w, out, R * S, 32, ldy, Cout, Cin);
   return dspn::check_launch("conv2d_input_sum_grad");
 }
 
+#ifndef DSPN_HALF
 size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int R, int S) {
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
@@ -1495,20 +1662,21 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
     m = std::max(m, (size_t)wgrad_plan(P, Cout, J, 4ll * P * Cin * stride * stride).splits);
   return sizeof(float) * m * Cout * J;
 }
+#endif
 
-static int conv2d_wgrad_one(int math, const float *x, InAffine tf, const float *dy, float *dw, int N, int H, int W, int Cin,
+static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy, float *dw, int N, int H, int W, int Cin,
                           int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   DSPN_REQUIRE(x && dy && workspace, "conv2d_wgrad: null pointer");   // dw == NULL: leave the partial slabs in workspace
-  DSPN_REQUIRE(Cin % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: channel strides must be multiples of 4");
+  DSPN_REQUIRE(Cin % kEPC == 0 && ldy % kEPC == 0, "conv2d_wgrad: channel strides must be multiples of %d", kEPC);
   WgradGeom g;
   g.N = N; g.Hin = H; g.Win = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
   g.sh = stride; g.sw = stride; g.ph = pad_h; g.pw = pad_w; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
   g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
-  g.bf16 = math;
+  g.bf16 = kHalf ? 1 : math;
   {
-    const long long xb = 4ll * N * H * W * Cin, yb = 4ll * N * Ho * Wo * ldy;
+    const long long xb = (long long)sizeof(st_t) * N * H * W * Cin, yb = (long long)sizeof(st_t) * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
       return dspn::fail(DSPN_ERR_ARG_, "conv2d_wgrad: tensors of 2 GiB or more are not supported");
     g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)yb;
@@ -1525,8 +1693,15 @@ static int conv2d_wgrad_one(int math, const float *x, InAffine tf, const float *
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
-  const size_t lds = sizeof(float) * std::max(2 * kBK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
+  const size_t lds = sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
   dspn::ProfScope prof(1, s);
+#ifdef DSPN_HALF
+#define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
+  {                                                                                                      \
+    if (g.in_scale) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                     \
+    else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                               \
+  }
+#else
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
     if (g.in_scale) {                                                                                    \
@@ -1537,6 +1712,7 @@ static int conv2d_wgrad_one(int math, const float *x, InAffine tf, const float *
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, false)                                            \
     }                                                                                                    \
   }
+#endif
 #define DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, BF, TF)                                                     \
   {                                                                                                      \
     auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF, TF>;                                             \
@@ -1564,15 +1740,16 @@ static int conv2d_wgrad_one(int math, const float *x, InAffine tf, const float *
   return dspn::check_launch("conv_wgrad_reduce");
 }
 
-int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
-                             const float *dy, float *dw, int N, int H, int W, int Cin,
+int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
+                             const st_t *dy, float *dw, int N, int H, int W, int Cin,
                              int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                              int Wo, int accumulate, int math, void *workspace, size_t workspace_bytes,
                              void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
   DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
-  const int nb = std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy));
+  const int nb = std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
+                          batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
     const int rc = conv2d_wgrad_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
@@ -1584,6 +1761,7 @@ int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float 
   return 0;
 }
 
+#ifndef DSPN_HALF
 /* number of split-K slabs ([splits][Cout][R*S*Cin] floats) the weight gradient of this geometry produces */
 int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, int S, int stride) {
   const long long P = (long long)N * Ho * Wo;
@@ -1591,22 +1769,25 @@ int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, in
   if (P <= 0 || J <= 0 || Cout <= 0) return 0;
   return wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0).splits;
 }
+#endif
 
 /* the weight-gradient GEMM alone: the split-K partial sums stay in `slabs` (dspn_conv2d_wgrad_splits() x Cout x
  * R*S*Cin floats) for a later dspn_conv2d_slab_reduce_batch_f32 */
-int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
-                                const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
+int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
+                                const st_t *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                                 int Wo, int math, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
   DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
-  DSPN_REQUIRE(std::min(batch_chunk(N, 4ll * H * W * Cin), batch_chunk(N, 4ll * Ho * Wo * ldy)) == N,
+  DSPN_REQUIRE(std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
+                        batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");
   return conv2d_wgrad_one(math, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
                           pad_h, pad_w, dil, Ho, Wo, 0, slabs, slabs_bytes, stream);
 }
 
+#ifndef DSPN_HALF
 /* table: n rows of 40 bytes in DEVICE memory, { const float *slabs; float *dw; int64 n4 (= Cout*R*S*Cin/4);
  * int32 splits, accumulate; int64 begin (= sum of n4 over the preceding rows) }; total4 = sum of n4 */
 int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream) {
@@ -1626,5 +1807,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
   return dspn_conv2d_wgrad_bn_f32(x, nullptr, nullptr, 0, dy, dw, N, H, W, Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil,
                                   Ho, Wo, accumulate, DSPN_MATH_FP32, workspace, workspace_bytes, stream);
 }
+
+#endif
 
 }  // extern "C"

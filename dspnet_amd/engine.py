@@ -192,7 +192,7 @@ class Graph:
             p.data = self.arena[p.offset:p.offset + p.size].view(p.shape)
             p.grad = self.grad_arena[p.offset:p.offset + p.size].view(p.shape)
         if self._wt_pairs_nodes and self.device.type == "cuda":
-            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt) for n in self._wt_pairs_nodes], self.device)
+            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, None) for n in self._wt_pairs_nodes], self.device)
         if self.device.type == "cuda":
             # every Conv keeps the split-K partial sums of its weight gradient in a buffer of its own, so that the
             # slab sums of many layers run as one launch (flush_slabs) instead of one small kernel per layer

@@ -93,8 +93,26 @@ _lib.register({
 })
 
 
+# the bfloat16-tensor twins (include/dspn_nn.h): same argument lists as the *_f32 entries
+for _name in ("dspn_conv2d_forward_bn", "dspn_conv2d_dgrad_bn", "dspn_conv2d_wgrad_bn", "dspn_conv2d_wgrad_slabs",
+              "dspn_conv2d_input_sum_grad"):
+    _lib.register({_name + "_bf16": _lib.SIGNATURES[_name + "_f32"]})
+_lib.register({
+    "dspn_conv2d_weight_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_prepare_batch_bf16": (_i, [_vp, _i, _ll, _vp]),
+})
+
+
 def L():
     return _lib.lib()
+
+
+def _f(name, t):
+    """the entry point of `name` for the storage type of activation tensor t (float32 -> *_f32, bfloat16 -> *_bf16)"""
+    if t.dtype == torch.bfloat16:
+        return getattr(L(), name + "_bf16")
+    assert t.dtype == torch.float32, t.dtype
+    return getattr(L(), name + "_f32")
 
 
 def stream():
@@ -130,12 +148,39 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
-def empty(*shape, device=None):
-    return torch.empty(shape, dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+# Storage type of ACTIVATION tensors (and of the convolution operands): torch.float32, or torch.bfloat16 for the
+# `*_bf16` kernels.  Parameters, statistics, losses and optimizer state are always float32.  A graph is built under one
+# setting (set_activation_dtype before get_multi_symbol_train); every wrapper below picks the kernel from the dtype of
+# the tensors it is handed.
+ACT_DTYPE = torch.float32
 
 
-def zeros(*shape, device=None):
-    return torch.zeros(shape, dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+def set_activation_dtype(dtype):
+    """"fp32" / torch.float32 or "bf16" / torch.bfloat16 for the activation tensors of graphs built from now on"""
+    global ACT_DTYPE
+    ACT_DTYPE = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}.get(dtype, dtype)
+    assert ACT_DTYPE in (torch.float32, torch.bfloat16)
+
+
+def padc(c, dtype=None):
+    """physical channel count of an activation tensor: a 16-byte chunk of channels (4 floats / 8 bf16)"""
+    return (c + 7) // 8 * 8 if (dtype or ACT_DTYPE) == torch.bfloat16 else pad4(c)
+
+
+def empty(*shape, device=None, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def zeros(*shape, device=None, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def act_zeros(*shape, device=None):
+    return zeros(*shape, device=device, dtype=ACT_DTYPE)
+
+
+def act_empty(*shape, device=None):
+    return empty(*shape, device=device, dtype=ACT_DTYPE)
 
 
 # ------------------------------------------------------------------ convolution
@@ -178,48 +223,65 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     ph, pw = _hw(pad)
     Ho, Wo = conv_out_size(H, R, stride, ph, dil), conv_out_size(W, S, stride, pw, dil)
     if out is None:
-        ldc = pad4(Cout)
-        out = zeros(N, Ho, Wo, ldc, device=x.device) if ldc != Cout else empty(N, Ho, Wo, ldc, device=x.device)
+        ldc = padc(Cout, x.dtype)
+        out = (zeros if ldc != Cout else empty)(N, Ho, Wo, ldc, device=x.device, dtype=x.dtype)
     ldc = out.shape[3]
+    assert w.dtype == x.dtype == out.dtype, (x.dtype, w.dtype, out.dtype)
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
-    assert residual is None or residual.shape == out.shape
+    assert residual is None or (residual.shape == out.shape and residual.dtype == out.dtype)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
-    check(L().dspn_conv2d_forward_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
+    check(_f("dspn_conv2d_forward_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
                                          _MATH, ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
 
 
-def weight_transpose_table(pairs, device):
-    """pairs: [(w [Cout,R,S,Cin], wt [Cin,R,S,Kp])] -> (device table, rows, total elements) for weight_transpose_batch"""
+def weight_transpose_table(triples, device):
+    """triples: [(w float32 [Cout,R,S,Cin], wt [Cin,R,S,Kp], wh or None)] -> (device table, rows, total elements, bf16?)
+    for weight_transpose_batch.  float32 operands: wt float32, wh None.  bfloat16 operands: wt bfloat16 and wh = the
+    bfloat16 copy of w itself (the forward operand), both refreshed from the float32 master by the one launch."""
     import numpy as np
-    rows = np.zeros(len(pairs), dtype=[("w", "<u8"), ("wt", "<u8"), ("K", "<i4"), ("T", "<i4"), ("C", "<i4"),
-                                       ("Kp", "<i4"), ("begin", "<i8")])
+    rows = np.zeros(len(triples), dtype=[("w", "<u8"), ("wt", "<u8"), ("K", "<i4"), ("T", "<i4"), ("C", "<i4"),
+                                         ("Kp", "<i4"), ("begin", "<i8"), ("wh", "<u8")])
     total = 0
-    for i, (w, wt) in enumerate(pairs):
+    half = triples[0][1].dtype == torch.bfloat16
+    for i, (w, wt, wh) in enumerate(triples):
         Cout, R, S, Cin = w.shape
-        assert wt.shape[:3] == (Cin, R, S) and w.is_contiguous() and wt.is_contiguous()
-        rows[i] = (w.data_ptr(), wt.data_ptr(), Cout, R * S, Cin, wt.shape[3], total)
+        assert w.dtype == torch.float32 and wt.shape[:3] == (Cin, R, S) and w.is_contiguous() and wt.is_contiguous()
+        assert (wt.dtype == torch.bfloat16) == half and (wh is None or (half and wh.shape == w.shape))
+        rows[i] = (w.data_ptr(), wt.data_ptr(), Cout, R * S, Cin, wt.shape[3], total, 0 if wh is None else wh.data_ptr())
         total += wt.numel()
-    assert rows.dtype.itemsize == 40
+    assert rows.dtype.itemsize == 48
     table = torch.from_numpy(rows.view(np.uint8).copy()).to(device)
-    return table, len(pairs), total
+    return table, len(triples), total, half
 
 
-def weight_transpose_batch(table, n, total):
-    check(L().dspn_conv2d_weight_transpose_batch_f32(ptr(table), n, total, stream()), "weight_transpose_batch")
+def weight_transpose_batch(table, n, total, half=False):
+    f = L().dspn_conv2d_weight_prepare_batch_bf16 if half else L().dspn_conv2d_weight_transpose_batch_f32
+    check(f(ptr(table), n, total, stream()), "weight_transpose_batch")
 
 
-def weight_transpose(w, out=None):
-    """[Cout,R,S,Cin] -> [Cin,R,S,pad4(Cout)] (zero padded), the operand of conv2d_dgrad"""
+def weight_transpose(w, out=None, dtype=None, copy=None):
+    """float32 master [Cout,R,S,Cin] -> [Cin,R,S,padc(Cout)] (zero padded), the operand of conv2d_dgrad, in `dtype`
+    (default: out's, else float32); bfloat16: `copy` (optional, w's shape) also receives the bf16 copy of w itself"""
     Cout, R, S, Cin = w.shape
-    Kp = pad4(Cout)
+    dtype = out.dtype if out is not None else (dtype or torch.float32)
+    Kp = padc(Cout, dtype) if out is None else out.shape[3]
     if out is None:
-        out = empty(Cin, R, S, Kp, device=w.device)
-    check(L().dspn_conv2d_weight_transpose_f32(ptr(w), ptr(out), Cout, R * S, Cin, Kp, stream()),
-          "weight_transpose")
+        out = empty(Cin, R, S, Kp, device=w.device, dtype=dtype)
+    if dtype == torch.bfloat16:
+        check(L().dspn_conv2d_weight_prepare_bf16(ptr(w), ptr(copy), ptr(out), Cout, R * S, Cin, Kp, stream()),
+              "weight_prepare")
+    else:
+        check(L().dspn_conv2d_weight_transpose_f32(ptr(w), ptr(out), Cout, R * S, Cin, Kp, stream()),
+              "weight_transpose")
     return out
+
+
+def weight_cast(w):
+    """bf16 operand copy of a float32 master weight (one-off helper for tests / small graphs)"""
+    return w.to(torch.bfloat16)
 
 
 def conv_dgrad_bn_tiles(x_shape, stride):
@@ -236,11 +298,12 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     assert dy.shape[3] == ldy, (dy.shape, wt.shape)
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
-        out = zeros(N, H, W, Cx, device=dy.device) if Cx != Cin else empty(N, H, W, Cx, device=dy.device)
+        out = (zeros if Cx != Cin else empty)(N, H, W, Cx, device=dy.device, dtype=dy.dtype)
+    assert wt.dtype == dy.dtype == out.dtype, (dy.dtype, wt.dtype, out.dtype)
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
     ph, pw = _hw(pad)
     bx, bsc, bsh, bmu, brs, brelu, bsums = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False, None)
-    check(L().dspn_conv2d_dgrad_bn_f32(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
+    check(_f("dspn_conv2d_dgrad_bn", dy)(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
                                        Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
                                        ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
                                        _MATH, ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
@@ -259,7 +322,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     ws = workspace(nbytes, x.device, "wgrad")
     ph, pw = _hw(pad)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
-    check(L().dspn_conv2d_wgrad_bn_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
+    assert x.dtype == dy.dtype and out.dtype == torch.float32
+    check(_f("dspn_conv2d_wgrad_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
                                        R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), _MATH, ptr(ws), ws.numel(),
                                        stream()), "conv2d_wgrad")
     return out
@@ -296,7 +360,8 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     assert Cw == Cin
     ph, pw = _hw(pad)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
-    check(L().dspn_conv2d_wgrad_slabs_f32(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
+    assert x.dtype == dy.dtype and slabs.dtype == torch.float32
+    check(_f("dspn_conv2d_wgrad_slabs", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
                                           dy.shape[2], _MATH, stream()), "conv2d_wgrad_slabs")
 
@@ -327,7 +392,7 @@ def conv2d_input_sum_grad(dy, w, x_shape, stride=1, pad=0, dil=1, out=None):
     out = empty(Cin, device=dy.device) if out is None else out
     ws = workspace(L().dspn_conv2d_input_sum_grad_workspace_bytes(Ho, Wo, ldy, R, S), dy.device, "sumgrad")
     ph, pw = _hw(pad)
-    check(L().dspn_conv2d_input_sum_grad_f32(ptr(dy), ptr(w), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride,
+    check(_f("dspn_conv2d_input_sum_grad", dy)(ptr(dy), ptr(w), ptr(out), N, H, W, Cin, Cout, ldy, R, S, stride,
                                              ph, pw, dil, Ho, Wo, ptr(ws), ws.numel(), stream()),
           "conv2d_input_sum_grad")
     return out

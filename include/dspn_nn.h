@@ -78,8 +78,8 @@ int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
                                      int Cout_pad, void *stream);
-/* every weight transpose of a training step in one launch.  table: n rows of 40 bytes in DEVICE memory,
- * { const float *w; float *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin } where begin = the sum of
+/* every weight transpose of a training step in one launch.  table: n rows of 48 bytes in DEVICE memory,
+ * { const float *w; float *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin; void *reserved (NULL) } where begin = the sum of
  * Cin*taps*Cout_pad over the preceding rows (rows sorted by begin); total_elements = that sum over all rows. */
 int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_elements, void *stream);
 
@@ -137,6 +137,49 @@ int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const flo
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                                 int Wo, int math, void *stream);
 int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream);
+
+/* ---- bfloat16 TENSORS in HBM: the `*_bf16` twins (BASELINE.json configs[3] "bf16 MFMA convs" with the operands stored
+ * as they are multiplied).  Same arguments and semantics as the `*_f32` entry of the same name, with every ACTIVATION
+ * pointer (x, y, dy, dx, residual, bn_x) and the convolution weight operands (w, wt) pointing at bfloat16 elements
+ * (dspn_bf16 = the raw 16 bits); physical channel counts are multiples of 8 for convolution operands (16-byte chunks), of
+ * 4 elsewhere.  Arithmetic is fp32 throughout: elements are widened on load, results rounded to nearest even on store;
+ * BatchNorm statistics gathered in a convolution epilogue are those of the ROUNDED values.  Parameters, per-channel
+ * vectors (scale / shift / bias / statistics), split-K slabs, weight GRADIENTS and workspaces stay float.  The float
+ * master weights are turned into the bf16 operands by dspn_conv2d_weight_prepare_bf16 (one batched launch per step).
+ * `math` is accepted for symmetry and ignored (always bf16 MFMA, fp32 accumulate). */
+typedef unsigned short dspn_bf16;
+int dspn_conv2d_forward_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
+                                const dspn_bf16 *w, const float *bias, const dspn_bf16 *residual, dspn_bf16 *y,
+                                int N, int H, int W, int Cin, int Cout, int R, int S,
+                                int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
+                                long long y_batch_stride, int y_ldc, int relu, int accumulate,
+                                float *out_stats, size_t out_stats_bytes, int math,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int dspn_conv2d_dgrad_bn_bf16(const dspn_bf16 *dy, const dspn_bf16 *wt, dspn_bf16 *dx, int N, int H, int W, int Cin,
+                              int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
+                              int dx_ldc, int accumulate, const dspn_bf16 *bn_x, const float *bn_scale,
+                              const float *bn_shift, const float *bn_mean, const float *bn_rstd, int bn_relu,
+                              float *bn_sums, size_t bn_sums_bytes, int math, void *workspace, size_t workspace_bytes,
+                              void *stream);
+int dspn_conv2d_wgrad_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
+                              const dspn_bf16 *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
+                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
+                              int accumulate, int math, void *workspace, size_t workspace_bytes, void *stream);
+int dspn_conv2d_wgrad_slabs_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
+                                 const dspn_bf16 *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
+                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
+                                 int Wo, int math, void *stream);
+int dspn_conv2d_input_sum_grad_bf16(const dspn_bf16 *dy, const float *w, float *out, int N, int H, int W,
+                                    int Cin, int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil,
+                                    int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream);
+/* bf16 operands of a float master weight w [Cout][taps][Cin]: wt [Cin][taps][Cout_pad] (zero padded, Cout_pad % 8 == 0;
+ * the data-gradient operand) and, when wh != NULL, the copy wh [Cout][taps][Cin] (the forward operand).  Batch form:
+ * table of n 48-byte rows in DEVICE memory { const float *w; dspn_bf16 *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin;
+ * dspn_bf16 *wh } with begin = the sum of Cin*taps*Cout_pad over the preceding rows.  (dspn_conv2d_weight_transpose_
+ * batch_f32 reads the same 48-byte rows with wh = NULL.) */
+int dspn_conv2d_weight_prepare_bf16(const float *w, dspn_bf16 *wh, dspn_bf16 *wt, int Cout, int taps, int Cin,
+                                    int Cout_pad, void *stream);
+int dspn_conv2d_weight_prepare_batch_bf16(const void *table, int n, long long total_elements, void *stream);
 
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
  * symbol/resnet.py:30-41,91,96; multitask_symbol_builder.py:545-585) ------------------ */

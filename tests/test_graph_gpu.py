@@ -242,18 +242,25 @@ def test_full_size_gradients_elementwise_with_pinned_decisions(gpu_device, netwo
     for n, v in zip(*m.get()):
         assert abs(v - ref[n]) <= 1e-4 * abs(ref[n]), (n, v, ref[n])
     ref["objective"].backward()
-    worst = {}
+    grads = {}
     for p in net.g.param_order:
         if p.name == "affine_matrix":
             continue
         gref = ot.import_grad(p.name, ref["params"][p.name].grad)
         gdev = p.grad.cpu().numpy()
         gdev = gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]]
-        worst[p.name] = rel(gdev, gref)
+        grads[p.name] = (gdev, gref)
+    # A gradient that is ZERO in exact arithmetic is rounding noise on both sides and has no relative error: bn0_gamma in
+    # the resnet graph (bn0_beta = 0 at initialisation, so ReLU and max-pool commute with the per-channel scale and the
+    # BatchNorm of stage1_unit1 removes it again).  Absolute floor: 1e-6 of the largest gradient entry of the whole model.
+    gmax = max(float(np.abs(r).max()) for _, r in grads.values())
+    worst = {k: float(np.abs(d - r).max()) / (float(np.abs(r).max()) + 1e-30) for k, (d, r) in grads.items()}
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
-    print("%s %dx%d bs %d, decisions pinned: worst gradient tensors" % (network, size, size, batch), top)
-    for name, e in worst.items():
-        assert e < 1e-3, (name, e)
+    print("%s %dx%d bs %d, decisions pinned: worst gradient tensors" % (network, size, size, batch), top,
+          "| largest gradient entry %.3e" % gmax,
+          {k: float(np.abs(grads[k][1]).max()) for k, _ in top})
+    for name, (d, r) in grads.items():
+        assert float(np.abs(d - r).max()) <= 1e-3 * float(np.abs(r).max()) + 1e-6 * gmax, (name, worst[name])
 
 
 def test_second_step_with_moved_affine_matrix_matches_cpu_restatement(gpu_device):
