@@ -44,6 +44,9 @@ def parse():
                          "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16"],
                     help="conv MFMA math: exact fp32 (default) or bf16 inputs with fp32 accumulate")
+    ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],
+                    help="storage type of activation tensors and convolution operands in HBM: float32 (default) or "
+                         "bfloat16 (the *_bf16 kernels: bf16 MFMA, fp32 accumulate, fp32 master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -327,8 +330,12 @@ def main():
     B, S = args.batch, args.size
     Wd = args.width or S
     from dspnet_amd import functional as fn
+    if args.store == "bf16":
+        args.math = "bf16"
     fn.set_conv_math(args.math)
+    fn.set_activation_dtype(args.store)
     net = get_multi_symbol_train(args.network, (3, S, Wd), num_classes=8, batch_size=B, device=dev, seed=0)
+    fn.set_activation_dtype("fp32")
     solver = MultiTaskSolver(net, process_group=None, world_size=world, force_reducer=use_dist)
     gen = synthetic.rng(233 + rank)
     solver.set_batch(torch.from_numpy(synthetic.images(B, S, Wd, gen)).to(dev),
@@ -410,7 +417,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "%s multitask (det+depth+seg) %dx%d, 8 det classes, 19 seg classes, "
-                                   "N=%d anchors, forward+backward+SGD" % (args.network, S, Wd, net.anchors.shape[1]),
+                                   "N=%d anchors, forward+backward+SGD%s" % (args.network, S, Wd, net.anchors.shape[1],
+                                                                            ", bf16 tensors in HBM" if args.store == "bf16" else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
                        "train_gflop_per_image_3x_convention": round(flops_3x / B / 1e9, 2),
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},

@@ -10,6 +10,7 @@
 // serves both storage types.
 #pragma once
 #include <hip/hip_runtime.h>
+#define DSPN_BF16_ELEMENT __bf16   /* include/dspn_nn.h: dspn_bf16 is this type inside the library */
 
 namespace dspn {
 

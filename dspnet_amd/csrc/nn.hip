@@ -8,7 +8,17 @@
 // in a caller workspace, then a fixed-order finalize in double), never float
 // atomics, so every result is bitwise reproducible run to run.
 #include "dspn_common.h"
+#include "dspn_store.h"
 #include "../../include/dspn_nn.h"
+
+// Compiled twice (dspn_store.h): float activations -> `*_f32`, and through nn_h.hip with DSPN_HALF -> bfloat16
+// activations -> `*_bf16` (element proxies CA4Ptr / A4Ptr / CA1Ptr / A1Ptr widen on load and round on store; all
+// arithmetic and every reduction stays fp32 / double).  Entry points that never touch an activation tensor exist once.
+using dspn::st_t;
+using dspn::A1Ptr;
+using dspn::A4Ptr;
+using dspn::CA1Ptr;
+using dspn::CA4Ptr;
 
 #pragma clang fp contract(fast)
 
@@ -28,7 +38,7 @@ inline int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64
 
 // ------------------------------------------------------------------ BN statistics
 // partial[slab][0][c] = sum (x - K[c]), partial[slab][1][c] = sum (x - K[c])^2, K = row 0
-__global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__restrict__ x,
+__global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const CA4Ptr x,
                                                               long long rows, int C4, int CL,
                                                               float *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float4 *__re
 
 // 64 channels x 16 slab-lanes per block; also folds gamma/beta into scale/shift for the apply pass
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(
-    const float *__restrict__ x, const float *__restrict__ partial, int nslabs, long long rows, int C,
+    const CA1Ptr x, const float *__restrict__ partial, int nslabs, long long rows, int C,
     float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ scale,
     float *__restrict__ shift) {
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict
   }
 }
 
-__global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
-                                const float4 *__restrict__ shift, float4 *__restrict__ y,
+__global__ void bn_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
+                                const float4 *__restrict__ shift, const A4Ptr y,
                                 long long n4, int C4, int relu) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
@@ -201,8 +211,8 @@ __global__ void bn_apply_kernel(const float4 *__restrict__ x, const float4 *__re
 // The ReLU mask is recomputed as (x*scale + shift > 0) -- the very fma of the forward apply pass --
 // so the forward output is never re-read.
 __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
-    const float4 *__restrict__ x, const float4 *__restrict__ scale, const float4 *__restrict__ shift,
-    const float4 *__restrict__ dy, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const CA4Ptr x, const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+    const CA4Ptr dy, const float *__restrict__ mean, const float *__restrict__ rstd,
     long long rows, int C4, int CL, int relu, float *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
@@ -275,9 +285,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
   }
 }
 
-__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
-                                    const float4 *__restrict__ shift, const float4 *__restrict__ dy,
-                                    const float4 *__restrict__ coef, float4 *__restrict__ dx,
+__global__ void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
+                                    const float4 *__restrict__ shift, const CA4Ptr dy,
+                                    const float4 *__restrict__ coef, const A4Ptr dx,
                                     long long n4, int C4, int relu, int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
@@ -298,20 +308,18 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *
 }
 
 // ------------------------------------------------------------------ element-wise
-__global__ void add_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
-                           float4 *__restrict__ o, long long n4) {
+__global__ void add_kernel(const CA4Ptr a, const CA4Ptr b, const A4Ptr o, long long n4) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     const float4 x = a[i], y = b[i];
     o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
   }
 }
-__global__ void add_tail_kernel(const float *a, const float *b, float *o, long long start, long long n) {
+__global__ void add_tail_kernel(const CA1Ptr a, const CA1Ptr b, const A1Ptr o, long long start, long long n) {
   const long long i = start + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] + b[i];
 }
-__global__ void relu_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
-                                float *__restrict__ dx, long long n, int accumulate) {
+__global__ void relu_bwd_kernel(const CA1Ptr y, const CA1Ptr dy, const A1Ptr dx, long long n, int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float v = y[i] > 0.f ? dy[i] : 0.f;
@@ -319,14 +327,16 @@ __global__ void relu_bwd_kernel(const float *__restrict__ y, const float *__rest
     dx[i] = v;
   }
 }
+#ifndef DSPN_HALF
 __global__ void fill_kernel(float *p, float v, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
     p[i] = v;
 }
+#endif
 
 // column sums, two stage
-__global__ __launch_bounds__(kT) void colsum_partial_kernel(const float *__restrict__ a,
+__global__ __launch_bounds__(kT) void colsum_partial_kernel(const CA1Ptr a,
                                                             long long rows, int C, int ld,
                                                             float *__restrict__ partial, int slab_rows) {
   __shared__ float sm[kT];
@@ -350,9 +360,9 @@ __global__ __launch_bounds__(kT) void colsum_partial_kernel(const float *__restr
 // dx = (y > 0) ? dy : 0 in place of a separate ReLU-backward pass, AND the per-slab column sums of dx (the bias
 // gradient of a convolution with a fused ReLU epilogue): one read of y and dy instead of three passes.
 // Layout: rows x ld floats, channels [0, C) summed; ld % 4 == 0; blocks of 256 threads = CL channel quads x RL rows.
-__global__ __launch_bounds__(kT) void relu_bwd_colsum_partial_kernel(const float4 *__restrict__ y,
-                                                                   const float4 *__restrict__ dy,
-                                                                   float4 *__restrict__ dx, long long rows, int ld4,
+__global__ __launch_bounds__(kT) void relu_bwd_colsum_partial_kernel(const CA4Ptr y,
+                                                                   const CA4Ptr dy,
+                                                                   const A4Ptr dx, long long rows, int ld4,
                                                                    int CL, float *__restrict__ partial, int C,
                                                                    int slab_rows) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float *partial
   }
 }
 
-__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, const A1Ptr dst,
                                     int C, long long HW, long long total_pix, int Cp) {
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total_pix;
        p += (long long)gridDim.x * blockDim.x) {
@@ -412,6 +422,7 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__rest
       dst[p * Cp + c] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
   }
 }
+#ifndef DSPN_HALF
 __global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                     int C, long long HW, long long total, int Cp) {
   // thread per dst element, hw fastest
@@ -422,7 +433,11 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__rest
     dst[i] = src[(n * HW + hw) * Cp + c];
   }
 }
-__global__ void copy_block_kernel(const float *__restrict__ src, float *__restrict__ dst,
+#endif
+// SRC / DST: element pointers of either storage type (the SSD head packing converts bf16 maps into the float
+// (B, N*5) / (B, N*(C+1)) tensors the losses and the multibox operators read, and their gradients back)
+template <typename SRC, typename DST>
+__global__ void copy_block_kernel(const SRC src, const DST dst,
                                   long long rows_per_sample, int C, long long sss, int lds, int soff,
                                   long long dss, int ldd, int doff, long long total, int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -431,10 +446,12 @@ __global__ void copy_block_kernel(const float *__restrict__ src, float *__restri
     const long long r = i / C;
     const long long s = r / rows_per_sample, rr = r - s * rows_per_sample;
     const float v = src[s * sss + rr * lds + soff + c];
-    float *d = dst + s * dss + rr * ldd + doff + c;
-    *d = accumulate ? *d + v : v;
+    const long long di = s * dss + rr * ldd + doff + c;
+    const float old = accumulate ? (float)dst[di] : 0.f;
+    dst[di] = old + v;
   }
 }
+#ifndef DSPN_HALF
 __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                      int N, int C, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -446,6 +463,7 @@ __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__res
     dst[i] = src[(b * N + n) * C + c];
   }
 }
+#endif
 
 
 // ------------------------------------------------------------------ tap-expanded convolution
@@ -455,7 +473,7 @@ __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__res
 // shifted sum over taps; the backward pass spreads dy into the same (co, tap) channel layout and runs
 // the 1x1 weight-gradient on it.
 //   y[n,h,w,co] = bias[co] + sum_{r,s} z[n, h + r - ph, w + s - pw, co*R*S + r*S + s]
-__global__ void tap_sum_kernel_(const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ y,
+__global__ void tap_sum_kernel_(const CA1Ptr z, const float *__restrict__ bias, const A1Ptr y,
                                 int H, int W, int Cout, int ldy, int ldz, int R, int S, int ph, int pw,
                                 long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -482,7 +500,7 @@ __global__ void tap_sum_kernel_(const float *__restrict__ z, const float *__rest
   }
 }
 //   dz[n,h,w,co*R*S + r*S + s] = dy[n, h - (r - ph), w - (s - pw), co]   (0 outside / in pad channels)
-__global__ void tap_spread_kernel_(const float *__restrict__ dy, float *__restrict__ dz, int H, int W, int Cout,
+__global__ void tap_spread_kernel_(const CA1Ptr dy, const A1Ptr dz, int H, int W, int Cout,
                                    int ldy, int ldz, int R, int S, int ph, int pw, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -506,7 +524,7 @@ __global__ void tap_spread_kernel_(const float *__restrict__ dy, float *__restri
 // optional argmax record: position r*k+s of the FIRST maximum of each window in (h, w) scan order, one
 // byte per element (255 = no finite maximum); the backward pass then needs neither x nor y
 template <bool IDX>
-__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+__global__ void maxpool_fwd_kernel(const CA4Ptr x, const A4Ptr y,
                                    uchar4 *__restrict__ argmax, int H, int W,
                                    int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -539,8 +557,8 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
 
 // gather form over the argmax record: every input pixel visits the (at most ceil(k/stride)^2) windows
 // covering it in a fixed order and takes dy where the record names its position.  No atomics.
-__global__ void maxpool_bwd_idx_kernel(const uchar4 *__restrict__ argmax, const float4 *__restrict__ dy,
-                                       float4 *__restrict__ dx, int H, int W, int C4, int k, int stride,
+__global__ void maxpool_bwd_idx_kernel(const uchar4 *__restrict__ argmax, const CA4Ptr dy,
+                                       const A4Ptr dx, int H, int W, int C4, int k, int stride,
                                        int pad, int Ho, int Wo, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -568,8 +586,8 @@ __global__ void maxpool_bwd_idx_kernel(const uchar4 *__restrict__ argmax, const 
 
 // gather form: for every input pixel, visit the windows covering it in a fixed order and take
 // dy where this pixel is the FIRST maximum of the window in (h, w) scan order.  4 channels per thread.
-__global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ y,
-                                   const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W,
+__global__ void maxpool_bwd_kernel(const CA4Ptr x, const CA4Ptr y,
+                                   const CA4Ptr dy, const A4Ptr dx, int H, int W,
                                    int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -613,7 +631,7 @@ __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *_
   }
 }
 
-__global__ void avgpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W,
+__global__ void avgpool_fwd_kernel(const CA4Ptr x, const A4Ptr y, int H, int W,
                                    int C4, int k, int Ho, int Wo, long long total) {
   const float inv = 1.f / (float)(k * k);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -632,7 +650,7 @@ __global__ void avgpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
     y[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
   }
 }
-__global__ void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W,
+__global__ void avgpool_bwd_kernel(const CA4Ptr dy, const A4Ptr dx, int H, int W,
                                    int C4, int k, int Ho, int Wo, long long total, int accumulate) {
   const float inv = 1.f / (float)(k * k);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -656,7 +674,7 @@ __global__ void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__rest
 // overlapping average pooling (symbol/inceptionv3.py:31,74,115: 3x3 stride 1 pad 1): the sum over the
 // in-image part of the window divided by k*k -- MXNet counts the padding (mshadow pool over a padded
 // tensor times 1/(ky*kx))
-__global__ void avgpool2d_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4,
+__global__ void avgpool2d_fwd_kernel(const CA4Ptr x, const A4Ptr y, int H, int W, int C4,
                                      int k, int stride, int pad, int Ho, int Wo, long long total) {
   const float inv = 1.f / (float)(k * k);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -681,7 +699,7 @@ __global__ void avgpool2d_fwd_kernel(const float4 *__restrict__ x, float4 *__res
   }
 }
 // gather form: every input pixel sums dy over the windows that contain it, in a fixed order
-__global__ void avgpool2d_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W, int C4,
+__global__ void avgpool2d_bwd_kernel(const CA4Ptr dy, const A4Ptr dx, int H, int W, int C4,
                                      int k, int stride, int pad, int Ho, int Wo, long long total, int accumulate) {
   const float inv = 1.f / (float)(k * k);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -706,6 +724,7 @@ __global__ void avgpool2d_bwd_kernel(const float4 *__restrict__ dy, float4 *__re
   }
 }
 
+#ifndef DSPN_HALF   // plain resize (identity grid) and the evaluation read-outs: float tensors only
 // ------------------------------------------------------------------ bilinear sampler
 // GridGenerator(affine identity, target (Ho,Wo)) + BilinearSampler: normalised target coordinate
 // g = -1 + o*2/(O-1); source coordinate s = (g+1)*(I-1)/2; corners outside [0,I-1] contribute 0.
@@ -949,17 +968,20 @@ __global__ __launch_bounds__(kT) void seg_upsample_argmax_kernel(const float *__
   }
 }
 
+#endif   // !DSPN_HALF
+
 // ------------------------------------------------------------------ losses
+// logits and their gradient are activations (storage type); the probabilities are a float output
 constexpr int kMaxSoftmaxC = 64;
-__global__ void softmax_output_kernel(const float *__restrict__ logits, const float *__restrict__ label,
-                                      float *__restrict__ prob, float *__restrict__ grad, long long rows,
+__global__ void softmax_output_kernel(const CA1Ptr logits, const float *__restrict__ label,
+                                      float *__restrict__ prob, const A1Ptr grad, long long rows,
                                       int C, int ld, float ignore_label, float grad_scale,
                                       const float *__restrict__ valid_count) {
   float scale = grad_scale;
   if (valid_count) scale = grad_scale / fmaxf(1.f, *valid_count);
   for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
        r += (long long)gridDim.x * blockDim.x) {
-    const float *p = logits + r * ld;
+    const CA1Ptr p = logits + r * ld;
     float v[kMaxSoftmaxC];
     float mx = -INFINITY;
 #pragma unroll 4
@@ -978,6 +1000,7 @@ __global__ void softmax_output_kernel(const float *__restrict__ logits, const fl
     }
   }
 }
+#ifndef DSPN_HALF
 __global__ void count_kernel(const float *__restrict__ a, long long n, int mode, float ref, float *out) {
   float c = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
@@ -1057,6 +1080,8 @@ __global__ void sgd_kernel(float4 *__restrict__ w, const float4 *__restrict__ g,
   }
 }
 
+#endif   // !DSPN_HALF
+
 int bn_slabs(long long rows) { return (int)((rows + kSlabRows - 1) / kSlabRows); }
 
 }  // namespace
@@ -1065,39 +1090,46 @@ int bn_slabs(long long rows) { return (int)((rows + kSlabRows - 1) / kSlabRows);
 
 extern "C" {
 
-size_t dspn_bn_workspace_bytes(long long rows, int C) {
+static size_t bn_workspace_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   return sizeof(float) * ((size_t)bn_slabs(rows) * 2 * C + 4 * (size_t)C);
 }
+static size_t bn_tiles_workspace_bytes(int tiles, int C) {
+  if (tiles <= 0 || C <= 0) return 0;
+  return sizeof(float) * 2 * (size_t)((tiles + kTileGroup - 1) / kTileGroup) * C;
+}
+#ifndef DSPN_HALF
+size_t dspn_bn_workspace_bytes(long long rows, int C) { return bn_workspace_bytes(rows, C); }
+#endif
 
-int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const float *gamma,
+int DSPN_FN(dspn_bn_stats)(const st_t *x, long long rows, int C, float eps, const float *gamma,
                       const float *beta, float *mean, float *rstd, float *scale, float *shift,
                       void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && beta && mean && rstd && scale && shift && workspace, "bn_stats: null pointer");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_stats: C must be a positive multiple of 4");
-  if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
+  if (workspace_bytes < bn_workspace_bytes(rows, C))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_stats: workspace too small");
   const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
   float *partial = static_cast<float *>(workspace);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
-                     sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x), rows,
+                     sizeof(float4) * 2 * kT, S_(stream), CA4Ptr(x), rows,
                      C4, CL, partial);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), x, partial,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), CA1Ptr(x), partial,
                      ns, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
   return dspn::check_launch("bn_stats");
 }
 
-size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) {
-  if (tiles <= 0 || C <= 0) return 0;
-  return sizeof(float) * 2 * (size_t)((tiles + kTileGroup - 1) / kTileGroup) * C;
-}
+#ifndef DSPN_HALF
+size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) { return bn_tiles_workspace_bytes(tiles, C); }
+#endif
+#ifndef DSPN_HALF
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
                                  float *shift, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
                "bn_stats_from_tiles: bad argument");
-  if (tiles >= 1024 && workspace && workspace_bytes >= dspn_bn_tiles_workspace_bytes(tiles, C)) {
+  if (tiles >= 1024 && workspace && workspace_bytes >= bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = static_cast<float *>(workspace);
     hipLaunchKernelGGL(tile_group_kernel<0>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_stats, tiles,
@@ -1108,50 +1140,51 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
                      tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
   return dspn::check_launch("bn_stats_from_tiles");
 }
-int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
+#endif
+int DSPN_FN(dspn_bn_apply)(const st_t *x, const float *scale, const float *shift, st_t *y, long long rows,
                       int C, int relu, void *stream) {
   DSPN_REQUIRE(x && scale && shift && y, "bn_apply: null pointer");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_apply: C must be a positive multiple of 4");
   const long long n4 = rows * (C / 4);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
-                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(y), n4, C / 4,
+                     CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), A4Ptr(y), n4, C / 4,
                      relu);
   return dspn::check_launch("bn_apply");
 }
 
-int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift, const float *dy,
-                         const float *mean, const float *rstd, const float *gamma, float *dx,
+int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
+                         const float *mean, const float *rstd, const float *gamma, st_t *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
                          void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace, "bn_backward: null pointer");
   DSPN_REQUIRE(!relu || (scale && shift), "bn_backward: relu needs the forward scale/shift");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward: C must be a positive multiple of 4");
-  if (workspace_bytes < dspn_bn_workspace_bytes(rows, C))
+  if (workspace_bytes < bn_workspace_bytes(rows, C))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward: workspace too small");
   const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
   float *partial = static_cast<float *>(workspace);
   float *coef = partial + (size_t)ns * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
-                     sizeof(float4) * 2 * kT, S_(stream), reinterpret_cast<const float4 *>(x),
+                     sizeof(float4) * 2 * kT, S_(stream), CA4Ptr(x),
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
-                     reinterpret_cast<const float4 *>(dy), mean, rstd, rows, C4, CL, relu, partial);
+                     CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
-                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<const float4 *>(dy),
-                     reinterpret_cast<const float4 *>(coef), reinterpret_cast<float4 *>(dx), n4, C4, relu,
+                     CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
+                     reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
                      accumulate);
   return dspn::check_launch("bn_backward");
 }
 
 // BatchNorm backward whose two reductions (sum dy', sum dy' xhat) were gathered per row tile by the data-gradient
 // kernel that produced dy (bn_sums of dspn_conv2d_dgrad_bn_f32): finalize + apply only
-int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
+int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
-                                   int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
+                                   int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
                                    int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
   DSPN_REQUIRE(!relu || (scale && shift), "bn_backward_from_sums: relu needs the forward scale/shift");
@@ -1160,7 +1193,7 @@ int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const flo
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_from_sums: workspace too small (3*C floats)");
   const int C4 = C / 4;
   float *coef = static_cast<float *>(workspace);
-  if (tiles >= 1024 && workspace_bytes >= sizeof(float) * 3 * (size_t)C + dspn_bn_tiles_workspace_bytes(tiles, C)) {
+  if (tiles >= 1024 && workspace_bytes >= sizeof(float) * 3 * (size_t)C + bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = coef + 3 * (size_t)C;
     hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
@@ -1171,35 +1204,35 @@ int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const flo
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
-                     reinterpret_cast<const float4 *>(shift), reinterpret_cast<const float4 *>(dy),
-                     reinterpret_cast<const float4 *>(coef), reinterpret_cast<float4 *>(dx), n4, C4, relu,
+                     CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
+                     reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
                      accumulate);
   return dspn::check_launch("bn_backward_from_sums");
 }
 
-int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream) {
+int DSPN_FN(dspn_add)(const st_t *a, const st_t *b, st_t *out, long long n, void *stream) {
   DSPN_REQUIRE(a && b && out && n >= 0, "add: bad argument");
   const long long n4 = n / 4;
   if (n4 > 0)
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
-                       reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
-                       reinterpret_cast<float4 *>(out), n4);
+                       CA4Ptr(a), CA4Ptr(b),
+                       A4Ptr(out), n4);
   if (n4 * 4 < n)
-    hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(64), 0, S_(stream), a, b, out, n4 * 4, n);
+    hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(64), 0, S_(stream), CA1Ptr(a), CA1Ptr(b), A1Ptr(out), n4 * 4, n);
   return dspn::check_launch("add");
 }
 
-int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long n, int accumulate,
+int DSPN_FN(dspn_relu_backward)(const st_t *y, const st_t *dy, st_t *dx, long long n, int accumulate,
                            void *stream) {
   DSPN_REQUIRE(y && dy && dx && n >= 0, "relu_backward: bad argument");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), y, dy, dx, n, accumulate);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), CA1Ptr(y), CA1Ptr(dy), A1Ptr(dx), n, accumulate);
   return dspn::check_launch("relu_backward");
 }
 
 /* dx = (y > 0) ? dy : 0 (dx may alias dy) and out[c] = sum over rows of dx[:, c], c < C, in one pass */
-int dspn_relu_backward_colsum_f32(const float *y, const float *dy, float *dx, long long rows, int C, int ld, float *out,
+int DSPN_FN(dspn_relu_backward_colsum)(const st_t *y, const st_t *dy, st_t *dx, long long rows, int C, int ld, float *out,
                                   void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(y && dy && dx && out && workspace && rows > 0 && C > 0 && ld >= C && ld % 4 == 0,
                "relu_backward_colsum: bad argument");
@@ -1210,25 +1243,29 @@ int dspn_relu_backward_colsum_f32(const float *y, const float *dy, float *dx, lo
   const int ld4 = ld / 4, CL = std::min(ld4, 64);
   float *partial = static_cast<float *>(workspace);
   hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(ns, (ld4 + CL - 1) / CL), dim3(kT), sizeof(float4) * kT,
-                     S_(stream), reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy),
-                     reinterpret_cast<float4 *>(dx), rows, ld4, CL, partial, C, sr);
+                     S_(stream), CA4Ptr(y), CA4Ptr(dy),
+                     A4Ptr(dx), rows, ld4, CL, partial, C, sr);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), partial, ns, C, out);
   return dspn::check_launch("relu_backward_colsum");
 }
 
+#ifndef DSPN_HALF
 int dspn_fill_f32(float *p, float v, long long n, void *stream) {
   DSPN_REQUIRE(p && n >= 0, "fill: bad argument");
   if (n == 0) return 0;
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), p, v, n);
   return dspn::check_launch("fill");
 }
+#endif
 
+#ifndef DSPN_HALF
 size_t dspn_colsum_workspace_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   const int sr = colsum_slab_rows(rows);
   return sizeof(float) * (size_t)((rows + sr - 1) / sr) * C;
 }
-int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out, void *workspace,
+#endif
+int DSPN_FN(dspn_colsum)(const st_t *a, long long rows, int C, int ld, float *out, void *workspace,
                     size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(a && out && workspace && rows > 0 && C > 0 && ld >= C, "colsum: bad argument");
   const int sr = colsum_slab_rows(rows);
@@ -1236,134 +1273,163 @@ int dspn_colsum_f32(const float *a, long long rows, int C, int ld, float *out, v
   if (workspace_bytes < sizeof(float) * (size_t)ns * C)
     return dspn::fail(DSPN_ERR_WORKSPACE_, "colsum: workspace too small");
   float *partial = static_cast<float *>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), a, rows, C, ld, partial, sr);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ns), dim3(kT), 0, S_(stream), CA1Ptr(a), rows, C, ld, partial, sr);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), partial, ns, C, out);
   return dspn::check_launch("colsum");
 }
 
-int dspn_nchw_to_nhwc_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream) {
+int DSPN_FN(dspn_nchw_to_nhwc)(const float *src, st_t *dst, int N, int C, int H, int W, int Cp, void *stream) {
   DSPN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad argument");
   const long long HW = (long long)H * W, total = HW * N;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, C, HW, total, Cp);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, A1Ptr(dst), C, HW, total, Cp);
   return dspn::check_launch("nchw_to_nhwc");
 }
+#ifndef DSPN_HALF
 int dspn_nhwc_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream) {
   DSPN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nhwc_to_nchw: bad argument");
   const long long HW = (long long)H * W, total = HW * N * C;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, C, HW, total, Cp);
   return dspn::check_launch("nhwc_to_nchw");
 }
+#endif
 
-int dspn_copy_block_f32(const float *src, float *dst, int samples, long long rows_per_sample, int C,
+int DSPN_FN(dspn_copy_block)(const st_t *src, st_t *dst, int samples, long long rows_per_sample, int C,
                         long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
                         int ldd, int doff, int accumulate, void *stream) {
   DSPN_REQUIRE(src && dst && samples > 0 && rows_per_sample > 0 && C > 0, "copy_block: bad argument");
   const long long total = (long long)samples * rows_per_sample * C;
-  hipLaunchKernelGGL(copy_block_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst,
-                     rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff,
+  hipLaunchKernelGGL((copy_block_kernel<CA1Ptr, A1Ptr>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), CA1Ptr(src),
+                     A1Ptr(dst), rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff,
                      total, accumulate);
   return dspn::check_launch("copy_block");
 }
+#ifdef DSPN_HALF
+/* the same strided block copy between storage types: bf16 -> float (SSD head maps into the float loss inputs) and
+ * float -> bf16 (their gradients back into the per-map gradient tensors) */
+int dspn_copy_block_bf16_f32(const st_t *src, float *dst, int samples, long long rows_per_sample, int C,
+                             long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
+                             int ldd, int doff, int accumulate, void *stream) {
+  DSPN_REQUIRE(src && dst && samples > 0 && rows_per_sample > 0 && C > 0, "copy_block: bad argument");
+  const long long total = (long long)samples * rows_per_sample * C;
+  hipLaunchKernelGGL((copy_block_kernel<CA1Ptr, float *>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), CA1Ptr(src),
+                     dst, rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff, total,
+                     accumulate);
+  return dspn::check_launch("copy_block");
+}
+int dspn_copy_block_f32_bf16(const float *src, st_t *dst, int samples, long long rows_per_sample, int C,
+                             long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
+                             int ldd, int doff, int accumulate, void *stream) {
+  DSPN_REQUIRE(src && dst && samples > 0 && rows_per_sample > 0 && C > 0, "copy_block: bad argument");
+  const long long total = (long long)samples * rows_per_sample * C;
+  hipLaunchKernelGGL((copy_block_kernel<const float *, A1Ptr>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), src,
+                     A1Ptr(dst), rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff, total,
+                     accumulate);
+  return dspn::check_launch("copy_block");
+}
+#endif
 
+#ifndef DSPN_HALF
 int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, void *stream) {
   DSPN_REQUIRE(src && dst && B > 0 && N > 0 && C > 0, "transpose_bnc: bad argument");
   const long long total = (long long)B * N * C;
   hipLaunchKernelGGL(transpose_bnc_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream), src, dst, N, C, total);
   return dspn::check_launch("transpose_bnc");
 }
+#endif
 
-int dspn_tap_sum_f32(const float *z, const float *bias, float *y, int N, int H, int W, int Cout, int ldy,
+int DSPN_FN(dspn_tap_sum)(const st_t *z, const float *bias, st_t *y, int N, int H, int W, int Cout, int ldy,
                      int ldz, int R, int S, int pad_h, int pad_w, void *stream) {
   DSPN_REQUIRE(z && y && N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldz >= Cout * R * S,
                "tap_sum: bad argument");
   const long long total = (long long)N * H * W * ldy;
-  hipLaunchKernelGGL(tap_sum_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), z, bias, y, H, W,
+  hipLaunchKernelGGL(tap_sum_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), CA1Ptr(z), bias, A1Ptr(y), H, W,
                      Cout, ldy, ldz, R, S, pad_h, pad_w, total);
   return dspn::check_launch("tap_sum");
 }
-int dspn_tap_spread_f32(const float *dy, float *dz, int N, int H, int W, int Cout, int ldy, int ldz, int R,
+int DSPN_FN(dspn_tap_spread)(const st_t *dy, st_t *dz, int N, int H, int W, int Cout, int ldy, int ldz, int R,
                         int S, int pad_h, int pad_w, void *stream) {
   DSPN_REQUIRE(dy && dz && N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldz >= Cout * R * S,
                "tap_spread: bad argument");
   const long long total = (long long)N * H * W * ldz;
-  hipLaunchKernelGGL(tap_spread_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), dy, dz, H, W,
+  hipLaunchKernelGGL(tap_spread_kernel_, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream), CA1Ptr(dy), A1Ptr(dz), H, W,
                      Cout, ldy, ldz, R, S, pad_h, pad_w, total);
   return dspn::check_launch("tap_spread");
 }
-int dspn_maxpool_forward_f32(const float *x, float *y, unsigned char *argmax, int N, int H, int W, int C, int k,
+int DSPN_FN(dspn_maxpool_forward)(const st_t *x, st_t *y, unsigned char *argmax, int N, int H, int W, int C, int k,
                              int stride, int pad, int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && N > 0, "maxpool_forward: bad argument");
   DSPN_REQUIRE(!argmax || k * k < 255, "maxpool_forward: argmax record needs k*k < 255");
   const long long total = (long long)N * Ho * Wo * (C / 4);
   if (argmax)
     hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       CA4Ptr(x), A4Ptr(y),
                        reinterpret_cast<uchar4 *>(argmax), H, W, C / 4, k, stride, pad, Ho, Wo, total);
   else
     hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       CA4Ptr(x), A4Ptr(y),
                        static_cast<uchar4 *>(nullptr), H, W, C / 4, k, stride, pad, Ho, Wo, total);
   return dspn::check_launch("maxpool_forward");
 }
-int dspn_maxpool_backward_argmax_f32(const unsigned char *argmax, const float *dy, float *dx, int N, int H,
+int DSPN_FN(dspn_maxpool_backward_argmax)(const unsigned char *argmax, const st_t *dy, st_t *dx, int N, int H,
                                      int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(argmax && dy && dx && N > 0 && C % 4 == 0, "maxpool_backward_argmax: bad argument");
   const long long total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<const float4 *>(dy),
-                     reinterpret_cast<float4 *>(dx), H, W, C / 4, k, stride, pad, Ho, Wo, total);
+                     reinterpret_cast<const uchar4 *>(argmax), CA4Ptr(dy),
+                     A4Ptr(dx), H, W, C / 4, k, stride, pad, Ho, Wo, total);
   return dspn::check_launch("maxpool_backward_argmax");
 }
-int dspn_maxpool_backward_f32(const float *x, const float *y, const float *dy, float *dx, int N, int H,
+int DSPN_FN(dspn_maxpool_backward)(const st_t *x, const st_t *y, const st_t *dy, st_t *dx, int N, int H,
                               int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(x && y && dy && dx && N > 0 && C % 4 == 0, "maxpool_backward: bad argument");
   const long long total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT, 65535)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(y),
-                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k,
+                     CA4Ptr(x), CA4Ptr(y),
+                     CA4Ptr(dy), A4Ptr(dx), H, W, C / 4, k,
                      stride, pad, Ho, Wo, total);
   return dspn::check_launch("maxpool_backward");
 }
-int dspn_avgpool_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int Ho, int Wo,
+int DSPN_FN(dspn_avgpool_forward)(const st_t *x, st_t *y, int N, int H, int W, int C, int k, int Ho, int Wo,
                              void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && k > 0 && Ho * k <= H && Wo * k <= W, "avgpool_forward: bad argument");
   const long long total = (long long)N * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k, Ho,
+                     CA4Ptr(x), A4Ptr(y), H, W, C / 4, k, Ho,
                      Wo, total);
   return dspn::check_launch("avgpool_forward");
 }
-int dspn_avgpool_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
+int DSPN_FN(dspn_avgpool_backward)(const st_t *dy, st_t *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
                               int accumulate, void *stream) {
   DSPN_REQUIRE(dy && dx && C % 4 == 0 && k > 0, "avgpool_backward: bad argument");
   const long long total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k,
+                     CA4Ptr(dy), A4Ptr(dx), H, W, C / 4, k,
                      Ho, Wo, total, accumulate);
   return dspn::check_launch("avgpool_backward");
 }
 
-int dspn_avgpool2d_forward_f32(const float *x, float *y, int N, int H, int W, int C, int k, int stride, int pad,
+int DSPN_FN(dspn_avgpool2d_forward)(const st_t *x, st_t *y, int N, int H, int W, int C, int k, int stride, int pad,
                                int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && pad < k, "avgpool2d_forward: bad argument");
   DSPN_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1,
                "avgpool2d_forward: output size mismatch");
   const long long total = (long long)N * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(avgpool2d_fwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, k, stride,
+                     CA4Ptr(x), A4Ptr(y), H, W, C / 4, k, stride,
                      pad, Ho, Wo, total);
   return dspn::check_launch("avgpool2d_forward");
 }
-int dspn_avgpool2d_backward_f32(const float *dy, float *dx, int N, int H, int W, int C, int k, int stride, int pad,
+int DSPN_FN(dspn_avgpool2d_backward)(const st_t *dy, st_t *dx, int N, int H, int W, int C, int k, int stride, int pad,
                                 int Ho, int Wo, int accumulate, void *stream) {
   DSPN_REQUIRE(dy && dx && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && pad < k, "avgpool2d_backward: bad argument");
   const long long total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(avgpool2d_bwd_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
-                     reinterpret_cast<const float4 *>(dy), reinterpret_cast<float4 *>(dx), H, W, C / 4, k, stride,
+                     CA4Ptr(dy), A4Ptr(dx), H, W, C / 4, k, stride,
                      pad, Ho, Wo, total, accumulate);
   return dspn::check_launch("avgpool2d_backward");
 }
 
+#ifndef DSPN_HALF
 int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
                               int ldo, int coff, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_forward: bad argument");
@@ -1372,6 +1438,8 @@ int dspn_bilinear_forward_f32(const float *x, float *y, int N, int Hin, int Win,
                      reinterpret_cast<const float4 *>(x), y, Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
   return dspn::check_launch("bilinear_forward");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_bilinear_forward_acc_f32(const float *x, float *y, int N, int Hin, int Win, int C, int Ho, int Wo,
                                   int ldo, int coff, void *stream) {
   DSPN_REQUIRE(x && y && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_forward_acc: bad argument");
@@ -1380,6 +1448,8 @@ int dspn_bilinear_forward_acc_f32(const float *x, float *y, int N, int Hin, int 
                      reinterpret_cast<const float4 *>(x), y, Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
   return dspn::check_launch("bilinear_forward_acc");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                int ldo, int coff, void *stream) {
   DSPN_REQUIRE(dy && dx && C % 4 == 0 && ldo % 4 == 0 && coff % 4 == 0 && coff + C <= ldo, "bilinear_backward: bad argument");
@@ -1388,11 +1458,15 @@ int dspn_bilinear_backward_f32(const float *dy, float *dx, int N, int Hin, int W
                      reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, total);
   return dspn::check_launch("bilinear_backward");
 }
+#endif
 
+#ifndef DSPN_HALF
 size_t dspn_bilinear_backward_workspace_bytes(int N, int Win, int C, int Ho) {
   if (N <= 0 || Win <= 0 || C <= 0 || Ho <= 0) return 0;
   return sizeof(float) * (size_t)N * Ho * Win * C;
 }
+#endif
+#ifndef DSPN_HALF
 /* separable two-pass backward (needs dspn_bilinear_backward_workspace_bytes of scratch) */
 int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, int Win, int C, int Ho, int Wo,
                                   int ldo, int coff, void *workspace, size_t workspace_bytes, void *stream) {
@@ -1407,7 +1481,9 @@ int dspn_bilinear_backward_ws_f32(const float *dy, float *dx, int N, int Hin, in
                      static_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, t2);
   return dspn::check_launch("bilinear_backward_ws");
 }
+#endif
 
+#ifndef DSPN_HALF
 int dspn_seg_counts_f32(const float *scores, const float *label, long long rows, int C, int ld,
                         unsigned long long *counts, void *stream) {
   DSPN_REQUIRE(scores && label && counts && rows > 0 && C > 0 && C <= kMaxSegC && ld >= C, "seg_counts: bad argument (C <= 64)");
@@ -1416,7 +1492,9 @@ int dspn_seg_counts_f32(const float *scores, const float *label, long long rows,
                      counts);
   return dspn::check_launch("seg_counts");
 }
+#endif
 
+#ifndef DSPN_HALF
 int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, int Hin, int Win, int C, int ld,
                                  int Ho, int Wo, void *stream) {
   DSPN_REQUIRE(prob && out && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C <= 256 && ld >= C,
@@ -1432,28 +1510,34 @@ int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, i
                        Hin, Win, C, ld, Ho, Wo, total);
   return dspn::check_launch("seg_upsample_argmax");
 }
+#endif
 
-int dspn_softmax_output_f32(const float *logits, const float *label, float *prob, float *grad,
+int DSPN_FN(dspn_softmax_output)(const st_t *logits, const float *label, float *prob, st_t *grad,
                             long long rows, int C, int ld, float ignore_label, float grad_scale,
                             const float *valid_count, void *stream) {
   DSPN_REQUIRE(logits && prob && rows > 0 && C > 0 && C <= kMaxSoftmaxC && ld >= C, "softmax_output: bad argument (C <= 64)");
   DSPN_REQUIRE(!grad || label, "softmax_output: gradient needs labels");
-  hipLaunchKernelGGL(softmax_output_kernel, dim3(grid_for(rows, 128)), dim3(128), 0, S_(stream), logits, label,
-                     prob, grad, rows, C, ld, ignore_label, grad_scale, valid_count);
+  hipLaunchKernelGGL(softmax_output_kernel, dim3(grid_for(rows, 128)), dim3(128), 0, S_(stream), CA1Ptr(logits), label,
+                     prob, A1Ptr(grad), rows, C, ld, ignore_label, grad_scale, valid_count);
   return dspn::check_launch("softmax_output");
 }
+#ifndef DSPN_HALF
 int dspn_count_f32(const float *a, long long n, int mode, float ref, float *out, void *stream) {
   DSPN_REQUIRE(a && out && n > 0 && n < (1ll << 24), "count: n must be in (0, 2^24)");
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, S_(stream), out, 0.f, 1ll);
   hipLaunchKernelGGL(count_kernel, dim3(grid_for(n, kT, 1024)), dim3(kT), 0, S_(stream), a, n, mode, ref, out);
   return dspn::check_launch("count");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_smooth_l1_forward_f32(const float *pred, const float *target, const float *mask, float *loss,
                                long long n, void *stream) {
   DSPN_REQUIRE(pred && target && mask && loss && n > 0, "smooth_l1_forward: bad argument");
   hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid_for(n)), dim3(kT), 0, S_(stream), pred, target, mask, loss, n);
   return dspn::check_launch("smooth_l1_forward");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_smooth_l1_backward_f32(const float *pred, const float *target, const float *mask, float *grad,
                                 long long n, float grad_scale, const float *valid_count, void *stream) {
   DSPN_REQUIRE(pred && target && mask && grad && valid_count && n > 0, "smooth_l1_backward: bad argument");
@@ -1461,18 +1545,24 @@ int dspn_smooth_l1_backward_f32(const float *pred, const float *target, const fl
                      n, grad_scale, valid_count);
   return dspn::check_launch("smooth_l1_backward");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_cross_entropy_sum_f32(const float *prob, const float *label, long long rows, int C, int ld,
                                float ignore_label, float eps, float *out2, void *stream) {
   DSPN_REQUIRE(prob && label && out2 && rows > 0 && C > 0 && ld >= C, "cross_entropy_sum: bad argument");
   hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(1024), 0, S_(stream), prob, label, rows, C, ld, ignore_label, eps, out2);
   return dspn::check_launch("cross_entropy_sum");
 }
+#endif
+#ifndef DSPN_HALF
 int dspn_sum_f32(const float *a, long long n, float *out, void *stream) {
   DSPN_REQUIRE(a && out && n > 0, "sum: bad argument");
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, S_(stream), a, n, out);
   return dspn::check_launch("sum");
 }
+#endif
 
+#ifndef DSPN_HALF
 int dspn_sgd_momentum_f32(float *w, const float *grad, float *mom, long long n, float lr, float momentum,
                           float wd, float rescale, void *stream) {
   DSPN_REQUIRE(w && grad && mom && n > 0 && n % 4 == 0, "sgd_momentum: n must be a positive multiple of 4");
@@ -1481,5 +1571,6 @@ int dspn_sgd_momentum_f32(float *w, const float *grad, float *mom, long long n, 
                      momentum, wd, rescale);
   return dspn::check_launch("sgd_momentum");
 }
+#endif
 
 }  // extern "C"

@@ -20,7 +20,14 @@
 // fixed order: no atomics, bitwise reproducible.  theta gradient: one wave per target pixel (lanes over
 // channels, butterfly reduction), per-wave double accumulators, fixed-order final sum.
 #include "dspn_common.h"
+#include "dspn_store.h"
 #include "../../include/dspn_nn.h"
+
+// compiled twice (dspn_store.h): float maps -> `*_f32`; through sampler_h.hip -> bfloat16 maps -> `*_bf16`
+// (theta, its gradient and the reduction workspace are float / double in both)
+using dspn::st_t;
+using dspn::A4Ptr;
+using dspn::CA4Ptr;
 
 #pragma clang fp contract(fast)   // as nn.hip: the identity grid then reproduces its plain resize kernel bit for bit
 
@@ -28,7 +35,8 @@ namespace {
 
 constexpr int kMaxSrc = DSPN_SAMPLER_MAX_SOURCES;
 
-struct Src { const float *x; int Hin, Win, C4, coff4; };
+struct Src { const st_t *x; int Hin, Win, C4, coff4; };
+__device__ __forceinline__ float4 ld4(const st_t *p) { return dspn::CA1Ptr(p).vec4()[0]; }
 struct SrcTable { Src s[kMaxSrc]; int n; };
 
 struct Theta { float t[6]; };
@@ -52,7 +60,7 @@ __device__ __forceinline__ void src_xy(const Theta &th, float xt, float yt, int 
   ys = fminf(fmaxf(ys, -2.f), (float)Hin + 1.f);
 }
 
-__global__ void sampler_fwd_kernel(const SrcTable tab, const float *__restrict__ theta, float4 *__restrict__ y,
+__global__ void sampler_fwd_kernel(const SrcTable tab, const float *__restrict__ theta, const A4Ptr y,
                                    int Ho, int Wo, int ld4, long long total) {
   const Theta th = load_theta(theta);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -72,7 +80,7 @@ __global__ void sampler_fwd_kernel(const SrcTable tab, const float *__restrict__
       src_xy(th, xt, yt, s.Hin, s.Win, xs, ys);
       const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
       const float wy0 = 1.f - (ys - (float)y0), wx0 = 1.f - (xs - (float)x0);
-      const float4 *x = reinterpret_cast<const float4 *>(s.x);
+      const CA4Ptr x(s.x);
 #pragma unroll
       for (int dyy = 0; dyy < 2; ++dyy)
 #pragma unroll
@@ -90,9 +98,9 @@ __global__ void sampler_fwd_kernel(const SrcTable tab, const float *__restrict__
 
 // one workgroup (64 channel lanes x SL slices) per source pixel
 template <int SL>
-__global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const float *__restrict__ dy,
+__global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *__restrict__ dy,
                                                                    const float *__restrict__ theta,
-                                                                   float4 *__restrict__ dx, int Hin, int Win, int C4,
+                                                                   const A4Ptr dx, int Hin, int Win, int C4,
                                                                    int Ho, int Wo, int ldo, int coff, int accumulate) {
   __shared__ float4 red[SL > 1 ? SL : 1][64];
   const Theta th = load_theta(theta);
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const float *
         else continue;
         if (c4 >= C4) continue;
         const float wgt = wy * wx;
-        const float4 v = *reinterpret_cast<const float4 *>(dy + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4);
+        const float4 v = ld4(dy + ((n * Ho + ho) * Wo + wo) * (long long)ldo + coff + c4 * 4);
         acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
       }
     }
@@ -157,9 +165,8 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const float *
       }
     }
     if (sl == 0 && c4 < C4) {
-      float4 *o = dx + pix * C4 + c4;
-      if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
-      *o = acc;
+      if (accumulate) { const float4 p = dx[pix * C4 + c4]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+      dx[pix * C4 + c4] = acc;
     }
     if (SL > 1) __syncthreads();
   }
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const float *
 // partial[wave][6] (double): this wave's target pixels, all sources
 constexpr int kThetaWavesPerBlock = 4;
 __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_kernel(
-    const SrcTable tab, const float *__restrict__ theta, const float *__restrict__ dy, double *__restrict__ partial,
+    const SrcTable tab, const float *__restrict__ theta, const st_t *__restrict__ dy, double *__restrict__ partial,
     int Ho, int Wo, int ldo, long long pixels) {
   const Theta th = load_theta(theta);
   const int lane = threadIdx.x & 63;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_ke
     const int ho = (int)((p / Wo) % Ho);
     const long long n = p / ((long long)Wo * Ho);
     const float xt = tgt_coord(wo, Wo), yt = tgt_coord(ho, Ho);
-    const float *g = dy + p * (long long)ldo;
+    const st_t *g = dy + p * (long long)ldo;
     for (int si = 0; si < tab.n; ++si) {
       const Src s = tab.s[si];
       float xs, ys;
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_ke
       const bool vx0 = (unsigned)x0 < (unsigned)s.Win, vx1 = (unsigned)(x0 + 1) < (unsigned)s.Win;
       float gx = 0.f, gy = 0.f;
       if ((vy0 || vy1) && (vx0 || vx1)) {
-        const float4 *x = reinterpret_cast<const float4 *>(s.x);
+        const CA4Ptr x(s.x);
         const long long base = ((n * s.Hin + y0) * s.Win + x0) * s.C4;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = lane; c < s.C4; c += 64) {
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_ke
           const float4 v01 = (vy0 && vx1) ? x[base + s.C4 + c] : z;
           const float4 v10 = (vy1 && vx0) ? x[base + (long long)s.Win * s.C4 + c] : z;
           const float4 v11 = (vy1 && vx1) ? x[base + (long long)(s.Win + 1) * s.C4 + c] : z;
-          const float4 d = *reinterpret_cast<const float4 *>(g + (s.coff4 + c) * 4);
+          const float4 d = ld4(g + (s.coff4 + c) * 4);
           const float ax_[4] = {v01.x - v00.x, v01.y - v00.y, v01.z - v00.z, v01.w - v00.w};
           const float bx_[4] = {v11.x - v10.x, v11.y - v10.y, v11.z - v10.z, v11.w - v10.w};
           const float ay_[4] = {v10.x - v00.x, v10.y - v00.y, v10.z - v00.z, v10.w - v00.w};
@@ -244,7 +251,7 @@ int theta_blocks(long long pixels) {
   return (int)std::max<long long>(1, std::min<long long>((pixels + 4 * kThetaWavesPerBlock - 1) / (4 * kThetaWavesPerBlock), 1024));
 }
 
-int make_table(SrcTable &tab, const float *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+int make_table(SrcTable &tab, const st_t *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
                int nsrc, int ldo, const char *what) {
   DSPN_REQUIRE(x && Hin && Win && C && coff && nsrc >= 1 && nsrc <= kMaxSrc, "%s: 1..%d sources", what, kMaxSrc);
   tab.n = nsrc;
@@ -260,19 +267,19 @@ int make_table(SrcTable &tab, const float *const *x, const int *Hin, const int *
 
 extern "C" {
 
-int dspn_affine_sampler_forward_f32(const float *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
-                                    int nsrc, const float *theta, float *y, int N, int Ho, int Wo, int ldo, void *stream) {
+int DSPN_FN(dspn_affine_sampler_forward)(const st_t *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+                                    int nsrc, const float *theta, st_t *y, int N, int Ho, int Wo, int ldo, void *stream) {
   DSPN_REQUIRE(theta && y && N > 0 && Ho > 0 && Wo > 0 && ldo > 0 && ldo % 4 == 0, "affine_sampler_forward: bad argument");
   SrcTable tab;
   if (int rc = make_table(tab, x, Hin, Win, C, coff, nsrc, ldo, "affine_sampler_forward")) return rc;
   const long long total = (long long)N * Ho * Wo * (ldo / 4);
   const int blocks = (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 16384));
   hipLaunchKernelGGL(sampler_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, theta,
-                     reinterpret_cast<float4 *>(y), Ho, Wo, ldo / 4, total);
+                     A4Ptr(y), Ho, Wo, ldo / 4, total);
   return dspn::check_launch("affine_sampler_forward");
 }
 
-int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, float *dx, int N, int Hin, int Win, int C,
+int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *theta, st_t *dx, int N, int Hin, int Win, int C,
                                           int Ho, int Wo, int ldo, int coff, int accumulate, void *stream) {
   DSPN_REQUIRE(dy && theta && dx && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 &&
                    ldo % 4 == 0 && coff >= 0 && coff % 4 == 0 && coff + C <= ldo, "affine_sampler_backward_data: bad argument");
@@ -282,7 +289,7 @@ int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, f
   const int rows = 2 * ((Ho + Hin - 1) / Hin) + 4;
   hipStream_t s = (hipStream_t)stream;
 #define DSPN_SBD_(SL) hipLaunchKernelGGL(sampler_bwd_data_kernel<SL>, dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
-                                         reinterpret_cast<float4 *>(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate)
+                                         A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate)
   if (rows >= 32) DSPN_SBD_(16);
   else if (rows >= 10) DSPN_SBD_(4);
   else DSPN_SBD_(1);
@@ -290,20 +297,23 @@ int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, f
   return dspn::check_launch("affine_sampler_backward_data");
 }
 
-size_t dspn_affine_sampler_theta_workspace_bytes(int N, int Ho, int Wo) {
+static size_t theta_workspace_bytes(int N, int Ho, int Wo) {
   if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
   return sizeof(double) * 6 * (size_t)theta_blocks((long long)N * Ho * Wo) * kThetaWavesPerBlock;
 }
+#ifndef DSPN_HALF
+size_t dspn_affine_sampler_theta_workspace_bytes(int N, int Ho, int Wo) { return theta_workspace_bytes(N, Ho, Wo); }
+#endif
 
-int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin, const int *Win, const int *C,
-                                           const int *coff, int nsrc, const float *theta, const float *dy, int N, int Ho,
+int DSPN_FN(dspn_affine_sampler_backward_theta)(const st_t *const *x, const int *Hin, const int *Win, const int *C,
+                                           const int *coff, int nsrc, const float *theta, const st_t *dy, int N, int Ho,
                                            int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
                                            size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(theta && dy && dtheta && workspace && N > 0 && Ho > 0 && Wo > 0 && ldo > 0 && ldo % 4 == 0,
                "affine_sampler_backward_theta: bad argument");
   SrcTable tab;
   if (int rc = make_table(tab, x, Hin, Win, C, coff, nsrc, ldo, "affine_sampler_backward_theta")) return rc;
-  if (workspace_bytes < dspn_affine_sampler_theta_workspace_bytes(N, Ho, Wo))
+  if (workspace_bytes < theta_workspace_bytes(N, Ho, Wo))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "affine_sampler_backward_theta: workspace too small");
   const long long pixels = (long long)N * Ho * Wo;
   const int blocks = theta_blocks(pixels);

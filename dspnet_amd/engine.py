@@ -34,26 +34,30 @@ COMMUTE_RESIZE_CONV = True
 
 
 class Tensor:
-    """An activation: NHWC (or any) float32 device buffer + its gradient slot."""
+    """An activation: NHWC (or any) device buffer + its gradient slot.  dtype: the graph's activation storage type
+    (functional.ACT_DTYPE: float32, or bfloat16 for the `*_bf16` kernels) unless given -- graph inputs, loss inputs
+    and graph outputs are float32 in both."""
 
-    def __init__(self, shape, name, requires_grad=True, data=None, device=None, virtual=False):
+    def __init__(self, shape, name, requires_grad=True, data=None, device=None, virtual=False, dtype=None):
         self.name = name
         self.shape = tuple(int(s) for s in shape)
         self.requires_grad = requires_grad
         self.device = device
+        self.dtype = data.dtype if data is not None else (dtype or fn.ACT_DTYPE)
         # virtual: never materialised (a BatchNorm output that only convolutions consume: they apply the affine in
         # their tile loaders, see BatchNorm(defer_apply=True)); .data stays None so any other consumer fails loudly
         self.affine_src = None
         self.producer = None       # the Conv node that writes this tensor (it can emit BatchNorm tile statistics)
         self.channels = None       # logical channel count when the last axis is padded (19 -> 20, 3 -> 4)
-        self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device))
+        self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device, dtype=self.dtype))
         self.grad = None
         self._own_grad = None
         self._gw = False  # gradient written in the current backward pass
 
     def own_grad(self):
         if self._own_grad is None:
-            self._own_grad = torch.zeros_like(self.data) if self.data is not None else fn.zeros(*self.shape, device=self.device)
+            self._own_grad = (torch.zeros_like(self.data) if self.data is not None
+                              else fn.zeros(*self.shape, device=self.device, dtype=self.dtype))
         return self._own_grad
 
     def grad_target(self):
@@ -110,10 +114,11 @@ class Graph:
         self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
         self.arena = self.grad_arena = self.mom_arena = None
+        self.half_operands = False  # bf16 convolution operands: refreshed from the float masters at the top of forward()
 
     # -- construction ---------------------------------------------------------
-    def tensor(self, shape, name, requires_grad=True, data=None, virtual=False):
-        t = Tensor(shape, name, requires_grad, data=data, device=self.device, virtual=virtual)
+    def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
+        t = Tensor(shape, name, requires_grad, data=data, device=self.device, virtual=virtual, dtype=dtype)
         assert name not in self.tensors, "duplicate tensor name " + name
         self.tensors[name] = t
         self.all_tensors.append(t)
@@ -151,7 +156,7 @@ class Graph:
                 continue
             n.defer_apply = False
             n.out.affine_src = None
-            n.out.data = fn.zeros(*n.out.shape, device=self.device)
+            n.out.data = fn.zeros(*n.out.shape, device=self.device, dtype=n.out.dtype)
             for c in n.conv_consumers:
                 c.x_raw, c.in_affine = c.x, None
             n.conv_consumers = []
@@ -175,7 +180,7 @@ class Graph:
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._resolve_auto_deferred()
         self._plan_bn_backward_fusion()
-        self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and n.wt is not None]
+        self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and (n.wt is not None or n.wh is not None)]
         off = 0
         for p in self.param_order:
             p.offset = off
@@ -192,7 +197,14 @@ class Graph:
             p.data = self.arena[p.offset:p.offset + p.size].view(p.shape)
             p.grad = self.grad_arena[p.offset:p.offset + p.size].view(p.shape)
         if self._wt_pairs_nodes and self.device.type == "cuda":
-            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, None) for n in self._wt_pairs_nodes], self.device)
+            # bf16 operands: every Conv has a bf16 copy wh of its float master (forward operand); a Conv whose input
+            # needs no gradient still gets a (scratch) transposed operand so that one table row serves it
+            for n in self._wt_pairs_nodes:
+                if n.wt is None:
+                    n.wt = fn.zeros(n.w.shape[3], n.w.shape[1], n.w.shape[2], n.out.shape[3], device=self.device,
+                                    dtype=n.wh.dtype)
+            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, n.wh) for n in self._wt_pairs_nodes], self.device)
+            self.half_operands = self.wt_table[3]
         if self.device.type == "cuda":
             # every Conv keeps the split-K partial sums of its weight gradient in a buffer of its own, so that the
             # slab sums of many layers run as one launch (flush_slabs) instead of one small kernel per layer
@@ -227,6 +239,9 @@ class Graph:
     # -- execution ------------------------------------------------------------
     def forward(self):
         self.wt_batched = False        # the weights may have changed since the last batched transpose
+        if self.half_operands:         # bf16 copies (forward) and transposes (data gradient) of every weight, one launch
+            fn.weight_transpose_batch(*self.wt_table)
+            self.wt_batched = True
         for f in self.pre_forward:
             f()
         for n in self.nodes:
@@ -237,6 +252,8 @@ class Graph:
         for t in self.all_tensors:
             t._gw = False
             t.grad = None
+        if self.half_operands:
+            return                     # prepared by forward(); the weights have not changed since
         self.wt_batched = self.wt_table is not None
         if self.wt_batched:
             fn.weight_transpose_batch(*self.wt_table)
@@ -361,7 +378,7 @@ class InputNCHW(Node):
     def __init__(self, g, src, name="data_nhwc"):
         self.src = src
         N, C, H, W = src.shape
-        self.out = g.tensor((N, H, W, fn.pad4(C)), name, requires_grad=False)
+        self.out = g.tensor((N, H, W, fn.padc(C)), name, requires_grad=False)
         self.out.channels = C
 
     def forward(self):
@@ -467,7 +484,7 @@ class Conv(Node):
         if self.b is not None:
             self.b.logical = (num_filter,)
         Ho, Wo = fn.conv_out_size(H, kh, stride, ph, dilate), fn.conv_out_size(W, kw, stride, pw, dilate)
-        ldc = fn.pad4(num_filter) if cout_phys is None else cout_phys
+        ldc = fn.padc(num_filter) if cout_phys is None else cout_phys
         self.out = g.tensor((N, Ho, Wo, ldc), out_name or (name + "_out"))
         self.out.channels = num_filter
         self.out.producer = self
@@ -478,14 +495,17 @@ class Conv(Node):
         # symbol/resnet.py:51); its gradient is the output gradient itself
         self.residual = residual
         assert residual is None or residual.shape == self.out.shape
-        self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device)
+        half = self.out.dtype == torch.bfloat16
+        self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device, dtype=self.out.dtype)
+        # bf16 operands: the copy of the float master the forward pass multiplies (refreshed once per step, Graph.forward)
+        self.wh = fn.zeros(num_filter, kh, kw, Cin, device=g.device, dtype=torch.bfloat16) if half else None
         # tap-expanded evaluation (few output channels, stride 1): 1x1 convolution to Cout*kh*kw channels
         # on the same weight buffer + shifted sum over taps (include/dspn_nn.h, dspn_tap_sum_f32)
         self.tap_expand = bool(tap_expand) and kh * kw > 1
         if self.tap_expand:
             assert stride == 1 and dilate == 1 and not relu and residual is None
             assert (Ho, Wo) == (H, W), "tap expansion needs a 'same' convolution"
-            self.z = fn.zeros(N, H, W, fn.pad4(num_filter * kh * kw), device=g.device)   # also holds dz in backward
+            self.z = fn.act_zeros(N, H, W, fn.padc(num_filter * kh * kw), device=g.device)   # also holds dz in backward
         # algorithmic FLOPs per batch (direct-conv count, logical channels)
         self.flops_fwd = 2.0 * cin_logical * num_filter * kh * kw * Ho * Wo * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
@@ -498,6 +518,10 @@ class Conv(Node):
                                         1 if self.tap_expand else self.stride)
         if splits > 0 and self.w.data.numel() % 4 == 0:
             self.slabs = fn.zeros(splits, self.w.data.numel(), device=self._g.device)
+
+    def wop(self):
+        """the weight operand of the forward kernels: the float master, or its bf16 copy"""
+        return self.w.data if self.wh is None else self.wh
 
     def enable_out_stats(self):
         """called by a BatchNorm on self.out: have the epilogue write per-tile statistics (None if unavailable)"""
@@ -514,10 +538,10 @@ class Conv(Node):
     def forward(self):
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
-            fn.conv2d_forward(self.x.data, self.w.data.view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z)
+            fn.conv2d_forward(self.x.data, self.wop().view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
-        fn.conv2d_forward(self.x_raw.data, self.w.data, None if self.b is None else self.b.data, self.stride,
+        fn.conv2d_forward(self.x_raw.data, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
                           residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine,
                           out_stats=None if self.out_stats is None else self.out_stats[0])
@@ -554,7 +578,7 @@ class Conv(Node):
                                      out=self.input_sum_grad.grad)
         if self.x.requires_grad:
             if not self._g.wt_batched:
-                fn.weight_transpose(self.w.data, out=self.wt)
+                fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
             dx, acc = self.x.grad_target()
             bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
             bn_bwd = None
@@ -595,20 +619,22 @@ class BilinearConcatConv(Node):
         self.w = g.param(name + "_weight", (num_filter, kh, kw, Cin), conv_weight_init(init, Cin))
         self.w.logical, self.w.kind = (num_filter, Cin, kh, kw), "conv"
         T = num_filter * kh * kw
-        Tp = fn.pad4(T)
+        Tp = fn.padc(T)
         self.T = T
-        self.z = fn.zeros(N, Ht, Wt, Tp, device=g.device)            # tap-expanded map at the target size (dz in backward)
-        self.zc, self.wc, self.wct, self.dwc = [], [], [], []
+        half = fn.ACT_DTYPE == torch.bfloat16
+        self.z = fn.act_zeros(N, Ht, Wt, Tp, device=g.device)        # tap-expanded map at the target size (dz in backward)
+        self.zc, self.wc, self.wct, self.dwc, self.wch = [], [], [], [], []
         for t in inputs:
             # W_c . x_c at the component's own resolution (its gradient in backward).  Every component goes through
             # the sampler, also the ones that already have the target size: once the optimizer has moved
             # affine_matrix off the identity they are resampled too, and their grid gradient is not zero
-            self.zc.append(fn.zeros(N, t.shape[1], t.shape[2], Tp, device=g.device))
-            self.wc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))      # W_c, contiguous
-            self.wct.append(fn.zeros(t.shape[3], 1, 1, Tp, device=g.device))    # its transpose (data-gradient operand)
+            self.zc.append(fn.act_zeros(N, t.shape[1], t.shape[2], Tp, device=g.device))
+            self.wc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))      # W_c, contiguous (float master slice)
+            self.wct.append(fn.act_zeros(t.shape[3], 1, 1, Tp, device=g.device))    # its transpose (data-gradient operand)
+            self.wch.append(fn.act_zeros(T, 1, 1, t.shape[3], device=g.device) if half else None)   # bf16 forward operand
             self.dwc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))
         self.sources = None           # fn.SamplerSources over zc, made at the first forward
-        self.out = g.tensor((N, Ht, Wt, fn.pad4(num_filter)), name + "_out")
+        self.out = g.tensor((N, Ht, Wt, fn.padc(num_filter)), name + "_out")
         self.out.channels = num_filter
         # multiply-adds actually executed (the direct form would be 2 * Cin * Cout * k * k * Ht * Wt * N)
         self.flops_fwd = sum(2.0 * t.shape[3] * T * t.shape[1] * t.shape[2] * N for t in inputs)
@@ -625,7 +651,9 @@ class BilinearConcatConv(Node):
     def forward(self):
         self._gather_weights()
         for c, t in enumerate(self.inputs):
-            fn.conv2d_forward(t.data, self.wc[c], None, 1, 0, 1, out=self.zc[c])
+            if self.wch[c] is not None:      # bf16 operands of this slice: copy + transpose in one launch
+                fn.weight_transpose(self.wc[c], out=self.wct[c], copy=self.wch[c])
+            fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c])
         if self.sources is None:
             self.sources = fn.SamplerSources([(z, 0) for z in self.zc])
         fn.affine_sampler_forward(self.sources, self.theta.data, self.z)       # z = sum_c U_c(theta)(W_c x_c), one pass
@@ -643,7 +671,8 @@ class BilinearConcatConv(Node):
             fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c])
             fn.copy_block(self.dwc[c], self.w.grad, 1, self.T, t.shape[3], 0, t.shape[3], 0, 0, Cin, self.offsets[c])
             if t.requires_grad:
-                fn.weight_transpose(self.wc[c], out=self.wct[c])
+                if self.wch[c] is None:
+                    fn.weight_transpose(self.wc[c], out=self.wct[c])
                 dx, acc = t.grad_target()
                 fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc)
 
@@ -657,14 +686,15 @@ class Deconv4x4s2(Node):
         self.x = x
         self.w = g.param(name + "_weight", (Cp, 4, 4, Cp), deconv_bilinear_init(channels))
         self.w.logical, self.w.kind = (channels, channels, 4, 4), "deconv"
-        self.wt = fn.zeros(Cp, 4, 4, Cp, device=g.device)
+        self.wt = fn.act_zeros(Cp, 4, 4, Cp, device=g.device)
+        self.wh = fn.act_zeros(Cp, 4, 4, Cp, device=g.device) if fn.ACT_DTYPE == torch.bfloat16 else None
         self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
         self.out.channels = channels
         self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
-        fn.weight_transpose(self.w.data, out=self.wt)
+        fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
         fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data)
 
     def backward(self):
@@ -674,7 +704,7 @@ class Deconv4x4s2(Node):
         fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad)
         if self.x.requires_grad:
             dx, acc = self.x.grad_target()
-            fn.conv2d_forward(dy, self.w.data, None, 2, 1, 1, out=dx, accumulate=acc)
+            fn.conv2d_forward(dy, self.w.data if self.wh is None else self.wh, None, 2, 1, 1, out=dx, accumulate=acc)
 
 
 class Add(Node):

@@ -95,11 +95,18 @@ _lib.register({
 
 # the bfloat16-tensor twins (include/dspn_nn.h): same argument lists as the *_f32 entries
 for _name in ("dspn_conv2d_forward_bn", "dspn_conv2d_dgrad_bn", "dspn_conv2d_wgrad_bn", "dspn_conv2d_wgrad_slabs",
-              "dspn_conv2d_input_sum_grad"):
+              "dspn_conv2d_input_sum_grad", "dspn_bn_stats", "dspn_bn_apply", "dspn_bn_backward",
+              "dspn_bn_backward_from_sums", "dspn_add", "dspn_relu_backward", "dspn_relu_backward_colsum", "dspn_colsum",
+              "dspn_nchw_to_nhwc", "dspn_copy_block", "dspn_tap_sum", "dspn_tap_spread", "dspn_maxpool_forward",
+              "dspn_maxpool_backward_argmax", "dspn_maxpool_backward", "dspn_avgpool_forward", "dspn_avgpool_backward",
+              "dspn_avgpool2d_forward", "dspn_avgpool2d_backward", "dspn_softmax_output", "dspn_affine_sampler_forward",
+              "dspn_affine_sampler_backward_data", "dspn_affine_sampler_backward_theta"):
     _lib.register({_name + "_bf16": _lib.SIGNATURES[_name + "_f32"]})
 _lib.register({
     "dspn_conv2d_weight_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_weight_prepare_batch_bf16": (_i, [_vp, _i, _ll, _vp]),
+    "dspn_copy_block_bf16_f32": _lib.SIGNATURES["dspn_copy_block_f32"],
+    "dspn_copy_block_f32_bf16": _lib.SIGNATURES["dspn_copy_block_f32"],
 })
 
 
@@ -333,7 +340,8 @@ def tap_sum(z, bias, cout, R, S, pad, out):
     """z (N,H,W,ldz >= cout*R*S) -> out (N,H,W,ldy): shifted sum over taps (+ bias); pad channels of out zeroed"""
     N, H, W, ldz = z.shape
     ph, pw = _hw(pad)
-    check(L().dspn_tap_sum_f32(ptr(z), ptr(bias), ptr(out), N, H, W, cout, out.shape[3], ldz, R, S, ph, pw, stream()),
+    assert z.dtype == out.dtype
+    check(_f("dspn_tap_sum", z)(ptr(z), ptr(bias), ptr(out), N, H, W, cout, out.shape[3], ldz, R, S, ph, pw, stream()),
           "tap_sum")
     return out
 
@@ -342,7 +350,8 @@ def tap_spread(dy, cout, R, S, pad, out):
     """dy (N,H,W,ldy) -> out (N,H,W,ldz >= cout*R*S): gradient of tap_sum with respect to z"""
     N, H, W, ldy = dy.shape
     ph, pw = _hw(pad)
-    check(L().dspn_tap_spread_f32(ptr(dy), ptr(out), N, H, W, cout, ldy, out.shape[3], R, S, ph, pw, stream()),
+    assert dy.dtype == out.dtype
+    check(_f("dspn_tap_spread", dy)(ptr(dy), ptr(out), N, H, W, cout, ldy, out.shape[3], R, S, ph, pw, stream()),
           "tap_spread")
     return out
 
@@ -412,14 +421,15 @@ def bn_stats(x, eps, gamma, beta, mean=None, rstd=None, scale=None, shift=None):
     scale = empty(C, device=x.device) if scale is None else scale
     shift = empty(C, device=x.device) if shift is None else shift
     ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
-    check(L().dspn_bn_stats_f32(ptr(x), rows, C, eps, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(scale),
+    check(_f("dspn_bn_stats", x)(ptr(x), rows, C, eps, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(scale),
                                 ptr(shift), ptr(ws), ws.numel(), stream()), "bn_stats")
     return mean, rstd, scale, shift
 
 
 def bn_apply(x, scale, shift, relu=False, out=None):
     out = torch.empty_like(x) if out is None else out
-    check(L().dspn_bn_apply_f32(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
+    assert out.dtype == x.dtype
+    check(_f("dspn_bn_apply", x)(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
                                 stream()), "bn_apply")
     return out
 
@@ -433,7 +443,8 @@ def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dga
     if gamma is not None and dgamma is None:
         dgamma = empty(C, device=x.device)
     ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
-    check(L().dspn_bn_backward_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+    assert dy.dtype == x.dtype == dx.dtype
+    check(_f("dspn_bn_backward", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
                                    ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(ws),
                                    ws.numel(), stream()), "bn_backward")
     return dx, dgamma, dbeta
@@ -449,7 +460,8 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     if gamma is not None and dgamma is None:
         dgamma = empty(C, device=x.device)
     ws = workspace(12 * C + L().dspn_bn_tiles_workspace_bytes(tiles, C), x.device, "bn")
-    check(L().dspn_bn_backward_from_sums_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
+    assert dy.dtype == x.dtype == dx.dtype
+    check(_f("dspn_bn_backward_from_sums", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
                                              int(accumulate), ptr(ws), ws.numel(), stream()), "bn_backward_from_sums")
     return dx, dgamma, dbeta
@@ -458,13 +470,15 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
 # ------------------------------------------------------------------ element-wise / layout
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
-    check(L().dspn_add_f32(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "add")
+    assert a.dtype == b.dtype == out.dtype
+    check(_f("dspn_add", a)(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "add")
     return out
 
 
 def relu_backward(y, dy, dx=None, accumulate=False):
     dx = torch.empty_like(y) if dx is None else dx
-    check(L().dspn_relu_backward_f32(ptr(y), ptr(dy), ptr(dx), y.numel(), int(accumulate), stream()),
+    assert y.dtype == dy.dtype == dx.dtype
+    check(_f("dspn_relu_backward", y)(ptr(y), ptr(dy), ptr(dx), y.numel(), int(accumulate), stream()),
           "relu_backward")
     return dx
 
@@ -476,7 +490,8 @@ def relu_backward_colsum(y, dy, C, dx=None, out=None):
     rows = _rows(y)
     out = empty(C, device=y.device) if out is None else out
     ws = workspace(L().dspn_colsum_workspace_bytes(rows, C), y.device, "colsum")
-    check(L().dspn_relu_backward_colsum_f32(ptr(y), ptr(dy), ptr(dx), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()),
+    assert y.dtype == dy.dtype == dx.dtype
+    check(_f("dspn_relu_backward_colsum", y)(ptr(y), ptr(dy), ptr(dx), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()),
           "relu_backward_colsum")
     return dx, out
 
@@ -492,15 +507,17 @@ def colsum(a, C, out=None):
     rows = _rows(a)
     out = empty(C, device=a.device) if out is None else out
     ws = workspace(L().dspn_colsum_workspace_bytes(rows, C), a.device, "colsum")
-    check(L().dspn_colsum_f32(ptr(a), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()), "colsum")
+    check(_f("dspn_colsum", a)(ptr(a), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()), "colsum")
     return out
 
 
 def nchw_to_nhwc(src, Cp=None, out=None):
+    """float32 NCHW -> NHWC in out's storage type (float32 / bfloat16), channels zero padded to Cp"""
     N, C, H, W = src.shape
-    Cp = pad4(C) if Cp is None else Cp
+    Cp = (pad4(C) if out is None else out.shape[3]) if Cp is None else Cp
     out = empty(N, H, W, Cp, device=src.device) if out is None else out
-    check(L().dspn_nchw_to_nhwc_f32(ptr(src), ptr(out), N, C, H, W, Cp, stream()), "nchw_to_nhwc")
+    assert src.dtype == torch.float32
+    check(_f("dspn_nchw_to_nhwc", out)(ptr(src), ptr(out), N, C, H, W, Cp, stream()), "nchw_to_nhwc")
     return out
 
 
@@ -514,7 +531,14 @@ def nhwc_to_nchw(src, C=None, out=None):
 
 def copy_block(src, dst, samples, rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd,
                doff, accumulate=False):
-    check(L().dspn_copy_block_f32(ptr(src), ptr(dst), samples, rows_per_sample, C, src_sample_stride, lds,
+    """strided block copy; src / dst may differ in storage type (bf16 map -> float loss input and back)"""
+    if src.dtype == dst.dtype:
+        f = _f("dspn_copy_block", src)
+    elif src.dtype == torch.bfloat16:
+        f = L().dspn_copy_block_bf16_f32
+    else:
+        f = L().dspn_copy_block_f32_bf16
+    check(f(ptr(src), ptr(dst), samples, rows_per_sample, C, src_sample_stride, lds,
                                   soff, dst_sample_stride, ldd, doff, int(accumulate), stream()), "copy_block")
     return dst
 
@@ -531,18 +555,20 @@ def maxpool_forward(x, k, stride, pad, out=None, argmax=None):
     """argmax: optional uint8 tensor of the output's shape receiving the window position of each maximum"""
     N, H, W, C = x.shape
     if out is None:
-        out = empty(N, conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad), C, device=x.device)
+        out = empty(N, conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad), C, device=x.device, dtype=x.dtype)
     Ho, Wo = out.shape[1], out.shape[2]     # a larger (pooling_convention='full') output is the caller's choice
     assert argmax is None or (argmax.dtype == torch.uint8 and argmax.shape == out.shape)
-    check(L().dspn_maxpool_forward_f32(ptr(x), ptr(out), ptr(argmax), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
+    assert out.dtype == x.dtype
+    check(_f("dspn_maxpool_forward", x)(ptr(x), ptr(out), ptr(argmax), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
           "maxpool_forward")
     return out
 
 
 def maxpool_backward_argmax(argmax, dy, x_shape, k, stride, pad, dx=None):
     N, H, W, C = x_shape
-    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
-    check(L().dspn_maxpool_backward_argmax_f32(ptr(argmax), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
+    dx = empty(N, H, W, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
+    assert dx.dtype == dy.dtype
+    check(_f("dspn_maxpool_backward_argmax", dy)(ptr(argmax), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
                                                dy.shape[1], dy.shape[2], stream()), "maxpool_backward_argmax")
     return dx
 
@@ -550,7 +576,8 @@ def maxpool_backward_argmax(argmax, dy, x_shape, k, stride, pad, dx=None):
 def maxpool_backward(x, y, dy, k, stride, pad, dx=None):
     N, H, W, C = x.shape
     dx = torch.empty_like(x) if dx is None else dx
-    check(L().dspn_maxpool_backward_f32(ptr(x), ptr(y), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
+    assert x.dtype == y.dtype == dy.dtype == dx.dtype
+    check(_f("dspn_maxpool_backward", x)(ptr(x), ptr(y), ptr(dy), ptr(dx), N, H, W, C, k, stride, pad,
                                         y.shape[1], y.shape[2], stream()), "maxpool_backward")
     return dx
 
@@ -558,8 +585,9 @@ def maxpool_backward(x, y, dy, k, stride, pad, dx=None):
 def avgpool_forward(x, k, out=None):
     N, H, W, C = x.shape
     Ho, Wo = H // k, W // k
-    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
-    check(L().dspn_avgpool_forward_f32(ptr(x), ptr(out), N, H, W, C, k, Ho, Wo, stream()), "avgpool_forward")
+    out = empty(N, Ho, Wo, C, device=x.device, dtype=x.dtype) if out is None else out
+    assert out.dtype == x.dtype
+    check(_f("dspn_avgpool_forward", x)(ptr(x), ptr(out), N, H, W, C, k, Ho, Wo, stream()), "avgpool_forward")
     return out
 
 
@@ -567,24 +595,27 @@ def avgpool2d_forward(x, k, stride, pad, out=None):
     """overlapping average pooling, divisor k*k (padding counted)"""
     N, H, W, C = x.shape
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    out = empty(N, Ho, Wo, C, device=x.device) if out is None else out
-    check(L().dspn_avgpool2d_forward_f32(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
+    out = empty(N, Ho, Wo, C, device=x.device, dtype=x.dtype) if out is None else out
+    assert out.dtype == x.dtype
+    check(_f("dspn_avgpool2d_forward", x)(ptr(x), ptr(out), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
           "avgpool2d_forward")
     return out
 
 
 def avgpool2d_backward(dy, x_shape, k, stride, pad, dx=None, accumulate=False):
     N, H, W, C = x_shape
-    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
-    check(L().dspn_avgpool2d_backward_f32(ptr(dy), ptr(dx), N, H, W, C, k, stride, pad, dy.shape[1], dy.shape[2],
+    dx = empty(N, H, W, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
+    assert dx.dtype == dy.dtype
+    check(_f("dspn_avgpool2d_backward", dy)(ptr(dy), ptr(dx), N, H, W, C, k, stride, pad, dy.shape[1], dy.shape[2],
                                           int(accumulate), stream()), "avgpool2d_backward")
     return dx
 
 
 def avgpool_backward(dy, x_shape, k, dx=None, accumulate=False):
     N, H, W, C = x_shape
-    dx = empty(N, H, W, C, device=dy.device) if dx is None else dx
-    check(L().dspn_avgpool_backward_f32(ptr(dy), ptr(dx), N, H, W, C, k, dy.shape[1], dy.shape[2],
+    dx = empty(N, H, W, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
+    assert dx.dtype == dy.dtype
+    check(_f("dspn_avgpool_backward", dy)(ptr(dy), ptr(dx), N, H, W, C, k, dy.shape[1], dy.shape[2],
                                         int(accumulate), stream()), "avgpool_backward")
     return dx
 
@@ -630,15 +661,17 @@ def affine_sampler_forward(sources, theta, out):
     """GridGenerator(affine theta, target out.shape[1:3]) + BilinearSampler of every source into its channel slice
     of out (N,Ho,Wo,ldo); coinciding slices are summed, uncovered channels zeroed"""
     N, Ho, Wo, ldo = out.shape
-    check(L().dspn_affine_sampler_forward_f32(sources.x, sources.Hin, sources.Win, sources.C, sources.coff, sources.n,
+    assert all(t.dtype == out.dtype for t in sources.tensors)
+    check(_f("dspn_affine_sampler_forward", out)(sources.x, sources.Hin, sources.Win, sources.C, sources.coff, sources.n,
                                               ptr(theta), ptr(out), N, Ho, Wo, ldo, stream()), "affine_sampler_forward")
     return out
 
 
 def affine_sampler_backward_data(dy, theta, x_shape, coff, dx=None, accumulate=False):
     N, Hin, Win, C = x_shape
-    dx = empty(N, Hin, Win, C, device=dy.device) if dx is None else dx
-    check(L().dspn_affine_sampler_backward_data_f32(ptr(dy), ptr(theta), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
+    dx = empty(N, Hin, Win, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
+    assert dx.dtype == dy.dtype
+    check(_f("dspn_affine_sampler_backward_data", dy)(ptr(dy), ptr(theta), ptr(dx), N, Hin, Win, C, dy.shape[1], dy.shape[2],
                                                     dy.shape[3], coff, int(accumulate), stream()),
           "affine_sampler_backward_data")
     return dx
@@ -647,7 +680,8 @@ def affine_sampler_backward_data(dy, theta, x_shape, coff, dx=None, accumulate=F
 def affine_sampler_backward_theta(sources, theta, dy, dtheta, accumulate=False):
     N, Ho, Wo, ldo = dy.shape
     ws = workspace(L().dspn_affine_sampler_theta_workspace_bytes(N, Ho, Wo), dy.device, "theta")
-    check(L().dspn_affine_sampler_backward_theta_f32(sources.x, sources.Hin, sources.Win, sources.C, sources.coff,
+    assert all(t.dtype == dy.dtype for t in sources.tensors) and dtheta.dtype == torch.float32
+    check(_f("dspn_affine_sampler_backward_theta", dy)(sources.x, sources.Hin, sources.Win, sources.C, sources.coff,
                                                      sources.n, ptr(theta), ptr(dy), N, Ho, Wo, ldo, ptr(dtheta),
                                                      int(accumulate), ptr(ws), ws.numel(), stream()),
           "affine_sampler_backward_theta")
@@ -681,10 +715,11 @@ def softmax_output(logits, label, C, ignore_label, grad_scale=1.0, valid_count=N
                    want_grad=True):
     ld = logits.shape[-1]
     rows = _rows(logits)
-    prob = torch.empty_like(logits) if prob is None else prob
+    prob = torch.empty_like(logits, dtype=torch.float32) if prob is None else prob
     if want_grad and grad is None:
         grad = torch.empty_like(logits)
-    check(L().dspn_softmax_output_f32(ptr(logits), ptr(label), ptr(prob), ptr(grad) if want_grad else 0, rows,
+    assert prob.dtype == torch.float32 and (grad is None or not want_grad or grad.dtype == logits.dtype)
+    check(_f("dspn_softmax_output", logits)(ptr(logits), ptr(label), ptr(prob), ptr(grad) if want_grad else 0, rows,
                                       C, ld, float(ignore_label), float(grad_scale), ptr(valid_count),
                                       stream()), "softmax_output")
     return prob, grad

@@ -44,7 +44,8 @@ class HeadPack(E.Node):
         self.sizes = [t.shape[1] * t.shape[2] * c for t, c in zip(maps, widths)]
         self.offsets = np.cumsum([0] + self.sizes).tolist()
         self.total = self.offsets[-1]
-        self.out = g.tensor((B, self.total), name)
+        import torch
+        self.out = g.tensor((B, self.total), name, dtype=torch.float32)     # loss / multibox-operator input: always float
 
     def forward(self):
         B = self.out.shape[0]

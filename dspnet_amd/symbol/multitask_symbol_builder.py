@@ -35,7 +35,7 @@ class MultiBoxTargetNode(E.Node):
     def __init__(self, g, anchors, label, cls_flat, num_cls):
         self.anchors, self.label, self.cls_flat, self.C = anchors, label, cls_flat, num_cls
         B, N = cls_flat.shape[0], anchors.shape[1]
-        self.cls_preds = g.tensor((B, num_cls, N), "multibox_cls_pred", requires_grad=False)
+        self.cls_preds = g.tensor((B, num_cls, N), "multibox_cls_pred", requires_grad=False, dtype=torch.float32)
         self.loc_target = self.loc_mask = self.cls_target = None
 
     def forward(self):
@@ -63,7 +63,7 @@ class ClsSoftmaxOutput(E.Node):
         self.prob_nc = fn.zeros(B, N, num_cls, device=g.device)
         self.gbuf = fn.zeros(*cls_flat.shape, device=g.device)   # d loss / d logits, made in forward
         self.valid = fn.zeros(1, device=g.device)
-        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False)
+        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False, dtype=torch.float32)
 
     def forward(self):
         B, C, N = self.cls_prob.shape
@@ -83,7 +83,7 @@ class LocLoss(E.Node):
     def __init__(self, g, loc_preds, target_node):
         self.x, self.tn = loc_preds, target_node
         self.valid = fn.zeros(1, device=g.device)
-        self.out = g.tensor(loc_preds.shape, "loc_loss", requires_grad=False)
+        self.out = g.tensor(loc_preds.shape, "loc_loss", requires_grad=False, dtype=torch.float32)
 
     def forward(self):
         fn.smooth_l1_forward(self.x.data, self.tn.loc_target, self.tn.loc_mask, out=self.out.data)
@@ -107,7 +107,7 @@ class Detection(E.Node):
         self.kw = dict(nms_threshold=nms_thresh, force_suppress=force_suppress,
                        variances=(0.1, 0.1, 0.2, 0.2), nms_topk=nms_topk)
         B, N = cls_prob.shape[0], anchors.shape[1]
-        self.out = g.tensor((B, N, 7), "det_out", requires_grad=False)
+        self.out = g.tensor((B, N, 7), "det_out", requires_grad=False, dtype=torch.float32)
         # det_out is a monitoring output: nothing in the step consumes it and it only reads cls_prob / loc_preds,
         # so its one-workgroup-per-sample sort + NMS kernels run on a second HIP stream beside the decoder and the
         # backward pass instead of leaving 7/8 of the CUs idle for ~1.3 ms.  join() (called at the top of the next
@@ -144,8 +144,8 @@ class SegSoftmaxOutput(E.Node):
     def __init__(self, g, logits, label, classes):
         self.x, self.label, self.C = logits, label, classes
         B, H, W, Cp = logits.shape
-        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False)
-        self.gbuf = fn.zeros(*logits.shape, device=g.device)
+        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False, dtype=torch.float32)
+        self.gbuf = fn.zeros(*logits.shape, device=g.device, dtype=logits.dtype)     # a gradient of an activation
         self.scale = 4.0 / float(H * W)
 
     def forward(self):
@@ -169,7 +169,7 @@ class ClsSoftmaxActivation(E.Node):
         B = cls_flat.shape[0]
         N = cls_flat.shape[1] // num_cls
         self.prob_nc = fn.zeros(B, N, num_cls, device=g.device)
-        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False)
+        self.cls_prob = g.tensor((B, num_cls, N), "cls_prob", requires_grad=False, dtype=torch.float32)
 
     def forward(self):
         B, C, N = self.cls_prob.shape
@@ -183,7 +183,7 @@ class SegSoftmax(E.Node):
 
     def __init__(self, g, logits, classes):
         self.x, self.C = logits, classes
-        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False)
+        self.prob = g.tensor(logits.shape, "seg_prob_nhwc", requires_grad=False, dtype=torch.float32)
 
     def forward(self):
         B, H, W, Cp = self.x.shape
@@ -253,9 +253,9 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     device = device or torch.device("cuda", torch.cuda.current_device())
     g = E.Graph(device)
     C, H, W = data_shape
-    data = g.tensor((batch_size, C, H, W), "data", requires_grad=False)
-    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False) if train else None
-    seg_label = (g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False)
+    data = g.tensor((batch_size, C, H, W), "data", requires_grad=False, dtype=torch.float32)
+    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False, dtype=torch.float32) if train else None
+    seg_label = (g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False, dtype=torch.float32)
                  if (train and with_seg) else None)
 
     if network == "resnet":

@@ -147,7 +147,11 @@ int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4
  * vectors (scale / shift / bias / statistics), split-K slabs, weight GRADIENTS and workspaces stay float.  The float
  * master weights are turned into the bf16 operands by dspn_conv2d_weight_prepare_bf16 (one batched launch per step).
  * `math` is accepted for symmetry and ignored (always bf16 MFMA, fp32 accumulate). */
+#ifdef DSPN_BF16_ELEMENT            /* inside the library: the compiler's own bfloat16 type (same 16 bits) */
+typedef DSPN_BF16_ELEMENT dspn_bf16;
+#else
 typedef unsigned short dspn_bf16;
+#endif
 int dspn_conv2d_forward_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
                                 const dspn_bf16 *w, const float *bias, const dspn_bf16 *residual, dspn_bf16 *y,
                                 int N, int H, int W, int Cin, int Cout, int R, int S,
@@ -364,6 +368,70 @@ int dspn_sum_f32(const float *a, long long n, float *out, void *stream);
  * g = rescale*grad + wd*w ; mom = momentum*mom - lr*g ; w += mom, over a flat parameter arena. */
 int dspn_sgd_momentum_f32(float *w, const float *grad, float *mom, long long n, float lr, float momentum,
                           float wd, float rescale, void *stream);
+
+/* ---- bfloat16 twins of the HBM-bound kernels (same conventions as the convolution twins above: activation pointers
+ * are bfloat16, everything per-channel / reduced / float-only keeps its type; dspn_nchw_to_nhwc_bf16 takes the float
+ * NCHW image and writes the bf16 NHWC tensor; dspn_softmax_output_bf16 reads bf16 logits, writes FLOAT probabilities
+ * and the bf16 gradient). ------------------------------------------------------------------------------------- */
+int dspn_bn_stats_bf16(const dspn_bf16 *x, long long rows, int C, float eps, const float *gamma,
+                      const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int dspn_bn_apply_bf16(const dspn_bf16 *x, const float *scale, const float *shift, dspn_bf16 *y, long long rows,
+                      int C, int relu, void *stream);
+int dspn_bn_backward_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
+                         const float *mean, const float *rstd, const float *gamma, dspn_bf16 *dx,
+                         float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int dspn_bn_backward_from_sums_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
+                                   const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
+                                   int tiles, dspn_bf16 *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
+                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+int dspn_add_bf16(const dspn_bf16 *a, const dspn_bf16 *b, dspn_bf16 *out, long long n, void *stream);
+int dspn_relu_backward_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long n, int accumulate, void *stream);
+int dspn_relu_backward_colsum_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long rows, int C, int ld,
+                                  float *out, void *workspace, size_t workspace_bytes, void *stream);
+int dspn_colsum_bf16(const dspn_bf16 *a, long long rows, int C, int ld, float *out,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int dspn_nchw_to_nhwc_bf16(const float *src, dspn_bf16 *dst, int N, int C, int H, int W, int Cp, void *stream);
+int dspn_copy_block_bf16(const dspn_bf16 *src, dspn_bf16 *dst, int samples, long long rows_per_sample, int C,
+                        long long src_sample_stride, int lds, int soff,
+                        long long dst_sample_stride, int ldd, int doff, int accumulate, void *stream);
+int dspn_tap_sum_bf16(const dspn_bf16 *z, const float *bias, dspn_bf16 *y, int N, int H, int W, int Cout, int ldy,
+                     int ldz, int R, int S, int pad_h, int pad_w, void *stream);
+int dspn_tap_spread_bf16(const dspn_bf16 *dy, dspn_bf16 *dz, int N, int H, int W, int Cout, int ldy, int ldz, int R,
+                        int S, int pad_h, int pad_w, void *stream);
+int dspn_maxpool_forward_bf16(const dspn_bf16 *x, dspn_bf16 *y, unsigned char *argmax, int N, int H, int W, int C, int k,
+                             int stride, int pad, int Ho, int Wo, void *stream);
+int dspn_maxpool_backward_argmax_bf16(const unsigned char *argmax, const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H,
+                                     int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
+int dspn_maxpool_backward_bf16(const dspn_bf16 *x, const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H,
+                              int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
+int dspn_avgpool_forward_bf16(const dspn_bf16 *x, dspn_bf16 *y, int N, int H, int W, int C, int k, int Ho, int Wo, void *stream);
+int dspn_avgpool_backward_bf16(const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H, int W, int C, int k, int Ho, int Wo,
+                              int accumulate, void *stream);
+int dspn_avgpool2d_forward_bf16(const dspn_bf16 *x, dspn_bf16 *y, int N, int H, int W, int C, int k, int stride, int pad,
+                               int Ho, int Wo, void *stream);
+int dspn_avgpool2d_backward_bf16(const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H, int W, int C, int k, int stride, int pad,
+                                int Ho, int Wo, int accumulate, void *stream);
+int dspn_softmax_output_bf16(const dspn_bf16 *logits, const float *label, float *prob, dspn_bf16 *grad,
+                            long long rows, int C, int ld, float ignore_label, float grad_scale,
+                            const float *valid_count, void *stream);
+int dspn_affine_sampler_backward_data_bf16(const dspn_bf16 *dy, const float *theta, dspn_bf16 *dx, int N, int Hin, int Win, int C,
+                                          int Ho, int Wo, int ldo, int coff, int accumulate, void *stream);
+int dspn_affine_sampler_forward_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
+                                    int nsrc, const float *theta, dspn_bf16 *y, int N, int Ho, int Wo, int ldo, void *stream);
+int dspn_affine_sampler_backward_theta_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C,
+                                           const int *coff, int nsrc, const float *theta, const dspn_bf16 *dy, int N, int Ho,
+                                           int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
+                                           size_t workspace_bytes, void *stream);
+/* dspn_copy_block between storage types: bf16 -> float (SSD head maps into the float loss inputs) and float -> bf16
+ * (their gradients back into the per-map gradient tensors) */
+int dspn_copy_block_bf16_f32(const dspn_bf16 *src, float *dst, int samples, long long rows_per_sample, int C,
+                             long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
+                             int ldd, int doff, int accumulate, void *stream);
+int dspn_copy_block_f32_bf16(const float *src, dspn_bf16 *dst, int samples, long long rows_per_sample, int C,
+                             long long src_sample_stride, int lds, int soff, long long dst_sample_stride,
+                             int ldd, int doff, int accumulate, void *stream);
 
 #ifdef __cplusplus
 }
