@@ -126,9 +126,10 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
       fw_lo = fminf(fw_lo, fw); fw_hi = fmaxf(fw_hi, fw); fh_lo = fminf(fh_lo, fh); fh_hi = fmaxf(fh_hi, fh);
     }
     if (isfinite(fw_lo) && isfinite(fw_hi) && isfinite(fh_lo) && isfinite(fh_hi)) {
-      // two pixels of slack for the rounding of the inverse; membership is tested exactly below
-      wo_lo = (int)fmaxf(floorf(fw_lo) - 2.f, 0.f); wo_hi = (int)fminf(ceilf(fw_hi) + 2.f, (float)(Wo - 1));
-      ho_lo = (int)fmaxf(floorf(fh_lo) - 2.f, 0.f); ho_hi = (int)fminf(ceilf(fh_hi) + 2.f, (float)(Ho - 1));
+      // one pixel of slack for the rounding of the inverse (a target pixel ON the edge of the pre-image has weight 0);
+      // membership is tested exactly below
+      wo_lo = (int)fmaxf(floorf(fw_lo) - 1.f, 0.f); wo_hi = (int)fminf(ceilf(fw_hi) + 1.f, (float)(Wo - 1));
+      ho_lo = (int)fmaxf(floorf(fh_lo) - 1.f, 0.f); ho_hi = (int)fminf(ceilf(fh_hi) + 1.f, (float)(Ho - 1));
     }
   }
   for (int cb = 0; cb < C4; cb += 64) {
@@ -172,7 +173,9 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
   }
 }
 
-// partial[wave][6] (double): this wave's target pixels, all sources
+// partial[wave][6] (double): this wave's target pixels, all sources.  Lanes run over channels; every lane keeps its own
+// six sums over all the pixels and sources its wave visits (the sum over lanes commutes with the sum over pixels), and
+// the lanes are combined ONCE, by a fixed butterfly in double, at the end.
 constexpr int kThetaWavesPerBlock = 4;
 __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_kernel(
     const SrcTable tab, const float *__restrict__ theta, const st_t *__restrict__ dy, double *__restrict__ partial,
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_ke
   const int lane = threadIdx.x & 63;
   const long long gw = (long long)blockIdx.x * kThetaWavesPerBlock + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * kThetaWavesPerBlock;
-  double a[6] = {0, 0, 0, 0, 0, 0};
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long long p = gw; p < pixels; p += nw) {
     const int wo = (int)(p % Wo);
     const int ho = (int)((p / Wo) % Ho);
@@ -196,40 +199,39 @@ __global__ __launch_bounds__(64 * kThetaWavesPerBlock) void sampler_bwd_theta_ke
       const float fy = ys - (float)y0, fx = xs - (float)x0;
       const bool vy0 = (unsigned)y0 < (unsigned)s.Hin, vy1 = (unsigned)(y0 + 1) < (unsigned)s.Hin;
       const bool vx0 = (unsigned)x0 < (unsigned)s.Win, vx1 = (unsigned)(x0 + 1) < (unsigned)s.Win;
+      if (!((vy0 || vy1) && (vx0 || vx1))) continue;
+      const CA4Ptr x(s.x);
+      const long long base = ((n * s.Hin + y0) * s.Win + x0) * s.C4;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       float gx = 0.f, gy = 0.f;
-      if ((vy0 || vy1) && (vx0 || vx1)) {
-        const CA4Ptr x(s.x);
-        const long long base = ((n * s.Hin + y0) * s.Win + x0) * s.C4;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = lane; c < s.C4; c += 64) {
-          const float4 v00 = (vy0 && vx0) ? x[base + c] : z;
-          const float4 v01 = (vy0 && vx1) ? x[base + s.C4 + c] : z;
-          const float4 v10 = (vy1 && vx0) ? x[base + (long long)s.Win * s.C4 + c] : z;
-          const float4 v11 = (vy1 && vx1) ? x[base + (long long)(s.Win + 1) * s.C4 + c] : z;
-          const float4 d = ld4(g + (s.coff4 + c) * 4);
-          const float ax_[4] = {v01.x - v00.x, v01.y - v00.y, v01.z - v00.z, v01.w - v00.w};
-          const float bx_[4] = {v11.x - v10.x, v11.y - v10.y, v11.z - v10.z, v11.w - v10.w};
-          const float ay_[4] = {v10.x - v00.x, v10.y - v00.y, v10.z - v00.z, v10.w - v00.w};
-          const float by_[4] = {v11.x - v01.x, v11.y - v01.y, v11.z - v01.z, v11.w - v01.w};
-          const float dd[4] = {d.x, d.y, d.z, d.w};
+      for (int c = lane; c < s.C4; c += 64) {
+        const float4 v00 = (vy0 && vx0) ? x[base + c] : z;
+        const float4 v01 = (vy0 && vx1) ? x[base + s.C4 + c] : z;
+        const float4 v10 = (vy1 && vx0) ? x[base + (long long)s.Win * s.C4 + c] : z;
+        const float4 v11 = (vy1 && vx1) ? x[base + (long long)(s.Win + 1) * s.C4 + c] : z;
+        const float4 d = ld4(g + (s.coff4 + c) * 4);
+        const float ax_[4] = {v01.x - v00.x, v01.y - v00.y, v01.z - v00.z, v01.w - v00.w};
+        const float bx_[4] = {v11.x - v10.x, v11.y - v10.y, v11.z - v10.z, v11.w - v10.w};
+        const float ay_[4] = {v10.x - v00.x, v10.y - v00.y, v10.z - v00.z, v10.w - v00.w};
+        const float by_[4] = {v11.x - v01.x, v11.y - v01.y, v11.z - v01.z, v11.w - v01.w};
+        const float dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            gx += dd[e] * ((1.f - fy) * ax_[e] + fy * bx_[e]);
-            gy += dd[e] * ((1.f - fx) * ay_[e] + fx * by_[e]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          gx += dd[e] * ((1.f - fy) * ax_[e] + fy * bx_[e]);
+          gy += dd[e] * ((1.f - fx) * ay_[e] + fx * by_[e]);
         }
       }
-      // fixed butterfly over the 64 lanes
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { gx += __shfl_xor(gx, o, 64); gy += __shfl_xor(gy, o, 64); }
-      const double cx = (double)gx * (double)(s.Win - 1) * 0.5, cy = (double)gy * (double)(s.Hin - 1) * 0.5;
+      const float cx = gx * ((float)(s.Win - 1) * 0.5f), cy = gy * ((float)(s.Hin - 1) * 0.5f);
       a[0] += cx * xt; a[1] += cx * yt; a[2] += cx;
       a[3] += cy * xt; a[4] += cy * yt; a[5] += cy;
     }
   }
-  if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) partial[gw * 6 + k] = a[k];
+  for (int k = 0; k < 6; ++k) {
+    double v = (double)a[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);     // fixed butterfly over the 64 lanes
+    if (lane == 0) partial[gw * 6 + k] = v;
   }
 }
 
@@ -286,7 +288,7 @@ int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *thet
   const long long pix = (long long)N * Hin * Win;
   DSPN_REQUIRE(pix < (1ll << 31), "affine_sampler_backward_data: too many source pixels");
   // slices by the nominal footprint (the grid is near the identity map): rows of the pre-image box per source pixel
-  const int rows = 2 * ((Ho + Hin - 1) / Hin) + 4;
+  const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
   hipStream_t s = (hipStream_t)stream;
 #define DSPN_SBD_(SL) hipLaunchKernelGGL(sampler_bwd_data_kernel<SL>, dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
                                          A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate)

@@ -185,3 +185,112 @@ def test_dgrad_epilogue_batchnorm_sums_bf16_tensors(gpu_device, case):
     got = sums.double().sum(0)
     assert float((got[0] - gsum).abs().max()) <= 2e-5 * float(gsum.abs().max()) + 1e-4
     assert float((got[1] - gxh).abs().max()) <= 2e-5 * float(gxh.abs().max()) + 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The HBM-bound kernels: each `*_bf16` twin runs the SAME fp32 arithmetic as its `*_f32` original on widened inputs and
+# rounds once on store.  On bf16-representable inputs therefore: a stored result == round_to_bf16(float result) bit
+# for bit, and a float result (statistics, column sums, probabilities) == the float kernel's, bit for bit.
+def _pair(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    h = (torch.randn(*shape, generator=g) * scale).to(BF).cuda()
+    return h, h.float()
+
+
+def _same_stored(h_out, f_out, what):
+    assert h_out.dtype == BF and f_out.dtype == torch.float32
+    assert torch.equal(h_out, f_out.to(BF)), f"{what}: bf16 kernel != round(float kernel), max diff {float((h_out.float() - f_out).abs().max()):.3e}"
+
+
+def test_batchnorm_kernels_bf16_twins(gpu_device):
+    for shape, relu in (((4, 16, 16, 64), True), ((2, 9, 7, 256), False), ((3, 5, 5, 24), True)):
+        xh, xf = _pair(shape, 1)
+        dyh, dyf = _pair(shape, 2)
+        C = shape[-1]
+        gamma = (torch.rand(C) + 0.5).cuda(); beta = torch.randn(C).cuda()
+        sh_, sf_ = fn.bn_stats(xh, 2e-5, gamma, beta), fn.bn_stats(xf, 2e-5, gamma, beta)
+        for a, b in zip(sh_, sf_):
+            assert torch.equal(a, b)                                    # statistics: float, same sums in the same order
+        mean, rstd, scale, shift = sf_
+        _same_stored(fn.bn_apply(xh, scale, shift, relu=relu), fn.bn_apply(xf, scale, shift, relu=relu), "bn_apply")
+        for acc in (False, True):
+            baseh, basef = _pair(shape, 3)
+            dxh, dgh, dbh = fn.bn_backward(xh, scale, shift, dyh, mean, rstd, gamma, relu=relu, dx=baseh.clone(), accumulate=acc)
+            dxf, dgf, dbf = fn.bn_backward(xf, scale, shift, dyf, mean, rstd, gamma, relu=relu, dx=basef.clone(), accumulate=acc)
+            _same_stored(dxh, dxf, "bn_backward dx")
+            assert torch.equal(dgh, dgf) and torch.equal(dbh, dbf)
+
+
+def test_elementwise_pool_layout_kernels_bf16_twins(gpu_device):
+    ah, af = _pair((2, 16, 16, 32), 4)
+    bh, bf_ = _pair((2, 16, 16, 32), 5)
+    _same_stored(fn.add(ah, bh), fn.add(af, bf_), "add")
+    yh, yf = ah.clamp(min=0), af.clamp(min=0)
+    _same_stored(fn.relu_backward(yh, bh), fn.relu_backward(yf, bf_), "relu_backward")
+    dxh, sh_ = fn.relu_backward_colsum(yh.view(-1, 32), bh.view(-1, 32).clone(), 30)
+    dxf, sf_ = fn.relu_backward_colsum(yf.view(-1, 32), bf_.view(-1, 32).clone(), 30)
+    _same_stored(dxh, dxf, "relu_backward_colsum dx")
+    assert torch.equal(sh_, sf_)
+    assert torch.equal(fn.colsum(ah.view(-1, 32), 30), fn.colsum(af.view(-1, 32), 30))
+    # pooling
+    am_h = torch.zeros(2, 8, 8, 32, dtype=torch.uint8, device="cuda"); am_f = torch.zeros_like(am_h)
+    ph, pf = fn.maxpool_forward(ah, 3, 2, 1, argmax=am_h), fn.maxpool_forward(af, 3, 2, 1, argmax=am_f)
+    _same_stored(ph, pf, "maxpool")
+    assert torch.equal(am_h, am_f)
+    gh, gf = _pair((2, 8, 8, 32), 6)
+    _same_stored(fn.maxpool_backward_argmax(am_h, gh, ah.shape, 3, 2, 1), fn.maxpool_backward_argmax(am_f, gf, af.shape, 3, 2, 1), "maxpool_bwd_idx")
+    _same_stored(fn.maxpool_backward(ah, ph, gh, 3, 2, 1), fn.maxpool_backward(af, pf, gf, 3, 2, 1), "maxpool_bwd")
+    _same_stored(fn.avgpool_forward(ah, 2), fn.avgpool_forward(af, 2), "avgpool")
+    _same_stored(fn.avgpool_backward(gh, ah.shape, 2), fn.avgpool_backward(gf, af.shape, 2), "avgpool_bwd")
+    _same_stored(fn.avgpool2d_forward(ah, 3, 1, 1), fn.avgpool2d_forward(af, 3, 1, 1), "avgpool2d")
+    _same_stored(fn.avgpool2d_backward(ah, ah.shape, 3, 1, 1), fn.avgpool2d_backward(af, af.shape, 3, 1, 1), "avgpool2d_bwd")
+    # tap sum / spread
+    zh, zf = _pair((2, 8, 8, 48), 7)
+    bias = torch.randn(5).cuda()
+    oh, of = torch.zeros(2, 8, 8, 8, dtype=BF, device="cuda"), torch.zeros(2, 8, 8, 8, device="cuda")
+    _same_stored(fn.tap_sum(zh, bias, 5, 3, 3, (1, 1), oh), fn.tap_sum(zf, bias, 5, 3, 3, (1, 1), of), "tap_sum")
+    sh2, sf2 = torch.zeros(2, 8, 8, 48, dtype=BF, device="cuda"), torch.zeros(2, 8, 8, 48, device="cuda")
+    _same_stored(fn.tap_spread(oh, 5, 3, 3, (1, 1), sh2), fn.tap_spread(of, 5, 3, 3, (1, 1), sf2), "tap_spread")
+    # layout: float NCHW image -> NHWC of either storage type; block copies within and across storage types
+    img = torch.randn(2, 3, 9, 7).to(BF).float().cuda()
+    nh = fn.nchw_to_nhwc(img, out=torch.empty(2, 9, 7, 8, dtype=BF, device="cuda"))
+    nf = fn.nchw_to_nhwc(img, out=torch.empty(2, 9, 7, 8, device="cuda"))
+    _same_stored(nh, nf, "nchw_to_nhwc")
+    src_h, src_f = _pair((2, 6, 6, 16), 8)
+    for acc in (False, True):
+        dh, df = _pair((2, 6 * 6 * 10 + 7,), 9)
+        dh, df = dh.view(2, -1), df.view(2, -1)
+        f32_out = df.clone()
+        fn.copy_block(src_f, f32_out, 2, 36, 10, 36 * 16, 16, 3, f32_out.shape[1], 10, 5, accumulate=acc)
+        h_out = dh.clone()
+        fn.copy_block(src_h, h_out, 2, 36, 10, 36 * 16, 16, 3, h_out.shape[1], 10, 5, accumulate=acc)       # bf16 -> bf16
+        _same_stored(h_out, f32_out, "copy_block bf16->bf16")
+        mixed = df.clone()
+        fn.copy_block(src_h, mixed, 2, 36, 10, 36 * 16, 16, 3, mixed.shape[1], 10, 5, accumulate=acc)       # bf16 -> float
+        assert torch.equal(mixed, f32_out)
+        back = dh.clone()
+        fn.copy_block(src_f, back, 2, 36, 10, 36 * 16, 16, 3, back.shape[1], 10, 5, accumulate=acc)         # float -> bf16
+        _same_stored(back, f32_out, "copy_block float->bf16")
+
+
+def test_softmax_output_and_affine_sampler_bf16_twins(gpu_device):
+    lh, lf = _pair((500, 24), 10, 3.0)
+    label = torch.randint(0, 19, (500,)).float().cuda(); label[::7] = 255.0
+    ph, gh = fn.softmax_output(lh, label, 19, 255.0, 0.25)
+    pf, gf = fn.softmax_output(lf, label, 19, 255.0, 0.25)
+    assert ph.dtype == torch.float32 and torch.equal(ph, pf)
+    _same_stored(gh, gf, "softmax gradient")
+    theta = torch.tensor([0.97, 0.02, 0.01, -0.03, 1.04, 0.02], device="cuda")
+    srcs_h, srcs_f = zip(*[_pair((2, h, w, 8), 20 + h) for h, w in ((4, 4), (8, 8), (16, 12))])
+    outh, outf = torch.empty(2, 16, 12, 8, dtype=BF, device="cuda"), torch.empty(2, 16, 12, 8, device="cuda")
+    fn.affine_sampler_forward(fn.SamplerSources([(t, 0) for t in srcs_h]), theta, outh)
+    fn.affine_sampler_forward(fn.SamplerSources([(t, 0) for t in srcs_f]), theta, outf)
+    _same_stored(outh, outf, "sampler forward")
+    dyh, dyf = _pair((2, 16, 12, 8), 30)
+    for th_, tf_ in zip(srcs_h, srcs_f):
+        _same_stored(fn.affine_sampler_backward_data(dyh, theta, th_.shape, 0), fn.affine_sampler_backward_data(dyf, theta, tf_.shape, 0),
+                     "sampler backward data")
+    dth, dtf = torch.zeros(6, device="cuda"), torch.zeros(6, device="cuda")
+    fn.affine_sampler_backward_theta(fn.SamplerSources([(t, 0) for t in srcs_h]), theta, dyh, dth)
+    fn.affine_sampler_backward_theta(fn.SamplerSources([(t, 0) for t in srcs_f]), theta, dyf, dtf)
+    assert torch.equal(dth, dtf)

@@ -553,20 +553,29 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
         fn.set_conv_math("fp32")
 
 
-def test_inceptionv3_bf16_every_convolution_layer_local(gpu_device):
-    """configs[3] layer by layer, without the chaos: EVERY Conv node of the inceptionv3 multi-task graph at 1024x512 in
-    bf16 mode -- forward (with its folded BatchNorm-apply+ReLU loader where the graph uses one), data gradient and weight
-    gradient -- against float64 convolutions of the SAME bf16-rounded operands, each fed with the device's OWN input
-    tensors (so no error propagates from layer to layer).  What is left is fp32 accumulation: 1e-5 of the output scale
-    (1e-4 where a data gradient is accumulated onto earlier contributions and has to be recovered as a difference)."""
+@pytest.mark.parametrize("network,H,W,B,store", [("inceptionv3", 512, 1024, 1, "fp32"), ("inceptionv3", 512, 1024, 1, "bf16"),
+                                                 ("resnet-50", 256, 256, 2, "bf16")])
+def test_bf16_every_convolution_layer_local(gpu_device, network, H, W, B, store):
+    """configs[3] layer by layer, without the chaos: EVERY Conv node of the multi-task graph (inceptionv3 at 1024x512)
+    in bf16 mode -- forward (with its folded BatchNorm-apply+ReLU loader where the graph uses one), data gradient and
+    weight gradient -- against float64 convolutions of the SAME bf16-rounded operands, each fed with the device's OWN
+    input tensors (so no error propagates from layer to layer).
+    store = "fp32": float tensors, operands rounded on the way into LDS.  What is left is fp32 accumulation: 1e-5 of the
+    output scale (1e-4 where a data gradient is accumulated onto earlier contributions and has to be recovered as a
+    difference).
+    store = "bf16": bfloat16 tensors in HBM (the `*_bf16` kernels).  Inputs are then bf16 exactly; an output tensor carries
+    its own rounding on top: |err| <= 2^-8 |ref| + 1e-5 scale per element; weight gradients (float) stay at 1e-5."""
     import torch.nn.functional as F
     from dspnet_amd import engine as E
     from dspnet_amd import functional as fn
     fn.set_conv_math("bf16")
+    fn.set_activation_dtype(store)
+    half = store == "bf16"
     try:
         dev = torch.device("cuda", 0)
-        H, W, B = 512, 1024, 1
-        net = get_multi_symbol_train("inceptionv3", (3, H, W), num_classes=8, batch_size=B, device=dev, seed=3)
+        net = get_multi_symbol_train(network, (3, H, W), num_classes=8, batch_size=B, device=dev, seed=3)
+        fn.set_activation_dtype("fp32")
+        assert net.g.tensors["multibox_loc_pred"].data.dtype == torch.float32
         gen = synthetic.rng(78)
         solver = MultiTaskSolver(net)
         solver.set_batch(torch.from_numpy(synthetic.images(B, H, W, gen)).to(dev),
@@ -597,11 +606,17 @@ def test_inceptionv3_bf16_every_convolution_layer_local(gpu_device):
             cout, cin = n.w.logical[0], n.w.logical[1]
             return n.w.data.detach().cpu().double()[:cout, :, :, :cin].permute(0, 3, 1, 2).contiguous()
 
-        def rel(a, b):
-            return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        def rel(a, b, stored=False):
+            """error in units of the bound: fp32 accumulation (1e-5 of the scale), plus the tensor's own bf16 rounding
+            when the result went through a bf16 store"""
+            scale = float(b.abs().max()) + 1e-30
+            if not stored:
+                return float((a - b).abs().max() / scale) / 1e-5
+            return float(((a - b).abs() / (b.abs() * 2.0 ** -8 + 1e-5 * scale)).max())
 
         convs = [n for n in g.nodes if isinstance(n, E.Conv)]
-        assert len(convs) > 100
+        assert len(convs) > (100 if network == "inceptionv3" else 60)
+        assert all(n.out.data.dtype == (torch.bfloat16 if half else torch.float32) for n in convs)
         kinds, worst_f = set(), 0.0
         for n in convs:
             xq, wq = q(conv_input(n)), q(weight(n))
@@ -611,12 +626,12 @@ def test_inceptionv3_bf16_every_convolution_layer_local(gpu_device):
                 ref = ref + nchw64(n.residual.data, n.cout)
             if n.relu:
                 ref = ref.clamp_min(0)
-            e = rel(nchw64(n.out.data, n.cout), ref)
+            e = rel(nchw64(n.out.data, n.cout), ref, stored=half)
             worst_f = max(worst_f, e)
-            assert e < 1e-5, ("forward", n.w.name, e)
+            assert e <= 1.0, ("forward", n.w.name, e)
             kinds.add((tuple(n.w.shape[1:3]), n.stride, n.pad, n.in_affine is not None, n.tap_expand))
-        # every conv class of symbol/inceptionv3.py is in there
-        assert {(1, 7), (7, 1), (1, 3), (3, 1), (5, 5), (3, 3), (1, 1)} <= {k[0] for k in kinds}
+        if network == "inceptionv3":     # every conv class of symbol/inceptionv3.py is in there
+            assert {(1, 7), (7, 1), (1, 3), (3, 1), (5, 5), (3, 3), (1, 1)} <= {k[0] for k in kinds}
 
         # backward, node by node, with the output gradient each convolution actually received
         g.begin_backward()
@@ -643,23 +658,28 @@ def test_inceptionv3_bf16_every_convolution_layer_local(gpu_device):
             got_w = n.w.grad.detach().cpu().double()[:cout, :, :, :cin].permute(0, 3, 1, 2)
             e = rel(got_w, gw)
             worst_w = max(worst_w, e)
-            assert e < 1e-5, ("wgrad", n.w.name, e)
+            assert e <= 1.0, ("wgrad", n.w.name, e)
             if n.x.requires_grad:
                 gx = torch.nn.grad.conv2d_input(xq.shape, wq, dq, stride=n.stride, padding=n.pad, dilation=n.dil)
                 after = nchw64(n.x.grad, cin)
-                if had:
-                    e = float(((after - nchw64(before, cin)) - gx).abs().max() / (after.abs().max() + 1e-30))
-                    assert e < 1e-4, ("dgrad(acc)", n.w.name, e)
+                if had and half:
+                    # accumulated onto an earlier (stored, rounded) contribution: the sum is rounded once more
+                    e = rel(after, nchw64(before, cin) + gx, stored=True)
+                    assert e <= 1.0, ("dgrad(acc)", n.w.name, e)
+                elif had:
+                    e = float(((after - nchw64(before, cin)) - gx).abs().max() / (after.abs().max() + 1e-30)) / 1e-4
+                    assert e <= 1.0, ("dgrad(acc)", n.w.name, e)
                 else:
-                    e = rel(after, gx)
-                    assert e < 1e-5, ("dgrad", n.w.name, e)
+                    e = rel(after, gx, stored=half)
+                    assert e <= 1.0, ("dgrad", n.w.name, e)
                 worst_d = max(worst_d, e)
                 checked_d += 1
-        assert checked_d > 90
-        print("bf16 inceptionv3 512x1024 layer-local: %d convolutions, worst forward %.2e, wgrad %.2e, dgrad %.2e"
-              % (len(convs), worst_f, worst_w, worst_d))
+        assert checked_d > (90 if network == "inceptionv3" else 55)
+        print("bf16 math, %s tensors, %s %dx%d layer-local: %d convolutions, worst error / bound: forward %.3f, wgrad %.3f, "
+              "dgrad %.3f" % (store, network, H, W, len(convs), worst_f, worst_w, worst_d))
     finally:
         fn.set_conv_math("fp32")
+        fn.set_activation_dtype("fp32")
 
 
 def test_fused_and_unfused_batchnorm_graphs_agree(gpu_device):
