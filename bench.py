@@ -188,7 +188,7 @@ def conv_nodes(net):
     return [n for n in net.g.nodes if isinstance(n, (E.Conv, E.Deconv4x4s2, E.BilinearConcatConv))]
 
 
-def side_train(network, H, W, B, math, steps, warmup, dev):
+def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
     """a short side measurement of another BASELINE.json training config on this GPU (never part of `value`)"""
     import torch
     from dspnet_amd import _lib, functional as fn, synthetic
@@ -196,8 +196,10 @@ def side_train(network, H, W, B, math, steps, warmup, dev):
     from dspnet_amd.train.solver import MultiTaskSolver
     lib = _lib.lib()
     fn.set_conv_math(math)
+    fn.set_activation_dtype(store)
     try:
         net = get_multi_symbol_train(network, (3, H, W), num_classes=8, batch_size=B, device=dev, seed=0)
+        fn.set_activation_dtype("fp32")
         solver = MultiTaskSolver(net)
         g = synthetic.rng(233)
         solver.set_batch(torch.from_numpy(synthetic.images(B, H, W, g)).to(dev),
@@ -217,12 +219,14 @@ def side_train(network, H, W, B, math, steps, warmup, dev):
         dt = time.perf_counter() - t0
         lib.dspn_profile_enable(0)
         return {"workload": "%s multitask (det+depth+seg) %dx%d (HxW), bs %d, %s, forward+backward+SGD, N=%d anchors"
-                            % (network, H, W, B, "fp32" if math == "fp32" else "bf16 MFMA convs", net.anchors.shape[1]),
+                            % (network, H, W, B, "fp32" if math == "fp32" else ("bf16 MFMA convs" + (
+                                ", bf16 tensors in HBM" if store == "bf16" else ", fp32 tensors in HBM")), net.anchors.shape[1]),
                 "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                 "steps": steps, "warmup": warmup, "dtype": "f32" if math == "fp32" else "bf16",
                 "roofline": conv_family_roofline(lib, steps, flops_step, flops_3x, math, dt / steps)}
     finally:
         fn.set_conv_math("fp32")
+        fn.set_activation_dtype("fp32")
 
 
 def side_infer(B, size, iters, warmup, dev):
@@ -395,7 +399,8 @@ def main():
         del solver
         other = {}
         for key, f in (("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "fp32", 5, 2, dev)),
-                       ("configs[3]", lambda: side_train("inceptionv3", 512, 1024, 8, "bf16", 8, 3, dev)),
+                       ("configs[3]", lambda: side_train("inceptionv3", 512, 1024, 8, "bf16", 8, 3, dev, store="bf16")),
+                       ("headline shape, bf16 tensors", lambda: side_train("resnet-50", 512, 512, 32, "bf16", 8, 3, dev, store="bf16")),
                        ("configs[4]", lambda: side_infer(64, 512, 100, 10, dev))):
             try:
                 other[key] = f()

@@ -22,11 +22,21 @@ struct ProfRec { hipEvent_t a, b; int family; };
 static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;      // events handed back by dspn_profile_collect, reused by later scopes
 static thread_local hipEvent_t t_prof_end = nullptr;
 bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed); }
+static hipEvent_t prof_event() {
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
 void prof_begin(int family, hipStream_t s) {
   ProfRec r; r.family = family;
-  (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+  r.a = prof_event(); r.b = prof_event();      // creating an event costs microseconds of host time per launch: pooled
   (void)hipEventRecord(r.a, s);
   t_prof_end = r.b;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -46,7 +56,7 @@ int dspn_profile_collect(int family, double *total_ms, long long *launches) {
     (void)hipEventSynchronize(r.b);
     float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
     t += ms; ++n;
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    dspn::g_prof_pool.push_back(r.a); dspn::g_prof_pool.push_back(r.b);
   }
   dspn::g_prof.swap(keep);
   if (total_ms) *total_ms = t;

@@ -293,4 +293,5 @@ def test_softmax_output_and_affine_sampler_bf16_twins(gpu_device):
     dth, dtf = torch.zeros(6, device="cuda"), torch.zeros(6, device="cuda")
     fn.affine_sampler_backward_theta(fn.SamplerSources([(t, 0) for t in srcs_h]), theta, dyh, dth)
     fn.affine_sampler_backward_theta(fn.SamplerSources([(t, 0) for t in srcs_f]), theta, dyf, dtf)
-    assert torch.equal(dth, dtf)
+    # (float sums of the same terms; the two builds may contract the per-lane multiply-adds differently)
+    assert float((dth - dtf).abs().max()) <= 1e-6 * float(dtf.abs().max())
