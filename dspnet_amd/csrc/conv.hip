@@ -58,7 +58,10 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
 constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
 constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
 constexpr int kBKF = 32;                       // ... of its fp32-MFMA path
-constexpr int kPK = 32;                        // pixels per k-step of the weight-gradient kernel
+#ifndef DSPN_WG_PK
+#define DSPN_WG_PK 32
+#endif
+constexpr int kPK = DSPN_WG_PK;                // pixels per k-step of the weight-gradient kernel
 __device__ __forceinline__ float4 ld4(const st_t *p) { return dspn::CA1Ptr(p).vec4()[0]; }
 __device__ __forceinline__ void st4(st_t *p, const float4 v) { dspn::A1Ptr(p).vec4()[0] = v; }
 // 8 bf16 of one 16-byte chunk <-> 8 floats
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         return r;
       };
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < kPK / 16; ++kk) {
         bf16x8 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = frag(a + kk * 16 * RAB + i * 64, RAB);
@@ -1303,7 +1306,9 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   static const char *eight_env = getenv("DSPN_NT_8WAVE");
   const int eight_mode = eight_env ? atoi(eight_env) : -1;   // -1 default, 0 never, 1 always, 2 default + 1x1 dgrads, 3 default + every 1x1
   const bool one_tap = g.TR * g.TS == 1;
-  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true
+  // bf16 tensors: the main loop is ~3x shorter, the fused epilogues cost relatively more, and the 8-wave form wins for
+  // every epilogue (measured on the resnet-50 step: 28.6 -> 26.1 ms)
+  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : kHalf ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
@@ -1315,6 +1320,10 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
 }
 
 struct WgradPlan { int bm; int bn; int splits; int pps; };
+// pixels per split are a multiple of this in BOTH builds (the float build steps 32 pixels per k-step, the bf16 build 64):
+// dspn_conv2d_wgrad_splits() -- exported once -- must size the slab buffers of either
+constexpr int kPlanPK = 64;
+static_assert(kPlanPK % kPK == 0, "split sizes must be whole k-steps");
 // Weight-gradient decomposition: tile height by Cout, split-K over pixels.  The number of splits is
 // the one that minimises a small cost model: workgroups run in rounds of `slots` (workgroups the chip
 // holds at once, set by LDS per workgroup), each costs its pixels plus a fixed prologue/epilogue, and
@@ -1345,7 +1354,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   double best = 1e30;
   long long splits = s_min;
   for (long long sp = s_min; sp <= s_max; ++sp) {
-    const long long pps = ((P + sp - 1) / sp + kPK - 1) / kPK * kPK;
+    const long long pps = ((P + sp - 1) / sp + kPlanPK - 1) / kPlanPK * kPlanPK;
     const long long real = (P + pps - 1) / pps;
     const long long rounds = (tiles * real + slots - 1) / slots;
     const double t = (double)rounds * ((double)pps + ovh_pix) * flop_per_pix / slot_rate +
@@ -1354,7 +1363,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
     if (tiles * sp > 8 * slots) break;
   }
   if (const char *e = getenv("DSPN_WG_SPLITS")) splits = std::max<long long>(1, std::min<long long>(atoll(e), s_max));   // experiments
-  long long pps = ((P + splits - 1) / splits + kPK - 1) / kPK * kPK;
+  long long pps = ((P + splits - 1) / splits + kPlanPK - 1) / kPlanPK * kPlanPK;
   p.splits = (int)((P + pps - 1) / pps);
   p.pps = (int)pps;
   return p;
@@ -1693,7 +1702,9 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
-  const size_t lds = sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4));   // mainloop buffers | staged output tile
+  // mainloop buffers | staged output tile
+  const size_t lds = kHalf ? std::max<size_t>(2 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)), sizeof(float) * BM * (BN + 4))
+                           : sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4));
   dspn::ProfScope prof(1, s);
 #ifdef DSPN_HALF
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \

@@ -4,6 +4,7 @@ sys.path.insert(0, '/root/repo')
 import torch
 from dspnet_amd import functional as fn
 dev = torch.device("cuda", 0)
+DT = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32   # tensor storage type
 def timeit(f, reps=20):
     f(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -15,8 +16,8 @@ shapes = [(32, 16, 16, 512, 512, 3), (32, 32, 32, 256, 256, 3), (32, 64, 64, 128
           (32, 32, 32, 1024, 256, 1), (32, 32, 32, 256, 1024, 1), (32, 64, 64, 128, 512, 1), (32, 128, 128, 256, 64, 1), (32, 128, 128, 64, 256, 1)]
 tot = [0, 0, 0, 0]
 for (N, H, W, Cin, Cout, k) in shapes:
-    x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
-    o = torch.empty(N, H, W, Cout, device=dev)
+    x = torch.randn(N, H, W, Cin, device=dev).to(DT); w = (torch.randn(Cout, k, k, Cin, device=dev) * 0.05).to(DT)
+    o = torch.empty(N, H, W, Cout, device=dev, dtype=DT)
     aff = (torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev), True)
     tiles, _ = fn.conv_stats_layout(N * H * W, Cout)
     st = torch.empty(tiles, 2, Cout, device=dev)
