@@ -164,10 +164,22 @@ class Graph:
     def _plan_bn_backward_fusion(self):
         """For every BatchNorm whose output only convolutions read: the convolution that runs LAST in backward (the
         first in forward order) gathers the BatchNorm-backward reductions in its data-gradient epilogue."""
+        # every reader of a tensor, to make sure the convolutions are the ONLY readers of a materialised BatchNorm output
+        readers = {}
+        for m in self.nodes:
+            for k, v in vars(m).items():
+                if k == "out":
+                    continue
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, Tensor):
+                        readers.setdefault(id(t), set()).add(id(m))
         for n in self.nodes:
-            if not isinstance(n, BatchNorm) or not n.defer_apply or not n.conv_consumers or not n.out.requires_grad:
+            if not isinstance(n, BatchNorm) or not n.out.requires_grad:
                 continue
-            last = min(n.conv_consumers, key=self.nodes.index)
+            cons = n.conv_consumers if n.defer_apply else n.mat_consumers
+            if not cons or (not n.defer_apply and readers.get(id(n.out), set()) != {id(c) for c in cons}):
+                continue
+            last = min(cons, key=self.nodes.index)
             if last.stride not in (1, 2) or (last.stride == 2 and last.dil != 1) or last.x.shape[3] % 4 != 0:
                 continue
             tiles = fn.conv_dgrad_bn_tiles(last.x.shape, last.stride)
@@ -420,6 +432,8 @@ class BatchNorm(Node):
             self.out.affine_src = (x, self.scale, self.shift, relu)
         self.out.bn_node = self
         self.conv_consumers = []     # convolutions reading self.out (deferred apply), in forward order
+        self.mat_consumers = []      # plain convolutions reading a MATERIALISED self.out (their last data gradient can
+                                     # still gather this BatchNorm's backward reductions in its epilogue)
         self.bwd_sums = None         # (buffer, tiles) written by the LAST data gradient into self.out.grad
         self.bwd_sums_ready = False
 
@@ -473,6 +487,8 @@ class Conv(Node):
             self.x_raw, self.in_affine = raw, (sc, sh, arelu)
             assert not tap_expand
             x.bn_node.conv_consumers.append(self)
+        elif getattr(x, "bn_node", None) is not None and not tap_expand:
+            x.bn_node.mat_consumers.append(self)
         self.cout = num_filter
         # Param that receives sum_pixels(dx) instead of a full data gradient (see conv2d_input_sum_grad)
         self.input_sum_grad = input_sum_grad

@@ -5,7 +5,14 @@ conv, bottleneck 1x1 / 3x3(stride) / 1x1, projection shortcut on act1 when the s
 (symbol/resnet.py:30-51); stem bn_data(fix_gamma) -> conv0 7x7/2 -> bn0 -> relu0 -> maxpool 3x3/2
 (:89-98).  The classifier tail (:109-116) is not built: get_multi_symbol_train only reads the
 `_plusN` internals.  BN+ReLU run as one fused kernel; every conv is the fp32-MFMA implicit GEMM."""
+import torch
+
 from .. import engine as E
+from .. import functional as fn
+
+
+import os
+MATERIALISE_3X3_INPUT = os.environ.get("DSPN_MAT3X3", "1") != "0"    # test / A-B switch (bf16 tensors only)
 
 
 def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottle_neck=True):
@@ -25,7 +32,12 @@ def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottl
     # writer of act1's gradient in backward and can gather bn1's backward reductions (engine._plan_bn_backward_fusion)
     conv1 = g.add(E.Conv(g, act1, name + "_conv1", q, 1, 1, 0)).out
     shortcut = data if dim_match else g.add(E.Conv(g, act1, name + "_sc", num_filter, 1, stride, 0)).out
-    act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True, defer_apply=True)).out
+    # bf16 tensors: the 3x3 convolution would re-apply the folded BatchNorm+ReLU to every element once per tap (9x) on a
+    # main loop that is 3x shorter than in fp32 (+45 % on these layers, scratch/fuse_cost.py bf16), while act2 is the
+    # smallest tensor of the unit -- materialising it costs one 4-byte-per-element pass.  Its backward reductions still
+    # come out of conv2's data-gradient epilogue.
+    act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True,
+                             defer_apply=not (MATERIALISE_3X3_INPUT and fn.ACT_DTYPE == torch.bfloat16))).out
     conv2 = g.add(E.Conv(g, act2, name + "_conv2", q, 3, stride, 1)).out
     act3 = g.add(E.BatchNorm(g, conv2, name + "_bn3", relu=True, defer_apply=True)).out
     return g.add(E.Conv(g, act3, name + "_conv3", num_filter, 1, 1, 0, residual=shortcut, out_name=plus_name)).out
