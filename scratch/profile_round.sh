@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 passes behind profiles/r02_*.  usage: bash scratch/profile_round.sh <tag>
+# Every pass profiles `python3 bench.py ...` directly (no env / sh -c hop under rocprofv3); counters are collected in
+# their own runs (--pmc with --kernel-trace only).
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT profiles
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+COMMON="--no-cpu-baseline --no-other-configs"
+for MODE in fp32 bf16; do
+  ST=""; [ $MODE = bf16 ] && ST="--store bf16"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python3 bench.py --steps 6 --warmup 2 $COMMON $ST > $OUT/bench_$MODE.log 2>&1
+  grep '^{"metric"' $OUT/bench_$MODE.log > profiles/${TAG}_${MODE}_bench_line.json
+  S=$(ls $OUT/kt_$MODE/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$S" ] && head -60 "$S" > profiles/${TAG}_${MODE}_kernel_stats_bench.csv
+  T=$(ls $OUT/kt_$MODE/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$T" ] && python3 scratch/step_profile_csv.py "$T" 70 > profiles/${TAG}_${MODE}_last_step_by_kernel.txt
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$MODE -o p -- python3 bench.py --steps 2 --warmup 1 --no-roofline $COMMON $ST > $OUT/pmc_fetch_$MODE.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$MODE -o p -- python3 bench.py --steps 2 --warmup 1 --no-roofline $COMMON $ST > $OUT/pmc_write_$MODE.log 2>&1
+  python3 scratch/pmc_traffic2.py $OUT/pmc_fetch_$MODE $OUT/pmc_write_$MODE 3 profiles/${TAG}_${MODE}_pmc_hbm_traffic.csv profiles/${TAG}_${MODE}_pmc_conv_family.json > $OUT/pmc_$MODE.txt 2>&1
+  cat $OUT/pmc_$MODE.txt
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o p -- python3 bench.py --steps 2 --warmup 1 --no-roofline $COMMON > $OUT/pmc_mfma.log 2>&1
+python3 scratch/pmc_mfma2.py $OUT/pmc_mfma > profiles/${TAG}_fp32_pmc_mfma_busy.csv 2>$OUT/pmc_mfma.err
+cp profiles/${TAG}_fp32_pmc_conv_family.json profiles/${TAG}_pmc_conv_family.json 2>/dev/null
+# keep the merged scratch small
+find $OUT -name "*.csv" -size +8M -delete
+ls -la profiles | grep $TAG
