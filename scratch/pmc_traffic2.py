@@ -8,6 +8,10 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter: continue
         n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        import re
+        m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I((?:L[ib]\d+E)+)', n)
+        if m:      # bf16-tensor instantiations come out mangled
+            n = "%s<%s> [bf16 tensors]" % (m.group(1), ",".join(v for _, v in re.findall(r'L([ib])(\d+)E', m.group(2))))
         agg[n][0] += 1; agg[n][1] += float(r['Counter_Value'])
     return agg
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')

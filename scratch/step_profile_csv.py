@@ -1,5 +1,15 @@
 """per-kernel time of the LAST training step of a rocprofv3 --kernel-trace --output-format csv run (file given)"""
 import csv, sys, collections, re
+def pretty(n):
+    """demangled names as they are; the bf16-tensor instantiations come out mangled (_ZN12_GLOBAL__N_1...I Li4E Lb1E ...)"""
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I((?:L[ib]\d+E)+)', n)
+    if m:
+        args = re.findall(r'L([ib])(\d+)E', m.group(2))
+        return "%s<%s> [bf16 tensors]" % (m.group(1), ", ".join(("true" if v == "1" else "false") if t == "b" else v for t, v in args))
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    return re.sub(r'\(.*$', '', n)[:66]
+
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 ends = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
@@ -8,8 +18,7 @@ step = rows[lo:hi]
 wall = (int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in step:
-    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
-    n = re.sub(r'\(.*$', '', n)[:66]
+    n = pretty(r['Kernel_Name'])
     agg[n][0] += 1
     agg[n][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
 tot = sum(v[1] for v in agg.values())
