@@ -25,7 +25,12 @@ using dspn::CA4Ptr;
 namespace {
 
 constexpr int kT = 256;
-constexpr int kSlabRows = 512;
+// rows per slab of the two-stage reductions: 512 on the large tensors; small ones (inceptionv3 at batch 8: 15 k rows)
+// are cut finer so that a reduction still spreads over ~1000 workgroups instead of 29 (2.5 ms per step went there)
+inline int slab_rows_for(long long rows) {
+  const long long want = (rows + 1023) / 1024;
+  return (int)std::min<long long>(512, std::max<long long>(32, (want + 7) / 8 * 8));
+}
 
 inline int grid_for(long long n, int per_block = kT, int cap = 8192) {
   long long b = (n + per_block - 1) / per_block;
@@ -40,7 +45,7 @@ inline int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64
 // partial[slab][0][c] = sum (x - K[c]), partial[slab][1][c] = sum (x - K[c])^2, K = row 0
 __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const CA4Ptr x,
                                                               long long rows, int C4, int CL,
-                                                              float *__restrict__ partial) {
+                                                              float *__restrict__ partial, int kSlabRows) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -213,7 +218,7 @@ __global__ void bn_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale
 __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
     const CA4Ptr x, const float4 *__restrict__ scale, const float4 *__restrict__ shift,
     const CA4Ptr dy, const float *__restrict__ mean, const float *__restrict__ rstd,
-    long long rows, int C4, int CL, int relu, float *__restrict__ partial) {
+    long long rows, int C4, int CL, int relu, float *__restrict__ partial, int kSlabRows) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -1120,7 +1125,7 @@ __global__ void sgd_kernel(float4 *__restrict__ w, const float4 *__restrict__ g,
 
 #endif   // !DSPN_HALF
 
-int bn_slabs(long long rows) { return (int)((rows + kSlabRows - 1) / kSlabRows); }
+int bn_slabs(long long rows) { const int sr = slab_rows_for(rows); return (int)((rows + sr - 1) / sr); }
 
 }  // namespace
 
@@ -1151,7 +1156,7 @@ int DSPN_FN(dspn_bn_stats)(const st_t *x, long long rows, int C, float eps, cons
   float *partial = static_cast<float *>(workspace);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), CA4Ptr(x), rows,
-                     C4, CL, partial);
+                     C4, CL, partial, slab_rows_for(rows));
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), CA1Ptr(x), partial,
                      ns, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
   return dspn::check_launch("bn_stats");
@@ -1206,7 +1211,7 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), CA4Ptr(x),
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
-                     CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial);
+                     CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows));
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
   const long long n4 = rows * C4;
