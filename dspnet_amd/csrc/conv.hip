@@ -114,10 +114,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-// EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums),
-//      3 = the statistics of 1 taken from the accumulator registers before the tile is staged (no residual / accumulate
-//          operand: the stored value is acc + bias): the row loop is then the plain one, which is what lets the 8-wave
-//          form (128 VGPRs) carry it
+// EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
@@ -490,7 +487,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         // 8 waves: the kernel has to fit in 128 VGPRs.  Rows in flight per thread and the unrolling of the chunk loop
         // are the settings that compile without scratch (hipcc 7.2): INTF + statistics 1 row / unrolled, the other
         // fused epilogues 2 rows / rolled, the plain epilogue 4 rows / unrolled
-        constexpr int RC8 = (EPI == 1 && INTF) ? 1 : (EPI == 1 || EPI == 2) ? 2 : 4;
+        constexpr int RC8 = (EPI == 1 && INTF) ? 1 : (EPI != 0) ? 2 : 4;
         constexpr int RC = NTHR == 512 ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
         float *st = smem;
         const int c4 = tid % C4, er0 = tid / C4;
@@ -527,46 +524,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           }
         };
         rows_begin(0);
-        if constexpr (EPI == 3) {
-          // (mean, M2, count) of what this lane's accumulators become in memory -- acc + bias, ReLU, bf16 rounding -- for
-          // its column (lane & 31 of block j) over its 16 * TM rows; the two lanes of a column (rows 4*(lane>>5) + ...)
-          // are merged with one shuffle, the WAVES_M waves of a column through LDS (behind the staged tile) after the
-          // staging barrier.  Chan's update in a fixed order throughout: deterministic.
-          float *part = smem + BM * SLD;            // [WAVES_M][BN][3]
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn + j * 32 + (lane & 31);
-            const float b = (has_bias && col < g.Cout) ? bias[col] : 0.f;
-            float K = 0.f, s1 = 0.f, s2 = 0.f;
-            int cnt = 0;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[i][j][r] + b;
-                if (relu) v = v > 0.f ? v : 0.f;
-                if constexpr (kHalf) v = dspn::round_bf16(v);
-                if (m < M) {
-                  if (cnt == 0) K = v;
-                  ++cnt;
-                  const float d = v - K;
-                  s1 += d; s2 += d * d;
-                }
-              }
-            const float n = (float)cnt, inv = cnt > 0 ? 1.f / n : 0.f;
-            const float mean = K + s1 * inv, m2 = s2 - s1 * s1 * inv;
-            const float on = __shfl_xor(n, 32, 64), om = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
-            if (lane < 32) {
-              const float nt_ = n + on;
-              const float dl = om - mean, w = nt_ > 0.f ? on / nt_ : 0.f;
-              float *q = part + ((wave / WAVES_N) * BN + wn + j * 32 + lane) * 3;
-              q[0] = n > 0.f ? mean + dl * w : om;
-              q[1] = n > 0.f ? m2 + om2 + dl * dl * n * w : om2;
-              q[2] = nt_;
-            }
-          }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -576,26 +533,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
               st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
         rows_bn_x();   // requested once the accumulators are staged (their registers are free), ahead of the barrier
         __syncthreads();
-        if constexpr (EPI == 3) {
-          if (tid < BN && n0 + tid < g.Cout) {
-            const float *part = smem + BM * SLD;
-            float n = part[tid * 3 + 2], mean = part[tid * 3], m2 = part[tid * 3 + 1];
-#pragma unroll
-            for (int wv = 1; wv < WAVES_M; ++wv) {
-              const float *q = part + (wv * BN + tid) * 3;
-              const float on = q[2], nt_ = n + on;
-              if (on > 0.f) {
-                const float dl = q[0] - mean, w = on / nt_;
-                m2 = n > 0.f ? m2 + q[1] + dl * dl * n * w : q[1];
-                mean = n > 0.f ? mean + dl * w : q[0];
-                n = nt_;
-              }
-            }
-            const long long mt_ = m0 / BM;
-            g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
-            g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = fmaxf(m2, 0.f);
-          }
-        }
         float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
         float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
         if (EPI == 2 && vec) {
@@ -613,7 +550,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         // BatchNorm statistics of the stored values (g.stats): shifted sums about the thread's first row
         float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         int scnt = 0;
-#pragma unroll (NTHR == 512 && (EPI == 1 || EPI == 2) && !(EPI == 1 && INTF) ? 1 : NP / RC)
+#pragma unroll (NTHR == 512 && EPI != 0 && !(EPI == 1 && INTF) ? 1 : NP / RC)
         for (int ch = 0; ch < NP / RC; ++ch) {
           if (ch > 0) { rows_begin(ch); rows_bn_x(); }
 #pragma unroll
@@ -1252,7 +1189,7 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
   const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
-                                      sizeof(float) * (BM * (BN + 4) + (EPI == 3 ? WAVES_M * BN * 3 : 0)));
+                                      sizeof(float) * BM * (BN + 4));
   auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
@@ -1285,11 +1222,6 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   return dspn::check_launch("conv_nt");
 }
 
-inline bool stats_from_registers() {       // DSPN_EPI3=0: A/B switch back to the row-loop statistics
-  static const int v = [] { const char *e = getenv("DSPN_EPI3"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
-
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
               hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
@@ -1302,10 +1234,8 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
                                   : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
 #endif
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
-  // statistics: from the accumulator registers (3) unless a residual / accumulate operand is added in the row loop
-  const bool epi3 = g.stats && !residual && !(g.flags & 4) && stats_from_registers();
-  if (g.in_scale) return g.stats ? (epi3 ? DSPN_NT_UB_(true, 3) : DSPN_NT_UB_(true, 1)) : DSPN_NT_UB_(true, 0);
-  return g.stats ? (epi3 ? DSPN_NT_UB_(false, 3) : DSPN_NT_UB_(false, 1)) : DSPN_NT_UB_(false, 0);
+  if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
+  return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
 #undef DSPN_NT_UB_
 #undef DSPN_NT_
 }
@@ -1378,9 +1308,8 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   const bool one_tap = g.TR * g.TS == 1;
   // bf16 tensors: the main loop is ~3x shorter, the fused epilogues cost relatively more, and the 8-wave form wins for
   // every epilogue (measured on the resnet-50 step: 28.6 -> 26.1 ms)
-  const bool epi3 = g.stats && !residual && !(g.flags & 4) && stats_from_registers();
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : kHalf ? true
-                     : (((!g.stats || epi3) && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
+                     : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
