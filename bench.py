@@ -246,21 +246,29 @@ def side_infer(B, size, iters, warmup, dev):
     for _ in range(warmup):
         det.forward()
     torch.cuda.synchronize()
+    # convolution-family time from HIP events on a few instrumented iterations FIRST (the events cost ~1 ms per batch);
+    # the latency percentiles come from uninstrumented iterations
+    ps = min(10, iters)
     lib.dspn_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(ps):
+        det.forward()
+    torch.cuda.synchronize()
+    inst_s = (time.perf_counter() - t0) / ps
+    lib.dspn_profile_enable(0)
     lat = []
     for _ in range(iters):
         t0 = time.perf_counter()
         det.forward()
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t0) * 1e3)
-    lib.dspn_profile_enable(0)
     lat = np.sort(np.asarray(lat))
     p50 = float(np.percentile(lat, 50))
     return {"workload": "resnet-50 multitask test graph %dx%d, batch %d, fp32, forward + MultiBoxDetection/NMS, random-init "
                         "weights (nearly all 6132 rows valid: worst case for sort + NMS)" % (size, size, B),
             "p50_ms_per_batch": round(p50, 3), "p90_ms_per_batch": round(float(np.percentile(lat, 90)), 3),
             "images_per_s": round(B / p50 * 1e3, 1), "iterations": iters, "warmup": warmup, "dtype": "f32",
-            "roofline": conv_family_roofline(lib, iters, flops_fwd, flops_direct, "fp32", float(lat.mean()) / 1e3)}
+            "roofline": conv_family_roofline(lib, ps, flops_fwd, flops_direct, "fp32", inst_s)}
 
 
 def spawn_ranks(args):
