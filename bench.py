@@ -331,7 +331,20 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "WARN")       # no RCCL version banner on stdout next to the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL prints a five-line version banner on STDOUT when the communicator is created: keep stdout for the one JSON
+        # line by pointing fd 1 at stderr while the group comes up (init + a first collective), then restoring it
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            torch.cuda.set_device(local)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         assert dist.get_world_size() == world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
