@@ -343,6 +343,10 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)      # the banner sits in libc's stdout buffer: push it out while fd 1 is stderr
+            except OSError:
+                pass
             os.dup2(saved, 1)
             os.close(saved)
         assert dist.get_world_size() == world
