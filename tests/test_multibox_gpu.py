@@ -58,7 +58,7 @@ def run_target(anc, lab, pred, **kw):
     return got
 
 
-def test_target_golden_fixture(gpu_device):
+def test_target_self_generated_regression_fixture(gpu_device):
     g = np.load(os.path.join(GOLDEN, "multibox_small.npz"))
     got = host(op.MultiBoxTarget(dev(g["anchors"]), dev(g["label"]), dev(g["cls_pred"]),
                                  negative_mining_ratio=3, negative_mining_thresh=.5,
@@ -158,7 +158,7 @@ def run_detection(anc, prob, loc, **kw):
     return got
 
 
-def test_detection_golden_fixture(gpu_device):
+def test_detection_self_generated_regression_fixture(gpu_device):
     g = np.load(os.path.join(GOLDEN, "multibox_small.npz"))
     got = op.MultiBoxDetection(dev(g["cls_prob"]), dev(g["loc_pred"]), dev(g["anchors"]),
                                nms_threshold=.45, nms_topk=20).cpu().numpy()

@@ -159,7 +159,7 @@ def test_detection_idempotent_under_row_permutation_of_scores():
 
 
 # ---- golden fixtures (regression pin of the oracle; consumed again by the GPU tests) ----
-def test_golden_fixtures_reproduce():
+def test_self_generated_regression_fixtures_reproduce():
     path = os.path.join(GOLDEN, "multibox_small.npz")
     g = np.load(path)
     anc = g["anchors"]
