@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],
                     help="storage type of activation tensors and convolution operands in HBM: float32 (default) or "
                          "bfloat16 (the *_bf16 kernels: bf16 MFMA, fp32 accumulate, fp32 master weights)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: record the step into a HIP graph after the warm-up and replay it (single GPU; no roofline events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -387,8 +389,9 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     sync()
+    graphed = bool(args.graph) and solver.capture(warmup=0)
     lib = _lib.lib()
-    prof = not args.no_roofline
+    prof = not args.no_roofline and not graphed
     # HIP events around every convolution launch cost ~2.5 ms of a 60 ms step (measured: 517 vs 539 images/s with every
     # step instrumented), so only PROF_STEPS steps of the timed region carry them; the other steps run as in production
     prof_steps = min(PROF_STEPS, args.steps) if prof else 0

@@ -69,6 +69,7 @@ class MultiTaskSolver:
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
+        self._graph = None
         g = self.g
         owner = {}
         for idx, n in enumerate(g.nodes):
@@ -120,9 +121,40 @@ class MultiTaskSolver:
                         1.0 / (self.batch_size * self.world_size))
 
     def step(self):
+        if self._graph is not None:
+            self._graph.replay()
+            return
         self.forward()
         self.backward()
         self.update()
+
+    def capture(self, warmup=2):
+        """Record one whole step (forward, backward, update: ~700 .. 1100 kernel launches issued from Python through
+        ctypes) into a HIP graph; step() then replays it with one host call.  Every launch of the library is
+        graph-capturable (no allocation, no synchronisation, explicit stream), the batch lives in fixed buffers
+        (set_batch copies into them) and the host-side bookkeeping of a step is the same every step, so the recorded
+        launch sequence IS the step.  The gradient all-reduce is not captured: with a reducer the step stays eager.
+        Returns True if the graph is in use."""
+        import torch
+        if self.reducer is not None or self.g.device.type != "cuda" or self._graph is not None:
+            return self._graph is not None
+        for _ in range(warmup):                   # first-use work (function attributes, workspace growth) happens eagerly
+            self.step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                self.forward()
+                self.backward()
+                self.update()
+                det = getattr(self.net, "det", None)
+                if det is not None:
+                    det.join()                    # the side stream of MultiBoxDetection joins before the capture ends
+        except Exception:
+            torch.cuda.synchronize()
+            return False
+        self._graph = graph
+        return True
 
 
 class BatchEndParam(object):
