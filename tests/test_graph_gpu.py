@@ -363,6 +363,22 @@ def test_training_reduces_losses_and_is_deterministic(gpu_device):
     assert torch.equal(net.g.arena, net2.g.arena)
 
 
+def test_step_replayed_from_a_hip_graph_is_bit_identical(gpu_device):
+    """MultiTaskSolver.capture(): the whole step (forward, backward incl. the side-stream MultiBoxDetection, SGD) recorded
+    into one HIP graph after two eager steps and replayed -- every library call is capturable (explicit stream, no
+    allocation, no synchronisation) -- gives the same parameters, bit for bit, as running the same steps eagerly."""
+    net_a, solver_a, *_ = make(2, 128, 128)
+    net_b, solver_b, *_ = make(2, 128, 128)
+    for _ in range(5):
+        solver_a.step()
+    assert solver_b.capture(warmup=2)          # 2 eager steps, then the recording pass (recording runs nothing)
+    for _ in range(3):
+        solver_b.step()                        # 3 replays
+    torch.cuda.synchronize()
+    assert torch.equal(net_a.g.arena, net_b.g.arena)
+    assert torch.equal(net_a.outputs()[3], net_b.outputs()[3])
+
+
 def test_test_graph_matches_training_graph_outputs(gpu_device):
     """get_multi_symbol (symbol/multitask_symbol_builder.py:595-726) yields the det / seg values of the
     training graph's outputs[3], outputs[4] (what detect/multitask_detector.py:234 reads)"""
