@@ -31,6 +31,10 @@ FUSE_BATCHNORM = True
 # Test switch: False builds score3_conv in the direct form (BilinearConcat + tap-expanded Conv) instead of
 # BilinearConcatConv.
 COMMUTE_RESIZE_CONV = True
+# A/B switch (bf16 tensors): BatchNorm outputs read by multi-tap convolutions are materialised instead of being applied in
+# the loaders ("auto" BatchNorms: inceptionv3 towers; the residual units set theirs in symbol/resnet.py)
+import os as _os
+MATERIALISE_MULTITAP_INPUT_BF16 = _os.environ.get("DSPN_MAT3X3", "1") != "0"
 
 
 class Tensor:
@@ -146,6 +150,10 @@ class Graph:
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
                     if isinstance(t, Tensor) and t.affine_src is not None:
                         ok = isinstance(n, Conv) and k == "x" and not n.tap_expand
+                        # bf16 tensors: a multi-tap convolution would re-apply the affine once per tap on a main loop that
+                        # is 3x shorter than in fp32 (scratch/fuse_cost.py bf16: +45 %); its input is materialised instead
+                        if ok and MATERIALISE_MULTITAP_INPUT_BF16 and t.dtype == torch.bfloat16 and n.w.shape[1] * n.w.shape[2] > 1:
+                            ok = False
                         readers.setdefault(id(t), []).append((n, ok))
         for n in self.nodes:
             if not isinstance(n, BatchNorm) or n.defer_apply != "auto":
@@ -159,6 +167,7 @@ class Graph:
             n.out.data = fn.zeros(*n.out.shape, device=self.device, dtype=n.out.dtype)
             for c in n.conv_consumers:
                 c.x_raw, c.in_affine = c.x, None
+            n.mat_consumers = list(n.conv_consumers)     # still candidates for gathering the backward reductions
             n.conv_consumers = []
 
     def _plan_bn_backward_fusion(self):
