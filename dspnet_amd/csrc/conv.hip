@@ -1254,8 +1254,9 @@ int nt_config(long long M, int Cout) {
   int cfg;
   // measured on MI355X (scratch/cfgtest.py): 128x128 wins once it yields >= 2 workgroups per CU,
   // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
-  if (Cout <= 32) cfg = tiles(256, 32) >= 512 ? 3 : 2;
-  else cfg = (Cout > 64 && tiles(128, 128) >= 512) ? 0 : 2;
+  static const long long min_tiles = [] { const char *e = getenv("DSPN_NT_MINTILES"); return e ? atoll(e) : 512ll; }();   // experiments
+  if (Cout <= 32) cfg = tiles(256, 32) >= min_tiles ? 3 : 2;
+  else cfg = (Cout > 64 && tiles(128, 128) >= min_tiles) ? 0 : 2;
   // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
   // 128-wide column tile: 64-wide columns cut the padding to < 64
   if (cfg == 0 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) cfg = 1;
