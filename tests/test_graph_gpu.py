@@ -379,6 +379,42 @@ def test_step_replayed_from_a_hip_graph_is_bit_identical(gpu_device):
     assert torch.equal(net_a.outputs()[3], net_b.outputs()[3])
 
 
+def test_bf16_tensor_training_tracks_the_float_run(gpu_device):
+    """End to end with bfloat16 tensors in HBM (every activation, every gradient of an activation, every convolution
+    operand; float master weights, statistics, losses): five SGD steps of the resnet-50 multi-task graph stay finite,
+    reduce the three losses, are bitwise reproducible run to run, and track the float-tensor run of the same graph --
+    each loss of each step within 5 % (bf16 carries 8 bits: per-tensor rounding 2^-9, and the float run here uses the
+    same bf16 MFMA math, so the difference is the storage rounding alone)."""
+    from dspnet_amd import functional as fn
+
+    def run(store):
+        fn.set_conv_math("bf16")
+        fn.set_activation_dtype(store)
+        try:
+            net, solver, *_ = make(2, 256, 256)
+        finally:
+            fn.set_activation_dtype("fp32")
+        m, hist = MultiBoxMetric(), []
+        for _ in range(5):
+            solver.step()
+            m.reset(); m.update(net); hist.append(m.get()[1])
+        torch.cuda.synchronize()
+        return net, np.asarray(hist)
+
+    try:
+        net_h, hist_h = run("bf16")
+        net_h2, hist_h2 = run("bf16")
+        net_f, hist_f = run("fp32")
+    finally:
+        fn.set_conv_math("fp32")
+    assert net_h.g.tensors["_plus15"].data.dtype == torch.bfloat16 and net_f.g.tensors["_plus15"].data.dtype == torch.float32
+    assert net_h.g.arena.dtype == torch.float32                       # master weights stay float
+    assert np.isfinite(hist_h).all() and torch.isfinite(net_h.g.arena).all()
+    assert np.array_equal(hist_h, hist_h2) and torch.equal(net_h.g.arena, net_h2.g.arena)
+    assert (hist_h[-1] < hist_h[0]).all()
+    assert np.abs(hist_h / hist_f - 1).max() < 5e-2, (hist_h, hist_f)
+
+
 def test_test_graph_matches_training_graph_outputs(gpu_device):
     """get_multi_symbol (symbol/multitask_symbol_builder.py:595-726) yields the det / seg values of the
     training graph's outputs[3], outputs[4] (what detect/multitask_detector.py:234 reads)"""
