@@ -203,10 +203,13 @@ class MultiTaskNet:
 
     def outputs(self):
         """training graph: [cls_prob, loc_loss, cls_label, det_out, seg_out] (multitask_symbol_builder.py:592);
-        test graph: [det, seg_out] (:726)"""
+        test graph: [det, seg_out] (:726); segmentation-only graphs: [seg_out] (:322, :439); detection-only
+        test graph: [det] (:208)"""
+        if self.det is None:
+            return [self.seg_out.nchw()]
         self.det.join()
         if self.target is None:
-            return [self.det.out.data, self.seg_out.nchw()]
+            return [self.det.out.data] if self.seg_out is None else [self.det.out.data, self.seg_out.nchw()]
         outs = [self.cls_out.cls_prob.data, self.loc_loss.out.data, self.target.cls_target, self.det.out.data]
         return outs if self.seg_out is None else outs + [self.seg_out.nchw()]
 
@@ -246,27 +249,41 @@ def get_det_symbol_train(network, num_classes, from_layers, num_filters, strides
                   num_labels, device, num_layers, seed)
 
 
-def _build(train, with_seg, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
-           steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
-           num_layers, seed):
-    assert network in ("resnet", "vgg16_reduced", "inceptionv3"), "backbones: resnet, vgg16_reduced, inceptionv3"
-    device = device or torch.device("cuda", torch.cuda.current_device())
-    g = E.Graph(device)
-    C, H, W = data_shape
-    data = g.tensor((batch_size, C, H, W), "data", requires_grad=False, dtype=torch.float32)
-    label = g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False, dtype=torch.float32) if train else None
-    seg_label = (g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False, dtype=torch.float32)
-                 if (train and with_seg) else None)
+def get_det_symbol(network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                   normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5, force_suppress=False,
+                   nms_topk=400, batch_size=1, data_shape=(3, 300, 300), device=None, num_layers=50, seed=0,
+                   **kwargs):
+    """Detection + depth test graph, symbol/multitask_symbol_builder.py:123-209: output [det]"""
+    return _build(False, False, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                  normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
+                  200, device, num_layers, seed)
 
-    if network == "resnet":
-        internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
-    elif network == "inceptionv3":
-        internals = inception_mod.get_symbol(g, data)
-    else:
-        internals = vgg_mod.get_symbol(g, data)
-    res3 = internals[from_layers[0] + "_output"]
-    res4 = internals[from_layers[1] + "_output"]
 
+def get_seg_symbol_train(network, num_classes, from_layers, num_filters=None, strides=None, pads=None, sizes=None,
+                         ratios=None, normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5,
+                         force_suppress=False, nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), device=None,
+                         num_layers=50, seed=0, **kwargs):
+    """Segmentation only, symbol/multitask_symbol_builder.py:211-323: backbone -> pyramid decoder ->
+    SoftmaxOutput(grad_scale=4, ignore 255); output [seg_out].  The SSD arguments are accepted and unused, as
+    in the reference.  Gradient reaches the backbone through conv_feat only (res3 / res4 are BlockGrad'ed)."""
+    return _build(True, True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                  normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
+                  0, device, num_layers, seed, with_det=False)
+
+
+def get_seg_symbol(network, num_classes, from_layers, num_filters=None, strides=None, pads=None, sizes=None,
+                   ratios=None, normalizations=-1, steps=(), min_filter=128, nms_thresh=0.5, force_suppress=False,
+                   nms_topk=400, batch_size=1, data_shape=(3, 512, 1024), device=None, num_layers=50, seed=0,
+                   **kwargs):
+    """Segmentation test graph, symbol/multitask_symbol_builder.py:325-440: output [seg_out] (softmax over classes)"""
+    return _build(False, True, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                  normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape,
+                  0, device, num_layers, seed, with_det=False)
+
+
+def _detection_branch(g, train, internals, label, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+                      normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk):
+    """SSD feature layers, heads, target matching / losses (training) and MultiBoxDetection (:502-539)"""
     # remove res3 from the input layers of SSD (:502-508).  The reference slices from_layers / num_filters /
     # strides / pads / sizes / ratios but not `normalizations` and `steps` (a list-valued preset then trips
     # the length asserts of symbol/common.py:350,356); this build slices those too.
@@ -292,6 +309,42 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
         target, loc_loss = None, None
         cls_out = g.add(ClsSoftmaxActivation(g, cls_flat, ncls))
     det = g.add(Detection(g, cls_out.cls_prob, loc_preds, anchor_boxes, nms_thresh, force_suppress, nms_topk))
+
+    return conv_feat, target, cls_out, loc_loss, det, anchor_boxes, loc_preds, cls_flat
+
+
+def _build(train, with_seg, network, num_classes, from_layers, num_filters, strides, pads, sizes, ratios, normalizations,
+           steps, min_filter, nms_thresh, force_suppress, nms_topk, batch_size, data_shape, num_labels, device,
+           num_layers, seed, with_det=True):
+    assert network in ("resnet", "vgg16_reduced", "inceptionv3"), "backbones: resnet, vgg16_reduced, inceptionv3"
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    g = E.Graph(device)
+    C, H, W = data_shape
+    data = g.tensor((batch_size, C, H, W), "data", requires_grad=False, dtype=torch.float32)
+    label = (g.tensor((batch_size, num_labels, 6), "label_det", requires_grad=False, dtype=torch.float32)
+             if (train and with_det) else None)
+    seg_label = (g.tensor((batch_size, H // 4, W // 4), "seg_out_label", requires_grad=False, dtype=torch.float32)
+                 if (train and with_seg) else None)
+
+    if network == "resnet":
+        internals = resnet_mod.get_symbol(g, data, num_layers=num_layers)
+    elif network == "inceptionv3":
+        internals = inception_mod.get_symbol(g, data)
+    else:
+        internals = vgg_mod.get_symbol(g, data)
+    res3 = internals[from_layers[0] + "_output"]
+    res4 = internals[from_layers[1] + "_output"]
+
+    if with_det:
+        (conv_feat, target, cls_out, loc_loss, det, anchor_boxes, loc_preds, cls_flat) = _detection_branch(
+            g, train, internals, label, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
+            normalizations, steps, min_filter, nms_thresh, force_suppress, nms_topk)
+    else:
+        # segmentation-only graphs read the third backbone map directly (:269, :383): no SSD extra layers exist
+        assert from_layers[2].strip(), \
+            "segmentation-only graphs need a backbone layer as from_layers[2] (the resnet presets)"
+        conv_feat = internals[from_layers[2].strip() + "_output"]
+        target = cls_out = loc_loss = det = anchor_boxes = loc_preds = cls_flat = None
 
     if not with_seg:
         g.finalize(seed)

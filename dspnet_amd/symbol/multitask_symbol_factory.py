@@ -90,3 +90,28 @@ def get_multi_symbol(network, data_shape, **kwargs):
     config.pop('data_shape', None)
     config.update(dict(kwargs))
     return builder.get_multi_symbol(data_shape=data_shape, **config)
+
+
+def _configured(build, network, data_shape, kwargs):
+    if isinstance(data_shape, int):
+        data_shape = (3, data_shape, data_shape)
+    config = get_config(network, data_shape, **kwargs)
+    config.pop('kwargs', None)
+    config.pop('data_shape', None)
+    config.update(dict(kwargs))
+    return build(data_shape=data_shape, **config)
+
+
+def get_det_symbol(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:123-144 (detection + depth test graph: outputs [det])"""
+    return _configured(builder.get_det_symbol, network, data_shape, kwargs)
+
+
+def get_seg_symbol_train(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:146-163 (segmentation only: outputs [seg_out])"""
+    return _configured(builder.get_seg_symbol_train, network, data_shape, kwargs)
+
+
+def get_seg_symbol(network, data_shape, **kwargs):
+    """symbol/multitask_symbol_factory.py:165-186 (segmentation test graph: outputs [seg_out])"""
+    return _configured(builder.get_seg_symbol, network, data_shape, kwargs)

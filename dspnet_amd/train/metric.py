@@ -19,9 +19,13 @@ class MultiBoxMetric:
 
     def update(self, net):
         """reads the device buffers of a MultiTaskNet after forward(); one small D2H copy"""
-        B, C, N = net.cls_out.cls_prob.shape
-        ce = fn.cross_entropy_sum(net.cls_out.prob_nc.view(B * N, C), net.target.cls_target, C, -1.0, self.eps)
-        sl1 = fn.sum_all(net.loc_loss.out.data)
+        if net.cls_out is not None:
+            B, C, N = net.cls_out.cls_prob.shape
+            ce = fn.cross_entropy_sum(net.cls_out.prob_nc.view(B * N, C), net.target.cls_target, C, -1.0, self.eps)
+            sl1 = fn.sum_all(net.loc_loss.out.data)
+        else:   # segmentation-only graph
+            import torch
+            ce, sl1 = torch.zeros(2), torch.zeros(1)
         if net.seg_out is not None:
             sp = net.seg_out.prob.data
             rows = sp.numel() // sp.shape[-1]

@@ -89,10 +89,13 @@ class MultiTaskSolver:
                                               and lo <= n.w.offset < hi]))
 
     def set_batch(self, data, label_det, label_seg):
-        """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4)"""
+        """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4); a label the graph has
+        no input for (detection-only / segmentation-only graphs) is ignored"""
         self.net.data.data.copy_(data)
-        self.net.label_det.data.copy_(label_det)
-        self.net.label_seg.data.copy_(label_seg)
+        if self.net.label_det is not None:
+            self.net.label_det.data.copy_(label_det)
+        if self.net.label_seg is not None:
+            self.net.label_seg.data.copy_(label_seg)
 
     def forward(self):
         self.g.forward()

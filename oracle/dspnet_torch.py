@@ -248,8 +248,9 @@ def inceptionv3(P, data):
 
 def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, num_classes=8, dtype=torch.float64,
                  nms_thresh=0.5, force_suppress=False, nms_topk=400, targets=None, config=None, with_seg=True,
-                 conv_quant=None, decisions=None):
-    """Runs the multi-task (or, with_seg=False, the detection+depth) training graph on the CPU.
+                 conv_quant=None, decisions=None, with_det=True):
+    """Runs the multi-task (or, with_seg=False, the detection+depth; with_det=False, the segmentation-only,
+    multitask_symbol_builder.py:211-323) training graph on the CPU.
     `config` is the preset of multitask_symbol_factory.get_config (un-sliced); without it the resnet-50
     preset wiring is assumed and sizes/ratios are the already sliced lists.  Returns dict with the graph
     outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params.
@@ -262,7 +263,7 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
     _POOL_CALLS[0] = 0
     try:
         return _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes, dtype, nms_thresh,
-                             force_suppress, nms_topk, targets, config, with_seg)
+                             force_suppress, nms_topk, targets, config, with_seg, with_det)
     finally:
         _QUANT, _DECISIONS = prev, prev_d
 
@@ -283,7 +284,7 @@ class quantized:
 
 
 def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes, dtype, nms_thresh, force_suppress,
-                  nms_topk, targets, config, with_seg):
+                  nms_topk, targets, config, with_seg, with_det=True):
     P = Params(values, dtype)
     x = torch.tensor(data, dtype=dtype)
     B, _, H, W = x.shape
@@ -294,6 +295,9 @@ def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes
     inter = {"resnet": resnet50, "vgg16_reduced": vgg16_reduced, "inceptionv3": inceptionv3}[config["network"]](P, x)
     fl = config["from_layers"]
     res3, res4 = inter[fl[0]], inter[fl[1]]
+    if not with_det:      # segmentation only: conv_feat is the third backbone map (:269), nothing of SSD exists
+        out = dict(params=P, objective=0.0)
+        return _segmentation_branch(out, P, inter[fl[2]], res3, res4, label_seg, B, H, W, dtype)
     fl, nfs, sts, pds = fl[1:], config["num_filters"][1:], config["strides"][1:], config["pads"][1:]
     sizes, ratios = config["sizes"][1:], config["ratios"][1:]
     steps = list(config.get("steps") or [])[1:]
@@ -348,10 +352,13 @@ def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes
     out = dict(cls_prob=cls_prob.detach(), loc_loss=loc_loss.detach(), cls_label=cls_t, det=det, CrossEntropy=ce,
                SmoothL1=float(loc_loss.detach().sum()) / nvalid, params=P, anchors=anchor_boxes,
                loc_preds=loc_preds.detach(), cls_preds=cls_preds.detach())
+    out["objective"] = obj_cls + obj_loc
     if not with_seg:
-        out["objective"] = obj_cls + obj_loc
         return out
+    return _segmentation_branch(out, P, conv_feat, res3, res4, label_seg, B, H, W, dtype)
 
+
+def _segmentation_branch(out, P, conv_feat, res3, res4, label_seg, B, H, W, dtype):
     # segmentation decoder (multitask_symbol_builder.py:541-589)
     r3 = conv_bn(P, conv_bn(P, res3.detach(), "res3_reduced", 0), "res3_reduced2", 1)
     r4 = conv_bn(P, conv_bn(P, res4.detach(), "res4_reduced", 0), "res4_reduced2", 1)
@@ -388,7 +395,7 @@ def _forward_loss(values, data, label_det, label_seg, sizes, ratios, num_classes
     slogp = torch.log_softmax(s4, dim=1).gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1)
     seg_ce_sum = -(slogp * svalid.to(dtype)).sum()
     obj_seg = seg_ce_sum * (4.0 / float(s4.shape[2] * s4.shape[3]))
-    out["objective"] = obj_cls + obj_loc + obj_seg
+    out["objective"] = out["objective"] + obj_seg
     out["seg_out"] = seg_prob.detach()
     out["SegCrossEntropy"] = float(-(torch.log(seg_prob.detach().gather(1, sl.clamp(max=18).unsqueeze(1)).squeeze(1) + 1e-8)
                                      * svalid.to(dtype)).sum() / max(1, int(svalid.sum())))

@@ -434,6 +434,70 @@ def test_test_graph_matches_training_graph_outputs(gpu_device):
     assert segp.shape == (2, 19, 64, 64)
 
 
+def test_segmentation_only_graphs_match_cpu_restatement(gpu_device):
+    """get_seg_symbol_train / get_seg_symbol (symbol/multitask_symbol_builder.py:211-440): backbone -> pyramid decoder
+    only, conv_feat read from the backbone (`_plus15`), no SSD layers; output [seg_out].  Values, SegCrossEntropy and
+    every gradient against the float64 restatement; the test graph reproduces the training graph's seg_out."""
+    from dspnet_amd.symbol.multitask_symbol_factory import get_seg_symbol, get_seg_symbol_train
+    dev = torch.device("cuda", 0)
+    B, S = 2, 256
+    net = get_seg_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=dev, seed=5)
+    names = [p.name for p in net.g.param_order]
+    assert not any(n.startswith("multi_feat") or "pred_conv" in n for n in names) and "affine_matrix" in names
+    assert net.label_det is None and net.det is None
+    gen = synthetic.rng(31)
+    data = synthetic.images(B, S, S, gen)
+    seg = synthetic.seg_labels(B, S, S, gen=gen)
+    solver = MultiTaskSolver(net)
+    solver.set_batch(torch.from_numpy(data).to(dev), None, torch.from_numpy(seg).to(dev))
+    solver.forward(); solver.backward(); torch.cuda.synchronize()
+    outs = net.outputs()
+    assert len(outs) == 1 and tuple(outs[0].shape) == (B, 19, S // 4, S // 4)
+    # the device's own ReLU signs / max-pool picks handed to the restatement (see the full-size test above): both then
+    # differentiate the same piecewise-linear function, and every gradient tensor is held element-wise
+    ref = ot.forward_loss(ot.export_params(net.g), data, None, seg, num_classes=8, dtype=torch.float64,
+                          config=get_config("resnet-50", S), with_det=False, decisions=device_decisions(net))
+    a, b = outs[0].cpu().numpy(), ref["seg_out"].numpy()
+    assert np.abs(a - b).max() < 1e-4 * np.abs(b).max()
+    m = MultiBoxMetric(); m.update(net)
+    v = dict(zip(*m.get()))
+    assert abs(v["SegCrossEntropy"] - ref["SegCrossEntropy"]) <= 1e-4 * ref["SegCrossEntropy"]
+    assert np.isnan(v["CrossEntropy"])                     # nothing counted for the tasks the graph does not have
+    ref["objective"].backward()
+    grads = {}
+    for p in net.g.param_order:
+        if p.name == "affine_matrix":      # identity grid: interpolation kinks (see test_second_step_with_moved_affine...)
+            continue
+        gref = ot.import_grad(p.name, ref["params"][p.name].grad)
+        gdev = p.grad.cpu().numpy()
+        grads[p.name] = (gdev[:gref.shape[0], :, :, :gref.shape[3]] if gdev.ndim == 4 else gdev[:gref.shape[0]], gref)
+    gmax = max(float(np.abs(r).max()) for _, r in grads.values())
+    for name, (d, r) in grads.items():      # absolute floor for gradients that are zero in exact arithmetic (bn0_gamma)
+        assert np.abs(d - r).max() <= 1e-3 * np.abs(r).max() + 1e-6 * gmax, (name, np.abs(d - r).max(), np.abs(r).max())
+
+    test_net = get_seg_symbol("resnet-50", S, num_classes=8, batch_size=B, device=dev, seed=5)
+    assert torch.equal(test_net.g.arena, net.g.arena)
+    test_net.data.data.copy_(torch.from_numpy(data).to(dev))
+    test_net.g.forward()
+    t_outs = test_net.outputs()
+    assert len(t_outs) == 1 and torch.equal(t_outs[0], outs[0])
+
+
+def test_detection_only_test_graph(gpu_device):
+    """get_det_symbol (symbol/multitask_symbol_builder.py:123-209): output [det], equal to outputs[3] of
+    get_det_symbol_train on the same parameters"""
+    from dspnet_amd.symbol.multitask_symbol_factory import get_det_symbol, get_det_symbol_train
+    dev = torch.device("cuda", 0)
+    net, solver, data, lab, seg = _vgg_case("det", 300, 1, 20)
+    solver.forward()
+    t = get_det_symbol("vgg16_reduced", 300, num_classes=20, batch_size=1, device=dev, seed=3)
+    assert torch.equal(t.g.arena, net.g.arena)
+    t.data.data.copy_(torch.from_numpy(data).to(dev))
+    t.g.forward()
+    outs = t.outputs()
+    assert len(outs) == 1 and torch.equal(outs[0], net.outputs()[3])
+
+
 def _vgg_case(kind, size, batch, classes, network="vgg16_reduced"):
     from dspnet_amd.symbol.multitask_symbol_factory import get_det_symbol_train
     dev = torch.device("cuda", 0)

@@ -173,3 +173,13 @@ def test_pretrained_ingestion_and_checkpoint_round_trip(gpu_device, tmp_path):
     for a, b in zip(out1, net.outputs()):
         assert torch.equal(a, b)
     assert arena1.shape == g.arena.shape
+
+
+def test_symbol_factory_exposes_the_six_builders():
+    """symbol/multitask_symbol_factory.py:104-224 and the callers' imports (multi_eval.py, train_multi.py)"""
+    from dspnet_amd.symbol import multitask_symbol_builder as b, multitask_symbol_factory as f
+    for name in ("get_det_symbol_train", "get_det_symbol", "get_seg_symbol_train", "get_seg_symbol",
+                 "get_multi_symbol_train", "get_multi_symbol"):
+        assert callable(getattr(f, name)) and callable(getattr(b, name)), name
+    cfg = f.get_config("resnet-50", 512)
+    assert cfg["network"] == "resnet" and cfg["from_layers"][2] == "_plus15"      # what the seg-only graphs read
