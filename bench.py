@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--network", default="resnet-50", choices=["resnet-50", "vgg16_reduced", "inceptionv3"],
                     help="backbone preset; the headline workload is resnet-50 (the other BASELINE.json configs: "
                          "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
-    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="conv MFMA math: exact fp32 (default) or bf16 inputs with fp32 accumulate")
     ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],
                     help="storage type of activation tensors and convolution operands in HBM: float32 (default) or "

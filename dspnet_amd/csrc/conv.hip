@@ -55,6 +55,22 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
   return r;
 }
 
+// DSPN_MATH_F32_BF16X3 ("split" mode, float tensors): every float operand x is cut into three bf16 pieces on its way into
+// LDS, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (both differences exact in fp32, p0 + p1 + p2 = x to within
+// 2^-27 |x|), and a product x * w is formed as the six partial products x_p * w_q with p + q <= 2 -- each exact, bf16 x bf16
+// fits the fp32 accumulator's 24 bits -- summed by the same fp32 accumulation as the fp32 MFMA.  What is dropped (x1 w2,
+// x2 w1, x2 w2) is below 2^-26 |x w|: less than the rounding of one fp32 product.  Six v_mfma_f32_32x32x16_bf16 replace
+// sixteen v_mfma_f32_32x32x2_f32 of twice the cycles each.
+constexpr int kSplitValuPerMfma = 8;   // vector instructions of the piece arithmetic scheduled behind each MFMA
+constexpr int kLdsRowS = 3 * 32 + 8;   // LDS row of the three-piece image (bf16): 208 B, conflict-free for ds_read_b128
+__device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2) {
+  p0 = to_bf16x4(v);
+  const float4 r1 = make_float4(v.x - (float)p0[0], v.y - (float)p0[1], v.z - (float)p0[2], v.w - (float)p0[3]);
+  p1 = to_bf16x4(r1);
+  const float4 r2 = make_float4(r1.x - (float)p1[0], r1.y - (float)p1[1], r1.z - (float)p1[2], r1.w - (float)p1[3]);
+  p2 = to_bf16x4(r2);
+}
+
 constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
 constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
 constexpr int kBKF = 32;                       // ... of its fp32-MFMA path
@@ -88,7 +104,7 @@ struct ConvGeom {
   int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal, 32 ReLU after the input affine
   int dense;                       // output address = m*ldc (no decomposition needed)
   int dbg;                         // timing-only ablation bits (DSPN_ABLATE builds), 0 in production
-  int bf16;                        // host side only: 1 = bf16 MFMA math (per call, DSPN_MATH_BF16), 0 = fp32 MFMA
+  int bf16;                        // host side only: the call's math mode (DSPN_MATH_*): 0 fp32 MFMA, 1 bf16 MFMA, 2 three-piece bf16
   unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
   // optional per-input-channel affine (+ReLU when flags & 32) applied to the gathered tensor on its way into
   // LDS: the BatchNorm(+ReLU) in front of a convolution (symbol/resnet.py:30-45) without materialising its output
@@ -115,12 +131,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
     const int ksteps_per_split, float *__restrict__ slab, const st_t *__restrict__ residual) {
-  static_assert(!kHalf || BF16, "bf16 tensors always run on the bf16 MFMA");
+  constexpr bool BF16 = MATH != 0;      // the bf16 matrix instruction
+  constexpr bool SPLIT = MATH == 2;     // ... fed with the three bf16 pieces of every float operand (kMathSplit)
+  static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
@@ -128,9 +146,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
-  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [2][BM][kLdsRowH], then [2][BN][kLdsRowH]
-  __bf16 *hB = hA + 2 * BM * kLdsRowH;
+  constexpr int ROWH = SPLIT ? kLdsRowS : kLdsRowH;   // LDS row (bf16 elements) of the bf16 images
+  constexpr int STAGES = SPLIT ? 1 : 2;               // the three-piece image is single-buffered (two barriers per k-step)
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
+  __bf16 *hB = hA + STAGES * BM * ROWH;
 
+#ifdef DSPN_ABLATE
+  const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
+#else
+  constexpr int dbg = 0;   // production build: every ablation branch below is compiled out
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = m_tiles * n_tiles;
   const int M = g.N * g.Hg * g.Wg;
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     int tr, ts, cq;
     bool qv;
     if constexpr (uniform_tap) {
-      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0;
+      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0 && !(dbg & 128);   // 128: timing-only, no loads
       ++u_ts;                                   // branch-free wave-uniform advance: taps inner, channels outer
       const bool wrap = u_ts == g.TS;
       u_ts = wrap ? 0 : u_ts;
@@ -270,6 +295,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
                                __uint_as_float(t[3]));
     }
   };
+  // float tensors: the input affine of this thread's A rows, in registers
+  auto affine_tiles = [&]() __attribute__((always_inline)) {
+    if constexpr (INTF) {   // u = x * scale[c] + shift[c] (ReLU), zero where the tap is outside the image
+      const bool in_relu = g.flags & 32;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        // fmaf, like every other place that evaluates this affine (nn.hip's apply / backward kernels, the
+        // EPI == 2 mask below): the ReLU mask must come out identical in forward and backward
+        float4 u = make_float4(fmaf(ra[i].x, tf_sc.x, tf_sh.x), fmaf(ra[i].y, tf_sc.y, tf_sh.y),
+                               fmaf(ra[i].z, tf_sc.z, tf_sh.z), fmaf(ra[i].w, tf_sc.w, tf_sh.w));
+        if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+        const bool v = (tf_mask >> i) & 1u;
+        ra[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
+      }
+    }
+  };
+  // split mode: the three bf16 pieces of the rows loaded last (after their affine), kept in registers until the LDS image
+  // of the current k-step has been read by every wave.  Called in the middle of a k-step's MFMAs, whose issue slots the
+  // ~25 vector instructions per 16-byte chunk then share, instead of between the two barriers where nothing overlaps them.
+  bf16x4 pa[SPLIT ? A_LD : 1][3], pb[SPLIT ? B_LD : 1][3];
+  auto split_tiles = [&]() __attribute__((always_inline)) {
+    if constexpr (SPLIT) {
+      affine_tiles();
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+    }
+  };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if constexpr (kHalf) {
       if constexpr (INTF) {   // widen, u = x * scale[c] + shift[c] (ReLU), zero outside the image, round back to bf16
@@ -299,20 +353,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         *reinterpret_cast<u32x4_t *>(b + (row0 + RSTEP * i) * kLdsRowH + chunk * 8) = hb[i];
       return;
     }
-    if constexpr (INTF) {   // u = x * scale[c] + shift[c] (ReLU), zero where the tap is outside the image
-      const bool in_relu = g.flags & 32;
+    if constexpr (!SPLIT) affine_tiles();
+    if constexpr (SPLIT) {
+      // x = p0 + p1 + p2 (split_tiles): piece p of channel k of a row lies at row * ROWH + p * 32 + k
+      __bf16 *a = hA + buf * BM * ROWH, *b = hB + buf * BN * ROWH;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        // fmaf, like every other place that evaluates this affine (nn.hip's apply / backward kernels, the
-        // EPI == 2 mask below): the ReLU mask must come out identical in forward and backward
-        float4 u = make_float4(fmaf(ra[i].x, tf_sc.x, tf_sh.x), fmaf(ra[i].y, tf_sc.y, tf_sh.y),
-                               fmaf(ra[i].z, tf_sc.z, tf_sh.z), fmaf(ra[i].w, tf_sc.w, tf_sh.w));
-        if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
-        const bool v = (tf_mask >> i) & 1u;
-        ra[i] = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
+        __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
       }
-    }
-    if constexpr (BF16) {
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        __bf16 *d = b + (row0 + RSTEP * i) * ROWH + chunk * 4;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pb[i][pc];
+      }
+    } else if constexpr (BF16) {
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
@@ -343,11 +400,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 
   const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
   const int frow = lane & 31, fk = (lane >> 5) * 2;
-#ifdef DSPN_ABLATE
-  const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
-#else
-  constexpr int dbg = 0;   // production build: every ablation branch below is compiled out
-#endif
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
 
   // ---- persistent loop over output tiles ----------------------------------------------------------
@@ -374,7 +426,57 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   // one k-step of matrix work on LDS buffer `buf`
   auto mma_step = [&](const int buf) __attribute__((always_inline)) {
-    if constexpr (BF16) {
+    if constexpr (SPLIT) {
+      // x * w = sum over piece pairs (p, q), p + q <= 2, of x_p * w_q: six bf16 MFMAs per 16-deep k block, every partial
+      // product exact in the fp32 accumulator's input, the three dropped pairs below 2^-26 of the product.  Small terms
+      // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
+      const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
+      const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
+      auto block = [&](const int kk) __attribute__((always_inline)) {
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6) {
+          if ((dbg & 64) && t6 > 0) break;     // timing-only ablation: one of the six products
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+        }
+      };
+      block(0);
+      // the rows requested before this k-step have had the first block's MFMAs to arrive: their pieces are formed on the
+      // vector ALU between the second block's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 256)) split_tiles();
+      block(1);
+      // pin the pieces HERE: their only readers (the LDS stores) sit behind the barrier, and hipcc otherwise sinks the
+      // whole piece arithmetic down there, next to them
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pa[i][pc]));
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pb[i][pc]));
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
+#pragma unroll
+      for (int m = 0; m < 6 * TM * TN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kSplitValuPerMfma, 0);
+      }
+    } else if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
       const __bf16 *a = hA + buf * BM * kLdsRowH + (wm + frow) * kLdsRowH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * kLdsRowH + (wn + frow) * kLdsRowH + (lane >> 5) * 8;
@@ -438,6 +540,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   setup_tile(t);
   load_tiles();
+  split_tiles();
   store_tiles(0);
   __syncthreads();
   zero_acc();
@@ -455,6 +558,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
     // (32 v_mov + a full MFMA drain per k-step, seen in the ISA of the non-INTF 8-wave variants)
     if (NTHR == 512 || nk > 0) mma_step(buf);
+    else split_tiles();   // (split mode forms the pieces of the rows just requested inside mma_step)
     if (last) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
@@ -677,9 +781,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       kt = -1;
       __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
     }
-    if (!(dbg & 2)) store_tiles(buf ^ 1);
-    if (!(dbg & 4)) __syncthreads();
-    buf ^= 1;
+    if constexpr (STAGES == 1) {
+      if (!last && !(dbg & 4)) __syncthreads();   // every wave has read the fragments of this k-step (the epilogue's barriers cover `last`)
+      if (!(dbg & 2)) store_tiles(0);
+      if (!(dbg & 4)) __syncthreads();
+    } else {
+      if (!(dbg & 2)) store_tiles(buf ^ 1);
+      if (!(dbg & 4)) __syncthreads();
+      buf ^= 1;
+    }
     ++kt;
   }
 }
@@ -705,11 +815,12 @@ struct WgradGeom {
 // consecutive pixels (= MFMA k) of its channel, two reads per 8-k fragment.
 constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool BF16, bool INTF>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool INTF>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
     const st_t *__restrict__ x, const st_t *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
-  static_assert(!kHalf || BF16, "bf16 tensors always run on the bf16 MFMA");
+  constexpr bool BF16 = MATH != 0, SPLIT = MATH == 2;   // as in conv_nt_kernel
+  static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;   // BM over cout, BN over (tap,c)
   constexpr int NTHR = WAVES_M * WAVES_N * 64;                     // 4 waves, or 8 (4 waves per SIMD with two workgroups per CU)
   constexpr int A_CH = BM / kEPC, B_CH = BN / kEPC;                // 16-B chunks per tile row
@@ -817,8 +928,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
   };
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
+  // split mode: three piece planes per operand, single-buffered: [3][kPK][RAB] then [3][kPK][RBB]
+  constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? 3 : 1;
   char *hA = reinterpret_cast<char *>(smem);            // [2][kPK][RAB]
-  char *hB = hA + 2 * kPK * RAB;                        // [2][kPK][RBB]
+  char *hB = hA + STAGES * PLANES * kPK * RAB;          // [2][kPK][RBB]
   // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
   auto transform_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (INTF && kHalf) {
@@ -860,6 +973,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int i = 0; i < B_LD; ++i)
         if (b_row0 + i * B_RSTEP < kPK)
           *reinterpret_cast<u32x4_t *>(b + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 16) = hb[i];
+    } else if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        bf16x4 p0, p1, p2;
+        split3(ra[i], p0, p1, p2);
+        char *d = hA + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8;
+        *reinterpret_cast<bf16x4 *>(d) = p0;
+        *reinterpret_cast<bf16x4 *>(d + kPK * RAB) = p1;
+        *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RAB) = p2;
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        bf16x4 p0, p1, p2;
+        split3(rb[i], p0, p1, p2);
+        char *d = hB + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8;
+        *reinterpret_cast<bf16x4 *>(d) = p0;
+        *reinterpret_cast<bf16x4 *>(d + kPK * RBB) = p1;
+        *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RBB) = p2;
+      }
     } else if constexpr (BF16) {
       char *a = hA + buf * kPK * RAB, *b = hB + buf * kPK * RBB;
 #pragma unroll
@@ -891,12 +1023,42 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   if (nk > 0) { load_tiles(0); store_tiles(0); }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = STAGES == 1 ? 0 : (kt & 1);
     load_tiles(kt + 1);   // past the last k-step: every offset out of range, zero-cost
     // keep the requests HERE: without the fence hipcc sinks the four buffer loads below the 32 MFMAs (to shorten their
     // live ranges) and waits for them at once -- the whole global-memory latency of every k-step was exposed
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (BF16) {
+    if constexpr (SPLIT) {
+      // the bf16 mode's transposed reads, once per piece plane; six MFMAs per accumulator and 16-pixel block (conv_nt_kernel)
+      const int gl = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+      const char *a = hA + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *b = hB + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
+      auto frag = [](const char *base, int row_bytes) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base + 4 * row_bytes));
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+      };
+#pragma unroll
+      for (int kk = 0; kk < kPK / 16; ++kk) {
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[p][i] = frag(a + p * kPK * RAB + kk * 16 * RAB + i * 64, RAB);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[p][j] = frag(b + p * kPK * RBB + kk * 16 * RBB + j * 64, RBB);
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (BF16) {
       // transposed-read addressing: 16-lane group gl = lane >> 4 covers channels 16*(gl&1) .. +15 of a 32-channel
       // block and pixels 8*(gl>>1) .. +7 of a 16-pixel MFMA k block; lane 4q+p of the group supplies the address
       // of pixel row q, channels 4p .. 4p+3, and receives its own channel's 4 pixels.
@@ -959,6 +1121,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
     // unconditional (the last iteration stores the zeros its out-of-range loads returned into the idle buffer): behind
     // `if (kt + 1 < nk)` hipcc sinks the loads of load_tiles into the branch, i.e. below the MFMAs
+    if constexpr (STAGES == 1) __syncthreads();   // every wave has read this k-step's fragments
     store_tiles(buf ^ 1, INTF && !BF16);
     __syncthreads();
   }
@@ -1180,7 +1343,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, bool BF16, bool INTF, int EPI>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -1188,9 +1351,11 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-  const size_t lds = std::max<size_t>(BF16 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH : sizeof(float) * 2 * (BM + BN) * kLdsRow,
+  const size_t lds = std::max<size_t>(MATH == 2   ? sizeof(__bf16) * (BM + BN) * kLdsRowS
+                                      : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
+                                                  : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, BF16, INTF, EPI>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
   static int slots = 0;
@@ -1205,7 +1370,7 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
     if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
       fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
-              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, (int)BF16, (int)INTF, EPI, lds, per_cu, cus, slots);
+              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
   }
   const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
@@ -1228,10 +1393,11 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
   const bool uni = ((g.Cin / kEPC) & 7) == 0;
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
 #ifdef DSPN_HALF
-#define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E))
+#define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E))
 #else
-#define DSPN_NT_UB_(T, E) (g.bf16 ? (uni ? DSPN_NT_(true, true, T, E) : DSPN_NT_(false, true, T, E)) \
-                                  : (uni ? DSPN_NT_(true, false, T, E) : DSPN_NT_(false, false, T, E)))
+#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
+                           : g.bf16 == 1 ? (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E)) \
+                                         : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
@@ -1309,7 +1475,8 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   const bool one_tap = g.TR * g.TS == 1;
   // bf16 tensors: the main loop is ~3x shorter, the fused epilogues cost relatively more, and the 8-wave form wins for
   // every epilogue (measured on the resnet-50 step: 28.6 -> 26.1 ms)
-  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : kHalf ? true
+  // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
+  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 == 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
@@ -1375,7 +1542,11 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
 extern "C" {
 
 #ifdef DSPN_ABLATE
+#ifdef DSPN_HALF
+int dspn_debug_set_bf16(int bits) { g_debug_bits = bits; return 0; }   // the bf16-tensor kernels have their own word
+#else
 int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
+#endif
 #endif
 
 #ifndef DSPN_HALF
@@ -1444,7 +1615,7 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
                                int relu, int accumulate, float *out_stats, size_t out_stats_bytes, int math,
                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_forward: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_forward: math is one of DSPN_MATH_*");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   if (out_stats) {
     int tile_rows = 0;
@@ -1606,7 +1777,7 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, st_t *dx, int 
                              const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, int math,
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_dgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_dgrad: math is one of DSPN_MATH_*");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy);
   if (bn_sums) {
@@ -1704,24 +1875,29 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
   // mainloop buffers | staged output tile
+  // (the float build sizes for its largest mode: float images 2 * kPK * (BM + BN) * 4 B; the three-piece bf16 image of the
+  // split mode, single-buffered, 3 * kPK * row bytes, is smaller than the staged output tile for every tile shape but 32 x 128)
   const size_t lds = kHalf ? std::max<size_t>(2 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)), sizeof(float) * BM * (BN + 4))
-                           : sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4));
+                           : std::max<size_t>(sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4)),
+                                              3 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)));
   dspn::ProfScope prof(1, s);
 #ifdef DSPN_HALF
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
-    if (g.in_scale) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                     \
-    else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                               \
+    if (g.in_scale) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, true)                                        \
+    else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, false)                                                  \
   }
 #else
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
     if (g.in_scale) {                                                                                    \
-      if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, true)                                       \
-      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, true)                                             \
+      if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, true)                                     \
+      else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, true)                                     \
+      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, true)                                                 \
     } else {                                                                                             \
-      if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, true, false)                                      \
-      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, false, false)                                            \
+      if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, false)                                    \
+      else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, false)                                    \
+      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, false)                                                \
     }                                                                                                    \
   }
 #endif
@@ -1759,7 +1935,7 @@ int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const fl
                              void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_wgrad: math is one of DSPN_MATH_*");
   const int nb = std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                           batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
@@ -1791,7 +1967,7 @@ int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const
                                 int Wo, int math, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16, "conv2d_wgrad: math is DSPN_MATH_FP32 or DSPN_MATH_BF16");
+  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                         batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");

@@ -4,6 +4,7 @@ torch tensors are device buffers only; every function launches HIP kernels on
 torch's current stream.  Activations are NHWC float32 with a physical channel
 count that is a multiple of 4; conv weights are [Cout, R, S, Cin]."""
 import ctypes
+import os
 
 import torch
 
@@ -191,7 +192,11 @@ def act_empty(*shape, device=None):
 
 
 # ------------------------------------------------------------------ convolution
-_MATH = 0      # DSPN_MATH_FP32 | DSPN_MATH_BF16: this module's default for the `math` argument it passes on every call
+_MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}      # include/dspn_nn.h DSPN_MATH_*
+# this module's default for the `math` argument it passes on every convolution call (float tensors); DSPN_CONV_MATH
+# overrides it for a whole process (the test suite is run once per mode)
+DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "fp32")
+_MATH = _MATH_CODES[DEFAULT_CONV_MATH]
 
 
 def set_conv_math(mode):
@@ -199,11 +204,11 @@ def set_conv_math(mode):
     this module from now on.  Host-side default only: the C ABI takes the mode per call (include/dspn_nn.h,
     DSPN_MATH_*), the library itself has no state."""
     global _MATH
-    _MATH = {"fp32": 0, "f32": 0, "bf16": 1}[mode]
+    _MATH = _MATH_CODES[mode]
 
 
 def get_conv_math():
-    return "bf16" if _MATH else "fp32"
+    return ("fp32", "bf16", "bf16x3")[_MATH]
 
 
 def conv_stats_layout(out_pixels, cout):

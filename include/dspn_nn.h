@@ -49,6 +49,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                   to bf16 (round-to-nearest-even) on the way into LDS -- BASELINE.json configs[3] "bf16 MFMA convs" */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
+#define DSPN_MATH_F32_BF16X3 2
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,

@@ -1,0 +1,29 @@
+"""timing-only ablations of conv_nt_kernel in the split (bf16x3) mode; needs the ABLATE build:
+make -C dspnet_amd/csrc ABLATE=1; DSPN_LIB=dspnet_amd/libdspn_hip_ablate.so python scratch/ablate_split.py"""
+import sys
+sys.path.insert(0, '/root/repo')
+import torch
+from dspnet_amd import functional as fn
+dev = torch.device("cuda", 0)
+def timeit(f, reps=10):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+shapes = [(32, 32, 32, 256, 256, 3), (32, 64, 64, 128, 128, 3), (32, 32, 32, 1024, 256, 1), (32, 128, 128, 256, 128, 1)]
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+fn.set_conv_math(mode)
+for (N, H, W, Cin, Cout, k) in shapes:
+    x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+    out = torch.empty(N, H, W, Cout, device=dev)
+    fl = 2.0 * N * H * W * Cin * Cout * k * k
+    res = []
+    for bits, nm in ((0, "full"), (32, "no-epi"), (32 + 64, "no-epi,1-of-6 mfma"), (32 + 128, "no-epi,no-loads"), (32 + 2, "no-epi,no-lds-store"),
+                     (32 + 2 + 128, "no-epi,no-loads,no-store"), (32 + 2 + 4 + 128, "..+no-barrier"), (32 + 2 + 4 + 128 + 64, "..+1-of-6")):
+        fn.L().dspn_debug_set(bits)
+        t = timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=out))
+        res.append("%s %.3f" % (nm, t))
+    fn.L().dspn_debug_set(0)
+    print((N, H, W, Cin, Cout, k), "6-product MFMA floor at 2.5PF %.3f ms |" % (6 * fl / 2.5e12), " | ".join(res))

@@ -407,7 +407,7 @@ def test_bf16_tensor_training_tracks_the_float_run(gpu_device):
         net_h2, hist_h2 = run("bf16")
         net_f, hist_f = run("fp32")
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
     assert net_h.g.tensors["_plus15"].data.dtype == torch.bfloat16 and net_f.g.tensors["_plus15"].data.dtype == torch.float32
     assert net_h.g.arena.dtype == torch.float32                       # master weights stay float
     assert np.isfinite(hist_h).all() and torch.isfinite(net_h.g.arena).all()
@@ -616,7 +616,7 @@ def test_bf16_mfma_graph_losses_close_to_fp32_restatement(gpu_device):
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
 
 
 def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
@@ -668,7 +668,7 @@ def test_inceptionv3_bf16_1024x512_matches_cpu_restatement(gpu_device):
         solver.forward(); solver.backward(); torch.cuda.synchronize()
         assert torch.equal(g1, net.g.grad_arena)              # deterministic in bf16 mode as well
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
 
 
 @pytest.mark.parametrize("network,H,W,B,store", [("inceptionv3", 512, 1024, 1, "fp32"), ("inceptionv3", 512, 1024, 1, "bf16"),
@@ -796,7 +796,7 @@ def test_bf16_every_convolution_layer_local(gpu_device, network, H, W, B, store)
         print("bf16 math, %s tensors, %s %dx%d layer-local: %d convolutions, worst error / bound: forward %.3f, wgrad %.3f, "
               "dgrad %.3f" % (store, network, H, W, len(convs), worst_f, worst_w, worst_d))
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
         fn.set_activation_dtype("fp32")
 
 

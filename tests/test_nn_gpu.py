@@ -413,7 +413,7 @@ def test_conv_inception_kernel_classes(gpu_device, kh, kw, ph, pw, stride, cin, 
         dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=(ph, pw))
         dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=(ph, pw))
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
     close(nchw(y, Cout), y_ref.detach())
     close(nchw(dx, Cin), x.grad)
     close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad)
@@ -465,7 +465,7 @@ def test_tap_expanded_conv_matches_direct(gpu_device, case):
 def bf16_math():
     fn.set_conv_math("bf16")
     yield
-    fn.set_conv_math("fp32")
+    fn.set_conv_math(fn.DEFAULT_CONV_MATH)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
