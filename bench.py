@@ -8,10 +8,18 @@ GPU, fp32 (the only preset the reference's graph builder accepts, SURVEY.md 2.1,
 BASELINE.json's scaling target is quoted on).  Weak scaling: every rank holds a replica and its own
 32-image shard; the only collective is the gradient all-reduce.
 
+fp32 here means fp32 tensors, fp32 accumulation and fp32-accurate products.  The default convolution
+math (--math bf16x3, DSPN_MATH_F32_BF16X3) forms every product from six exact bf16 x bf16 partial
+products of a three-piece split of both fp32 operands on the bf16 MFMA -- its error against float64 is
+the same as the fp32 MFMA's (tests/test_nn_gpu.py::test_split_bf16_math_is_as_accurate_as_the_fp32_mfma,
+and every graph parity test runs in both modes at one tolerance); --math fp32 runs v_mfma_f32_32x32x2_f32
+and is reported beside the headline under other_configs.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     - the implicit-GEMM convolution family (fp32 MFMA, peak 157.3 TFLOP/s): algorithmic
-                 conv FLOPs executed per step / conv kernel time per step, the latter measured live
-                 with HIP events on the launch stream over the timed region;
+  roofline     - the implicit-GEMM convolution family: algorithmic conv FLOPs executed per step / conv
+                 kernel time per step, the latter measured live with HIP events on the launch stream
+                 over the timed region; peak = the instruction that bounds the mode (bf16x3: bf16 MFMA
+                 2500 TFLOP/s / 6 products per multiply-add = 416.7; fp32: 157.3; bf16: 2500);
   cpu_baseline - the CPU restatement of the same step (oracle/dspnet_torch.py, fp32, all host cores)
                  on a bounded sample; rank 0, N = 1 only.
 """
@@ -27,8 +35,13 @@ sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
-# committed rocprofv3 --pmc passes of the headline workload, newest first (roofline.traffic is read from these)
-TRAFFIC_PROFILES = ["r02_pmc_conv_family.json", "r01_j_pmc_conv_family.json"]
+# algorithmic (fp32 multiply-add) peak of each math mode: bf16x3 issues six bf16 MFMAs per fp32 multiply-add
+MATH_PEAK_TFLOPS = {"fp32": FP32_MATRIX_PEAK_TFLOPS, "bf16": BF16_MATRIX_PEAK_TFLOPS, "bf16x3": BF16_MATRIX_PEAK_TFLOPS / 6.0}
+MATH_LABEL = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (operands rounded to bf16)",
+              "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)"}
+# committed rocprofv3 --pmc passes of the headline workload per math mode, newest first (roofline.traffic is read from these)
+TRAFFIC_PROFILES = {"bf16x3": ["r02_x3_pmc_conv_family.json"],
+                    "fp32": ["r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json", "r01_j_pmc_conv_family.json"]}
 PROF_STEPS = 2   # steps of the timed region whose convolution launches are bracketed by HIP events (roofline.achieved)
 
 
@@ -43,8 +56,9 @@ def parse():
     ap.add_argument("--network", default="resnet-50", choices=["resnet-50", "vgg16_reduced", "inceptionv3"],
                     help="backbone preset; the headline workload is resnet-50 (the other BASELINE.json configs: "
                          "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
-    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
-                    help="conv MFMA math: exact fp32 (default) or bf16 inputs with fp32 accumulate")
+    ap.add_argument("--math", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
+                    help="convolution math on float tensors: bf16x3 = fp32 results from six exact bf16 products per "
+                         "multiply on the bf16 MFMA (default), fp32 = fp32 MFMA, bf16 = operands rounded to bf16")
     ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],
                     help="storage type of activation tensors and convolution operands in HBM: float32 (default) or "
                          "bfloat16 (the *_bf16 kernels: bf16 MFMA, fp32 accumulate, fp32 master weights)")
@@ -173,17 +187,23 @@ def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, tr
     if conv_s <= 0:
         return None
     ach = flops_step / conv_s / 1e12
-    peak = FP32_MATRIX_PEAK_TFLOPS if math == "fp32" else BF16_MATRIX_PEAK_TFLOPS
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "frac_end_to_end_3x": round(flops_3x_step / step_s / 1e12 / peak, 4),
-            "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: %s implicit-GEMM family" % math,
-            "launches_per_step": (nt_n + wg_n) // steps,
-            "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
-            "conv_ms_per_step": round(conv_s * 1e3, 3),
-            "nt_ms_per_step": round(nt_ms / steps, 3), "wgrad_ms_per_step": round(wg_ms / steps, 3),
-            "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
-            "share_of_step_time": round(conv_s / step_s, 3)}
+    peak = MATH_PEAK_TFLOPS[math]
+    out = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+           "frac_end_to_end_3x": round(flops_3x_step / step_s / 1e12 / peak, 4),
+           "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: implicit-GEMM family, %s" % MATH_LABEL[math],
+           "launches_per_step": (nt_n + wg_n) // steps,
+           "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
+           "conv_ms_per_step": round(conv_s * 1e3, 3),
+           "nt_ms_per_step": round(nt_ms / steps, 3), "wgrad_ms_per_step": round(wg_ms / steps, 3),
+           "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
+           "share_of_step_time": round(conv_s / step_s, 3)}
+    if math == "bf16x3":
+        # the same work priced two other ways: against the fp32 MFMA it replaces, and as issued bf16 MFMA flops
+        out["peak_note"] = "2500 TFLOP/s bf16 MFMA / 6 bf16 products per fp32 multiply-add"
+        out["achieved_vs_fp32_mfma_peak"] = round(ach / FP32_MATRIX_PEAK_TFLOPS, 4)
+        out["issued_bf16_mfma_tflops"] = round(6.0 * ach, 1)
+    return out
 
 
 def conv_nodes(net):
@@ -223,13 +243,13 @@ def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
         dt = time.perf_counter() - t0
         lib.dspn_profile_enable(0)
         return {"workload": "%s multitask (det+depth+seg) %dx%d (HxW), bs %d, %s, forward+backward+SGD, N=%d anchors"
-                            % (network, H, W, B, "fp32" if math == "fp32" else ("bf16 MFMA convs" + (
+                            % (network, H, W, B, MATH_LABEL[math] if math != "bf16" else ("bf16 MFMA convs" + (
                                 ", bf16 tensors in HBM" if store == "bf16" else ", fp32 tensors in HBM")), net.anchors.shape[1]),
                 "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
-                "steps": steps, "warmup": warmup, "dtype": "f32" if math == "fp32" else "bf16",
+                "steps": steps, "warmup": warmup, "dtype": "bf16" if math == "bf16" else "f32",
                 "roofline": conv_family_roofline(lib, ps, flops_step, flops_3x, math, dt / steps)}
     finally:
-        fn.set_conv_math("fp32")
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
         fn.set_activation_dtype("fp32")
 
 
@@ -237,7 +257,7 @@ def side_infer(B, size, iters, warmup, dev):
     """BASELINE.json configs[4]: inference-only detector path, p50 latency of forward + MultiBoxDetection/NMS"""
     import numpy as np
     import torch
-    from dspnet_amd import _lib, synthetic
+    from dspnet_amd import _lib, functional as fn, synthetic
     from dspnet_amd.detect.multitask_detector import Detector
     lib = _lib.lib()
     det = Detector("resnet-50", size, num_classes=8, batch_size=B, device=dev)
@@ -270,7 +290,7 @@ def side_infer(B, size, iters, warmup, dev):
                         "weights (nearly all 6132 rows valid: worst case for sort + NMS)" % (size, size, B),
             "p50_ms_per_batch": round(p50, 3), "p90_ms_per_batch": round(float(np.percentile(lat, 90)), 3),
             "images_per_s": round(B / p50 * 1e3, 1), "iterations": iters, "warmup": warmup, "dtype": "f32",
-            "roofline": conv_family_roofline(lib, ps, flops_fwd, flops_direct, "fp32", inst_s)}
+            "roofline": conv_family_roofline(lib, ps, flops_fwd, flops_direct, fn.get_conv_math(), inst_s)}
 
 
 def spawn_ranks(args):
@@ -415,9 +435,9 @@ def main():
         # HBM bytes per conv launch: rocprofv3 --pmc cannot run inside bench.py, so this figure is OFFLINE -- read from
         # the committed PMC passes of the headline workload named in traffic_source -- not a measurement of this run
         traffic = tsrc = None
-        headline = (args.network, S, Wd, B, args.math) == ("resnet-50", 512, 512, 32, "fp32")
+        headline = (args.network, S, Wd, B, args.store) == ("resnet-50", 512, 512, 32, "fp32")
         if headline:
-            for name in TRAFFIC_PROFILES:
+            for name in TRAFFIC_PROFILES.get(args.math, []):
                 try:
                     traffic = round(json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"])
                     tsrc = "offline: profiles/" + name
@@ -431,11 +451,12 @@ def main():
     # the other BASELINE.json configs beside the headline workload: short side measurements OUTSIDE the timed region
     # above (never part of `value`), N=1 only, each with its own roofline block
     other = None
-    headline = (args.network, S, Wd, B, args.math) == ("resnet-50", 512, 512, 32, "fp32")
+    headline = (args.network, S, Wd, B, args.math, args.store) == ("resnet-50", 512, 512, 32, "bf16x3", "fp32")
     if rank == 0 and world == 1 and headline and not args.no_other_configs and not args.no_cpu_baseline:
         del solver
         other = {}
-        for key, f in (("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "fp32", 5, 2, dev)),
+        for key, f in (("headline shape, fp32 MFMA", lambda: side_train("resnet-50", 512, 512, 32, "fp32", 6, 2, dev)),
+                       ("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "bf16x3", 5, 2, dev)),
                        ("configs[3]", lambda: side_train("inceptionv3", 512, 1024, 8, "bf16", 8, 3, dev, store="bf16")),
                        ("headline shape, bf16 tensors", lambda: side_train("resnet-50", 512, 512, 32, "bf16", 8, 3, dev, store="bf16")),
                        ("configs[4]", lambda: side_infer(64, 512, 100, 10, dev))):
@@ -457,10 +478,11 @@ def main():
             "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.math == "fp32" else "bf16", "data": "synthetic",
+            "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "%s multitask (det+depth+seg) %dx%d, 8 det classes, 19 seg classes, "
                                    "N=%d anchors, forward+backward+SGD%s" % (args.network, S, Wd, net.anchors.shape[1],
                                                                             ", bf16 tensors in HBM" if args.store == "bf16" else ""),
+                       "conv_math": MATH_LABEL[args.math],
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
                        "train_gflop_per_image_3x_convention": round(flops_3x / B / 1e9, 2),
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},

@@ -195,14 +195,17 @@ def act_empty(*shape, device=None):
 _MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}      # include/dspn_nn.h DSPN_MATH_*
 # this module's default for the `math` argument it passes on every convolution call (float tensors); DSPN_CONV_MATH
 # overrides it for a whole process (the test suite is run once per mode)
-DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "fp32")
+DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "bf16x3")
 _MATH = _MATH_CODES[DEFAULT_CONV_MATH]
 
 
 def set_conv_math(mode):
-    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA, fp32 accumulate) for the convolution calls made through
-    this module from now on.  Host-side default only: the C ABI takes the mode per call (include/dspn_nn.h,
-    DSPN_MATH_*), the library itself has no state."""
+    """math of the float-tensor convolution calls made through this module from now on (include/dspn_nn.h DSPN_MATH_*):
+      "bf16x3"  fp32 results on the bf16 MFMA: every float operand cut into three bf16 pieces on its way into LDS, six
+                exact partial products per multiply, fp32 accumulate (default: as accurate as "fp32", ~1.3x faster)
+      "fp32"    fp32 MFMA (v_mfma_f32_32x32x2_f32)
+      "bf16"    operands ROUNDED to bf16 (2^-9 relative), fp32 accumulate: BASELINE.json configs[3]
+    Host-side default only: the C ABI takes the mode per call, the library itself has no state."""
     global _MATH
     _MATH = _MATH_CODES[mode]
 

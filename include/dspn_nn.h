@@ -44,9 +44,15 @@ extern "C" {
 size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
 /* Math mode of one convolution call -- the `math` argument of the *_bn_f32 / *_slabs_f32 entry points (the plain
  * *_f32 entries are always DSPN_MATH_FP32).  A per-call argument, not library state: the library keeps no globals.
- *   DSPN_MATH_FP32  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fmaf chains
- *   DSPN_MATH_BF16  bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: tensors stay fp32 in HBM and are rounded
- *                   to bf16 (round-to-nearest-even) on the way into LDS -- BASELINE.json configs[3] "bf16 MFMA convs" */
+ *   DSPN_MATH_FP32        fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   DSPN_MATH_BF16        bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: tensors stay fp32 in HBM and are ROUNDED
+ *                         to bf16 (round-to-nearest-even, 2^-9 relative) on the way into LDS -- BASELINE.json configs[3]
+ *                         "bf16 MFMA convs"
+ *   DSPN_MATH_F32_BF16X3  fp32 RESULTS on the bf16 MFMA: each float operand is cut into three bf16 pieces on the way into
+ *                         LDS (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)) and a product is the sum of the six
+ *                         exact partial products x_p * w_q, p + q <= 2, accumulated in fp32.  Error against float64 equal
+ *                         to DSPN_MATH_FP32's (tests/test_nn_gpu.py), ~1.3x its speed; what dspnet_amd passes by default.
+ * The *_bf16 entry points (bf16 tensors in HBM) ignore the argument: their operands are bf16 already. */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
 #define DSPN_MATH_F32_BF16X3 2

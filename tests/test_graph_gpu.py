@@ -16,6 +16,15 @@ from oracle import multibox as om
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bf16x3", "fp32"])
+def conv_math(request):
+    """both fp32-result math modes of the float-tensor convolutions (functional.set_conv_math), same tolerances"""
+    from dspnet_amd import functional as fn
+    fn.set_conv_math(request.param)
+    yield request.param
+    fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+
+
 def make(batch, h, w, seed=233):
     dev = torch.device("cuda", 0)
     net = get_multi_symbol_train("resnet-50", (3, h, w), num_classes=8, batch_size=batch, device=dev, seed=1)
@@ -114,7 +123,7 @@ def test_recorded_shapes_512x1024(gpu_device):
     assert tuple(outs[4].shape) == (1, 19, 128, 256)       # seg_out_output
 
 
-def test_forward_backward_matches_cpu_restatement(gpu_device):
+def test_forward_backward_matches_cpu_restatement(gpu_device, conv_math):
     net, solver, data, lab, seg = make(2, 256, 256)
     solver.forward()
     solver.backward()
@@ -208,7 +217,7 @@ def device_decisions(net):
 
 
 @pytest.mark.parametrize("network,batch,size", [("resnet-50", 2, 512), ("vgg16_reduced", 2, 512)])
-def test_full_size_gradients_elementwise_with_pinned_decisions(gpu_device, network, batch, size):
+def test_full_size_gradients_elementwise_with_pinned_decisions(gpu_device, conv_math, network, batch, size):
     """BASELINE.json's shape (512x512) instead of a reduced one, and an ELEMENT-WISE bound on every parameter gradient,
     backbone included: the float64 restatement is handed the device's own discrete decisions (ReLU signs, max-pool
     picks, MultiBoxTarget matching), so both differentiate the same piecewise-linear function and what is left is fp32

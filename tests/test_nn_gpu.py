@@ -41,6 +41,16 @@ def close(got, exp, tol=1e-4):
     assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
 
 
+@pytest.fixture(params=["bf16x3", "fp32"])
+def conv_math(request):
+    """the two math modes of float-tensor convolutions that promise fp32 results -- DSPN_MATH_F32_BF16X3 (three-piece bf16
+    split, six exact products per multiply, fp32 accumulate: the default) and DSPN_MATH_FP32 (fp32 MFMA) -- held to the same
+    tolerances"""
+    fn.set_conv_math(request.param)
+    yield request.param
+    fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+
+
 CONV_CASES = [
     # N, H, W, Cin, Cout, k, stride, pad, dil
     (2, 16, 16, 64, 64, 3, 1, 1, 1),      # backbone 3x3
@@ -59,7 +69,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_dgrad_wgrad(gpu_device, case):
+def test_conv_forward_dgrad_wgrad(gpu_device, conv_math, case):
     N, H, W, Cin, Cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
@@ -91,7 +101,7 @@ def test_conv_forward_dgrad_wgrad(gpu_device, case):
     close(fn.colsum(dyd, Cout).cpu().double(), dy.sum(dim=(0, 2, 3)))
 
 
-def test_conv_large_k_and_split_k_determinism(gpu_device):
+def test_conv_large_k_and_split_k_determinism(gpu_device, conv_math):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 832, 16, 16, generator=g, dtype=torch.float64)
     w = torch.randn(19, 832, 3, 3, generator=g, dtype=torch.float64) / 80
@@ -106,7 +116,7 @@ def test_conv_large_k_and_split_k_determinism(gpu_device):
     close(a.cpu().double().permute(0, 3, 1, 2), ref)
 
 
-def test_deconv_4x4_s2_forward_backward(gpu_device):
+def test_deconv_4x4_s2_forward_backward(gpu_device, conv_math):
     """mx.sym.Deconvolution(kernel 4, stride 2, pad 1, no bias) == dgrad of a 4x4/2 conv"""
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 19, 12, 10, generator=g, dtype=torch.float64, requires_grad=True)
@@ -390,7 +400,7 @@ def test_conv_input_sum_grad(gpu_device, case):
     close(got[:Cin].cpu().double(), x.grad.sum(dim=(0, 2, 3)), 1e-4)
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("cin", [32, 48])
 @pytest.mark.parametrize("kh,kw,ph,pw,stride", [(1, 7, 0, 3, 1), (7, 1, 3, 0, 1), (1, 3, 0, 1, 1), (3, 1, 1, 0, 1),
                                                 (5, 5, 2, 2, 1), (3, 3, 0, 0, 2)])
@@ -437,7 +447,7 @@ def test_maxpool_full_convention(gpu_device):
 
 
 @pytest.mark.parametrize("case", [(2, 12, 10, 40, 19, 3, 3, 1, 1), (1, 9, 9, 64, 5, 1, 7, 0, 3), (2, 64, 64, 256, 19, 3, 3, 1, 1)])
-def test_tap_expanded_conv_matches_direct(gpu_device, case):
+def test_tap_expanded_conv_matches_direct(gpu_device, conv_math, case):
     """1x1 convolution to Cout*R*S channels + tap_sum == the RxS convolution; tap_spread + 1x1 wgrad == its
     weight gradient (score3_conv's evaluation, engine.Conv(tap_expand=True))"""
     N, H, W, Cin, Cout, R, S, ph, pw = case
@@ -499,7 +509,7 @@ def test_conv_bf16_mfma_math(gpu_device, bf16_math, case):
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1, 1), (2, 17, 19, 32, 48, 3, 2, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0, 1),
                                   (2, 16, 16, 128, 256, 1, 2, 0, 1), (1, 9, 9, 36, 40, 3, 1, 1, 1), (4, 64, 64, 64, 128, 3, 1, 1, 1)])
 @pytest.mark.parametrize("relu", [True, False])
-def test_conv_with_input_affine(gpu_device, case, relu):
+def test_conv_with_input_affine(gpu_device, conv_math, case, relu):
     """dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32: BatchNorm-apply (+ReLU) folded into the tile loader ==
     the convolution of the materialised (relu)(x*scale+shift), including zero padding AFTER the affine"""
     N, H, W, Cin, Cout, k, stride, pad, dil = case
@@ -528,7 +538,7 @@ def test_conv_with_input_affine(gpu_device, case, relu):
                                   (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0),
                                   (8, 128, 128, 16, 64, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("with_res", [False, True])
-def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
+def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_res):
     """out_stats of dspn_conv2d_forward_bn_f32 + dspn_bn_stats_from_tiles_f32 == dspn_bn_stats_f32 on the stored
     output (mean / rstd / scale / shift), including a large common offset (cancellation) and the residual add"""
     N, H, W, Cin, Cout, k, stride, pad = case
@@ -564,7 +574,7 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, case, with_res):
                                   (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0),
                                   (8, 128, 128, 64, 16, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, case, accumulate):
+def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, conv_math, case, accumulate):
     """dspn_conv2d_dgrad_bn_f32 + dspn_bn_backward_from_sums_f32 == dspn_conv2d_dgrad_f32 + dspn_bn_backward_f32
     (stride 1 and the four parity classes of stride 2, with and without accumulation into dx)"""
     N, H, W, Cin, Cout, k, stride, pad = case
@@ -658,3 +668,55 @@ def test_conv_full_size_properties(gpu_device, case):
     F.conv2d(xr, wr, None, stride=stride, padding=pad).backward(dy.permute(0, 3, 1, 2))
     assert float((dx.permute(0, 3, 1, 2) - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
     assert float((dw.permute(0, 3, 1, 2) - wr.grad).abs().max()) <= 2e-4 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("case", [(8, 32, 32, 256, 256, 3, 1, 1), (8, 64, 64, 128, 512, 1, 1, 0), (8, 64, 64, 64, 64, 3, 1, 1),
+                                  (4, 64, 64, 256, 128, 1, 2, 0), (2, 32, 32, 36, 40, 3, 1, 1)])
+def test_split_bf16_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
+    """DSPN_MATH_F32_BF16X3 against DSPN_MATH_FP32, both against float64, on operands with full 24-bit mantissas: forward,
+    data gradient and weight gradient (plain, and with the fused input affine + output statistics).  The split mode's
+    root-mean-square error may not exceed 1.25x the fp32 MFMA's on any of them and its largest error 2x (measured: rms
+    0.85 .. 1.05x, largest 0.8 .. 1.6x), and both stay below 1e-5 of the tensor's scale -- i.e. the six-product bf16 evaluation
+    is an fp32 convolution, not a reduced-precision one."""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64).float().double().requires_grad_()
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)).float().double().requires_grad_()
+    sc = (torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5).float().double()
+    sh = torch.randn(Cin, generator=g, dtype=torch.float64).float().double()
+    y_ref = F.conv2d(x, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64).float().double()
+    y_ref.backward(dy)
+    u = (x.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).float().double().clamp(min=0)   # the device forms u in fp32 (one fmaf)
+    yu_ref = F.conv2d(u, w.detach(), None, stride=stride, padding=pad)
+    dwu_ref = torch.nn.grad.conv2d_weight(u, w.shape, dy, stride=stride, padding=pad)
+    xd, wd_, dyd = nhwc(x.detach()), wdev(w.detach()), nhwc(dy)
+    cp = fn.pad4(Cin)
+    aff = (torch.cat([sc.float(), torch.zeros(cp - Cin)]).cuda(), torch.cat([sh.float(), torch.zeros(cp - Cin)]).cuda(), True)
+
+    def rel(got, exp):      # (largest, root-mean-square) error in units of the tensor's largest entry
+        d = (got.double().cpu() - exp)
+        return float(d.abs().max() / exp.abs().max()), float((d * d).mean().sqrt() / exp.abs().max())
+
+    errs = {}
+    for mode in ("fp32", "bf16x3"):
+        fn.set_conv_math(mode)
+        try:
+            y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=pad)
+            dx = fn.conv2d_dgrad(dyd, fn.weight_transpose(wd_), tuple(xd.shape), stride=stride, pad=pad)
+            dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=pad)
+            yu = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=pad, in_affine=aff)
+            dwu = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=pad, in_affine=aff)
+        finally:
+            fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+        errs[mode] = dict(fwd=rel(nchw(y, Cout), y_ref.detach()), dgrad=rel(nchw(dx, Cin), x.grad),
+                          wgrad=rel(dw.permute(0, 3, 1, 2)[:, :Cin], w.grad), fwd_affine=rel(nchw(yu, Cout), yu_ref),
+                          wgrad_affine=rel(dwu.permute(0, 3, 1, 2)[:, :Cin], dwu_ref))
+    print(case, {k: "max %.2f rms %.2f of fp32's" % (errs["bf16x3"][k][0] / errs["fp32"][k][0], errs["bf16x3"][k][1] / errs["fp32"][k][1])
+                 for k in errs["fp32"]})
+    for key in errs["fp32"]:
+        (mx, rx), (mf, rf) = errs["bf16x3"][key], errs["fp32"][key]
+        assert mx < 1e-5 and mf < 1e-5, (key, errs)
+        # the root-mean-square error is the stable statistic (the largest of 10^5 .. 10^7 errors fluctuates by tens of percent
+        # between two evaluations of equal quality): within 1.25x; the largest error within 2x
+        assert rx <= 1.25 * rf + 1e-9 and mx <= 2.0 * mf + 1e-8, (key, errs)
