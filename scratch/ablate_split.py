@@ -21,7 +21,7 @@ for (N, H, W, Cin, Cout, k) in shapes:
     fl = 2.0 * N * H * W * Cin * Cout * k * k
     res = []
     for bits, nm in ((0, "full"), (32, "no-epi"), (32 + 64, "no-epi,1-of-6 mfma"), (32 + 128, "no-epi,no-loads"), (32 + 2, "no-epi,no-lds-store"),
-                     (32 + 2 + 128, "no-epi,no-loads,no-store"), (32 + 2 + 4 + 128, "..+no-barrier"), (32 + 2 + 4 + 128 + 64, "..+1-of-6")):
+                     (32 + 2 + 128, "no-epi,no-loads,no-store"), (32 + 2 + 4 + 128, "..+no-barrier"), (32 + 2 + 4 + 128 + 64, "..+1-of-6"), (256, "no piece arithmetic"), (32 + 256, "no-epi,no piece arithmetic")):
         fn.L().dspn_debug_set(bits)
         t = timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=out))
         res.append("%s %.3f" % (nm, t))
