@@ -68,3 +68,33 @@ def test_operator_front_end_rejects_cpu_tensors():
         op.MultiBoxTarget(torch.zeros(1, 4, 4), torch.zeros(1, 2, 5), torch.zeros(1, 3, 4))
     with pytest.raises(_lib.DspnError, match="anchors mismatch"):
         op.MultiBoxDetection(torch.zeros(1, 3, 4), torch.zeros(1, 19), torch.zeros(1, 4, 4))
+
+
+def test_convolution_argument_validation_without_gpu():
+    """the graph kernels' entry points reject bad geometry / math modes / unpaired affine vectors before any HIP call"""
+    import ctypes
+    lib = _lib.lib()
+    p = ctypes.c_void_p(256)        # never dereferenced: every call below fails its checks first
+
+    def fwd(N=1, H=8, W=8, Cin=4, math=0, in_scale=None, in_shift=None):
+        return lib.dspn_conv2d_forward_bn_f32(p, in_scale, in_shift, 0, p, None, None, p, N, H, W, Cin, 8, 3, 3, 1, 1, 1, 1, 8, 8,
+                                              8 * 8 * 8, 8, 0, 0, None, 0, math, None, 0, None)
+
+    assert fwd(N=0) == -1 and b"bad geometry" in lib.dspn_last_error()
+    assert fwd(math=3) == -1 and b"DSPN_MATH" in lib.dspn_last_error()
+    assert fwd(math=-1) == -1
+    assert fwd(in_scale=p) == -1 and b"go together" in lib.dspn_last_error()
+    for math in (0, 1, 2):          # DSPN_MATH_FP32, DSPN_MATH_BF16, DSPN_MATH_F32_BF16X3 are the accepted values
+        assert fwd(N=0, math=math) == -1 and b"bad geometry" in lib.dspn_last_error()
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """SURVEY.md section 5 (sanitizers on the host build): the C oracle's three operators over exactly-sized heap buffers and the
+    degenerate inputs of the GPU tests, built with -fsanitize=address,undefined (oracle/sanitize_driver.c)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sanitize_driver: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
