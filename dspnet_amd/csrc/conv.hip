@@ -57,10 +57,11 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
 
 // DSPN_MATH_F32_BF16X3 ("split" mode, float tensors): every float operand x is cut into three bf16 pieces on its way into
 // LDS, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (both differences exact in fp32, p0 + p1 + p2 = x to within
-// 2^-27 |x|), and a product x * w is formed as the six partial products x_p * w_q with p + q <= 2 -- each exact, bf16 x bf16
+// 2^-24 |x|), and a product x * w is formed as the six partial products x_p * w_q with p + q <= 2 -- each exact, bf16 x bf16
 // fits the fp32 accumulator's 24 bits -- summed by the same fp32 accumulation as the fp32 MFMA.  What is dropped (x1 w2,
-// x2 w1, x2 w2) is below 2^-26 |x w|: less than the rounding of one fp32 product.  Six v_mfma_f32_32x32x16_bf16 replace
-// sixteen v_mfma_f32_32x32x2_f32 of twice the cycles each.
+// x2 w1, x2 w2) is below 2^-22 |x w| in the worst case and 2^-25 |x w| rms (tests/test_split_math.py): the order of the
+// rounding of one fp32 product.  Six v_mfma_f32_32x32x16_bf16 replace sixteen v_mfma_f32_32x32x2_f32 of twice the cycles
+// each.  Operands beyond the largest bf16 (|x| > 3.39e38) become inf on the way in.
 constexpr int kSplitValuPerMfma = 8;   // vector instructions of the piece arithmetic scheduled behind each MFMA
 constexpr int kLdsRowS = 3 * 32 + 8;   // LDS row of the three-piece image (bf16): 208 B, conflict-free for ds_read_b128
 __device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2) {
@@ -1418,9 +1419,10 @@ static const int kNtBm[4] = {128, 128, 64, 256}, kNtBn[4] = {128, 64, 64, 32};
 int nt_config(long long M, int Cout) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
   int cfg;
-  // measured on MI355X (scratch/cfgtest.py): 128x128 wins once it yields >= 2 workgroups per CU,
-  // otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD) is the fastest
-  static const long long min_tiles = [] { const char *e = getenv("DSPN_NT_MINTILES"); return e ? atoll(e) : 512ll; }();   // experiments
+  // measured on MI355X (scratch/cfgtest.py, scratch/x3_knobs.sh): 128x128 wins once it yields >= one workgroup per CU
+  // in the split math (667 vs 656 images/s against the round-1 threshold of two per CU, which the fp32-MFMA and bf16-tensor
+  // modes prefer by 0.3 .. 0.5 %); otherwise the 64x64 tile (4 workgroups of 36 KiB LDS per CU, 4 waves per SIMD)
+  static const long long min_tiles = [] { const char *e = getenv("DSPN_NT_MINTILES"); return e ? atoll(e) : 256ll; }();   // experiments
   if (Cout <= 32) cfg = tiles(256, 32) >= min_tiles ? 3 : 2;
   else cfg = (Cout > 64 && tiles(128, 128) >= min_tiles) ? 0 : 2;
   // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
