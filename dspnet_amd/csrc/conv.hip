@@ -429,7 +429,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   auto mma_step = [&](const int buf) __attribute__((always_inline)) {
     if constexpr (SPLIT) {
       // x * w = sum over piece pairs (p, q), p + q <= 2, of x_p * w_q: six bf16 MFMAs per 16-deep k block, every partial
-      // product exact in the fp32 accumulator's input, the three dropped pairs below 2^-26 of the product.  Small terms
+      // product exact in the fp32 accumulator's input, the three dropped pairs at the level of one fp32 rounding (see kLdsRowS above).  Small terms
       // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
       const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
