@@ -43,6 +43,7 @@ def get_config(network, data_shape, **kwargs):
         return locals()
     if network == 'resnet-50':
         num_layers = 50
+        image_shape = '3,224,224'  # (the reference hands it to symbol/resnet.py as a shape check; unused here)
         network = 'resnet'
         from_layers = ['_plus6', '_plus12', '_plus15', '', '', '', '']
         num_filters = [-1, -1, -1, 512, 256, 256, 128]
@@ -50,6 +51,20 @@ def get_config(network, data_shape, **kwargs):
         pads = [-1, -1, -1, 1, 1, 1, 1]
         sizes = [[.5, .705], [.1, .141], [.2, .272], [.37, .447], [.54, .619], [.71, .79], [.88, .961]]
         ratios = [[1, 2, .5], [1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3],
+                  [1, 2, .5], [1, 2, .5]]
+        normalizations = -1
+        steps = []
+        return locals()
+    if network == 'resnet101':       # symbol/multitask_symbol_factory.py:82-95 (table only: the multi-task builder reads
+        num_layers = 101             # from_layers[2], which this six-entry preset leaves empty)
+        image_shape = '3,224,224'
+        network = 'resnet'
+        from_layers = ['_plus12', '_plus15', '', '', '', '']
+        num_filters = [-1, -1, 512, 256, 256, 128]
+        strides = [-1, -1, 2, 2, 2, 2]
+        pads = [-1, -1, 1, 1, 1, 1]
+        sizes = [[.1, .141], [.2, .272], [.37, .447], [.54, .619], [.71, .79], [.88, .961]]
+        ratios = [[1, 2, .5], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3], [1, 2, .5, 3, 1. / 3],
                   [1, 2, .5], [1, 2, .5]]
         normalizations = -1
         steps = []
