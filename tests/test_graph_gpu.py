@@ -426,6 +426,50 @@ def test_bf16_tensor_training_tracks_the_float_run(gpu_device):
     assert dev[0] < 3e-2 and dev[2] < 3e-2 and dev[1] < 0.15, (dev, hist_h, hist_f)
 
 
+def test_split_math_training_tracks_the_fp32_mfma_run(gpu_device):
+    """The default convolution math (DSPN_MATH_F32_BF16X3: fp32 products from six exact bf16 partial products) against the
+    fp32 MFMA over five SGD steps of the resnet-50 multi-task graph from the same initial state.  The first step's losses
+    agree to 2e-6 (the precision of either evaluation).  After that this training problem (random initialisation, batch
+    statistics over two 256x256 images, re-matched anchors every step) amplifies ANY fp32 rounding difference by about three
+    orders of magnitude per step, so the yardstick for the later steps is a control pair of two fp32-MFMA evaluations of the
+    same run that differ only in summation order (BatchNorm folded into the convolutions vs the stand-alone kernels,
+    scratch/chaos_control.py: losses 0.9 % / 3 % / 0.4 %, parameters 2.1e-3): the split math stays within 4x of that pair
+    (measured 2 % / 8 % / 0.45 %, parameters 2.3e-3 = 1.1x).  Bitwise reproducible run to run."""
+    from dspnet_amd import engine as E
+    from dspnet_amd import functional as fn
+
+    def run(math, fuse=True):
+        fn.set_conv_math(math)
+        E.FUSE_BATCHNORM = fuse
+        try:
+            net, solver, *_ = make(2, 256, 256)
+        finally:
+            E.FUSE_BATCHNORM = True
+        m, hist = MultiBoxMetric(), []
+        for _ in range(5):
+            solver.step()
+            m.reset(); m.update(net); hist.append(m.get()[1])
+        torch.cuda.synchronize()
+        return net.g.arena.double().clone(), np.asarray(hist)
+
+    try:
+        a_s, hist_s = run("bf16x3")
+        a_s2, hist_s2 = run("bf16x3")
+        a_f, hist_f = run("fp32")
+        a_u, hist_u = run("fp32", fuse=False)
+    finally:
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+    assert np.array_equal(hist_s, hist_s2) and torch.equal(a_s, a_s2)
+    assert np.isfinite(hist_s).all() and (hist_s[-1] < hist_s[0]).all()
+    dev, ctl = np.abs(hist_s / hist_f - 1), np.abs(hist_u / hist_f - 1)       # columns: CrossEntropy, SmoothL1, SegCrossEntropy
+    pdev, pctl = float((a_s - a_f).norm() / a_f.norm()), float((a_u - a_f).norm() / a_f.norm())
+    print("bf16x3 vs fp32 MFMA: first step", dev[0], "worst", dev.max(axis=0), "parameters %.2e | control (two fp32 orders): worst" % pdev,
+          ctl.max(axis=0), "parameters %.2e" % pctl)
+    assert dev[0].max() < 2e-6, dev[0]
+    assert pdev < 4 * pctl, (pdev, pctl)
+    assert (dev.max(axis=0) < 4 * ctl.max(axis=0) + 1e-3).all(), (dev, ctl)
+
+
 def test_test_graph_matches_training_graph_outputs(gpu_device):
     """get_multi_symbol (symbol/multitask_symbol_builder.py:595-726) yields the det / seg values of the
     training graph's outputs[3], outputs[4] (what detect/multitask_detector.py:234 reads)"""
