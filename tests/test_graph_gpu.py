@@ -584,7 +584,7 @@ def test_inceptionv3_shapes_1024x512(gpu_device):
 @pytest.mark.parametrize("network,kind,size,batch,classes", [("vgg16_reduced", "det", 300, 1, 20),
                                                              ("vgg16_reduced", "multi", 320, 2, 8),
                                                              ("inceptionv3", "multi", 512, 1, 8)])
-def test_other_backbone_graphs_match_cpu_restatement(gpu_device, network, kind, size, batch, classes):
+def test_other_backbone_graphs_match_cpu_restatement(gpu_device, conv_math, network, kind, size, batch, classes):
     """BASELINE.json configs[0] (vgg16_reduced SSD-300 single-task det, bs=1, 20 VOC classes: N = 2956 anchors
     after the reference's [1:] slice of the 8732-anchor preset), the build's vgg16_reduced multi-task wiring, and
     the inceptionv3 multi-task wiring (configs[3]'s backbone; every conv class of symbol/inceptionv3.py)"""
