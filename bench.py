@@ -20,6 +20,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  kernel time per step, the latter measured live with HIP events on the launch stream
                  over the timed region; peak = the instruction that bounds the mode (bf16x3: bf16 MFMA
                  2500 TFLOP/s / 6 products per multiply-add = 416.7; fp32: 157.3; bf16: 2500);
+  math_accuracy_check - one backbone layer in the three math modes against float64 (N = 1): the default math's error next
+                 to the fp32 MFMA's and the bf16 mode's, measured in this run;
   cpu_baseline - the CPU restatement of the same step (oracle/dspnet_torch.py, fp32, all host cores)
                  on a bounded sample; rank 0, N = 1 only.
 """
@@ -154,6 +156,38 @@ def cpu_baseline(size, images, cfg, width=None):
     return {"value": round(images * reps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d x (forward+backward of the same %s multitask graph, %d images %dx%d, fp32 torch-CPU "
                       "ops + C multibox oracle; no optimizer step)" % (reps, cfg["network"], images, size, width)}
+
+
+def math_accuracy_check(dev):
+    """One backbone layer (3x3, 256 -> 256 channels, 8 x 32 x 32) in the three math modes against a float64 CPU convolution
+    of the same float32 operands: forward and data gradient, largest error over the tensor's largest entry.  Shows in the
+    bench line itself that the default math (bf16x3) is an fp32 evaluation and what the bf16 mode of configs[3] gives up.
+    Outside the timed region, rank 0 at N = 1 only."""
+    import torch
+    import torch.nn.functional as F
+    from dspnet_amd import functional as fn
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 256, 32, 32, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    dy = torch.randn(8, 256, 32, 32, generator=g)
+    xr = x.double().requires_grad_()
+    y_ref = F.conv2d(xr, w.double(), None, 1, 1)
+    y_ref.backward(dy.double())
+    xd, wd, dyd = (t.permute(0, 2, 3, 1).contiguous().to(dev) for t in (x, w, dy))
+    wt = fn.weight_transpose(wd)
+    out = {"layer": "3x3 conv 256->256, 8x32x32, K = 2304; max |err| / max |ref| against float64"}
+    prev = fn.get_conv_math()
+    try:
+        for mode in ("bf16x3", "fp32", "bf16"):
+            fn.set_conv_math(mode)
+            y = fn.conv2d_forward(xd, wd, None, 1, 1, 1)
+            dx = fn.conv2d_dgrad(dyd, wt, tuple(xd.shape), 1, 1, 1)
+            ey = float((y.permute(0, 3, 1, 2).double().cpu() - y_ref.detach()).abs().max() / y_ref.detach().abs().max())
+            ed = float((dx.permute(0, 3, 1, 2).double().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+            out[mode] = {"forward": float("%.3g" % ey), "data_gradient": float("%.3g" % ed)}
+    finally:
+        fn.set_conv_math(prev)
+    return out
 
 
 def spawn_ranks(args):
@@ -291,23 +325,6 @@ def side_infer(B, size, iters, warmup, dev):
             "p50_ms_per_batch": round(p50, 3), "p90_ms_per_batch": round(float(np.percentile(lat, 90)), 3),
             "images_per_s": round(B / p50 * 1e3, 1), "iterations": iters, "warmup": warmup, "dtype": "f32",
             "roofline": conv_family_roofline(lib, ps, flops_fwd, flops_direct, fn.get_conv_math(), inst_s)}
-
-
-def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run and
-    pass their exit status on.  Runs BEFORE anything in this process touches the GPU (no torch.cuda call, no HIP
-    library loaded): the children are ordinary child processes, never an exec of a process that initialised HIP."""
-    import socket
-    import subprocess
-    with socket.socket() as so:                       # a free rendezvous port on the loopback interface
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("NCCL_DEBUG", "WARN")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
 
 
 def dry_run(args):
@@ -490,6 +507,11 @@ def main():
         }
         if other is not None:
             line["other_configs"] = other
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["math_accuracy_check"] = math_accuracy_check(dev)
+            except Exception as e:      # never costs the headline line
+                line["math_accuracy_check"] = {"error": str(e)[:200]}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
