@@ -536,6 +536,37 @@ def test_segmentation_only_graphs_match_cpu_restatement(gpu_device):
     assert len(t_outs) == 1 and torch.equal(t_outs[0], outs[0])
 
 
+def test_single_task_graphs_train(gpu_device):
+    """MultiTaskSolver on the two single-task training graphs (get_seg_symbol_train / get_det_symbol_train, the graphs
+    seg_solver.py / det_solver.py of the reference drive): five SGD steps reduce the task's losses, bitwise reproducibly"""
+    from dspnet_amd.symbol.multitask_symbol_factory import get_det_symbol_train, get_seg_symbol_train
+    dev = torch.device("cuda", 0)
+
+    def run(kind):
+        f = get_seg_symbol_train if kind == "seg" else get_det_symbol_train
+        net = f("resnet-50", 256, num_classes=8, batch_size=2, device=dev, seed=11)
+        gen = synthetic.rng(5)
+        data = synthetic.images(2, 256, 256, gen)
+        lab = synthetic.det_labels(2, gen=gen, height=256, width=256, first_empty=False)
+        seg = synthetic.seg_labels(2, 256, 256, gen=gen)
+        solver = MultiTaskSolver(net)
+        solver.set_batch(torch.from_numpy(data).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(seg).to(dev))
+        m, hist = MultiBoxMetric(), []
+        for _ in range(5):
+            solver.step()
+            m.reset(); m.update(net); hist.append(m.get()[1])
+        torch.cuda.synchronize()
+        return np.asarray(hist), net.g.arena.clone()
+
+    for kind, cols in (("seg", [2]), ("det", [0, 1])):
+        h1, a1 = run(kind)
+        h2, a2 = run(kind)
+        assert torch.equal(a1, a2) and np.array_equal(h1[:, cols], h2[:, cols])
+        assert np.isfinite(h1[:, cols]).all() and (h1[-1, cols] < h1[0, cols]).all(), (kind, h1)
+        other = [c for c in range(3) if c not in cols]
+        assert np.isnan(h1[:, other]).all() or (h1[:, other] == 0).all()      # the absent tasks are not counted
+
+
 def test_detection_only_test_graph(gpu_device):
     """get_det_symbol (symbol/multitask_symbol_builder.py:123-209): output [det], equal to outputs[3] of
     get_det_symbol_train on the same parameters"""
