@@ -96,5 +96,9 @@ def test_oracle_is_clean_under_address_and_ub_sanitizers():
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and "LeakSanitizer has encountered a fatal error" in r.stderr:
+        # leak checking needs ptrace, which some sandboxes deny: the address / UB checks still run without it
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_build", "sanitize_driver")], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "sanitize_driver: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
