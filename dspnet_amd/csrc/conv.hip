@@ -121,6 +121,9 @@ struct ConvGeom {
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   float *bn_sums;
   int bn_relu, bn_tile_base;
+  // host side only: the weight operand as three bf16 piece planes [Cout][WTAPS][Cin / 32][3][32] (split mode, Cin % 32 == 0:
+  // dspn_conv2d_weight_planes_f32); the kernel then receives this pointer in place of the float weights
+  const void *w_planes;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -131,8 +134,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
+// Split mode, round 3: what the loaders no longer do once per (element, tap, column tile).
+//  * PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand arrives as three
+//    bf16 piece planes, [row][tap][Cin / 32][piece][32] (dspn_conv2d_weight_planes_*: cut once per step for the whole
+//    graph), so the B tile goes global -> registers -> LDS as three 16-byte chunks per 32 channels with no arithmetic.
+//  * HALO (3x3, stride 1, 'same': forward and data gradient of the backbone's 3x3 layers): an M tile is a patch of
+//    BM / 16 rows x 16 columns of output pixels; per block of 32 channels the (BM / 16 + 2) x 18 input pixels under it are
+//    loaded, run through the input affine and cut into pieces ONCE, and all nine taps' MFMAs read their A fragments from
+//    that LDS image at a per-tap offset: 1.4 element loads / affines / splits per nine k-steps instead of 9, and the tap
+//    re-reads that missed L2 are gone.  LDS rows of the image stay 208 B per pixel; a row of 18 pixels is padded to
+//    3840 B (= 0 mod 256) so that the 16-lane groups of a ds_read_b128, which now span two patch rows, still land on 16
+//    distinct 16-byte slots of the bank row.
+constexpr int kPlaneBlk = 3 * 32;      // bf16 elements of one (row, tap, 32-channel block) of a piece-plane operand
+constexpr int kHaloPitch = 1920;       // bf16 elements (3840 B) of one 18-pixel row of the halo image
+
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI, bool HALO = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -143,14 +160,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
-  constexpr int A_LD = BM / RSTEP, B_LD = BN / RSTEP;   // 16-B loads per thread per k-step
+  constexpr bool PRE = SPLIT && UNIFORM_TAP;            // the weight operand is three bf16 piece planes (see above)
+  static_assert(!HALO || PRE, "the halo-resident A tile exists in the split mode only");
+  constexpr int PH = BM / 16, HR = PH + 2, HPIX = HR * 18;   // HALO: patch rows, image rows, image pixels
+  // 16-B loads per thread per k-step (HALO: A loads per block of nine k-steps)
+  constexpr int A_LD = HALO ? (HPIX + RSTEP - 1) / RSTEP : BM / RSTEP;
+  constexpr int B_LD = PRE ? 3 * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
+  constexpr bool B_EXACT = (4 * BN) % NTHR == 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
   constexpr int ROWH = SPLIT ? kLdsRowS : kLdsRowH;   // LDS row (bf16 elements) of the bf16 images
   constexpr int STAGES = SPLIT ? 1 : 2;               // the three-piece image is single-buffered (two barriers per k-step)
-  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
-  __bf16 *hB = hA + STAGES * BM * ROWH;
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH] (HALO: [HR][kHaloPitch]), then [STAGES][BN][ROWH]
+  __bf16 *hB = hA + (HALO ? HR * kHaloPitch : STAGES * BM * ROWH);
 
 #ifdef DSPN_ABLATE
   const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
@@ -206,10 +229,45 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // back to back, so the (overlapping) input pixels of neighbouring taps are re-read while they are
   // still in L1/L2 instead of once per sweep over all channels (3328-channel score3_conv: 9x less HBM).
   const int ntaps = g.TR * g.TS;
+  // state of the two round-3 loaders (kept small: the 8-wave kernels live within 128 registers)
+  unsigned h_mask = 0;        // HALO: bit i: image pixel i of the current tile lies inside the gathered tensor
+  bool a_fresh = false;       // HALO: the k-step requested last carried a new image (it starts a block of 32 channels)
+  int ld_mt = 0;              // row-tile index of the tile set up last (statistics slots)
+  // HALO: image pixel i of this thread = row0 + RSTEP * i -> (image row, image column); recomputed where needed
+  auto halo_rc = [&](const int i, int &hr, int &hc) __attribute__((always_inline)) {
+    const int hp = row0 + RSTEP * i;
+    hr = hp / 18; hc = hp - hr * 18;
+    return hp < HPIX;
+  };
+  // PRE: thread (row = tid >> 2, part = tid & 3) moves chunks 3 * part .. 3 * part + 2 of the 12 chunks (192 B) of tile
+  // row `row` (+ NTHR / 4 per pass): one address register per pass, the three chunks at immediate offsets
+  constexpr int B_PASS = PRE ? (4 * BN + NTHR - 1) / NTHR : 1;
+  static_assert(!PRE || B_LD == 3 * B_PASS || (4 * BN) % NTHR != 0, "chunk count of the piece-plane loader");
+  const int CB = g.Cin >> 5;                 // PRE: 32-channel blocks per tap
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
     const int mt = tile / n_tiles, nt = tile - mt * n_tiles;   // n fastest: A tile reuse in L2
-    ld_m0 = mt * BM; ld_n0 = nt * BN;
+    ld_m0 = mt * BM; ld_n0 = nt * BN; ld_mt = mt;
+    if constexpr (HALO) {
+      // tile mt = patch (ty, tx) of image n; ld_m0 = linear index of its first pixel
+      const int tw = g.Wg >> 4, tpi = (g.Hg / PH) * tw;
+      const int n = mt / tpi, rem = mt - n * tpi;
+      const int ty = rem / tw, tx = rem - ty * tw;
+      const int oi0 = ty * PH, oj0 = tx * 16;
+      ld_m0 = (n * g.Hg + oi0) * g.Wg + oj0;
+      // image origin in the gathered tensor: the smallest coordinate any tap reaches (|idh| = |idw| = 1, three taps)
+      const int hh0 = oi0 + g.ioh + (g.idh < 0 ? 2 * g.idh : 0), hw0 = oj0 + g.iow + (g.idw < 0 ? 2 * g.idw : 0);
+      h_mask = 0;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int hr, hc;
+        const bool in_img = halo_rc(i, hr, hc);
+        const int ih = hh0 + hr, iw = hw0 + hc;
+        const bool v = in_img && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+        h_mask |= v ? (1u << i) : 0u;
+        a_eoff[i] = v ? ((n * g.Hin + ih) * g.Win + iw) * g.Cin : 0;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int m = ld_m0 + row0 + RSTEP * i;
@@ -222,10 +280,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       a_iw0[i] = mv ? iw0 : 0;
       a_eoff[i] = mv ? ((n * g.Hin + ih0) * g.Win + iw0) * g.Cin : 0;
     }
+    }
+    if constexpr (PRE) {
+#pragma unroll
+      for (int ps = 0; ps < B_PASS; ++ps) {
+        const int br = (tid >> 2) + ps * (NTHR / 4), k = ld_n0 + br;
+        b_eoff[ps] = ((B_EXACT || br < BN) && k < g.Cout) ? k * (g.WTAPS * CB * kPlaneBlk) + (tid & 3) * 24 : -1;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int k = ld_n0 + row0 + RSTEP * i;
       b_eoff[i] = k < g.Cout ? k * g.WTAPS * g.Cin : -1;
+    }
     }
     ld_kt = 0;
     u_tr = 0; u_ts = 0; u_cq = 0;
@@ -238,10 +305,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   float4 ra[A_LD], rb[B_LD];
   u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
   auto load_tiles = [&]() __attribute__((always_inline)) {     // issues the global loads of k-step ld_kt of the tile set up last
-    int tr, ts, cq;
+    int tr, ts, cq, cq0 = 0;
     bool qv;
     if constexpr (uniform_tap) {
-      tr = u_tr; ts = u_ts; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0 && !(dbg & 128);   // 128: timing-only, no loads
+      tr = u_tr; ts = u_ts; cq0 = u_cq; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0 && !(dbg & 128);   // 128: timing-only, no loads
       ++u_ts;                                   // branch-free wave-uniform advance: taps inner, channels outer
       const bool wrap = u_ts == g.TS;
       u_ts = wrap ? 0 : u_ts;
@@ -258,7 +325,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     ++ld_kt;
     const int dh = tr * g.idh, dw = ts * g.idw;
     const int a_off = (dh * g.Win + dw) * g.Cin + cq * kEPC;
-    if constexpr (INTF) {
+    auto load_affine = [&]() __attribute__((always_inline)) {
       const unsigned coff = qv ? (unsigned)cq * (4u * kEPC) : kOOB;
       const auto s4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)coff, 0, 0);
       const auto h4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)coff, 0, 0);
@@ -270,6 +337,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         tf_sc2 = make_float4(__uint_as_float(s8[0]), __uint_as_float(s8[1]), __uint_as_float(s8[2]), __uint_as_float(s8[3]));
         tf_sh2 = make_float4(__uint_as_float(h8[0]), __uint_as_float(h8[1]), __uint_as_float(h8[2]), __uint_as_float(h8[3]));
       }
+    };
+    if constexpr (HALO) {
+      // a new image with the first tap of every block of 32 channels (wave-uniform); the other eight k-steps load weights only
+      a_fresh = (tr | ts) == 0;
+      if (a_fresh) {
+        if constexpr (INTF) { load_affine(); tf_mask = qv ? h_mask : 0u; }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          const bool v = qv && ((h_mask >> i) & 1u);
+          const unsigned off = ((unsigned)(a_eoff[i] + cq * kEPC) * (unsigned)sizeof(st_t)) | (v ? 0u : kOOB);
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
+          ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+        }
+      }
+    } else {
+    if constexpr (INTF) {
+      load_affine();
       tf_mask = 0;
     }
 #pragma unroll
@@ -284,7 +368,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       else ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
                                __uint_as_float(t[3]));
     }
+    }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
+    if constexpr (PRE) {
+      // piece planes: the 192 bytes of (row, tap, block of 32 channels) are contiguous; 12 chunks per row
+      const int boff = (wtap * CB + (cq0 >> 3)) * kPlaneBlk;
+#pragma unroll
+      for (int ps = 0; ps < B_PASS; ++ps) {
+        const bool v = qv && b_eoff[ps] >= 0;
+        const unsigned off = ((unsigned)(b_eoff[ps] + boff) * 2u) | (v ? 0u : kOOB);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hb[3 * ps + c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off + 16 * c, 0, 0);
+      }
+    } else {
     const int b_off = wtap * g.Cin + cq * kEPC;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -294,6 +390,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       if constexpr (kHalf) hb[i] = t;
       else rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
                                __uint_as_float(t[3]));
+    }
     }
   };
   // float tensors: the input affine of this thread's A rows, in registers
@@ -315,14 +412,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // split mode: the three bf16 pieces of the rows loaded last (after their affine), kept in registers until the LDS image
   // of the current k-step has been read by every wave.  Called in the middle of a k-step's MFMAs, whose issue slots the
   // ~25 vector instructions per 16-byte chunk then share, instead of between the two barriers where nothing overlaps them.
-  bf16x4 pa[SPLIT ? A_LD : 1][3], pb[SPLIT ? B_LD : 1][3];
+  bf16x4 pa[SPLIT ? A_LD : 1][3], pb[(SPLIT && !PRE) ? B_LD : 1][3];
   auto split_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT) {
-      affine_tiles();
+      if constexpr (HALO) {
+        if (a_fresh) {      // wave-uniform: one k-step in nine
+          affine_tiles();
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+          for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+        }
+      } else {
+        affine_tiles();
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i) split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+        for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+      }
+      if constexpr (!PRE) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+      }
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
@@ -358,17 +465,44 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     if constexpr (SPLIT) {
       // x = p0 + p1 + p2 (split_tiles): piece p of channel k of a row lies at row * ROWH + p * 32 + k
       __bf16 *a = hA + buf * BM * ROWH, *b = hB + buf * BN * ROWH;
+      if constexpr (HALO) {
+        if (a_fresh) {      // the image of the next nine k-steps (every wave is past the last tap of the previous block)
+#pragma unroll
+          for (int i = 0; i < A_LD; ++i) {
+            int hr, hc;
+            if (halo_rc(i, hr, hc)) {   // (only the last pass can run past the image)
+              __bf16 *d = hA + hr * kHaloPitch + hc * ROWH + chunk * 4;
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
+            }
+          }
+          a_fresh = false;
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
       }
+      }
+      if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
+#pragma unroll
+        for (int ps = 0; ps < B_PASS; ++ps) {
+          const int br = (tid >> 2) + ps * (NTHR / 4);
+          if (B_EXACT || br < BN) {
+            __bf16 *d = hB + br * ROWH + (tid & 3) * 24;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4_t *>(d + 8 * c) = hb[3 * ps + c];
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         __bf16 *d = b + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pb[i][pc];
+      }
       }
     } else if constexpr (BF16) {
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
@@ -402,6 +536,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
   const int frow = lane & 31, fk = (lane >> 5) * 2;
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
+  int a_hl[TM];     // HALO: bf16 offset of this lane's row of MFMA tile i in the image, before the tap's offset
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_hl[i] = ((wm + i * 32 + frow) >> 4) * kHaloPitch + (frow & 15) * ROWH;
+  int c_tap = 0;    // HALO: tap of the k-step the MFMAs are working on (k order: taps inner, 32-channel blocks outer)
 
   // ---- persistent loop over output tiles ----------------------------------------------------------
   // The workgroup walks tiles t, t + gridDim.x, ...  While the last k-step of a tile is in the matrix
@@ -431,7 +569,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // x * w = sum over piece pairs (p, q), p + q <= 2, of x_p * w_q: six bf16 MFMAs per 16-deep k block, every partial
       // product exact in the fp32 accumulator's input, the three dropped pairs at the level of one fp32 rounding (see kLdsRowS above).  Small terms
       // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
-      const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
+      // HALO: row r of the tile is pixel (r >> 4, r & 15) of the patch; tap (tr, ts) of the current k-step reads image pixel
+      // (r >> 4) + dr, (r & 15) + dc, with (dr, dc) = the tap's distance from the image origin -- one wave-uniform offset
+      int c_toff = 0;
+      if constexpr (HALO) {
+        const int ctr = c_tap / 3, cts = c_tap - 3 * ctr;
+        c_toff = (g.idh > 0 ? ctr : 2 - ctr) * kHaloPitch + (g.idw > 0 ? cts : 2 - cts) * ROWH;
+      }
+      const __bf16 *a = HALO ? hA + c_toff + (lane >> 5) * 8
+                             : hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
       auto block = [&](const int kk) __attribute__((always_inline)) {
         bf16x8 fa[3][TM], fb[3][TN];
@@ -439,7 +585,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
+            fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + (HALO ? a_hl[i] : i * 32 * ROWH) + p * 32 + kk * 16);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
@@ -460,22 +606,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // vector ALU between the second block's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       if (!(dbg & 256)) split_tiles();
+      if constexpr (HALO) __builtin_amdgcn_sched_barrier(0);   // (the image's pieces sit in their own, rarely taken block)
       block(1);
+      if constexpr (!HALO) {
       // pin the pieces HERE: their only readers (the LDS stores) sit behind the barrier, and hipcc otherwise sinks the
       // whole piece arithmetic down there, next to them
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pa[i][pc]));
+      if constexpr (!PRE) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pb[i][pc]));
+      }
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
 #pragma unroll
       for (int m = 0; m < 6 * TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, kSplitValuPerMfma, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (kSplitValuPerMfma + 1) / 2 : kSplitValuPerMfma, 0);
+      }
       }
     } else if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
@@ -545,15 +696,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   store_tiles(0);
   __syncthreads();
   zero_acc();
-  int m0 = ld_m0, n0 = ld_n0;
+  int m0 = ld_m0, n0 = ld_n0, cur_mt = ld_mt;
   int tn = t + gridDim.x;
   int kt = 0, buf = 0;
   // ONE loop over (tile, k-step): a single copy of the load + MFMA block; the end-of-tile work hangs off it
   while (true) {
     const bool last = kt == nk1 - 1;
     const bool has_next = tn < ntiles;
+    // HALO: no prefetch across the epilogue (a tile is 9 x Cin / 32 k-steps long and the image + weight chunks of the next
+    // tile would sit in 24 registers of a 128-register kernel through all of it): the next tile's first loads follow it
+    if constexpr (HALO) {
+      // the image rows / pieces are written and read under the wave-uniform `a_fresh` only, all within one iteration: tell
+      // the register allocator that nothing is carried around the loop (as conditionally defined values they were, and
+      // cost 30 registers in every one of the eight k-steps that do not touch them)
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        ra[i].x = __builtin_nondeterministic_value(ra[i].x); ra[i].y = __builtin_nondeterministic_value(ra[i].y);
+        ra[i].z = __builtin_nondeterministic_value(ra[i].z); ra[i].w = __builtin_nondeterministic_value(ra[i].w);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) pa[i][pc] = __builtin_nondeterministic_value(pa[i][pc]);
+      }
+      if (!last) load_tiles();
+    } else {
     if (last && has_next) setup_tile(tn);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
+    }
     // nk == 0 (a parity class of a strided data gradient without taps): the loads return zeros, so the k-step may run
     // (accumulators stay 0) or be skipped.  The 8-wave build must NOT branch here: with the branch hipcc keeps the
     // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
@@ -605,7 +772,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         auto rows_begin = [&](const int ch) __attribute__((always_inline)) {   // addresses + additive operand of chunk ch
 #pragma unroll
           for (int p = 0; p < RC; ++p) {
-            const int m = m0 + er0 + (ch * RC + p) * RPP;
+            const int rl = er0 + (ch * RC + p) * RPP;
+            const int m = HALO ? m0 + (rl >> 4) * g.Wg + (rl & 15) : m0 + rl;   // HALO: row rl = pixel (rl >> 4, rl & 15) of the patch
             if (g.dense) {
               offs[p] = m * g.ldc + co;
             } else {
@@ -724,7 +892,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           if (tid < BN && n0 + tid < g.Cout) {
             // merge of the RPP row groups about the first group's mean (no division inside the loop):
             //   mean = m_0 + sum n_e d_e / n,  M2 = sum (M2_e + n_e d_e^2) - n (mean - m_0)^2,  d_e = mean_e - m_0
-            const int lim = min(M - m0, BM);
+            const int lim = HALO ? BM : min(M - m0, BM);
             const float mref = red[tid * 2];            // row group 0 is never empty
             float n = 0.f, sd = 0.f, sq = 0.f;
 #pragma unroll 4
@@ -738,7 +906,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             const float dm = sd / n;
             const float mean = mref + dm;
             const float m2 = fmaxf(sq - n * dm * dm, 0.f);
-            const long long mt_ = m0 / BM;
+            const long long mt_ = HALO ? cur_mt : m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
           }
@@ -758,7 +926,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           if (tid < BN && n0 + tid < g.Cout) {
             float a = 0.f, b = 0.f;
             for (int er = 0; er < RPP; ++er) { a += red[(er * BN + tid) * 2]; b += red[(er * BN + tid) * 2 + 1]; }
-            const long long mt_ = g.bn_tile_base + m0 / BM;
+            const long long mt_ = g.bn_tile_base + (HALO ? cur_mt : m0 / BM);
             g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + tid] = a;
             g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + tid] = b;
           }
@@ -776,9 +944,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         }
         break;
       }
+      if constexpr (HALO) { setup_tile(tn); load_tiles(); split_tiles(); }
       zero_acc();
       t = tn; tn += gridDim.x;
-      m0 = ld_m0; n0 = ld_n0;
+      m0 = ld_m0; n0 = ld_n0; cur_mt = ld_mt;
       kt = -1;
       __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
     }
@@ -792,6 +961,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       buf ^= 1;
     }
     ++kt;
+    if constexpr (HALO) c_tap = (kt == 0 || c_tap == 8) ? 0 : c_tap + 1;
   }
 }
 
@@ -1321,6 +1491,45 @@ __global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int 
   }
 }
 
+// Piece planes of a weight operand for the split mode (DSPN_MATH_F32_BF16X3): the matrix D[rows][T][cols], cols % 32 == 0,
+//   D = W itself   (rows = K, cols = C; forward operand)                 when !transposed,
+//   D = W^T        (rows = C, cols = Kp >= K zero padded; data gradient) when transposed,
+// of a float master W[K][T][C], every element cut into its three bf16 pieces by the same split3 the loaders use and stored
+// as planes[row][t][cols / 32][piece][32].  One thread per element; rows of the table sorted by `begin` as in the
+// batched transpose.
+struct WpDesc { const float *w; __bf16 *planes; int K, T, C, cols; long long begin; int transposed, pad_; };
+__device__ __forceinline__ void weight_planes_one(const WpDesc &e, long long j) {
+  const int col = (int)(j % e.cols);
+  const long long rt = j / e.cols;
+  const int t = (int)(rt % e.T), row = (int)(rt / e.T);
+  float v;
+  if (e.transposed) v = col < e.K ? e.w[((long long)col * e.T + t) * e.C + row] : 0.f;
+  else v = e.w[((long long)row * e.T + t) * e.C + col];
+  const __bf16 p0 = (__bf16)v;
+  const float r1 = v - (float)p0;
+  const __bf16 p1 = (__bf16)r1;
+  const __bf16 p2 = (__bf16)(r1 - (float)p1);
+  __bf16 *d = e.planes + (rt * (e.cols >> 5) + (col >> 5)) * kPlaneBlk + (col & 31);
+  d[0] = p0; d[32] = p1; d[64] = p2;
+}
+__global__ void weight_planes_batch_kernel(const WpDesc *__restrict__ d, int n, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const WpDesc e = d[lo];
+    weight_planes_one(e, i - e.begin);
+  }
+}
+__global__ void weight_planes_kernel(const WpDesc e, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    weight_planes_one(e, i);
+}
+
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
 __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
                                        st_t *__restrict__ out, long long M, int Cout, int ldc, int splits,
@@ -1344,7 +1553,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI, bool HALO = false>
 int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -1352,11 +1561,12 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-  const size_t lds = std::max<size_t>(MATH == 2   ? sizeof(__bf16) * (BM + BN) * kLdsRowS
+  const size_t lds = std::max<size_t>(HALO        ? sizeof(__bf16) * ((BM / 16 + 2) * kHaloPitch + BN * kLdsRowS)
+                                      : MATH == 2 ? sizeof(__bf16) * (BM + BN) * kLdsRowS
                                       : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
                                                   : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI, HALO>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
   static int slots = 0;
@@ -1370,8 +1580,8 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
     if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
-              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
+      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d,halo=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
+              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, (int)HALO, lds, per_cu, cus, slots);
   }
   const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
@@ -1390,20 +1600,33 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
-              hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
+              hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual, bool halo = false) {
   const bool uni = ((g.Cin / kEPC) & 7) == 0;
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
 #ifdef DSPN_HALF
 #define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E))
 #else
-#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
+  // the halo-resident form of the split mode (tiles of up to 128 rows: the image state lives in 8-entry register vectors)
+  constexpr bool kHaloTile = WAVES_M * TM * 32 <= 128;
+#define DSPN_NT_H_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 2, T, E, kHaloTile>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+#ifdef DSPN_DEV_X3ONLY   /* development builds (make DEV=1): only the split-mode kernels are instantiated */
+#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? ((halo && kHaloTile) ? DSPN_NT_H_(T, E) : DSPN_NT_(true, 2, T, E)) : DSPN_NT_(false, 2, T, E)) \
+                                         : dspn::fail(DSPN_ERR_ARG_, "development build: DSPN_MATH_F32_BF16X3 only"))
+#else
+#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? ((halo && kHaloTile) ? DSPN_NT_H_(T, E) : DSPN_NT_(true, 2, T, E)) : DSPN_NT_(false, 2, T, E)) \
                            : g.bf16 == 1 ? (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E)) \
                                          : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
+#endif
+#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2   /* one kernel only: register / ISA inspection */
+  return DSPN_NT_H_(DSPN_DEV_INTF, DSPN_DEV_EPI);
+#else
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
   return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
+#endif
 #undef DSPN_NT_UB_
+#undef DSPN_NT_H_
 #undef DSPN_NT_
 }
 
@@ -1449,6 +1672,14 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   }
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
+  // split mode with whole 32-channel blocks per tap: the kernels read the weights as piece planes
+  const bool pre = !kHalf && g.bf16 == 2 && ((g.Cin / kEPC) & 7) == 0;
+  if (pre) {
+    if (!g.w_planes)
+      return dspn::fail(DSPN_ERR_ARG_, "conv: DSPN_MATH_F32_BF16X3 with a multiple of 32 input channels (%d) needs the weight operand as piece planes (dspn_conv2d_weight_planes_f32)", g.Cin);
+    w = static_cast<const st_t *>(g.w_planes);
+    g.w_bytes = (unsigned)(6ll * g.Cout * g.WTAPS * g.Cin);
+  }
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
   const int cfg = nt_config(M, g.Cout);
   const int *bm_ = kNtBm, *bn_ = kNtBn;
@@ -1480,13 +1711,24 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 == 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
-  if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+  // 3x3, stride 1, 'same', whole patches of (tile rows / 16) x 16 pixels: the halo-resident A tile (conv_nt_kernel)
+  static const bool halo_off = getenv("DSPN_NT_NOHALO") != nullptr;   // experiments
+  const int ph = bm_[cfg] / 16;
+  const bool halo = pre && !halo_off && splits == 1 && cfg != 3 && g.TR == 3 && g.TS == 3 && g.ish == 1 && g.isw == 1 &&
+                    (g.idh == 1 || g.idh == -1) && (g.idw == 1 || g.idw == -1) && g.Hin == g.Hg && g.Win == g.Wg && g.dense &&
+                    g.Hg % ph == 0 && g.Wg % 16 == 0 && g.wrs == 1 && g.wss == 1 &&
+                    g.ioh + (g.idh < 0 ? 2 * g.idh : 0) == -1 && g.iow + (g.idw < 0 ? 2 * g.idw : 0) == -1;
+  if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
+#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2
+  return -1;
+#else
   switch (cfg) {
-    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
-    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
-    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
+    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
+    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
     default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   }
+#endif
 }
 
 struct WgradPlan { int bm; int bn; int splits; int pps; };
@@ -1562,12 +1804,12 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 
 struct InAffine { const float *scale, *shift; int relu; };
 
-static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats, const st_t *w, const float *bias, const st_t *residual, st_t *y, int N,
+static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats, const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
-  DSPN_REQUIRE(x && w && y, "conv2d_forward: null pointer");
+  DSPN_REQUIRE(x && (w || w_planes) && y, "conv2d_forward: null pointer");
   DSPN_REQUIRE(Cin % kEPC == 0, "conv2d_forward: Cin must be a multiple of %d (pad channels), got %d", kEPC, Cin);
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0,
                "conv2d_forward: bad geometry");
@@ -1588,6 +1830,7 @@ static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats
   g.in_scale = tf.scale; g.in_shift = tf.shift;
   g.stats = stats;
   g.bf16 = kHalf ? 1 : math;
+  g.w_planes = w_planes;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -1611,7 +1854,7 @@ int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows) { r
 #endif
 
 int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
-                               const st_t *w, const float *bias, const st_t *residual, st_t *y, int N,
+                               const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                                int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                                int relu, int accumulate, float *out_stats, size_t out_stats_bytes, int math,
@@ -1631,7 +1874,7 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, bias,
+    const int rc = conv2d_forward_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, w_planes, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
@@ -1646,7 +1889,7 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
-  return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
+  return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, nullptr, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
                                     pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, DSPN_MATH_FP32,
                                     workspace, workspace_bytes, stream);
 }
@@ -1669,6 +1912,27 @@ int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long t
   hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WtDesc *>(table), n, total_elements);
   return dspn::check_launch("weight_transpose_batch");
+}
+
+/* piece planes of a weight operand (DSPN_MATH_F32_BF16X3, include/dspn_nn.h) */
+int dspn_conv2d_weight_planes_f32(const float *w, void *planes, int Cout, int taps, int Cin, int cols, int transposed,
+                                  void *stream) {
+  DSPN_REQUIRE(w && planes && Cout > 0 && taps > 0 && Cin > 0 && cols > 0 && cols % 32 == 0, "weight_planes: bad argument");
+  DSPN_REQUIRE(transposed ? cols >= Cout : cols == Cin, "weight_planes: cols is Cin (forward operand) or the padded Cout (transposed operand)");
+  WpDesc e{w, static_cast<__bf16 *>(planes), Cout, taps, Cin, cols, 0, transposed ? 1 : 0, 0};
+  const long long total = (long long)(transposed ? Cin : Cout) * taps * cols;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(weight_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, total);
+  return dspn::check_launch("weight_planes");
+}
+
+int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_elements, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_elements > 0, "weight_planes_batch: bad argument");
+  static_assert(sizeof(WpDesc) == 48, "table row layout: 2 pointers, 4 ints, 1 int64, 2 ints");
+  const int blocks = (int)std::min<long long>((total_elements + 255) / 256, 16384);
+  hipLaunchKernelGGL(weight_planes_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WpDesc *>(table), n, total_elements);
+  return dspn::check_launch("weight_planes_batch");
 }
 #else
 /* bf16 operands of a float master weight w [Cout][taps][Cin]: wt [Cin][taps][Cout_pad] (data gradient) and, when
@@ -1712,11 +1976,11 @@ static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class 
   return total;
 }
 
-static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, st_t *dx, int N, int H, int W,
+static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, const void *wt_planes, st_t *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, BnBwd bn, void *workspace, size_t workspace_bytes,
                           void *stream) {
-  DSPN_REQUIRE(dy && wt && dx, "conv2d_dgrad: null pointer");
+  DSPN_REQUIRE(dy && (wt || wt_planes) && dx, "conv2d_dgrad: null pointer");
   DSPN_REQUIRE(ldy % kEPC == 0, "conv2d_dgrad: dy channel stride must be a multiple of %d", kEPC);
   DSPN_REQUIRE(stride == 1 || (stride == 2 && dil == 1), "conv2d_dgrad: stride 1, or stride 2 with dilation 1");
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && R > 0 && S > 0, "conv2d_dgrad: bad geometry");
@@ -1729,6 +1993,7 @@ static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, st_t *dx, 
   g.OW = W;
   g.flags = accumulate ? 4 : 0;
   g.bf16 = kHalf ? 1 : math;
+  g.w_planes = wt_planes;
   g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
   g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
   int class_tiles[4] = {0, 0, 0, 0};
@@ -1772,7 +2037,7 @@ static int dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) {
 int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride) { return dgrad_bn_tiles(N, H, W, Cin, stride); }
 #endif
 
-int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, st_t *dx, int N, int H, int W,
+int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt_planes, st_t *dx, int N, int H, int W,
                              int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                              int Wo, int dx_ldc, int accumulate,
                              const st_t *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
@@ -1791,7 +2056,7 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, st_t *dx, int 
   }
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_dgrad_one(math, dy + (long long)n0 * Ho * Wo * ldy, wt, dx + (long long)n0 * H * W * ldc, n, H,
+    const int rc = conv2d_dgrad_one(math, dy + (long long)n0 * Ho * Wo * ldy, wt, wt_planes, dx + (long long)n0 * H * W * ldc, n, H,
                                     W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate,
                                     BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums}, workspace,
                                     workspace_bytes, stream);
@@ -1805,7 +2070,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
-  return dspn_conv2d_dgrad_bn_f32(dy, wt, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
+  return dspn_conv2d_dgrad_bn_f32(dy, wt, nullptr, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
                                   accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, DSPN_MATH_FP32,
                                   workspace, workspace_bytes, stream);
 }
@@ -1914,10 +2179,14 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
     }                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
+#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2
+  (void)kt; (void)jt; (void)slab; (void)lds; (void)s;
+#else
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64
   else DSPN_WGRAD_LAUNCH(4, 2, 1, 2)   // 128 x 128 on 8 waves: two workgroups = 4 waves per SIMD (+3..6 % over <2,2,2,2>)
+#endif
 #undef DSPN_WGRAD_LAUNCH
 #undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");

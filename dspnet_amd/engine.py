@@ -119,6 +119,10 @@ class Graph:
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
         self.arena = self.grad_arena = self.mom_arena = None
         self.half_operands = False  # bf16 convolution operands: refreshed from the float masters at the top of forward()
+        # math of the float-tensor convolutions of THIS graph (include/dspn_nn.h DSPN_MATH_*), fixed when the graph is
+        # created: a later functional.set_conv_math() does not change what an existing graph computes
+        self.math = fn.get_conv_math()
+        self.wp_table = None       # split math: descriptor table of every piece-plane weight operand (one launch per step)
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -224,8 +228,19 @@ class Graph:
                 if n.wt is None:
                     n.wt = fn.zeros(n.w.shape[3], n.w.shape[1], n.w.shape[2], n.out.shape[3], device=self.device,
                                     dtype=n.wh.dtype)
-            self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, n.wh) for n in self._wt_pairs_nodes], self.device)
-            self.half_operands = self.wt_table[3]
+            # split math: a data gradient that contracts over whole 32-channel blocks reads piece planes, not the float
+            # transpose (Conv.__init__ allocated them); only the other layers stay in the transpose table
+            pairs = [n for n in self._wt_pairs_nodes if n.wtp is None or n.wh is not None]
+            if pairs:
+                self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, n.wh) for n in pairs], self.device)
+                self.half_operands = self.wt_table[3]
+        if self.device.type == "cuda":
+            planes = []
+            for n in self.nodes:
+                if isinstance(n, Conv):
+                    planes += [(n.w.data, pl, tr) for pl, tr in ((n.wp, False), (n.wtp, True)) if pl is not None]
+            if planes:
+                self.wp_table = fn.weight_planes_table(planes, self.device)
         if self.device.type == "cuda":
             # every Conv keeps the split-K partial sums of its weight gradient in a buffer of its own, so that the
             # slab sums of many layers run as one launch (flush_slabs) instead of one small kernel per layer
@@ -263,6 +278,8 @@ class Graph:
         if self.half_operands:         # bf16 copies (forward) and transposes (data gradient) of every weight, one launch
             fn.weight_transpose_batch(*self.wt_table)
             self.wt_batched = True
+        if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands)
+            fn.weight_planes_batch(*self.wp_table)
         for f in self.pre_forward:
             f()
         for n in self.nodes:
@@ -524,6 +541,15 @@ class Conv(Node):
         self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device, dtype=self.out.dtype)
         # bf16 operands: the copy of the float master the forward pass multiplies (refreshed once per step, Graph.forward)
         self.wh = fn.zeros(num_filter, kh, kw, Cin, device=g.device, dtype=torch.bfloat16) if half else None
+        # split math: piece planes of the weight (forward operand) and of its transpose (data-gradient operand), cut once
+        # per step by Graph.forward for the whole graph instead of once per tile inside the kernels
+        self.math = g.math
+        self.wp = self.wtp = None
+        if g.device.type == "cuda":
+            if fn.needs_planes(self.out.dtype, Cin, g.math):
+                self.wp = fn.zeros(num_filter, kh * kw, Cin // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
+            if x.requires_grad and fn.needs_planes(self.out.dtype, ldc, g.math):
+                self.wtp = fn.zeros(Cin, kh * kw, ldc // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
         # tap-expanded evaluation (few output channels, stride 1): 1x1 convolution to Cout*kh*kw channels
         # on the same weight buffer + shifted sum over taps (include/dspn_nn.h, dspn_tap_sum_f32)
         self.tap_expand = bool(tap_expand) and kh * kw > 1
@@ -563,13 +589,15 @@ class Conv(Node):
     def forward(self):
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
-            fn.conv2d_forward(self.x.data, self.wop().view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z)
+            fn.conv2d_forward(self.x.data, self.wop().view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z,
+                              w_planes=self.wp, math=self.math)     # (the planes of [Cout][taps][..] ARE those of the view)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
         fn.conv2d_forward(self.x_raw.data, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
                           residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine,
-                          out_stats=None if self.out_stats is None else self.out_stats[0])
+                          out_stats=None if self.out_stats is None else self.out_stats[0], w_planes=self.wp,
+                          math=self.math)
 
     def backward(self):
         if not self.out._gw:
@@ -587,22 +615,24 @@ class Conv(Node):
             cout, kh, kw, cin = self.w.shape
             fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
             if self.slabs is not None:
-                fn.conv2d_wgrad_slabs(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), self.slabs, 1, 0, 1)
+                fn.conv2d_wgrad_slabs(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), self.slabs, 1, 0, 1, math=self.math)
             else:
                 fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
-                                out=self.w.grad.view(cout * kh * kw, 1, 1, cin))
+                                out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math)
         elif self.slabs is not None:
             fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
-                                  in_affine=self.in_affine)
+                                  in_affine=self.in_affine, math=self.math)
         else:
             fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
-                            in_affine=self.in_affine)
+                            in_affine=self.in_affine, math=self.math)
         self.slabs_fresh = self.slabs is not None
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                      out=self.input_sum_grad.grad)
         if self.x.requires_grad:
-            if not self._g.wt_batched:
+            if self.wtp is not None and self._g.wp_table is None:
+                fn.weight_planes(self.w.data, transposed=True, cols=self.wtp.shape[2] * 32, out=self.wtp)
+            elif self.wtp is None and not self._g.wt_batched:
                 fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
             dx, acc = self.x.grad_target()
             bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
@@ -611,7 +641,7 @@ class Conv(Node):
                 bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
                 bn.bwd_sums_ready = True
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
-                            bn_bwd=bn_bwd)
+                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math)
 
 
 class BilinearConcatConv(Node):
@@ -648,7 +678,8 @@ class BilinearConcatConv(Node):
         self.T = T
         half = fn.ACT_DTYPE == torch.bfloat16
         self.z = fn.act_zeros(N, Ht, Wt, Tp, device=g.device)        # tap-expanded map at the target size (dz in backward)
-        self.zc, self.wc, self.wct, self.dwc, self.wch = [], [], [], [], []
+        self.zc, self.wc, self.wct, self.dwc, self.wch, self.wcp = [], [], [], [], [], []
+        self.math = g.math
         for t in inputs:
             # W_c . x_c at the component's own resolution (its gradient in backward).  Every component goes through
             # the sampler, also the ones that already have the target size: once the optimizer has moved
@@ -658,6 +689,9 @@ class BilinearConcatConv(Node):
             self.wct.append(fn.act_zeros(t.shape[3], 1, 1, Tp, device=g.device))    # its transpose (data-gradient operand)
             self.wch.append(fn.act_zeros(T, 1, 1, t.shape[3], device=g.device) if half else None)   # bf16 forward operand
             self.dwc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))
+            # split math: piece planes of W_c (the forward operand), refreshed after every gather of the slices
+            self.wcp.append(fn.zeros(T, 1, t.shape[3] // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
+                            if g.device.type == "cuda" and fn.needs_planes(self.zc[-1].dtype, t.shape[3], g.math) else None)
         self.sources = None           # fn.SamplerSources over zc, made at the first forward
         self.out = g.tensor((N, Ht, Wt, fn.padc(num_filter)), name + "_out")
         self.out.channels = num_filter
@@ -678,7 +712,10 @@ class BilinearConcatConv(Node):
         for c, t in enumerate(self.inputs):
             if self.wch[c] is not None:      # bf16 operands of this slice: copy + transpose in one launch
                 fn.weight_transpose(self.wc[c], out=self.wct[c], copy=self.wch[c])
-            fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c])
+            if self.wcp[c] is not None:
+                fn.weight_planes(self.wc[c], out=self.wcp[c])
+            fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c],
+                              w_planes=self.wcp[c], math=self.math)
         if self.sources is None:
             self.sources = fn.SamplerSources([(z, 0) for z in self.zc])
         fn.affine_sampler_forward(self.sources, self.theta.data, self.z)       # z = sum_c U_c(theta)(W_c x_c), one pass
@@ -693,13 +730,13 @@ class BilinearConcatConv(Node):
         Cin = self.offsets[-1]
         for c, t in enumerate(self.inputs):
             dz = fn.affine_sampler_backward_data(self.z, self.theta.data, self.zc[c].shape, 0, dx=self.zc[c])
-            fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c])
+            fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c], math=self.math)
             fn.copy_block(self.dwc[c], self.w.grad, 1, self.T, t.shape[3], 0, t.shape[3], 0, 0, Cin, self.offsets[c])
             if t.requires_grad:
                 if self.wch[c] is None:
                     fn.weight_transpose(self.wc[c], out=self.wct[c])
                 dx, acc = t.grad_target()
-                fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc)
+                fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc, math=self.math)
 
 
 class Deconv4x4s2(Node):
@@ -715,21 +752,23 @@ class Deconv4x4s2(Node):
         self.wh = fn.act_zeros(Cp, 4, 4, Cp, device=g.device) if fn.ACT_DTYPE == torch.bfloat16 else None
         self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
         self.out.channels = channels
+        self.math = g.math
         self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
         fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
-        fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data)
+        fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data, math=self.math)
 
     def backward(self):
         if not self.out._gw:
             return
         dy = self.out.grad
-        fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad)
+        fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad, math=self.math)
         if self.x.requires_grad:
             dx, acc = self.x.grad_target()
-            fn.conv2d_forward(dy, self.w.data if self.wh is None else self.wh, None, 2, 1, 1, out=dx, accumulate=acc)
+            fn.conv2d_forward(dy, self.w.data if self.wh is None else self.wh, None, 2, 1, 1, out=dx, accumulate=acc,
+                              math=self.math)
 
 
 class Add(Node):

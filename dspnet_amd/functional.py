@@ -22,8 +22,10 @@ _lib.register({
     "dspn_conv2d_split_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
-    "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                         _i, _ll, _i, _i, _i, _vp, _sz, _i, _vp, _sz, _vp]),
+    "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
@@ -38,7 +40,7 @@ _lib.register({
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
     "dspn_conv2d_dgrad_bn_tiles": (_i, [_i, _i, _i, _i, _i]),
-    "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp]),
     "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
                                             _vp, _sz, _vp]),
@@ -196,6 +198,8 @@ _MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}      # include/dspn_
 # this module's default for the `math` argument it passes on every convolution call (float tensors); DSPN_CONV_MATH
 # overrides it for a whole process (the test suite is run once per mode)
 DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "bf16x3")
+if DEFAULT_CONV_MATH not in _MATH_CODES:
+    raise ValueError("DSPN_CONV_MATH=%r: expected one of %s" % (DEFAULT_CONV_MATH, ", ".join(sorted(_MATH_CODES))))
 _MATH = _MATH_CODES[DEFAULT_CONV_MATH]
 
 
@@ -228,13 +232,70 @@ def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta,
           "bn_stats_from_tiles")
 
 
+def _math_code(math):
+    return _MATH if math is None else (_MATH_CODES[math] if isinstance(math, str) else int(math))
+
+
+def needs_planes(t_dtype, k_channels, math=None):
+    """True when a forward / data-gradient call contracting over k_channels per tap reads its weight operand as piece
+    planes (include/dspn_nn.h: DSPN_MATH_F32_BF16X3, float tensors, whole 32-channel blocks)"""
+    return t_dtype == torch.float32 and _math_code(math) == 2 and k_channels % 32 == 0
+
+
+def weight_planes(w, transposed=False, cols=None, out=None):
+    """piece planes (rows, taps, cols / 32, 3, 32) bfloat16 of the float32 master w (Cout, R, S, Cin): of w itself
+    (rows = Cout, cols = Cin: `w_planes` of conv2d_forward) or, transposed, of its transpose (rows = Cin, cols >= Cout zero
+    padded: `wt_planes` of conv2d_dgrad)"""
+    Cout, R, S, Cin = w.shape
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    rows, cols = (Cin, cols or (Cout + 31) // 32 * 32) if transposed else (Cout, Cin)
+    assert cols % 32 == 0
+    if out is None:
+        out = empty(rows, R * S, cols // 32, 3, 32, device=w.device, dtype=torch.bfloat16)
+    assert out.numel() == rows * R * S * cols * 3 and out.dtype == torch.bfloat16
+    check(L().dspn_conv2d_weight_planes_f32(ptr(w), ptr(out), Cout, R * S, Cin, cols, int(transposed), stream()),
+          "weight_planes")
+    return out
+
+
+def weight_planes_table(entries, device):
+    """entries: [(w float32 [Cout,R,S,Cin], planes, transposed)] -> (device table, rows, total elements) for
+    weight_planes_batch: every piece-plane operand of a graph refreshed from the float masters by ONE launch"""
+    import numpy as np
+    rows = np.zeros(len(entries), dtype=[("w", "<u8"), ("planes", "<u8"), ("K", "<i4"), ("T", "<i4"), ("C", "<i4"),
+                                         ("cols", "<i4"), ("begin", "<i8"), ("tr", "<i4"), ("pad", "<i4")])
+    total = 0
+    for i, (w, planes, tr) in enumerate(entries):
+        Cout, R, S, Cin = w.shape
+        cols = planes.shape[2] * 32
+        nrows = Cin if tr else Cout
+        assert w.dtype == torch.float32 and w.is_contiguous() and planes.dtype == torch.bfloat16
+        assert planes.shape == (nrows, R * S, cols // 32, 3, 32) and (cols >= Cout if tr else cols == Cin)
+        rows[i] = (w.data_ptr(), planes.data_ptr(), Cout, R * S, Cin, cols, total, int(tr), 0)
+        total += nrows * R * S * cols
+    assert rows.dtype.itemsize == 48
+    return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(entries), total
+
+
+def weight_planes_batch(table, n, total):
+    check(L().dspn_conv2d_weight_planes_batch_f32(ptr(table), n, total, stream()), "weight_planes_batch")
+
+
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
-                   in_affine=None, out_stats=None):
+                   in_affine=None, out_stats=None, w_planes=None, math=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
-    in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x"""
+    in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x.
+    math: "fp32" / "bf16" / "bf16x3" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split math when
+    Cin % 32 == 0 (made here, one extra launch, when the caller keeps none)."""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
+    math = _math_code(math)
+    if needs_planes(x.dtype, Cin, math):
+        if w_planes is None:
+            w_planes = weight_planes(w)
+    else:
+        w_planes = None
     ph, pw = _hw(pad)
     Ho, Wo = conv_out_size(H, R, stride, ph, dil), conv_out_size(W, S, stride, pw, dil)
     if out is None:
@@ -245,10 +306,11 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * Ho * Wo, Cout), x.device, "split")
     assert residual is None or (residual.shape == out.shape and residual.dtype == out.dtype)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
-    check(_f("dspn_conv2d_forward_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(bias), ptr(residual), ptr(out),
+    check(_f("dspn_conv2d_forward_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(w), ptr(w_planes), ptr(bias),
+                                         ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
-                                         _MATH, ptr(ws), ws.numel(), stream()), "conv2d_forward")
+                                         math, ptr(ws), ws.numel(), stream()), "conv2d_forward")
     return out
 
 
@@ -304,13 +366,22 @@ def conv_dgrad_bn_tiles(x_shape, stride):
     return L().dspn_conv2d_dgrad_bn_tiles(N, H, W, C, stride)
 
 
-def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None):
+def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None, wt_planes=None,
+                 math=None):
     """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin).
     bn_bwd = (bn_x, scale, shift, mean, rstd, relu, sums): dx is the complete gradient of a BatchNorm(+ReLU) output
-    whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin)"""
+    whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin).
+    wt_planes: the piece planes of wt (weight_planes(w, transposed=True, cols=ldy)), used in the split math when
+    ldy % 32 == 0 (made here from wt when the caller keeps none)."""
     N, H, W, Cx = x_shape
     Cin, R, S, ldy = wt.shape
     assert dy.shape[3] == ldy, (dy.shape, wt.shape)
+    math = _math_code(math)
+    if needs_planes(dy.dtype, ldy, math):
+        if wt_planes is None:
+            wt_planes = weight_planes(wt)        # planes of the matrix wt itself: rows = Cin, cols = ldy
+    else:
+        wt_planes = None
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
         out = (zeros if Cx != Cin else empty)(N, H, W, Cx, device=dy.device, dtype=dy.dtype)
@@ -318,14 +389,14 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
     ph, pw = _hw(pad)
     bx, bsc, bsh, bmu, brs, brelu, bsums = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False, None)
-    check(_f("dspn_conv2d_dgrad_bn", dy)(ptr(dy), ptr(wt), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw, dil,
-                                       Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
+    check(_f("dspn_conv2d_dgrad_bn", dy)(ptr(dy), ptr(wt), ptr(wt_planes), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw,
+                                       dil, Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
                                        ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
-                                       _MATH, ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
+                                       math, ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
     return out
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None):
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None, math=None):
     """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -339,8 +410,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     assert x.dtype == dy.dtype and out.dtype == torch.float32
     check(_f("dspn_conv2d_wgrad_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
-                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), _MATH, ptr(ws), ws.numel(),
-                                       stream()), "conv2d_wgrad")
+                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), _math_code(math), ptr(ws),
+                                       ws.numel(), stream()), "conv2d_wgrad")
     return out
 
 
@@ -370,7 +441,7 @@ def conv2d_wgrad_splits(x_shape, dy_shape, w_shape, stride):
     return L().dspn_conv2d_wgrad_splits(N, dy_shape[1], dy_shape[2], Cin, Cout, R, S, stride)
 
 
-def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None):
+def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None, math=None):
     """the weight-gradient GEMM alone: split-K partial sums -> slabs (splits, Cout, R, S, Cin); see slab_reduce_batch"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -380,7 +451,7 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     assert x.dtype == dy.dtype and slabs.dtype == torch.float32
     check(_f("dspn_conv2d_wgrad_slabs", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
-                                          dy.shape[2], _MATH, stream()), "conv2d_wgrad_slabs")
+                                          dy.shape[2], _math_code(math), stream()), "conv2d_wgrad_slabs")
 
 
 def slab_reduce_table(entries, device):

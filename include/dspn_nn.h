@@ -52,6 +52,12 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                         LDS (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)) and a product is the sum of the six
  *                         exact partial products x_p * w_q, p + q <= 2, accumulated in fp32.  Error against float64 equal
  *                         to DSPN_MATH_FP32's (tests/test_nn_gpu.py), ~1.3x its speed; what dspnet_amd passes by default.
+ *                         WEIGHT OPERANDS in this mode: a forward / data-gradient call whose contraction runs over a multiple
+ *                         of 32 channels per tap (Cin % 32 == 0, resp. ldy % 32 == 0) reads the weights as PIECE PLANES
+ *                         (`w_planes` / `wt_planes`, made by dspn_conv2d_weight_planes_f32 once per weight update) instead
+ *                         of cutting the float weights again in every tile of every call; the float operand may then be
+ *                         NULL.  Other channel counts (3 -> 4, 20, 36 ...) read the float operand and ignore the planes.
+ *                         Non-finite operands: +-inf and |x| > 3.39e38 give NaN / inf pieces (x - bf16(x) is inf - inf).
  * The *_bf16 entry points (bf16 tensors in HBM) ignore the argument: their operands are bf16 already. */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
@@ -69,7 +75,7 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
  * tensor is never written to or re-read from HBM.  in_scale / in_shift: Cin floats each, e.g. the scale / shift
  * outputs of dspn_bn_stats_f32; both NULL = plain convolution. */
 int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
-                               const float *w, const float *bias, const float *residual, float *y,
+                               const float *w, const void *w_planes, const float *bias, const float *residual, float *y,
                                int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                long long y_batch_stride, int y_ldc, int relu, int accumulate,
@@ -81,6 +87,18 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
  * the rows per tile for an output of out_pixels x Cout; dspn_bn_stats_from_tiles_f32 merges them.  Requires a dense
  * output (y_ldc == Cout or 0). */
 int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
+
+/* Piece planes of a weight operand for DSPN_MATH_F32_BF16X3: the matrix D[rows][taps][cols] (cols % 32 == 0) with
+ *   transposed == 0: D = w itself, rows = Cout, cols = Cin             -> `w_planes` of dspn_conv2d_forward_bn_f32,
+ *   transposed != 0: D = w^T, rows = Cin, cols >= Cout (zero padded)   -> `wt_planes` of dspn_conv2d_dgrad_bn_f32 (cols = ldy),
+ * every element x cut into p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even) and stored as
+ * planes[row][tap][cols / 32][piece][32] bfloat16: rows * taps * cols * 6 bytes.  w is the float master [Cout][taps][Cin].
+ * Batch form (every weight of a training step in one launch): table of n 48-byte rows in DEVICE memory
+ * { const float *w; void *planes; int32 Cout, taps, Cin, cols; int64 begin; int32 transposed, reserved } with begin = the sum
+ * of rows * taps * cols over the preceding rows; total_elements = that sum over all rows. */
+int dspn_conv2d_weight_planes_f32(const float *w, void *planes, int Cout, int taps, int Cin, int cols, int transposed,
+                                  void *stream);
+int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_elements, void *stream);
 
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -105,7 +123,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx,
  * forward statistics.  bn_sums[(t*2 + 0)*Cin + c] = sum over row tile t of dy', [(t*2 + 1)*Cin + c] = sum of dy'*xhat,
  * t < dspn_conv2d_dgrad_bn_tiles(); dspn_bn_backward_from_sums_f32 finishes the backward pass from them. */
 int dspn_conv2d_dgrad_bn_tiles(int N, int H, int W, int Cin, int stride);
-int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, float *dx, int N, int H, int W, int Cin, int ldy,
+int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, const void *wt_planes, float *dx, int N, int H, int W, int Cin, int ldy,
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                              int accumulate, const float *bn_x, const float *bn_scale, const float *bn_shift,
                              const float *bn_mean, const float *bn_rstd, int bn_relu, float *bn_sums,
@@ -160,13 +178,13 @@ typedef DSPN_BF16_ELEMENT dspn_bf16;
 typedef unsigned short dspn_bf16;
 #endif
 int dspn_conv2d_forward_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
-                                const dspn_bf16 *w, const float *bias, const dspn_bf16 *residual, dspn_bf16 *y,
+                                const dspn_bf16 *w, const void *w_planes_unused, const float *bias, const dspn_bf16 *residual, dspn_bf16 *y,
                                 int N, int H, int W, int Cin, int Cout, int R, int S,
                                 int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                 long long y_batch_stride, int y_ldc, int relu, int accumulate,
                                 float *out_stats, size_t out_stats_bytes, int math,
                                 void *workspace, size_t workspace_bytes, void *stream);
-int dspn_conv2d_dgrad_bn_bf16(const dspn_bf16 *dy, const dspn_bf16 *wt, dspn_bf16 *dx, int N, int H, int W, int Cin,
+int dspn_conv2d_dgrad_bn_bf16(const dspn_bf16 *dy, const dspn_bf16 *wt, const void *wt_planes_unused, dspn_bf16 *dx, int N, int H, int W, int Cin,
                               int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                               int dx_ldc, int accumulate, const dspn_bf16 *bn_x, const float *bn_scale,
                               const float *bn_shift, const float *bn_mean, const float *bn_rstd, int bn_relu,

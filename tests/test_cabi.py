@@ -77,8 +77,8 @@ def test_convolution_argument_validation_without_gpu():
     p = ctypes.c_void_p(256)        # never dereferenced: every call below fails its checks first
 
     def fwd(N=1, H=8, W=8, Cin=4, math=0, in_scale=None, in_shift=None):
-        return lib.dspn_conv2d_forward_bn_f32(p, in_scale, in_shift, 0, p, None, None, p, N, H, W, Cin, 8, 3, 3, 1, 1, 1, 1, 8, 8,
-                                              8 * 8 * 8, 8, 0, 0, None, 0, math, None, 0, None)
+        return lib.dspn_conv2d_forward_bn_f32(p, in_scale, in_shift, 0, p, None, None, None, p, N, H, W, Cin, 8, 3, 3, 1, 1, 1, 1,
+                                              8, 8, 8 * 8 * 8, 8, 0, 0, None, 0, math, None, 0, None)
 
     assert fwd(N=0) == -1 and b"bad geometry" in lib.dspn_last_error()
     assert fwd(math=3) == -1 and b"DSPN_MATH" in lib.dspn_last_error()
@@ -86,6 +86,11 @@ def test_convolution_argument_validation_without_gpu():
     assert fwd(in_scale=p) == -1 and b"go together" in lib.dspn_last_error()
     for math in (0, 1, 2):          # DSPN_MATH_FP32, DSPN_MATH_BF16, DSPN_MATH_F32_BF16X3 are the accepted values
         assert fwd(N=0, math=math) == -1 and b"bad geometry" in lib.dspn_last_error()
+    # the split math reads whole 32-channel blocks from piece planes: without them the call is rejected (before any launch)
+    assert fwd(Cin=64, math=2) == -1 and b"piece planes" in lib.dspn_last_error()
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, 8, 9, 64, 48, 0, None) == -1      # cols % 32
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, 8, 9, 64, 32, 0, None) == -1      # forward operand: cols == Cin
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, 40, 9, 64, 32, 1, None) == -1     # transposed operand: cols >= Cout
 
 
 def test_oracle_is_clean_under_address_and_ub_sanitizers():

@@ -64,7 +64,16 @@ CONV_CASES = [
     (1, 16, 16, 200, 19, 3, 1, 1, 1),     # score3_conv-like (Cout 19)
     (2, 5, 5, 128, 130, 3, 2, 1, 1),      # extras, tiny maps
     (1, 3, 3, 128, 128, 3, 2, 1, 1),
-    (4, 64, 64, 64, 128, 3, 1, 1, 1),     # enough tiles for the 128x128 config
+    (4, 64, 64, 64, 128, 3, 1, 1, 1),     # 512 tiles of 64x64; split math: halo-resident A tile, 4x16 patches
+    # split math (DSPN_MATH_F32_BF16X3), 3x3 / stride 1 / 'same' with whole 16-column patches: the halo-resident A tile in
+    # each of its tile shapes (conv.hip conv_nt_kernel<..., HALO>), forward and data gradient
+    (8, 64, 64, 64, 128, 3, 1, 1, 1),     # forward: 128x128 on 8 waves (8x16 patches); data gradient: 64x64
+    (8, 64, 64, 128, 128, 3, 1, 1, 1),    # both on 8 waves, two 32-channel blocks per image load on the gradient side
+    (4, 64, 64, 128, 192, 3, 1, 1, 1),    # forward: 128x64 tiles (Cout just past 128)
+    (32, 16, 16, 64, 128, 3, 1, 1, 1),    # one patch column per image row (stage-4 maps)
+    (4, 24, 48, 64, 128, 3, 1, 1, 1),     # 24 rows: whole 4-row and 8-row patches, three patch columns
+    (3, 20, 32, 64, 96, 3, 1, 1, 1),      # 20 rows: 4-row patches only
+    (2, 18, 32, 64, 64, 3, 1, 1, 1),      # 18 rows: no whole patches -> the generic kernel
 ]
 
 
@@ -99,6 +108,48 @@ def test_conv_forward_dgrad_wgrad(gpu_device, conv_math, case):
     dw = fn.conv2d_wgrad(xd, dyd, tuple(wd_.shape), stride=stride, pad=pad, dil=dil)
     close(dw.cpu().double().permute(0, 3, 1, 2)[:, :Cin], w.grad)
     close(fn.colsum(dyd, Cout).cpu().double(), dy.sum(dim=(0, 2, 3)))
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 3, 64), (19, 1, 1, 128), (40, 3, 3, 32)])
+def test_weight_planes_layout_and_pieces(gpu_device, shape):
+    """dspn_conv2d_weight_planes_f32: planes[row][tap][cols / 32][piece][32] with p0 = bf16(x), p1 = bf16(x - p0),
+    p2 = bf16(x - p0 - p1), of the weight itself and of its zero-padded transpose; the batch form writes the same bits"""
+    Cout, R, S, Cin = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    w = (torch.randn(shape, generator=g) * torch.exp(4 * torch.randn(shape, generator=g))).cuda()
+
+    def pieces(m):      # m (rows, taps, cols) float32 -> (rows, taps, cols / 32, 3, 32) bfloat16
+        p0 = m.bfloat16(); r1 = m - p0.float()
+        p1 = r1.bfloat16(); p2 = (r1 - p1.float()).bfloat16()
+        st = torch.stack([p0, p1, p2], dim=0)                      # (3, rows, taps, cols)
+        rows, taps, cols = m.shape
+        return st.view(3, rows, taps, cols // 32, 32).permute(1, 2, 3, 0, 4).contiguous()
+
+    fwd = fn.weight_planes(w)
+    assert torch.equal(fwd.view(torch.int16), pieces(w.view(Cout, R * S, Cin)).view(torch.int16))
+    cols = (Cout + 31) // 32 * 32
+    wt = torch.zeros(Cin, R * S, cols, device="cuda")
+    wt[:, :, :Cout] = w.view(Cout, R * S, Cin).permute(2, 1, 0)
+    bwd = fn.weight_planes(w, transposed=True, cols=cols)
+    assert torch.equal(bwd.view(torch.int16), pieces(wt).view(torch.int16))
+    # p0 + p1 + p2 reproduces the float to half an fp32 ulp
+    back = fwd.float().sum(dim=3).view(Cout, R * S, Cin)
+    assert float(((back - w.view(Cout, R * S, Cin)).abs() / w.view(Cout, R * S, Cin).abs().clamp(min=1e-30)).max()) <= 2.0 ** -23
+    a, b = torch.zeros_like(fwd), torch.zeros_like(bwd)
+    fn.weight_planes_batch(*fn.weight_planes_table([(w, a, False), (w, b, True)], w.device))
+    assert torch.equal(a.view(torch.int16), fwd.view(torch.int16)) and torch.equal(b.view(torch.int16), bwd.view(torch.int16))
+
+
+def test_split_math_needs_planes_at_the_c_abi(gpu_device):
+    """DSPN_MATH_F32_BF16X3 with Cin % 32 == 0 and no piece planes is an argument error, not a silent slow path"""
+    from dspnet_amd._lib import DspnError
+    x = torch.zeros(1, 8, 16, 64, device="cuda"); w = torch.zeros(64, 3, 3, 64, device="cuda"); y = torch.zeros(1, 8, 16, 64, device="cuda")
+    L = fn.L()
+    rc = L.dspn_conv2d_forward_bn_f32(fn.ptr(x), 0, 0, 0, fn.ptr(w), 0, 0, 0, fn.ptr(y), 1, 8, 16, 64, 64, 3, 3, 1, 1, 1, 1, 8, 16,
+                                      0, 64, 0, 0, 0, 0, 2, 0, 0, fn.stream())
+    assert rc != 0 and b"piece planes" in L.dspn_last_error()
+    with pytest.raises(DspnError):
+        fn.check(rc, "conv2d_forward")
 
 
 def test_conv_large_k_and_split_k_determinism(gpu_device, conv_math):
@@ -507,7 +558,8 @@ def test_conv_bf16_mfma_math(gpu_device, bf16_math, case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1, 1), (2, 17, 19, 32, 48, 3, 2, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0, 1),
-                                  (2, 16, 16, 128, 256, 1, 2, 0, 1), (1, 9, 9, 36, 40, 3, 1, 1, 1), (4, 64, 64, 64, 128, 3, 1, 1, 1)])
+                                  (2, 16, 16, 128, 256, 1, 2, 0, 1), (1, 9, 9, 36, 40, 3, 1, 1, 1), (4, 64, 64, 64, 128, 3, 1, 1, 1),
+                                  (8, 64, 64, 64, 128, 3, 1, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1, 1)])   # (halo tile: 8 waves, 128x64)
 @pytest.mark.parametrize("relu", [True, False])
 def test_conv_with_input_affine(gpu_device, conv_math, case, relu):
     """dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32: BatchNorm-apply (+ReLU) folded into the tile loader ==
@@ -536,6 +588,7 @@ def test_conv_with_input_affine(gpu_device, conv_math, case, relu):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
                                   (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0),
+                                  (8, 64, 64, 64, 128, 3, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1),   # halo tile: 8 waves, 128x64
                                   (8, 128, 128, 16, 64, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("with_res", [False, True])
 def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_res):
@@ -572,6 +625,7 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_re
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 256, 64, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
                                   (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0),
+                                  (8, 64, 64, 128, 128, 3, 1, 1), (4, 64, 64, 192, 64, 3, 1, 1),   # halo tile: 8 waves, 128x64
                                   (8, 128, 128, 64, 16, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, conv_math, case, accumulate):
@@ -632,7 +686,7 @@ FULL_SIZE_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", FULL_SIZE_CASES)
-def test_conv_full_size_properties(gpu_device, case):
+def test_conv_full_size_properties(gpu_device, conv_math, case):
     """<conv(x; w), y> = <x, dgrad(y; w)> = <w, wgrad(x, y)> (the three kernels are adjoint views of one trilinear
     form), linearity of the forward, and agreement with torch's own ROCm convolution (MIOpen) on the same operands.
     Tolerances: 2e-5 relative on the inner products (fp64 reductions of fp32 results), 1e-4 of the output's max on the
