@@ -22,8 +22,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  2500 TFLOP/s / 6 products per multiply-add = 416.7; fp32: 157.3; bf16: 2500);
   math_accuracy_check - one backbone layer in the three math modes against float64 (N = 1): the default math's error next
                  to the fp32 MFMA's and the bf16 mode's, measured in this run;
-  cpu_baseline - the CPU restatement of the same step (oracle/dspnet_torch.py, fp32, all host cores)
-                 on a bounded sample; rank 0, N = 1 only.
+  roofline_ops - the HBM-bound operators SURVEY.md 8(d) names (MultiBoxTarget, MultiBoxDetection, the BatchNorm backward
+                 apply, SGD): algorithmic bytes / event-timed kernel time / 8 TB/s, measured after the timed region;
+  cpu_baseline - the CPU restatement of the same step (oracle/dspnet_torch.py, fp32, all host cores) on a bounded sample
+                 at B = 4 (`value`) and B = 1 (`conv_path`), and the multibox operators alone through the C restatement,
+                 one thread and over the batch (`multibox_ops`); rank 0, N = 1 only.
 """
 import argparse
 import ctypes
@@ -125,7 +128,122 @@ def host_cores():
     return n
 
 
-def cpu_baseline(size, images, cfg, width=None):
+HBM_PEAK_TBS = 8.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def cpu_multibox_ops(anchors, batch=32, seconds=1.5):
+    """the multibox operators ALONE on the host -- the C restatement of the reference's CPU kernels
+    (oracle/multibox_oracle.c) at the bench shape (B = 32, N = 6132 anchors, L = 200 label rows, 8 + 1 classes), timed
+    single-threaded (the reference loops over the batch serially, operator/multibox_target.cc:92) and with the batch
+    spread over the host cores (one slice of the batch per core from a thread pool; ctypes releases the GIL: what an
+    OpenMP `parallel for` over the batch would give)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from dspnet_amd import synthetic
+    from oracle import multibox as om
+    gen = synthetic.rng(233)
+    A = anchors.shape[1]
+    lab = synthetic.det_labels(batch, gen=gen, first_empty=False)
+    pred = gen.standard_normal((batch, 9, A)).astype(np.float32)
+    e = np.exp(pred - pred.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    loc = (0.1 * gen.standard_normal((batch, A * 5))).astype(np.float32)
+    cores = host_cores()
+
+    def target(b0, b1):
+        om.multibox_target(anchors, lab[b0:b1], pred[b0:b1], negative_mining_ratio=3)
+
+    def detection(b0, b1):
+        om.multibox_detection(prob[b0:b1], loc[b0:b1], anchors, nms_topk=400)
+
+    def rate(fn_, parallel):
+        pool = ThreadPoolExecutor(cores) if parallel else None
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            if parallel:     # one contiguous slice of the batch per core, each one C call
+                cuts = [batch * i // cores for i in range(cores + 1)]
+                list(pool.map(lambda i: fn_(cuts[i], cuts[i + 1]), [i for i in range(cores) if cuts[i] < cuts[i + 1]]))
+            else:
+                fn_(0, batch)
+            reps += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+        if pool:
+            pool.shutdown()
+        return round(batch * reps / dt, 1)
+
+    return {"workload": "B = %d, N = %d anchors, L = 200 label rows, 8 + 1 classes; C restatement of the reference's CPU "
+                        "kernels (oracle/multibox_oracle.c)" % (batch, A), "unit": "samples/s", "cores": cores,
+            "MultiBoxTarget": {"1_thread": rate(target, False), "batch_parallel": rate(target, True)},
+            "MultiBoxDetection": {"1_thread": rate(detection, False), "batch_parallel": rate(detection, True)}}
+
+
+def roofline_ops(net, solver, dev):
+    """the HBM-bound operators of the step, each priced against the HBM roof: algorithmic bytes (read
+    once + written once) / kernel time / 8 TB/s.  Timed with events on the stream the kernels are launched on (torch's
+    current stream: the operator front ends and dspnet_amd.functional launch there), 20 back-to-back calls each, after
+    and outside the timed region."""
+    import torch
+    from dspnet_amd import functional as fn, operator as op, synthetic
+
+    def timed(f, reps=20):
+        f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    def row(name, nbytes, sec, note):
+        gbs = nbytes / sec / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "algorithmic_bytes": int(nbytes),
+                "ms": round(sec * 1e3, 4), "note": note}
+
+    out = {}
+    B = net.data.shape[0]
+    anchors = net.anchors
+    A = anchors.shape[1]
+    g = synthetic.rng(7)
+    lab = torch.from_numpy(synthetic.det_labels(B, gen=g)).to(dev)
+    pred = torch.randn(B, 9, A, device=dev)
+    prob = torch.softmax(pred, dim=1).contiguous()
+    loc = 0.1 * torch.randn(B, A * 5, device=dev)
+    # MultiBoxTarget: reads cls_pred + labels (+ the anchor table once), writes loc_target, loc_mask, cls_target
+    tb = B * (9 * A * 4 + 200 * 6 * 4 + A * 11 * 4) + A * 16
+    out["MultiBoxTarget"] = row("target", tb, timed(lambda: op.MultiBoxTarget(anchors, lab, pred, negative_mining_ratio=3)),
+                                "B = %d, one workgroup per sample in the matching kernel: latency-bound by construction" % B)
+    db = B * (9 * A * 4 + A * 5 * 4 + A * 7 * 4) + A * 16
+    det_out = torch.empty(B, A, 7, device=dev)
+    out["MultiBoxDetection"] = row("detection", db, timed(lambda: op.MultiBoxDetection(prob, loc, anchors, nms_topk=400, out=det_out)),
+                                   "B = %d, nearly every row valid (random scores): worst case for sort + NMS" % B)
+    # BatchNorm backward apply on the largest tensor of the graph it runs on (stage 1: 128 x 128 x 256 per image)
+    x = torch.randn(B, 128, 128, 256, device=dev)
+    dy = torch.randn_like(x)
+    dx = torch.empty_like(x)
+    C = 256
+    gamma = torch.rand(C, device=dev) + 0.5
+    beta = torch.randn(C, device=dev)
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    tiles = 64
+    sums = torch.randn(tiles, 2, C, device=dev)
+    out["bn_bwd_apply"] = row("bn_bwd_apply", 3 * 4 * x.numel(),
+                              timed(lambda: fn.bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=True, dx=dx)),
+                              "dx = a dy' + c1 x + c0 on a %d x 128 x 128 x 256 tensor (reads x, dy; writes dx), incl. its per-channel finalize launch" % B)
+    del x, dy, dx
+    gr = net.g
+    n = gr.arena.numel()
+    out["sgd"] = row("sgd", 5 * 4 * n, timed(lambda: fn.sgd_momentum(gr.arena, gr.grad_arena, gr.mom_arena, 0.0, 0.9, 0.0005, 1.0 / B)),
+                     "one launch over the %.1f M-parameter arena: reads w, g, m; writes m, w (lr = 0 here: the weights do not move)" % (n / 1e6))
+    return out
+
+
+def cpu_baseline(size, images, cfg, width=None, seconds=12.0):
     """forward + backward of the same graph with torch CPU ops, fp32, all cores"""
     width = width or size
     import numpy as np
@@ -150,7 +268,7 @@ def cpu_baseline(size, images, cfg, width=None):
     while True:
         once()
         reps += 1
-        if time.perf_counter() - t0 > 12.0 or reps >= 200:
+        if time.perf_counter() - t0 > seconds or reps >= 200:
             break
     dt = time.perf_counter() - t0
     return {"value": round(images * reps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
@@ -252,6 +370,7 @@ def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
     from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
     from dspnet_amd.train.solver import MultiTaskSolver
     lib = _lib.lib()
+    prev_math, prev_dtype = fn.get_conv_math(), fn.ACT_DTYPE
     fn.set_conv_math(math)
     fn.set_activation_dtype(store)
     try:
@@ -283,8 +402,8 @@ def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
                 "steps": steps, "warmup": warmup, "dtype": "bf16" if math == "bf16" else "f32",
                 "roofline": conv_family_roofline(lib, ps, flops_step, flops_3x, math, dt / steps)}
     finally:
-        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
-        fn.set_activation_dtype("fp32")
+        fn.set_conv_math(prev_math)
+        fn.set_activation_dtype(prev_dtype)
 
 
 def side_infer(B, size, iters, warmup, dev):
@@ -465,6 +584,13 @@ def main():
         if roofline is not None:
             roofline["instrumented_steps"] = "%d of the %d timed steps" % (prof_steps, args.steps)
 
+    ops_roofline = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.store == "fp32":
+        try:
+            ops_roofline = roofline_ops(net, solver, dev)
+        except Exception as e:          # never costs the headline line
+            ops_roofline = {"error": str(e)[:200]}
+
     # the other BASELINE.json configs beside the headline workload: short side measurements OUTSIDE the timed region
     # above (never part of `value`), N=1 only, each with its own roofline block
     other = None
@@ -489,7 +615,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import dspnet_torch as ot
             cpu_baseline.values = ot.export_params(net.g)
-            cpu = cpu_baseline(S, args.cpu_images, cfg, Wd)
+            # the convolution path (whole graph, torch-CPU ops) at B = 1 and B = 4; `value` is the
+            # B = 4 figure.  8(d)(i): the multibox operators alone (C restatement), serial and over the batch.
+            cpu = cpu_baseline(S, 4 if args.cpu_images == 2 else args.cpu_images, cfg, Wd, seconds=8.0)
+            try:
+                b1 = cpu_baseline(S, 1, cfg, Wd, seconds=5.0)
+                cpu["conv_path"] = {"B=1": {"value": b1["value"], "unit": "images/s", "sample": b1["sample"]},
+                                    "B=%d" % (4 if args.cpu_images == 2 else args.cpu_images):
+                                        {"value": cpu["value"], "unit": "images/s", "sample": cpu["sample"]}}
+                cpu["multibox_ops"] = cpu_multibox_ops(net.anchors.detach().cpu().numpy())
+            except Exception as e:      # never costs the headline line
+                cpu["split_error"] = str(e)[:200]
         line = {
             "metric": "training images/sec at %dx%d multitask" % (S, Wd),
             "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
@@ -512,6 +648,8 @@ def main():
                 line["math_accuracy_check"] = math_accuracy_check(dev)
             except Exception as e:      # never costs the headline line
                 line["math_accuracy_check"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_roofline and ops_roofline is not None:
+            line["roofline_ops"] = ops_roofline
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

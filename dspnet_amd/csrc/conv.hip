@@ -134,22 +134,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-// Split mode, round 3: what the loaders no longer do once per (element, tap, column tile).
-//  * PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand arrives as three
-//    bf16 piece planes, [row][tap][Cin / 32][piece][32] (dspn_conv2d_weight_planes_*: cut once per step for the whole
-//    graph), so the B tile goes global -> registers -> LDS as three 16-byte chunks per 32 channels with no arithmetic.
-//  * HALO (3x3, stride 1, 'same': forward and data gradient of the backbone's 3x3 layers): an M tile is a patch of
-//    BM / 16 rows x 16 columns of output pixels; per block of 32 channels the (BM / 16 + 2) x 18 input pixels under it are
-//    loaded, run through the input affine and cut into pieces ONCE, and all nine taps' MFMAs read their A fragments from
-//    that LDS image at a per-tap offset: 1.4 element loads / affines / splits per nine k-steps instead of 9, and the tap
-//    re-reads that missed L2 are gone.  LDS rows of the image stay 208 B per pixel; a row of 18 pixels is padded to
-//    3840 B (= 0 mod 256) so that the 16-lane groups of a ds_read_b128, which now span two patch rows, still land on 16
-//    distinct 16-byte slots of the bank row.
+// Split mode, round 3 -- PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand
+// arrives as three bf16 piece planes, [row][tap][Cin / 32][piece][32] (dspn_conv2d_weight_planes_*: cut once per step for
+// the whole graph), so the B tile goes global -> registers -> LDS as three 16-byte chunks per 32 channels with no
+// arithmetic: 9.5 -> 3.5 non-MFMA vector instructions per MFMA on the 3x3 layers.
+// (A halo-resident A tile for the 3x3 stride-1 layers -- the (8 + 2) x (16 + 2) input patch under an 8 x 16 output tile loaded,
+// affine-transformed and cut once per 32 channels for all nine taps -- was built on top of this and removed again: 2.2
+// instructions per MFMA and a 4 % higher clock, but 14 % more wave cycles (the image load is exposed once per nine k-steps
+// and its 30 registers do not fit beside the fused epilogues of the 128-register kernels): 630 against 675 images/s, DESIGN.md.)
 constexpr int kPlaneBlk = 3 * 32;      // bf16 elements of one (row, tap, 32-channel block) of a piece-plane operand
-constexpr int kHaloPitch = 1920;       // bf16 elements (3840 B) of one 18-pixel row of the halo image
 
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI, bool HALO = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -161,10 +157,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
   constexpr bool PRE = SPLIT && UNIFORM_TAP;            // the weight operand is three bf16 piece planes (see above)
-  static_assert(!HALO || PRE, "the halo-resident A tile exists in the split mode only");
-  constexpr int PH = BM / 16, HR = PH + 2, HPIX = HR * 18;   // HALO: patch rows, image rows, image pixels
-  // 16-B loads per thread per k-step (HALO: A loads per block of nine k-steps)
-  constexpr int A_LD = HALO ? (HPIX + RSTEP - 1) / RSTEP : BM / RSTEP;
+  // 16-B loads per thread per k-step
+  constexpr int A_LD = BM / RSTEP;
   constexpr int B_LD = PRE ? 3 * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
   constexpr bool B_EXACT = (4 * BN) % NTHR == 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -172,8 +166,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
   constexpr int ROWH = SPLIT ? kLdsRowS : kLdsRowH;   // LDS row (bf16 elements) of the bf16 images
   constexpr int STAGES = SPLIT ? 1 : 2;               // the three-piece image is single-buffered (two barriers per k-step)
-  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH] (HALO: [HR][kHaloPitch]), then [STAGES][BN][ROWH]
-  __bf16 *hB = hA + (HALO ? HR * kHaloPitch : STAGES * BM * ROWH);
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
+  __bf16 *hB = hA + STAGES * BM * ROWH;
 
 #ifdef DSPN_ABLATE
   const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
@@ -229,16 +223,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // back to back, so the (overlapping) input pixels of neighbouring taps are re-read while they are
   // still in L1/L2 instead of once per sweep over all channels (3328-channel score3_conv: 9x less HBM).
   const int ntaps = g.TR * g.TS;
-  // state of the two round-3 loaders (kept small: the 8-wave kernels live within 128 registers)
-  unsigned h_mask = 0;        // HALO: bit i: image pixel i of the current tile lies inside the gathered tensor
-  bool a_fresh = false;       // HALO: the k-step requested last carried a new image (it starts a block of 32 channels)
-  int ld_mt = 0;              // row-tile index of the tile set up last (statistics slots)
-  // HALO: image pixel i of this thread = row0 + RSTEP * i -> (image row, image column); recomputed where needed
-  auto halo_rc = [&](const int i, int &hr, int &hc) __attribute__((always_inline)) {
-    const int hp = row0 + RSTEP * i;
-    hr = hp / 18; hc = hp - hr * 18;
-    return hp < HPIX;
-  };
   // PRE: thread (row = tid >> 2, part = tid & 3) moves chunks 3 * part .. 3 * part + 2 of the 12 chunks (192 B) of tile
   // row `row` (+ NTHR / 4 per pass): one address register per pass, the three chunks at immediate offsets
   constexpr int B_PASS = PRE ? (4 * BN + NTHR - 1) / NTHR : 1;
@@ -247,27 +231,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
     const int mt = tile / n_tiles, nt = tile - mt * n_tiles;   // n fastest: A tile reuse in L2
-    ld_m0 = mt * BM; ld_n0 = nt * BN; ld_mt = mt;
-    if constexpr (HALO) {
-      // tile mt = patch (ty, tx) of image n; ld_m0 = linear index of its first pixel
-      const int tw = g.Wg >> 4, tpi = (g.Hg / PH) * tw;
-      const int n = mt / tpi, rem = mt - n * tpi;
-      const int ty = rem / tw, tx = rem - ty * tw;
-      const int oi0 = ty * PH, oj0 = tx * 16;
-      ld_m0 = (n * g.Hg + oi0) * g.Wg + oj0;
-      // image origin in the gathered tensor: the smallest coordinate any tap reaches (|idh| = |idw| = 1, three taps)
-      const int hh0 = oi0 + g.ioh + (g.idh < 0 ? 2 * g.idh : 0), hw0 = oj0 + g.iow + (g.idw < 0 ? 2 * g.idw : 0);
-      h_mask = 0;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        int hr, hc;
-        const bool in_img = halo_rc(i, hr, hc);
-        const int ih = hh0 + hr, iw = hw0 + hc;
-        const bool v = in_img && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
-        h_mask |= v ? (1u << i) : 0u;
-        a_eoff[i] = v ? ((n * g.Hin + ih) * g.Win + iw) * g.Cin : 0;
-      }
-    } else {
+    ld_m0 = mt * BM; ld_n0 = nt * BN;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int m = ld_m0 + row0 + RSTEP * i;
@@ -279,7 +243,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       a_ih0[i] = mv ? ih0 : -0x40000000;
       a_iw0[i] = mv ? iw0 : 0;
       a_eoff[i] = mv ? ((n * g.Hin + ih0) * g.Win + iw0) * g.Cin : 0;
-    }
     }
     if constexpr (PRE) {
 #pragma unroll
@@ -338,20 +301,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         tf_sh2 = make_float4(__uint_as_float(h8[0]), __uint_as_float(h8[1]), __uint_as_float(h8[2]), __uint_as_float(h8[3]));
       }
     };
-    if constexpr (HALO) {
-      // a new image with the first tap of every block of 32 channels (wave-uniform); the other eight k-steps load weights only
-      a_fresh = (tr | ts) == 0;
-      if (a_fresh) {
-        if constexpr (INTF) { load_affine(); tf_mask = qv ? h_mask : 0u; }
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-          const bool v = qv && ((h_mask >> i) & 1u);
-          const unsigned off = ((unsigned)(a_eoff[i] + cq * kEPC) * (unsigned)sizeof(st_t)) | (v ? 0u : kOOB);
-          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
-          ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
-        }
-      }
-    } else {
     if constexpr (INTF) {
       load_affine();
       tf_mask = 0;
@@ -367,7 +316,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       if constexpr (kHalf) ha[i] = t;
       else ra[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
                                __uint_as_float(t[3]));
-    }
     }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
     if constexpr (PRE) {
@@ -415,17 +363,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   bf16x4 pa[SPLIT ? A_LD : 1][3], pb[(SPLIT && !PRE) ? B_LD : 1][3];
   auto split_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT) {
-      if constexpr (HALO) {
-        if (a_fresh) {      // wave-uniform: one k-step in nine
-          affine_tiles();
+      affine_tiles();
 #pragma unroll
-          for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
-        }
-      } else {
-        affine_tiles();
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
-      }
+      for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
       if constexpr (!PRE) {
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
@@ -465,26 +405,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     if constexpr (SPLIT) {
       // x = p0 + p1 + p2 (split_tiles): piece p of channel k of a row lies at row * ROWH + p * 32 + k
       __bf16 *a = hA + buf * BM * ROWH, *b = hB + buf * BN * ROWH;
-      if constexpr (HALO) {
-        if (a_fresh) {      // the image of the next nine k-steps (every wave is past the last tap of the previous block)
-#pragma unroll
-          for (int i = 0; i < A_LD; ++i) {
-            int hr, hc;
-            if (halo_rc(i, hr, hc)) {   // (only the last pass can run past the image)
-              __bf16 *d = hA + hr * kHaloPitch + hc * ROWH + chunk * 4;
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
-            }
-          }
-          a_fresh = false;
-        }
-      } else {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
-      }
       }
       if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
 #pragma unroll
@@ -536,10 +461,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int wm = (wave / WAVES_N) * TM * 32, wn = (wave % WAVES_N) * TN * 32;
   const int frow = lane & 31, fk = (lane >> 5) * 2;
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
-  int a_hl[TM];     // HALO: bf16 offset of this lane's row of MFMA tile i in the image, before the tap's offset
-#pragma unroll
-  for (int i = 0; i < TM; ++i) a_hl[i] = ((wm + i * 32 + frow) >> 4) * kHaloPitch + (frow & 15) * ROWH;
-  int c_tap = 0;    // HALO: tap of the k-step the MFMAs are working on (k order: taps inner, 32-channel blocks outer)
 
   // ---- persistent loop over output tiles ----------------------------------------------------------
   // The workgroup walks tiles t, t + gridDim.x, ...  While the last k-step of a tile is in the matrix
@@ -569,15 +490,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // x * w = sum over piece pairs (p, q), p + q <= 2, of x_p * w_q: six bf16 MFMAs per 16-deep k block, every partial
       // product exact in the fp32 accumulator's input, the three dropped pairs at the level of one fp32 rounding (see kLdsRowS above).  Small terms
       // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
-      // HALO: row r of the tile is pixel (r >> 4, r & 15) of the patch; tap (tr, ts) of the current k-step reads image pixel
-      // (r >> 4) + dr, (r & 15) + dc, with (dr, dc) = the tap's distance from the image origin -- one wave-uniform offset
-      int c_toff = 0;
-      if constexpr (HALO) {
-        const int ctr = c_tap / 3, cts = c_tap - 3 * ctr;
-        c_toff = (g.idh > 0 ? ctr : 2 - ctr) * kHaloPitch + (g.idw > 0 ? cts : 2 - cts) * ROWH;
-      }
-      const __bf16 *a = HALO ? hA + c_toff + (lane >> 5) * 8
-                             : hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
+      const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
       auto block = [&](const int kk) __attribute__((always_inline)) {
         bf16x8 fa[3][TM], fb[3][TN];
@@ -585,7 +498,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + (HALO ? a_hl[i] : i * 32 * ROWH) + p * 32 + kk * 16);
+            fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
@@ -606,9 +519,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // vector ALU between the second block's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       if (!(dbg & 256)) split_tiles();
-      if constexpr (HALO) __builtin_amdgcn_sched_barrier(0);   // (the image's pieces sit in their own, rarely taken block)
       block(1);
-      if constexpr (!HALO) {
       // pin the pieces HERE: their only readers (the LDS stores) sit behind the barrier, and hipcc otherwise sinks the
       // whole piece arithmetic down there, next to them
 #pragma unroll
@@ -626,7 +537,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int m = 0; m < 6 * TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (kSplitValuPerMfma + 1) / 2 : kSplitValuPerMfma, 0);
-      }
       }
     } else if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
@@ -696,31 +606,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   store_tiles(0);
   __syncthreads();
   zero_acc();
-  int m0 = ld_m0, n0 = ld_n0, cur_mt = ld_mt;
+  int m0 = ld_m0, n0 = ld_n0;
   int tn = t + gridDim.x;
   int kt = 0, buf = 0;
   // ONE loop over (tile, k-step): a single copy of the load + MFMA block; the end-of-tile work hangs off it
   while (true) {
     const bool last = kt == nk1 - 1;
     const bool has_next = tn < ntiles;
-    // HALO: no prefetch across the epilogue (a tile is 9 x Cin / 32 k-steps long and the image + weight chunks of the next
-    // tile would sit in 24 registers of a 128-register kernel through all of it): the next tile's first loads follow it
-    if constexpr (HALO) {
-      // the image rows / pieces are written and read under the wave-uniform `a_fresh` only, all within one iteration: tell
-      // the register allocator that nothing is carried around the loop (as conditionally defined values they were, and
-      // cost 30 registers in every one of the eight k-steps that do not touch them)
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        ra[i].x = __builtin_nondeterministic_value(ra[i].x); ra[i].y = __builtin_nondeterministic_value(ra[i].y);
-        ra[i].z = __builtin_nondeterministic_value(ra[i].z); ra[i].w = __builtin_nondeterministic_value(ra[i].w);
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) pa[i][pc] = __builtin_nondeterministic_value(pa[i][pc]);
-      }
-      if (!last) load_tiles();
-    } else {
     if (last && has_next) setup_tile(tn);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
-    }
     // nk == 0 (a parity class of a strided data gradient without taps): the loads return zeros, so the k-step may run
     // (accumulators stay 0) or be skipped.  The 8-wave build must NOT branch here: with the branch hipcc keeps the
     // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
@@ -772,8 +666,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         auto rows_begin = [&](const int ch) __attribute__((always_inline)) {   // addresses + additive operand of chunk ch
 #pragma unroll
           for (int p = 0; p < RC; ++p) {
-            const int rl = er0 + (ch * RC + p) * RPP;
-            const int m = HALO ? m0 + (rl >> 4) * g.Wg + (rl & 15) : m0 + rl;   // HALO: row rl = pixel (rl >> 4, rl & 15) of the patch
+            const int m = m0 + er0 + (ch * RC + p) * RPP;
             if (g.dense) {
               offs[p] = m * g.ldc + co;
             } else {
@@ -892,7 +785,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           if (tid < BN && n0 + tid < g.Cout) {
             // merge of the RPP row groups about the first group's mean (no division inside the loop):
             //   mean = m_0 + sum n_e d_e / n,  M2 = sum (M2_e + n_e d_e^2) - n (mean - m_0)^2,  d_e = mean_e - m_0
-            const int lim = HALO ? BM : min(M - m0, BM);
+            const int lim = min(M - m0, BM);
             const float mref = red[tid * 2];            // row group 0 is never empty
             float n = 0.f, sd = 0.f, sq = 0.f;
 #pragma unroll 4
@@ -906,7 +799,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             const float dm = sd / n;
             const float mean = mref + dm;
             const float m2 = fmaxf(sq - n * dm * dm, 0.f);
-            const long long mt_ = HALO ? cur_mt : m0 / BM;
+            const long long mt_ = m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
           }
@@ -926,7 +819,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           if (tid < BN && n0 + tid < g.Cout) {
             float a = 0.f, b = 0.f;
             for (int er = 0; er < RPP; ++er) { a += red[(er * BN + tid) * 2]; b += red[(er * BN + tid) * 2 + 1]; }
-            const long long mt_ = g.bn_tile_base + (HALO ? cur_mt : m0 / BM);
+            const long long mt_ = g.bn_tile_base + m0 / BM;
             g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + tid] = a;
             g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + tid] = b;
           }
@@ -944,10 +837,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         }
         break;
       }
-      if constexpr (HALO) { setup_tile(tn); load_tiles(); split_tiles(); }
       zero_acc();
       t = tn; tn += gridDim.x;
-      m0 = ld_m0; n0 = ld_n0; cur_mt = ld_mt;
+      m0 = ld_m0; n0 = ld_n0;
       kt = -1;
       __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
     }
@@ -961,7 +853,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       buf ^= 1;
     }
     ++kt;
-    if constexpr (HALO) c_tap = (kt == 0 || c_tap == 8) ? 0 : c_tap + 1;
   }
 }
 
@@ -1553,7 +1444,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI, bool HALO = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -1561,12 +1452,11 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-  const size_t lds = std::max<size_t>(HALO        ? sizeof(__bf16) * ((BM / 16 + 2) * kHaloPitch + BN * kLdsRowS)
-                                      : MATH == 2 ? sizeof(__bf16) * (BM + BN) * kLdsRowS
+  const size_t lds = std::max<size_t>(MATH == 2   ? sizeof(__bf16) * (BM + BN) * kLdsRowS
                                       : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
                                                   : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
-  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI, HALO>;
+  auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
   static int slots = 0;
@@ -1580,8 +1470,8 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
     if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d,halo=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
-              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, (int)HALO, lds, per_cu, cus, slots);
+      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
+              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
   }
   const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
   {
@@ -1600,33 +1490,23 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
-              hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual, bool halo = false) {
+              hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
   const bool uni = ((g.Cin / kEPC) & 7) == 0;
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
 #ifdef DSPN_HALF
 #define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E))
-#else
-  // the halo-resident form of the split mode (tiles of up to 128 rows: the image state lives in 8-entry register vectors)
-  constexpr bool kHaloTile = WAVES_M * TM * 32 <= 128;
-#define DSPN_NT_H_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 2, T, E, kHaloTile>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
-#ifdef DSPN_DEV_X3ONLY   /* development builds (make DEV=1): only the split-mode kernels are instantiated */
-#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? ((halo && kHaloTile) ? DSPN_NT_H_(T, E) : DSPN_NT_(true, 2, T, E)) : DSPN_NT_(false, 2, T, E)) \
+#elif defined(DSPN_DEV_X3ONLY)   /* development builds: only the split-mode kernels are instantiated (compile time) */
+#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
                                          : dspn::fail(DSPN_ERR_ARG_, "development build: DSPN_MATH_F32_BF16X3 only"))
 #else
-#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? ((halo && kHaloTile) ? DSPN_NT_H_(T, E) : DSPN_NT_(true, 2, T, E)) : DSPN_NT_(false, 2, T, E)) \
+#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
                            : g.bf16 == 1 ? (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E)) \
                                          : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
-#endif
-#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2   /* one kernel only: register / ISA inspection */
-  return DSPN_NT_H_(DSPN_DEV_INTF, DSPN_DEV_EPI);
-#else
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
   return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
-#endif
 #undef DSPN_NT_UB_
-#undef DSPN_NT_H_
 #undef DSPN_NT_
 }
 
@@ -1711,24 +1591,13 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 == 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
-  // 3x3, stride 1, 'same', whole patches of (tile rows / 16) x 16 pixels: the halo-resident A tile (conv_nt_kernel)
-  static const bool halo_off = getenv("DSPN_NT_NOHALO") != nullptr;   // experiments
-  const int ph = bm_[cfg] / 16;
-  const bool halo = pre && !halo_off && splits == 1 && cfg != 3 && g.TR == 3 && g.TS == 3 && g.ish == 1 && g.isw == 1 &&
-                    (g.idh == 1 || g.idh == -1) && (g.idw == 1 || g.idw == -1) && g.Hin == g.Hg && g.Win == g.Wg && g.dense &&
-                    g.Hg % ph == 0 && g.Wg % 16 == 0 && g.wrs == 1 && g.wss == 1 &&
-                    g.ioh + (g.idh < 0 ? 2 * g.idh : 0) == -1 && g.iow + (g.idw < 0 ? 2 * g.idw : 0) == -1;
-  if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
-#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2
-  return -1;
-#else
+  if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
-    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
-    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
-    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual, halo);
+    case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    case 1: return launch_nt<2, 2, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+    case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
     default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   }
-#endif
 }
 
 struct WgradPlan { int bm; int bn; int splits; int pps; };
@@ -2179,14 +2048,10 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
     }                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
-#if defined(DSPN_DEV_X3ONLY) && DSPN_DEV_X3ONLY == 2
-  (void)kt; (void)jt; (void)slab; (void)lds; (void)s;
-#else
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64
   else DSPN_WGRAD_LAUNCH(4, 2, 1, 2)   // 128 x 128 on 8 waves: two workgroups = 4 waves per SIMD (+3..6 % over <2,2,2,2>)
-#endif
 #undef DSPN_WGRAD_LAUNCH
 #undef DSPN_WGRAD_LAUNCH_
   int rc = dspn::check_launch("conv_wgrad");

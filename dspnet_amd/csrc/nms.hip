@@ -121,6 +121,42 @@ __global__ __launch_bounds__(64) void nms_scan_kernel_px(const unsigned long lon
 
 int pow2_at_least(int n) { int p = 64; while (p < n) p <<= 1; return p; }
 
+// cython/bbox.pyx:15-55 (bbox_overlaps_cython): overlaps[n][k] of (N,4) boxes against (K,4) query boxes, float64, "+1"
+// pixel convention, the reference's operation order (this file is built with -ffp-contract=off; the f64 division is
+// IEEE).  A workgroup takes 256 consecutive rows n against a block of up to 64 queries held in LDS with their areas;
+// each thread owns one row and writes its K doubles in order (the reference's K is a few dozen ground-truth boxes).
+__global__ __launch_bounds__(256) void bbox_overlaps_kernel(const double *__restrict__ boxes, int N,
+                                                            const double *__restrict__ query, int K,
+                                                            double *__restrict__ out) {
+  __shared__ double q[64][5];
+  const int k0 = blockIdx.y * 64, kn = min(64, K - k0);
+  for (int i = threadIdx.x; i < kn; i += 256) {
+    const double x1 = query[(long long)(k0 + i) * 4], y1 = query[(long long)(k0 + i) * 4 + 1];
+    const double x2 = query[(long long)(k0 + i) * 4 + 2], y2 = query[(long long)(k0 + i) * 4 + 3];
+    q[i][0] = x1; q[i][1] = y1; q[i][2] = x2; q[i][3] = y2;
+    q[i][4] = (x2 - x1 + 1) * (y2 - y1 + 1);                      // box_area (bbox.pyx:35-38)
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const double bx1 = boxes[(long long)n * 4], by1 = boxes[(long long)n * 4 + 1];
+  const double bx2 = boxes[(long long)n * 4 + 2], by2 = boxes[(long long)n * 4 + 3];
+  const double barea = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+  double *o = out + (long long)n * K + k0;
+  for (int k = 0; k < kn; ++k) {
+    double v = 0.0;
+    const double iw = fmin(bx2, q[k][2]) - fmax(bx1, q[k][0]) + 1;
+    if (iw > 0) {
+      const double ih = fmin(by2, q[k][3]) - fmax(by1, q[k][1]) + 1;
+      if (ih > 0) {
+        const double ua = barea + q[k][4] - iw * ih;
+        v = iw * ih / ua;
+      }
+    }
+    o[k] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -157,6 +193,16 @@ int dspn_nms_pixel_f32(const float *dets_dev, int n, float thresh, int suppress_
   hipLaunchKernelGGL(nms_mask_kernel_px, dim3(cb, cb), dim3(64), 0, s, sorted, n, thresh, suppress_ge, mask, cb);
   hipLaunchKernelGGL(nms_scan_kernel_px, dim3(1), dim3(64), 0, s, mask, order, n, cb, keep_dev, num_keep_dev);
   return dspn::check_launch("nms_pixel");
+}
+
+int dspn_bbox_overlaps_f64(const double *boxes_dev, int N, const double *query_dev, int K, double *overlaps_dev,
+                           void *stream) {
+  DSPN_REQUIRE(N >= 0 && K >= 0, "bbox_overlaps: negative count");
+  if (N == 0 || K == 0) return 0;
+  DSPN_REQUIRE(boxes_dev && query_dev && overlaps_dev, "bbox_overlaps: null pointer");
+  hipLaunchKernelGGL(bbox_overlaps_kernel, dim3((N + 255) / 256, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     boxes_dev, N, query_dev, K, overlaps_dev);
+  return dspn::check_launch("bbox_overlaps");
 }
 
 }  // extern "C"

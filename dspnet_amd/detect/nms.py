@@ -4,7 +4,8 @@ Same callables -- `nms(dets, thresh)`, `cpu_nms`, `gpu_nms` and the three `*_wra
 (detect/nms.py:6-21) -- all backed by the HIP kernels behind include/dspn_nms.h; there is no CPU path.
 `dets`: (n, 5) [x1, y1, x2, y2, score], numpy array or torch tensor; returns the list of kept indices in
 descending score order, like the reference.  `nms` / `gpu_nms` drop a box whose overlap with a kept one is
-> thresh (detect/nms.py:55, cython/nms_kernel.cu:68), `cpu_nms` when it is >= thresh (cython/cpu_nms.pyx:65)."""
+> thresh (detect/nms.py:55, cython/nms_kernel.cu:68), `cpu_nms` when it is >= thresh (cython/cpu_nms.pyx:65).
+`bbox_overlaps` / `bbox_overlaps_cython`: the (N, K) float64 overlap matrix of cython/bbox.pyx:15-55."""
 import ctypes
 
 import numpy as np
@@ -17,7 +18,30 @@ _lib.register({
     "dspn_nms_pixel_workspace_bytes": (_c.c_size_t, [_c.c_int]),
     "dspn_nms_pixel_f32": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_float, _c.c_int, _c.c_void_p, _c.c_void_p,
                                       _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "dspn_bbox_overlaps_f64": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
 })
+
+
+def bbox_overlaps(boxes, query_boxes, device=None):
+    """cython/bbox.pyx:15-55 `bbox_overlaps_cython(boxes (N,4), query_boxes (K,4)) -> (N,K)`, float64, on the GPU.
+    numpy arrays in -> numpy array out (the reference's contract); torch CUDA tensors in -> a CUDA tensor out."""
+    as_numpy = isinstance(boxes, np.ndarray) or isinstance(query_boxes, np.ndarray)
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+
+    def dev64(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if isinstance(a, np.ndarray) else a.detach().to(torch.float64)
+        if t.ndim != 2 or t.shape[1] != 4:
+            raise _lib.DspnError("bbox_overlaps: boxes must be (n, 4) [x1, y1, x2, y2]")
+        return (t if t.is_cuda else t.to(dev)).contiguous()
+
+    b, q = dev64(boxes), dev64(query_boxes)
+    out = torch.zeros(b.shape[0], q.shape[0], dtype=torch.float64, device=b.device)
+    _lib.check(_lib.lib().dspn_bbox_overlaps_f64(b.data_ptr(), b.shape[0], q.data_ptr(), q.shape[0], out.data_ptr(),
+                                                 torch.cuda.current_stream(b.device).cuda_stream), "bbox_overlaps")
+    return out.cpu().numpy() if as_numpy else out
+
+
+bbox_overlaps_cython = bbox_overlaps      # the reference's name (cython/bbox.pyx:15)
 
 
 def _run(dets, thresh, suppress_ge, device=None):

@@ -85,12 +85,15 @@ def MultiBoxPrior(data, sizes=(1.0,), ratios=(1.0,), clip=False, steps=(-1.0, -1
 def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=-1.0,
                    negative_mining_ratio=-1.0, negative_mining_thresh=0.5,
                    minimum_negative_samples=0, variances=(0.1, 0.1, 0.2, 0.2),
-                   check_errors=False):
+                   check_errors=False, workspace=None):
     """Training targets.  anchor (1,N,4), label (B,L,6), cls_pred (B,C+1,N) ->
     [loc_target (B,N*5), loc_mask (B,N*5), cls_target (B,N)].
     Shape rules and messages: multibox_target-inl.h:213-238.
     check_errors=True synchronises and raises on the data-dependent aborts of the
-    reference (multibox_target.cc:98-101, :236)."""
+    reference (multibox_target.cc:98-101, :236).
+    workspace: a caller-owned uint8 device buffer of at least target_workspace_bytes(B, N, L) bytes (the reference's
+    kTempSpace request); it also receives the per-sample abort codes MultiBoxTarget_check reads.  Default: a buffer
+    shared by every call on the device."""
     variances = _tuple(variances)
     if anchor.dim() != 3:
         raise DspnError("Anchor should be batch shared N*4 tensor")
@@ -121,7 +124,12 @@ def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=
     cls_target = torch.empty((B, N), dtype=torch.float32, device=dev)
     L = _lib.lib()
     nbytes = L.dspn_multibox_target_workspace_bytes(B, N, Lr)
-    ws = _workspace(nbytes, dev, "target")
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or workspace.device != dev or workspace.numel() < nbytes:
+            raise DspnError(f"MultiBoxTarget: workspace must be a uint8 tensor of >= {nbytes} bytes on {dev}")
+        ws = workspace
+    else:
+        ws = _workspace(nbytes, dev, "target")
     check(L.dspn_multibox_target_f32(
         anchor.data_ptr(), label.data_ptr(), cls_pred.data_ptr(), B, N, Lr, int(label.shape[2]),
         int(cls_pred.shape[1]), float(overlap_threshold), float(ignore_label),
@@ -136,12 +144,18 @@ def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=
     return [loc_target, loc_mask, cls_target]
 
 
-def MultiBoxTarget_check(batch, device):
-    """Deferred form of check_errors=True: reads the per-sample abort codes the LAST MultiBoxTarget call on `device`
-    left in its workspace (synchronises) and raises DspnError with the reference's message if a label row after the
+def target_workspace_bytes(batch, num_anchors, num_labels):
+    return int(_lib.lib().dspn_multibox_target_workspace_bytes(int(batch), int(num_anchors), int(num_labels)))
+
+
+def MultiBoxTarget_check(batch, device, workspace=None):
+    """Deferred form of check_errors=True: reads the per-sample abort codes a MultiBoxTarget call of `batch` samples left
+    in its workspace (synchronises) and raises DspnError with the reference's message if a label row after the
     terminator was not all -1 (multibox_target.cc:98-101) or hard-negative mining ran out of candidates (:236).  A
-    training loop calls this once per step where it synchronises anyway (solver.fit does, at the metric read-out)."""
-    ws = _ws_cache.get(("target", device))
+    training loop calls this once per step where it synchronises anyway (solver.fit does, at the metric read-out).
+    workspace: the buffer that call was given (a graph node keeps its own, so two graphs on one device never read each
+    other's codes); default: the shared buffer, i.e. the LAST call on `device` without a workspace of its own."""
+    ws = workspace if workspace is not None else _ws_cache.get(("target", device))
     if ws is None:
         return
     L = _lib.lib()

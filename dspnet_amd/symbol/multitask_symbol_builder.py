@@ -37,6 +37,10 @@ class MultiBoxTargetNode(E.Node):
         B, N = cls_flat.shape[0], anchors.shape[1]
         self.cls_preds = g.tensor((B, num_cls, N), "multibox_cls_pred", requires_grad=False, dtype=torch.float32)
         self.loc_target = self.loc_mask = self.cls_target = None
+        # the operator's temp space, owned by this node: it also holds the per-sample abort codes of THIS node's last
+        # forward (two graphs on one device -- a training and an evaluation net -- never read each other's)
+        self.ws = (torch.empty(op.target_workspace_bytes(B, N, label.shape[1]), dtype=torch.uint8, device=g.device)
+                   if g.device.type == "cuda" else None)
 
     def forward(self):
         B, C, N = self.cls_preds.shape
@@ -44,12 +48,12 @@ class MultiBoxTargetNode(E.Node):
         self.loc_target, self.loc_mask, self.cls_target = op.MultiBoxTarget(
             self.anchors, self.label.data, self.cls_preds.data, overlap_threshold=.5, ignore_label=-1,
             negative_mining_ratio=3, minimum_negative_samples=0, negative_mining_thresh=.5,
-            variances=(0.1, 0.1, 0.2, 0.2))
+            variances=(0.1, 0.1, 0.2, 0.2), workspace=self.ws)
 
     def raise_on_errors(self):
         """the reference's data-dependent CHECKs (multibox_target.cc:98-101, :236) for the last forward: synchronises;
         the kernel itself only records the codes so that the step never waits on the host"""
-        op.MultiBoxTarget_check(self.cls_preds.shape[0], self.cls_preds.data.device)
+        op.MultiBoxTarget_check(self.cls_preds.shape[0], self.cls_preds.data.device, workspace=self.ws)
 
 
 class ClsSoftmaxOutput(E.Node):

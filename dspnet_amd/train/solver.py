@@ -69,7 +69,7 @@ class MultiTaskSolver:
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
-        self._graph = None
+        self._graph, self._graph_hyper = None, None
         g = self.g
         owner = {}
         for idx, n in enumerate(g.nodes):
@@ -125,6 +125,13 @@ class MultiTaskSolver:
 
     def step(self):
         if self._graph is not None:
+            # the recorded SGD launch carries lr / momentum / wd BY VALUE: a schedule that moved them since the recording
+            # (the reference's optimizer takes an lr_scheduler, multi_solver.py:221) drops the graph and records a new one
+            if (self.lr, self.momentum, self.wd) != self._graph_hyper:
+                self._graph = None
+                if not self.capture(warmup=0):
+                    self.forward(); self.backward(); self.update()
+                    return
             self._graph.replay()
             return
         self.forward()
@@ -145,18 +152,24 @@ class MultiTaskSolver:
             self.step()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        det = getattr(self.net, "det", None)
         try:
             with torch.cuda.graph(graph):
                 self.forward()
                 self.backward()
                 self.update()
-                det = getattr(self.net, "det", None)
                 if det is not None:
                     det.join()                    # the side stream of MultiBoxDetection joins before the capture ends
-        except Exception:
+        except Exception as e:                    # noqa: BLE001 -- whatever broke the recording, the step stays eager
+            import logging
+            logging.getLogger(__name__).warning("MultiTaskSolver.capture: recording failed, the step stays eager: %r", e)
             torch.cuda.synchronize()
+            if det is not None:
+                # an event recorded inside the aborted capture must not be waited on by the next eager join()
+                det.pending = False
             return False
         self._graph = graph
+        self._graph_hyper = (self.lr, self.momentum, self.wd)
         return True
 
 
@@ -194,29 +207,37 @@ def fit(solver, train_data, begin_epoch=0, num_epoch=1, batch_end_callback=None,
     logger = logger or logging
     net = solver.net
     multibox_metric = MultiBoxMetric()
-    acc_metric = CustomAccuracyMetric(num_classes=net.seg_out.C)
+    # a detection-only graph (get_det_symbol_train) has no segmentation output: no pixel-accuracy metric, as in the
+    # reference's det_solver.py; a segmentation-only graph keeps MultiBoxMetric's SegCrossEntropy slot only
+    has_seg = getattr(net, "seg_out", None) is not None
+    acc_metric = CustomAccuracyMetric(num_classes=net.seg_out.C) if has_seg else None
     history = []
     for epoch in range(begin_epoch, num_epoch):
         nbatch = 0
         train_data.reset()
-        multibox_metric.reset(); acc_metric.reset()
+        multibox_metric.reset()
+        if acc_metric is not None:
+            acc_metric.reset()
         while train_data.iter_next():
             batch, _ = train_data.next()
             nbatch += 1
             solver.set_batch(batch.data[0], batch.label[0], batch.label[1])
             solver.step()
             multibox_metric.update(net)
-            acc_metric.update([net.label_seg.data], [net.seg_out.prob.data])
-            if check_label_errors and net.target is not None:
+            if acc_metric is not None:
+                acc_metric.update([net.label_seg.data], [net.seg_out.prob.data])
+            if check_label_errors and getattr(net, "target", None) is not None:
                 net.target.raise_on_errors()
             if batch_end_callback is not None:
-                batch_end_callback(BatchEndParam(epoch, nbatch, (multibox_metric, acc_metric)))
+                batch_end_callback(BatchEndParam(epoch, nbatch, (multibox_metric, acc_metric) if acc_metric is not None
+                                                 else (multibox_metric,)))
         if epoch_end_callback is not None:
             epoch_end_callback(epoch, net)
         names, values = multibox_metric.get()
         out = dict(zip(names, values))
-        name, value = acc_metric.get()
-        out[name] = value
+        if acc_metric is not None:
+            name, value = acc_metric.get()
+            out[name] = value
         for k, v in out.items():
             logger.info("                     --->Epoch[%d] Train-%s=%f", epoch, k, v)
         if eval_data is not None:

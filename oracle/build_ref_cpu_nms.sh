@@ -1,7 +1,8 @@
 #!/bin/bash
-# Builds the REFERENCE's own CPU NMS (cython/cpu_nms.pyx:17-68, unmodified, read where it lies under
-# /root/reference) into oracle/_ref/ -- test infrastructure, build container only (oracle/_ref/ is git-ignored and
-# nothing on the GPU box needs it: the vectors it produces are committed under tests/golden/).
+# Builds the REFERENCE's own CPU NMS (cython/cpu_nms.pyx:17-68) and box-overlap function (cython/bbox.pyx:15-55), both
+# unmodified, read where they lie under /root/reference, into oracle/_ref/ -- test infrastructure, build container only
+# (oracle/_ref/ is git-ignored and nothing on the GPU box needs it: the vectors they produce are committed under
+# tests/golden/).
 #
 # Toolchain: the .pyx is Cython-0.2x / numpy-1.x era code (`np.int_t` buffers, `np.int` dtype).  The image's main
 # interpreter (python3.10, Cython 3.2, numpy 2.2) rejects it at compile time (numpy 2 dropped `int_t` from its .pxd),
@@ -19,10 +20,13 @@ OUT="$HERE/_ref"
 mkdir -p "$OUT"
 TMP="$(mktemp -d)"
 trap 'rm -rf "$TMP"' EXIT
-ln -s "$REF/cython/cpu_nms.pyx" "$TMP/cpu_nms.pyx"
-"$PY" -m cython -3 "$TMP/cpu_nms.pyx" -o "$TMP/cpu_nms.c"
 NPINC="$("$PY" -c 'import numpy; print(numpy.get_include())')"
 PYINC="$("$PY" -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
 EXT="$("$PY" -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')"
-gcc -O2 -fPIC -shared -fno-fast-math -ffp-contract=off -Wno-cpp -I"$NPINC" -I"$PYINC" "$TMP/cpu_nms.c" -o "$OUT/cpu_nms$EXT"
-echo "built $OUT/cpu_nms$EXT"
+for MOD in cpu_nms bbox; do
+  [ -f "$REF/cython/$MOD.pyx" ] || continue
+  ln -s "$REF/cython/$MOD.pyx" "$TMP/$MOD.pyx"
+  "$PY" -m cython -3 "$TMP/$MOD.pyx" -o "$TMP/$MOD.c"
+  gcc -O2 -fPIC -shared -fno-fast-math -ffp-contract=off -Wno-cpp -I"$NPINC" -I"$PYINC" "$TMP/$MOD.c" -o "$OUT/$MOD$EXT"
+  echo "built $OUT/$MOD$EXT"
+done

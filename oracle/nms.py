@@ -63,3 +63,19 @@ def cpu_nms(dets, thresh, order=None):
             ovr = inter / (areas[i] + areas[rest] - inter)
         suppressed[rest[ovr >= np.float32(thresh)]] = True
     return keep
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """cython/bbox.pyx:15-55 (`bbox_overlaps_cython`): (N, 4) x (K, 4) float64 -> (N, K) float64 overlaps in the "+1"
+    pixel convention, operation for operation in float64 (iw first; a pair with iw <= 0 or ih <= 0 stays exactly 0 and
+    never reaches the division).  PINNED: the reference file compiles unmodified (oracle/build_ref_cpu_nms.sh) and its
+    outputs on 12 cases are committed as tests/golden/bbox_overlaps.npz, reproduced bit for bit (tests/test_nms_pixel.py)."""
+    b = np.asarray(boxes, np.float64).reshape(-1, 4)
+    q = np.asarray(query_boxes, np.float64).reshape(-1, 4)
+    box_area = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)                       # (K,)
+    iw = np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0]) + 1
+    ih = np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1]) + 1
+    ua = (b[:, 2] - b[:, 0] + 1)[:, None] * (b[:, 3] - b[:, 1] + 1)[:, None] + box_area[None, :] - iw * ih
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ov = iw * ih / ua
+    return np.where((iw > 0) & (ih > 0), ov, 0.0)

@@ -109,3 +109,45 @@ def test_hip_nms_reproduces_reference_golden_vectors(gpu_device):
             assert dn.cpu_nms(d, t) == keep_cpu, (name, t)
         n += 1
     assert n >= 20
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bbox_overlaps (cython/bbox.pyx:15-55), pinned the same way: the .pyx compiles unmodified (oracle/build_ref_cpu_nms.sh),
+# tests/golden/make_bbox_golden.py stores its inputs and outputs.
+def _bbox_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bbox_overlaps.npz"))
+    for k in range(int(z["count"])):
+        yield str(z["name_%d" % k]), z["boxes_%d" % k], z["query_%d" % k], z["overlaps_%d" % k]
+
+
+def test_bbox_overlaps_oracle_reproduces_reference_golden_vectors():
+    """pins oracle/nms.py: bbox_overlaps bit for bit (float64) on every case, incl. empty inputs and touching boxes"""
+    seen = set()
+    for name, b, q, exp in _bbox_golden():
+        seen.add(name)
+        got = onms.bbox_overlaps(b, q)
+        assert got.shape == exp.shape and got.dtype == np.float64
+        assert np.array_equal(got, exp), name
+    assert {"random_2000x64", "touching", "identical", "degenerate", "empty_boxes", "empty_query"} <= seen
+    # hand case: a shared edge column still intersects with the +1 convention (iw = 1); one pixel apart does not
+    name, b, q, exp = [c for c in _bbox_golden() if c[0] == "touching"][0]
+    assert exp[0, 0] == 1.0 and exp[1, 0] == 0.0 and exp[2, 0] == 0.0
+    assert exp[0, 1] == 1.0 / (100 + 16 - 1)            # boxes share exactly the pixel (9, 9)
+
+
+@pytest.mark.gpu
+def test_hip_bbox_overlaps_reproduces_reference_golden_vectors(gpu_device):
+    """dspn_bbox_overlaps_f64 against the reference-generated matrices: identical bits"""
+    import torch
+    from dspnet_amd.detect import nms as dn
+    for name, b, q, exp in _bbox_golden():
+        got = dn.bbox_overlaps(b, q)
+        assert isinstance(got, np.ndarray) and got.shape == exp.shape and got.dtype == np.float64
+        assert np.array_equal(got, exp), name
+    g = np.random.Generator(np.random.PCG64(5))
+    b = g.uniform(0, 500, (5000, 4)); b[:, 2:] += b[:, :2]
+    q = g.uniform(0, 500, (200, 4)); q[:, 2:] += q[:, :2]
+    assert np.array_equal(dn.bbox_overlaps_cython(b, q), onms.bbox_overlaps(b, q))         # several query blocks
+    t = dn.bbox_overlaps(torch.from_numpy(b).cuda(), torch.from_numpy(q).cuda())
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), onms.bbox_overlaps(b, q))

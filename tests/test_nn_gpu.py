@@ -64,16 +64,14 @@ CONV_CASES = [
     (1, 16, 16, 200, 19, 3, 1, 1, 1),     # score3_conv-like (Cout 19)
     (2, 5, 5, 128, 130, 3, 2, 1, 1),      # extras, tiny maps
     (1, 3, 3, 128, 128, 3, 2, 1, 1),
-    (4, 64, 64, 64, 128, 3, 1, 1, 1),     # 512 tiles of 64x64; split math: halo-resident A tile, 4x16 patches
-    # split math (DSPN_MATH_F32_BF16X3), 3x3 / stride 1 / 'same' with whole 16-column patches: the halo-resident A tile in
-    # each of its tile shapes (conv.hip conv_nt_kernel<..., HALO>), forward and data gradient
-    (8, 64, 64, 64, 128, 3, 1, 1, 1),     # forward: 128x128 on 8 waves (8x16 patches); data gradient: 64x64
-    (8, 64, 64, 128, 128, 3, 1, 1, 1),    # both on 8 waves, two 32-channel blocks per image load on the gradient side
+    (4, 64, 64, 64, 128, 3, 1, 1, 1),     # 512 tiles of 64x64
+    # 3x3 / stride 1 layers large enough for every tile shape of conv_nt_kernel without split-K (the split math reads the
+    # weights of all of these as piece planes)
+    (8, 64, 64, 64, 128, 3, 1, 1, 1),     # forward: 128x128 on 8 waves; data gradient: 64x64
+    (8, 64, 64, 128, 128, 3, 1, 1, 1),    # both on 8 waves
     (4, 64, 64, 128, 192, 3, 1, 1, 1),    # forward: 128x64 tiles (Cout just past 128)
-    (32, 16, 16, 64, 128, 3, 1, 1, 1),    # one patch column per image row (stage-4 maps)
-    (4, 24, 48, 64, 128, 3, 1, 1, 1),     # 24 rows: whole 4-row and 8-row patches, three patch columns
-    (3, 20, 32, 64, 96, 3, 1, 1, 1),      # 20 rows: 4-row patches only
-    (2, 18, 32, 64, 64, 3, 1, 1, 1),      # 18 rows: no whole patches -> the generic kernel
+    (32, 16, 16, 64, 128, 3, 1, 1, 1),    # stage-4 sized maps
+    (3, 20, 32, 64, 96, 3, 1, 1, 1),
 ]
 
 
@@ -559,7 +557,7 @@ def test_conv_bf16_mfma_math(gpu_device, bf16_math, case):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1, 1), (2, 17, 19, 32, 48, 3, 2, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0, 1),
                                   (2, 16, 16, 128, 256, 1, 2, 0, 1), (1, 9, 9, 36, 40, 3, 1, 1, 1), (4, 64, 64, 64, 128, 3, 1, 1, 1),
-                                  (8, 64, 64, 64, 128, 3, 1, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1, 1)])   # (halo tile: 8 waves, 128x64)
+                                  (8, 64, 64, 64, 128, 3, 1, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1, 1)])   # (8 waves; 128x64 tiles)
 @pytest.mark.parametrize("relu", [True, False])
 def test_conv_with_input_affine(gpu_device, conv_math, case, relu):
     """dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32: BatchNorm-apply (+ReLU) folded into the tile loader ==
@@ -588,7 +586,7 @@ def test_conv_with_input_affine(gpu_device, conv_math, case, relu):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 64, 256, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
                                   (4, 64, 64, 64, 128, 3, 1, 1), (1, 5, 7, 128, 132, 1, 1, 0), (32, 32, 32, 64, 256, 1, 1, 0),
-                                  (8, 64, 64, 64, 128, 3, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1),   # halo tile: 8 waves, 128x64
+                                  (8, 64, 64, 64, 128, 3, 1, 1), (4, 64, 64, 64, 192, 3, 1, 1),   # 8 waves; 128x64 tiles
                                   (8, 128, 128, 16, 64, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("with_res", [False, True])
 def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_res):
@@ -625,7 +623,7 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_re
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 16, 16, 256, 64, 1, 1, 0), (2, 17, 19, 32, 48, 3, 2, 1),
                                   (2, 16, 16, 128, 256, 1, 2, 0), (4, 64, 64, 128, 64, 3, 1, 1), (32, 32, 32, 256, 64, 1, 1, 0),
-                                  (8, 64, 64, 128, 128, 3, 1, 1), (4, 64, 64, 192, 64, 3, 1, 1),   # halo tile: 8 waves, 128x64
+                                  (8, 64, 64, 128, 128, 3, 1, 1), (4, 64, 64, 192, 64, 3, 1, 1),   # 8 waves; 64x64 tiles
                                   (8, 128, 128, 64, 16, 1, 1, 0)])      # last: 2048 tiles -> grouped pre-reduction
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, conv_math, case, accumulate):
