@@ -551,6 +551,8 @@ def main():
     # HIP events around every convolution launch cost ~2.5 ms of a 60 ms step (measured: 517 vs 539 images/s with every
     # step instrumented), so only PROF_STEPS steps of the timed region carry them; the other steps run as in production
     prof_steps = min(PROF_STEPS, args.steps) if prof else 0
+    if solver.reducer is not None:
+        solver.reducer.measure_exposed = True          # two event records per step around the collective waits
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == 0 and prof_steps:
@@ -561,6 +563,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     lib.dspn_profile_enable(0)
+    exposed_ms = solver.reducer.exposed_ms() if solver.reducer is not None else None
+    n_buckets = len(solver.buckets)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -641,6 +645,11 @@ def main():
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if exposed_ms is not None:
+            # what rank 0's compute stream waited for the gradient all-reduce after the last backward kernel (mean per step):
+            # the part of the bucketed collectives that backward did NOT hide
+            line["allreduce_exposed_ms"] = round(exposed_ms, 4)
+            line["allreduce_buckets"] = n_buckets
         if other is not None:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

@@ -1610,7 +1610,7 @@ static_assert(kPlanPK % kPK == 0, "split sizes must be whole k-steps");
 // holds at once, set by LDS per workgroup), each costs its pixels plus a fixed prologue/epilogue, and
 // every split adds one slab to write and re-read.  (A plain "about 1024 workgroups" rule lands just
 // past a round boundary for the 3x3 layers: 36 tiles x 29 splits = 1044 = 2.04 rounds.)
-WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
+WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0, long long max_splits = 1 << 30) {
   WgradPlan p;
   p.bm = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
   if (p.bm == 128 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) p.bm = 64;   // less row padding
@@ -1629,7 +1629,9 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
   // L2 so that only the first tap's workgroups fetch it from HBM
   long long s_min = 1;
   if (x_bytes > 0) s_min = (x_bytes + (32ll << 20) - 1) / (32ll << 20);
-  const long long s_max = std::max<long long>(1, std::min<long long>(P / 128, 1024));
+  // (max_splits: what the caller's slab workspace holds -- a batch chunk of a >= 2 GiB tensor can want more slabs than the
+  // plan of the whole batch that sized the workspace)
+  const long long s_max = std::max<long long>(1, std::min<long long>(std::min<long long>(P / 128, 1024), max_splits));
   s_min = std::min(s_min, s_max);
   const double flop_per_pix = 2.0 * p.bm * p.bn, slot_rate = 120e12 / (double)slots, ovh_pix = 160;
   double best = 1e30;
@@ -1644,6 +1646,7 @@ WgradPlan wgrad_plan(long long P, int Cout, int J, long long x_bytes = 0) {
     if (tiles * sp > 8 * slots) break;
   }
   if (const char *e = getenv("DSPN_WG_SPLITS")) splits = std::max<long long>(1, std::min<long long>(atoll(e), s_max));   // experiments
+  splits = std::min(splits, s_max);
   long long pps = ((P + splits - 1) / splits + kPlanPK - 1) / kPlanPK * kPlanPK;
   p.splits = (int)((P + pps - 1) / pps);
   p.pps = (int)pps;
@@ -2000,7 +2003,10 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
   }
   const long long P = (long long)N * Ho * Wo;
   const int J = R * S * Cin;
-  const WgradPlan plan = wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0);
+  const long long ws_splits = (long long)(workspace_bytes / (sizeof(float) * (size_t)Cout * J));
+  if (ws_splits < 1)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu (one slab)", workspace_bytes, sizeof(float) * (size_t)Cout * J);
+  const WgradPlan plan = wgrad_plan(P, Cout, J, R * S > 1 ? 4ll * P * Cin * std::min(stride, 2) * std::min(stride, 2) : 0, ws_splits);
   const int BM = plan.bm, BN = plan.bn;
   const int kt = (Cout + BM - 1) / BM, jt = (J + BN - 1) / BN;
   const long long splits = plan.splits;

@@ -44,6 +44,10 @@ class GradBucketReducer:
     def __init__(self, grad_arena, buckets, process_group=None):
         self.arena, self.buckets, self.pg = grad_arena, buckets, process_group
         self.pending, self.works, self.launched = [], [], []
+        # measure_exposed = True: bracket the waits of finish() with events on the compute stream; the time between them
+        # is what the step waits for the collectives AFTER backward has run out of kernels to overlap them with
+        # (bench.py reports the mean as allreduce_exposed_ms)
+        self.measure_exposed, self.exposed_events = False, []
 
     def begin(self):
         self.pending = list(self.buckets)
@@ -58,8 +62,24 @@ class GradBucketReducer:
 
     def finish(self):
         assert not self.pending, "backward ended before every bucket was released"
+        timed = self.measure_exposed and self.arena.is_cuda
+        if timed:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.works:
             w.wait()
+        if timed:
+            e1.record()
+            self.exposed_events.append((e0, e1))
+
+    def exposed_ms(self):
+        """mean time per step the compute stream spent blocked in finish() (call after a device synchronize)"""
+        if not self.exposed_events:
+            return None
+        t = sum(a.elapsed_time(b) for a, b in self.exposed_events) / len(self.exposed_events)
+        self.exposed_events = []
+        return t
 
 
 class MultiTaskSolver:

@@ -189,10 +189,10 @@ def inceptionv3(P, data):
         y = _conv(x, P[n + "_conv2d_weight"], stride=stride, padding=pad)
         mean = y.mean(dim=(0, 2, 3), keepdim=True)
         var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
-        return F.relu((y - mean) / torch.sqrt(var + 1e-3) + P[n + "_batchnorm_beta"].view(1, -1, 1, 1))
+        return _relu((y - mean) / torch.sqrt(var + 1e-3) + P[n + "_batchnorm_beta"].view(1, -1, 1, 1), n + "_batchnorm")
 
     def pool(x, kind, k, s, p):
-        return F.max_pool2d(x, k, s, p) if kind == "max" else F.avg_pool2d(x, k, s, p, count_include_pad=True)
+        return _max_pool(x, k, s, p) if kind == "max" else F.avg_pool2d(x, k, s, p, count_include_pad=True)
 
     def A(x, kind, name):
         t1 = C(x, name + '_conv')
@@ -231,9 +231,9 @@ def inceptionv3(P, data):
 
     inter = {}
     x = C(C(C(data, "conv", stride=2), "conv_1"), "conv_2", pad=(1, 1))
-    x = F.max_pool2d(x, 3, 2)
+    x = _max_pool(x, 3, 2)
     x = C(C(x, "conv_3"), "conv_4")
-    x = F.max_pool2d(x, 3, 2)
+    x = _max_pool(x, 3, 2)
     x = A(x, "avg", "mixed"); x = A(x, "avg", "mixed_1"); x = A(x, "avg", "mixed_2")
     x = Bk(x, "mixed_3")
     for nm in ("mixed_4", "mixed_5", "mixed_6", "mixed_7"):
@@ -256,7 +256,7 @@ def forward_loss(values, data, label_det, label_seg, sizes=None, ratios=None, nu
     outputs, the loss readouts, the scalar objective whose gradient MXNet's loss ops inject, and Params.
     conv_quant="bf16": bf16-operand convolutions (see _QUANT above); call .backward() on the objective INSIDE
     `with quantized("bf16"):` as well, the gradient GEMMs read the same switch.
-    decisions: pinned ReLU / max-pool choices (see _DECISIONS above; resnet and vgg16_reduced wiring)."""
+    decisions: pinned ReLU / max-pool choices (see _DECISIONS above; every backbone)."""
     global _QUANT, _DECISIONS
     prev, _QUANT = _QUANT, conv_quant
     prev_d, _DECISIONS = _DECISIONS, decisions

@@ -29,6 +29,15 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 4 and lines[0]["warmup"] == 1
 
 
+def test_gpus_8_spawns_eight_ranks_and_prints_one_line():
+    """the driver's largest configuration: eight ranks rendezvous on the loopback interface, the sum all-reduce sees all
+    of them, ONE line comes out (this container has 8 cores; the GPU box gives the job 16)"""
+    r = _run("--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0] == {"dry_run": True, "n_gpus": 8, "steps": 2, "warmup": 0}
+
+
 def test_gpus_1_runs_in_process():
     r = _run("--dry-run")
     assert r.returncode == 0 and _json_lines(r.stdout) == [{"dry_run": True, "n_gpus": 1, "steps": 10, "warmup": 3}]

@@ -772,3 +772,36 @@ def test_split_bf16_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
         # the root-mean-square error is the stable statistic (the largest of 10^5 .. 10^7 errors fluctuates by tens of percent
         # between two evaluations of equal quality): within 1.25x; the largest error within 2x
         assert rx <= 1.25 * rf + 1e-9 and mx <= 2.0 * mf + 1e-8, (key, errs)
+
+
+@pytest.mark.parametrize("k,cout", [(1, 64), (3, 32)])
+def test_conv_tensors_of_2_gib_and_more_run_in_batch_chunks(gpu_device, conv_math, k, cout):
+    """The buffer-addressed kernels take tensors below 2 GiB (32-bit offsets, bit 31 = out of range); the C entry points cut
+    larger batches into chunks of images (conv.hip batch_chunk).  x here is 130 x 128 x 128 x 256 floats = 2.03 GiB:
+    forward, data gradient (dx of 2.03 GiB written by chunks of dy) and weight gradient (accumulated over the chunks)
+    against torch's own ROCm convolution evaluated on sub-batches of 26 images."""
+    N, H, W, Cin = 130, 128, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(k + cout)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    assert x.numel() * 4 >= 2 ** 31
+    w = torch.randn(cout, k, k, Cin, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    dy = torch.randn(N, H, W, cout, device="cuda", generator=g)
+    pad = k // 2
+    y = fn.conv2d_forward(x, w, None, 1, pad, 1)
+    dx = fn.conv2d_dgrad(dy, fn.weight_transpose(w), tuple(x.shape), 1, pad, 1)
+    dw = fn.conv2d_wgrad(x, dy, tuple(w.shape), 1, pad, 1)
+    wr = w.permute(0, 3, 1, 2).contiguous()
+    dw_ref = torch.zeros_like(wr, dtype=torch.float64)
+    ymax = dxmax = yerr = dxerr = 0.0
+    for n0 in range(0, N, 26):
+        xs = x[n0:n0 + 26].permute(0, 3, 1, 2).detach().requires_grad_()
+        ws = wr.detach().requires_grad_()
+        ys = F.conv2d(xs, ws, None, 1, pad)
+        ys.backward(dy[n0:n0 + 26].permute(0, 3, 1, 2))
+        yerr = max(yerr, float((y[n0:n0 + 26].permute(0, 3, 1, 2) - ys).abs().max())); ymax = max(ymax, float(ys.abs().max()))
+        dxerr = max(dxerr, float((dx[n0:n0 + 26].permute(0, 3, 1, 2) - xs.grad).abs().max())); dxmax = max(dxmax, float(xs.grad.abs().max()))
+        dw_ref += ws.grad.double()
+        del xs, ys
+    assert yerr <= 1e-4 * ymax and dxerr <= 1e-4 * dxmax, (yerr, ymax, dxerr, dxmax)
+    dwerr = float((dw.permute(0, 3, 1, 2).double() - dw_ref).abs().max())
+    assert dwerr <= 2e-4 * float(dw_ref.abs().max()), (dwerr, float(dw_ref.abs().max()))
