@@ -1382,43 +1382,65 @@ __global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int 
   }
 }
 
-// Piece planes of a weight operand for the split mode (DSPN_MATH_F32_BF16X3): the matrix D[rows][T][cols], cols % 32 == 0,
-//   D = W itself   (rows = K, cols = C; forward operand)                 when !transposed,
-//   D = W^T        (rows = C, cols = Kp >= K zero padded; data gradient) when transposed,
-// of a float master W[K][T][C], every element cut into its three bf16 pieces by the same split3 the loaders use and stored
-// as planes[row][t][cols / 32][piece][32].  One thread per element; rows of the table sorted by `begin` as in the
-// batched transpose.
-struct WpDesc { const float *w; __bf16 *planes; int K, T, C, cols; long long begin; int transposed, pad_; };
-__device__ __forceinline__ void weight_planes_one(const WpDesc &e, long long j) {
-  const int col = (int)(j % e.cols);
-  const long long rt = j / e.cols;
-  const int t = (int)(rt % e.T), row = (int)(rt / e.T);
-  float v;
-  if (e.transposed) v = col < e.K ? e.w[((long long)col * e.T + t) * e.C + row] : 0.f;
-  else v = e.w[((long long)row * e.T + t) * e.C + col];
-  const __bf16 p0 = (__bf16)v;
-  const float r1 = v - (float)p0;
-  const __bf16 p1 = (__bf16)r1;
-  const __bf16 p2 = (__bf16)(r1 - (float)p1);
-  __bf16 *d = e.planes + (rt * (e.cols >> 5) + (col >> 5)) * kPlaneBlk + (col & 31);
-  d[0] = p0; d[32] = p1; d[64] = p2;
-}
-__global__ void weight_planes_batch_kernel(const WpDesc *__restrict__ d, int n, long long total) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (d[mid].begin <= i) lo = mid; else hi = mid - 1;
+// Piece planes of a weight operand for the split mode (DSPN_MATH_F32_BF16X3), of a float master W[K][T][C]:
+//   planes   = those of W itself      [K][T][C / 32][piece][32]        (forward operand; C % 32 == 0)
+//   planes_t = those of its transpose [C][T][cols_t / 32][piece][32]   (data-gradient operand; cols_t >= K zero padded)
+// every element cut into its three bf16 pieces by the same split3 the loaders use.  One workgroup per (32 k) x (32 c) tile of
+// one tap: the tile is read once as 128-byte rows, the forward planes leave as 64-byte runs per row and piece, the
+// transposed ones go through a 6-KB LDS image and leave the same way -- both operands of a layer from ONE read of its
+// weights, every access a full line (the first version, one thread per element with 2-byte stores, took 0.51 ms per step;
+// the float transpose it replaced 0.27).  Table rows sorted by `begin` (tile index), found by binary search per workgroup.
+struct WpDesc { const float *w; __bf16 *planes; __bf16 *planes_t; int K, T, C, cols_t; long long begin; };
+__device__ __forceinline__ void weight_planes_tile(const WpDesc &e, long long tile, __bf16 (*sm)[32][36]) {
+  const int cblocks = (e.C + 31) >> 5;
+  const int cb = (int)(tile % cblocks);
+  const long long kt = tile / cblocks;
+  const int t = (int)(kt % e.T), kb = (int)(kt / e.T);
+  const int r = threadIdx.x >> 3, q = threadIdx.x & 7;          // row of the tile, group of 4 consecutive columns
+  const int k = kb * 32 + r, c = cb * 32 + 4 * q;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < e.K && c < e.C) v = *reinterpret_cast<const float4 *>(e.w + ((long long)k * e.T + t) * e.C + c);   // C % 4 == 0
+  bf16x4 p[3];
+  split3(v, p[0], p[1], p[2]);
+  if (e.planes && k < e.K && c < e.C) {      // (C % 32 == 0 whenever the forward planes exist)
+    __bf16 *d = e.planes + (((long long)k * e.T + t) * (e.C >> 5) + cb) * kPlaneBlk + 4 * q;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = p[pc];
+  }
+  if (!e.planes_t) return;                    // block-uniform
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[pc][4 * q + i][r] = p[pc][i];    // [piece][c][k]
+  __syncthreads();
+  const int cc = cb * 32 + r;                 // this thread's row of the transposed operand, columns k = 4q .. 4q+3 of the block
+  if (cc < e.C && kb * 32 < e.cols_t) {
+    __bf16 *d = e.planes_t + (((long long)cc * e.T + t) * (e.cols_t >> 5) + kb) * kPlaneBlk + 4 * q;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      bf16x4 o = {sm[pc][r][4 * q], sm[pc][r][4 * q + 1], sm[pc][r][4 * q + 2], sm[pc][r][4 * q + 3]};
+      *reinterpret_cast<bf16x4 *>(d + 32 * pc) = o;
     }
-    const WpDesc e = d[lo];
-    weight_planes_one(e, i - e.begin);
   }
 }
-__global__ void weight_planes_kernel(const WpDesc e, long long total) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x)
-    weight_planes_one(e, i);
+__global__ __launch_bounds__(256) void weight_planes_batch_kernel(const WpDesc *__restrict__ d, int n) {
+  __shared__ __bf16 sm[3][32][36];
+  const long long tile = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].begin <= tile) lo = mid; else hi = mid - 1;
+  }
+  const WpDesc e = d[lo];
+  weight_planes_tile(e, tile - e.begin, sm);
+}
+__global__ __launch_bounds__(256) void weight_planes_kernel(const WpDesc e) {
+  __shared__ __bf16 sm[3][32][36];
+  weight_planes_tile(e, blockIdx.x, sm);
+}
+// tiles of one table row: k blocks (of the padded transposed operand, if any) x taps x c blocks
+long long weight_planes_tiles(int K, int T, int C, int cols_t, bool with_t) {
+  return (long long)((std::max(K, with_t ? cols_t : K) + 31) / 32) * T * ((C + 31) / 32);
 }
 
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
@@ -1787,23 +1809,28 @@ int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long t
 }
 
 /* piece planes of a weight operand (DSPN_MATH_F32_BF16X3, include/dspn_nn.h) */
-int dspn_conv2d_weight_planes_f32(const float *w, void *planes, int Cout, int taps, int Cin, int cols, int transposed,
+int dspn_conv2d_weight_planes_f32(const float *w, void *planes, void *planes_t, int Cout, int taps, int Cin, int cols_t,
                                   void *stream) {
-  DSPN_REQUIRE(w && planes && Cout > 0 && taps > 0 && Cin > 0 && cols > 0 && cols % 32 == 0, "weight_planes: bad argument");
-  DSPN_REQUIRE(transposed ? cols >= Cout : cols == Cin, "weight_planes: cols is Cin (forward operand) or the padded Cout (transposed operand)");
-  WpDesc e{w, static_cast<__bf16 *>(planes), Cout, taps, Cin, cols, 0, transposed ? 1 : 0, 0};
-  const long long total = (long long)(transposed ? Cin : Cout) * taps * cols;
-  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(weight_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, total);
+  DSPN_REQUIRE(w && (planes || planes_t) && Cout > 0 && taps > 0 && Cin > 0 && Cin % 4 == 0, "weight_planes: bad argument");
+  DSPN_REQUIRE(!planes || Cin % 32 == 0, "weight_planes: the forward planes need Cin %% 32 == 0, got %d", Cin);
+  DSPN_REQUIRE(!planes_t || (cols_t % 32 == 0 && cols_t >= Cout), "weight_planes: cols_t is the padded Cout, a multiple of 32");
+  WpDesc e{w, static_cast<__bf16 *>(planes), static_cast<__bf16 *>(planes_t), Cout, taps, Cin, planes_t ? cols_t : 0, 0};
+  const long long tiles = weight_planes_tiles(Cout, taps, Cin, cols_t, planes_t != nullptr);
+  DSPN_REQUIRE(tiles < (1ll << 31), "weight_planes: too many tiles");
+  hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, e);
   return dspn::check_launch("weight_planes");
 }
 
-int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_elements, void *stream) {
-  DSPN_REQUIRE(table && n > 0 && total_elements > 0, "weight_planes_batch: bad argument");
-  static_assert(sizeof(WpDesc) == 48, "table row layout: 2 pointers, 4 ints, 1 int64, 2 ints");
-  const int blocks = (int)std::min<long long>((total_elements + 255) / 256, 16384);
-  hipLaunchKernelGGL(weight_planes_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<const WpDesc *>(table), n, total_elements);
+long long dspn_conv2d_weight_planes_tiles(int Cout, int taps, int Cin, int cols_t, int with_transposed) {
+  if (Cout <= 0 || taps <= 0 || Cin <= 0) return 0;
+  return weight_planes_tiles(Cout, taps, Cin, cols_t, with_transposed != 0);
+}
+
+int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_tiles, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "weight_planes_batch: bad argument");
+  static_assert(sizeof(WpDesc) == 48, "table row layout: 3 pointers, 4 ints, 1 int64");
+  hipLaunchKernelGGL(weight_planes_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WpDesc *>(table), n);
   return dspn::check_launch("weight_planes_batch");
 }
 #else

@@ -551,38 +551,50 @@ __device__ __forceinline__ float nms_iou(const float *a, const float *b) {
 
 // 64x64 tiles of the upper-triangular suppression matrix:
 // bit (i,j), j>i: row i would suppress row j (multibox_detection.cc:153-167).
+// One single-wave workgroup per (64-row tile, sample) walks the column tiles to its right: (A / 64) x B long-lived waves
+// instead of (A / 64)^2 x B short ones.  The kernel runs on MultiBoxDetection's side stream beside the training step, and
+// the dispatcher hands out the workgroups of ONE queue's kernel at a time: with 295 000 tiny workgroups (96 x 96 tiles x
+// 32 samples) every main-stream kernel that became ready meanwhile waited for the whole dispatch (a 7-us BatchNorm table
+// merge took 0.46 ms, rocprofv3 kernel trace of the step); 3072 workgroups are handed out in microseconds and the main
+// stream's kernels then slot in beside them.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ out, int A,
                                                       int nwords, float nms_threshold,
                                                       int force, DetWs ws) {
-  const int ct = blockIdx.x, rt = blockIdx.y, b = blockIdx.z;
-  if (ct < rt) return;
+  const int rt = blockIdx.x, b = blockIdx.y;
   const int V = ws.nms_count[b];
-  if (rt * 64 >= V || ct * 64 >= V) return;
+  if (rt * 64 >= V) return;
   __shared__ float s_box[64][5];
   const float *po = out + (size_t)b * A * 7;
   const int lane = threadIdx.x;
-  const int jc = ct * 64 + lane;
-  if (jc < V) {
-    const float *r = po + (size_t)jc * 7;
-    s_box[lane][0] = r[2]; s_box[lane][1] = r[3]; s_box[lane][2] = r[4]; s_box[lane][3] = r[5];
-    s_box[lane][4] = r[0];
-  }
-  __syncthreads();
   const int i = rt * 64 + lane;
-  if (i >= V) return;
-  const float *ri = po + (size_t)i * 7;
-  const float bi[4] = {ri[2], ri[3], ri[4], ri[5]};
-  const float idi = ri[0];
-  unsigned long long bits = 0;
-  const int jmax = min(64, V - ct * 64);
-  for (int t = 0; t < jmax; ++t) {
-    const int j = ct * 64 + t;
-    if (j <= i) continue;
-    if (force || idi == s_box[t][4]) {
-      if (nms_iou(bi, s_box[t]) >= nms_threshold) bits |= 1ull << t;
-    }
+  float bi[4] = {0.f, 0.f, 0.f, 0.f}, idi = -1.f;
+  if (i < V) {
+    const float *ri = po + (size_t)i * 7;
+    bi[0] = ri[2]; bi[1] = ri[3]; bi[2] = ri[4]; bi[3] = ri[5];
+    idi = ri[0];
   }
-  ws.mask[((size_t)b * A + i) * nwords + ct] = bits;
+  const int ntile = (V + 63) >> 6;
+  for (int ct = rt; ct < ntile; ++ct) {
+    __syncthreads();                      // the previous column tile has been read by every lane
+    const int jc = ct * 64 + lane;
+    if (jc < V) {
+      const float *r = po + (size_t)jc * 7;
+      s_box[lane][0] = r[2]; s_box[lane][1] = r[3]; s_box[lane][2] = r[4]; s_box[lane][3] = r[5];
+      s_box[lane][4] = r[0];
+    }
+    __syncthreads();
+    if (i >= V) continue;
+    unsigned long long bits = 0;
+    const int jmax = min(64, V - ct * 64);
+    for (int t = 0; t < jmax; ++t) {
+      const int j = ct * 64 + t;
+      if (j <= i) continue;
+      if (force || idi == s_box[t][4]) {
+        if (nms_iou(bi, s_box[t]) >= nms_threshold) bits |= 1ull << t;
+      }
+    }
+    ws.mask[((size_t)b * A + i) * nwords + ct] = bits;
+  }
 }
 
 // One wave per sample walks the rows in order and ORs the masks of surviving rows.
@@ -840,7 +852,7 @@ int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred
   }
   if (nms_enabled) {
     const int nt = l.nwords;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, nt, batch), dim3(64), 0, s, out_dev, num_anchors,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, batch), dim3(64), 0, s, out_dev, num_anchors,
                        l.nwords, nms_threshold, force_suppress, ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(kScanThreads), 8 * (size_t)l.nwords, s, out_dev,
                        num_anchors, l.nwords, ws);

@@ -235,10 +235,8 @@ class Graph:
                 self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, n.wh) for n in pairs], self.device)
                 self.half_operands = self.wt_table[3]
         if self.device.type == "cuda":
-            planes = []
-            for n in self.nodes:
-                if isinstance(n, Conv):
-                    planes += [(n.w.data, pl, tr) for pl, tr in ((n.wp, False), (n.wtp, True)) if pl is not None]
+            planes = [(n.w.data, n.wp, n.wtp) for n in self.nodes
+                      if isinstance(n, Conv) and (n.wp is not None or n.wtp is not None)]
             if planes:
                 self.wp_table = fn.weight_planes_table(planes, self.device)
         if self.device.type == "cuda":

@@ -24,7 +24,8 @@ _lib.register({
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                         _i, _ll, _i, _i, _i, _vp, _sz, _i, _vp, _sz, _vp]),
-    "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_planes_tiles": (_ll, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -253,26 +254,29 @@ def weight_planes(w, transposed=False, cols=None, out=None):
     if out is None:
         out = empty(rows, R * S, cols // 32, 3, 32, device=w.device, dtype=torch.bfloat16)
     assert out.numel() == rows * R * S * cols * 3 and out.dtype == torch.bfloat16
-    check(L().dspn_conv2d_weight_planes_f32(ptr(w), ptr(out), Cout, R * S, Cin, cols, int(transposed), stream()),
-          "weight_planes")
+    check(L().dspn_conv2d_weight_planes_f32(ptr(w), 0 if transposed else ptr(out), ptr(out) if transposed else 0, Cout,
+                                            R * S, Cin, cols if transposed else 0, stream()), "weight_planes")
     return out
 
 
 def weight_planes_table(entries, device):
-    """entries: [(w float32 [Cout,R,S,Cin], planes, transposed)] -> (device table, rows, total elements) for
+    """entries: [(w float32 [Cout,R,S,Cin], planes or None, planes_t or None)] -> (device table, rows, total tiles) for
     weight_planes_batch: every piece-plane operand of a graph refreshed from the float masters by ONE launch"""
     import numpy as np
-    rows = np.zeros(len(entries), dtype=[("w", "<u8"), ("planes", "<u8"), ("K", "<i4"), ("T", "<i4"), ("C", "<i4"),
-                                         ("cols", "<i4"), ("begin", "<i8"), ("tr", "<i4"), ("pad", "<i4")])
+    rows = np.zeros(len(entries), dtype=[("w", "<u8"), ("planes", "<u8"), ("planes_t", "<u8"), ("K", "<i4"), ("T", "<i4"),
+                                         ("C", "<i4"), ("cols_t", "<i4"), ("begin", "<i8")])
     total = 0
-    for i, (w, planes, tr) in enumerate(entries):
+    for i, (w, pl, plt) in enumerate(entries):
         Cout, R, S, Cin = w.shape
-        cols = planes.shape[2] * 32
-        nrows = Cin if tr else Cout
-        assert w.dtype == torch.float32 and w.is_contiguous() and planes.dtype == torch.bfloat16
-        assert planes.shape == (nrows, R * S, cols // 32, 3, 32) and (cols >= Cout if tr else cols == Cin)
-        rows[i] = (w.data_ptr(), planes.data_ptr(), Cout, R * S, Cin, cols, total, int(tr), 0)
-        total += nrows * R * S * cols
+        assert w.dtype == torch.float32 and w.is_contiguous() and (pl is not None or plt is not None)
+        assert pl is None or (pl.dtype == torch.bfloat16 and pl.shape == (Cout, R * S, Cin // 32, 3, 32) and Cin % 32 == 0)
+        cols_t = 0
+        if plt is not None:
+            cols_t = plt.shape[2] * 32
+            assert plt.dtype == torch.bfloat16 and plt.shape == (Cin, R * S, cols_t // 32, 3, 32) and cols_t >= Cout
+        rows[i] = (w.data_ptr(), 0 if pl is None else pl.data_ptr(), 0 if plt is None else plt.data_ptr(), Cout, R * S, Cin,
+                   cols_t, total)
+        total += int(L().dspn_conv2d_weight_planes_tiles(Cout, R * S, Cin, cols_t, int(plt is not None)))
     assert rows.dtype.itemsize == 48
     return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(entries), total
 

@@ -13,6 +13,7 @@ from .. import functional as fn
 
 import os
 MATERIALISE_3X3_INPUT = os.environ.get("DSPN_MAT3X3", "1") != "0"    # test / A-B switch (bf16 tensors only)
+MATERIALISE_3X3_INPUT_F32 = os.environ.get("DSPN_MAT3X3_F32", "0") != "0"   # A-B switch: the same for float tensors
 
 
 def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottle_neck=True):
@@ -37,7 +38,7 @@ def residual_unit(g, data, num_filter, stride, dim_match, name, plus_name, bottl
     # smallest tensor of the unit -- materialising it costs one 4-byte-per-element pass.  Its backward reductions still
     # come out of conv2's data-gradient epilogue.
     act2 = g.add(E.BatchNorm(g, conv1, name + "_bn2", relu=True,
-                             defer_apply=not (MATERIALISE_3X3_INPUT and fn.ACT_DTYPE == torch.bfloat16))).out
+                             defer_apply=not (MATERIALISE_3X3_INPUT and (fn.ACT_DTYPE == torch.bfloat16 or MATERIALISE_3X3_INPUT_F32)))).out
     conv2 = g.add(E.Conv(g, act2, name + "_conv2", q, 3, stride, 1)).out
     act3 = g.add(E.BatchNorm(g, conv2, name + "_bn3", relu=True, defer_apply=True)).out
     return g.add(E.Conv(g, act3, name + "_conv3", num_filter, 1, 1, 0, residual=shortcut, out_name=plus_name)).out

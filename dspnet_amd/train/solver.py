@@ -84,8 +84,16 @@ class GradBucketReducer:
 
 class MultiTaskSolver:
     def __init__(self, net, learning_rate=0.0005, momentum=0.9, wd=0.0005, process_group=None,
-                 world_size=1, bucket_mb=16.0, force_reducer=False):
+                 world_size=1, bucket_mb=16.0, force_reducer=False, high_priority=True):
         self.net, self.g = net, net.g
+        # the step runs on a HIGH-priority stream of its own: MultiBoxDetection's side stream (normal priority) then never
+        # gets its workgroups handed out ahead of a main-path kernel that is ready (HIP has two levels, and torch's
+        # current stream already sits on the lower one).  step() orders that stream behind the caller's current stream
+        # on entry and the caller's stream behind it on exit, so callers see ordinary stream semantics.
+        self.stream = None
+        if high_priority and net.g.device.type == "cuda":
+            import torch
+            self.stream = torch.cuda.Stream(device=net.g.device, priority=-1)
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
@@ -144,6 +152,18 @@ class MultiTaskSolver:
                         1.0 / (self.batch_size * self.world_size))
 
     def step(self):
+        if self.stream is None:
+            return self._step()
+        import torch
+        cur = torch.cuda.current_stream(self.g.device)
+        if cur == self.stream:
+            return self._step()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._step()
+        cur.wait_stream(self.stream)
+
+    def _step(self):
         if self._graph is not None:
             # the recorded SGD launch carries lr / momentum / wd BY VALUE: a schedule that moved them since the recording
             # (the reference's optimizer takes an lr_scheduler, multi_solver.py:221) drops the graph and records a new one

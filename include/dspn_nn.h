@@ -88,17 +88,20 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
  * output (y_ldc == Cout or 0). */
 int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
 
-/* Piece planes of a weight operand for DSPN_MATH_F32_BF16X3: the matrix D[rows][taps][cols] (cols % 32 == 0) with
- *   transposed == 0: D = w itself, rows = Cout, cols = Cin             -> `w_planes` of dspn_conv2d_forward_bn_f32,
- *   transposed != 0: D = w^T, rows = Cin, cols >= Cout (zero padded)   -> `wt_planes` of dspn_conv2d_dgrad_bn_f32 (cols = ldy),
- * every element x cut into p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even) and stored as
- * planes[row][tap][cols / 32][piece][32] bfloat16: rows * taps * cols * 6 bytes.  w is the float master [Cout][taps][Cin].
+/* Piece planes of a weight operand for DSPN_MATH_F32_BF16X3, from the float master w [Cout][taps][Cin] (Cin % 4 == 0):
+ *   planes   (optional, needs Cin % 32 == 0): of w itself, [Cout][taps][Cin / 32][piece][32]
+ *                                             -> `w_planes` of dspn_conv2d_forward_bn_f32,
+ *   planes_t (optional, cols_t % 32 == 0, cols_t >= Cout): of w^T zero padded, [Cin][taps][cols_t / 32][piece][32]
+ *                                             -> `wt_planes` of dspn_conv2d_dgrad_bn_f32 (cols_t = ldy),
+ * bfloat16, every element x cut into p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even):
+ * rows * taps * cols * 6 bytes each.  Either pointer may be NULL.  One read of w serves both.
  * Batch form (every weight of a training step in one launch): table of n 48-byte rows in DEVICE memory
- * { const float *w; void *planes; int32 Cout, taps, Cin, cols; int64 begin; int32 transposed, reserved } with begin = the sum
- * of rows * taps * cols over the preceding rows; total_elements = that sum over all rows. */
-int dspn_conv2d_weight_planes_f32(const float *w, void *planes, int Cout, int taps, int Cin, int cols, int transposed,
+ * { const float *w; void *planes; void *planes_t; int32 Cout, taps, Cin, cols_t; int64 begin } with begin = the sum of
+ * dspn_conv2d_weight_planes_tiles() over the preceding rows; total_tiles = that sum over all rows. */
+int dspn_conv2d_weight_planes_f32(const float *w, void *planes, void *planes_t, int Cout, int taps, int Cin, int cols_t,
                                   void *stream);
-int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_elements, void *stream);
+long long dspn_conv2d_weight_planes_tiles(int Cout, int taps, int Cin, int cols_t, int with_transposed);
+int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_tiles, void *stream);
 
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,

@@ -13,7 +13,10 @@ def pretty(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 ends = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
-lo, hi = ends[-2] + 1, ends[-1] + 1
+# the last interval between two SGD launches that holds a whole step (bench.py's roofline_ops block launches sgd_kernel
+# back to back after the timed region: those one-kernel intervals are not steps)
+pairs = [(a + 1, b + 1) for a, b in zip(ends, ends[1:]) if b - a > 400]
+lo, hi = pairs[-1]
 step = rows[lo:hi]
 wall = (int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6
 agg = collections.defaultdict(lambda: [0, 0.0])

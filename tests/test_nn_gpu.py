@@ -108,7 +108,7 @@ def test_conv_forward_dgrad_wgrad(gpu_device, conv_math, case):
     close(fn.colsum(dyd, Cout).cpu().double(), dy.sum(dim=(0, 2, 3)))
 
 
-@pytest.mark.parametrize("shape", [(64, 3, 3, 64), (19, 1, 1, 128), (40, 3, 3, 32)])
+@pytest.mark.parametrize("shape", [(64, 3, 3, 64), (19, 1, 1, 128), (40, 3, 3, 32), (171, 1, 1, 2048), (96, 1, 7, 160)])
 def test_weight_planes_layout_and_pieces(gpu_device, shape):
     """dspn_conv2d_weight_planes_f32: planes[row][tap][cols / 32][piece][32] with p0 = bf16(x), p1 = bf16(x - p0),
     p2 = bf16(x - p0 - p1), of the weight itself and of its zero-padded transpose; the batch form writes the same bits"""
@@ -134,7 +134,8 @@ def test_weight_planes_layout_and_pieces(gpu_device, shape):
     back = fwd.float().sum(dim=3).view(Cout, R * S, Cin)
     assert float(((back - w.view(Cout, R * S, Cin)).abs() / w.view(Cout, R * S, Cin).abs().clamp(min=1e-30)).max()) <= 2.0 ** -23
     a, b = torch.zeros_like(fwd), torch.zeros_like(bwd)
-    fn.weight_planes_batch(*fn.weight_planes_table([(w, a, False), (w, b, True)], w.device))
+    fn.weight_planes_batch(*fn.weight_planes_table([(w, a, b), (w, None, torch.zeros_like(b)), (w, torch.zeros_like(a), None)],
+                                                   w.device))
     assert torch.equal(a.view(torch.int16), fwd.view(torch.int16)) and torch.equal(b.view(torch.int16), bwd.view(torch.int16))
 
 
