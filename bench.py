@@ -41,9 +41,11 @@ sys.path.insert(0, ROOT)
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
 # algorithmic (fp32 multiply-add) peak of each math mode: bf16x3 issues six bf16 MFMAs per fp32 multiply-add
-MATH_PEAK_TFLOPS = {"fp32": FP32_MATRIX_PEAK_TFLOPS, "bf16": BF16_MATRIX_PEAK_TFLOPS, "bf16x3": BF16_MATRIX_PEAK_TFLOPS / 6.0}
+MATH_PEAK_TFLOPS = {"fp32": FP32_MATRIX_PEAK_TFLOPS, "bf16": BF16_MATRIX_PEAK_TFLOPS, "bf16x3": BF16_MATRIX_PEAK_TFLOPS / 6.0,
+                    "f16x2": BF16_MATRIX_PEAK_TFLOPS / 3.0}    # (the fp16 MFMA has the bf16 MFMA's rate)
 MATH_LABEL = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (operands rounded to bf16)",
-              "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)"}
+              "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)",
+              "f16x2": "fp32 on the fp16 MFMA (2-piece split after a per-tensor power-of-two scale, 3 products)"}
 # committed rocprofv3 --pmc passes of the headline workload per math mode, newest first (roofline.traffic is read from these)
 TRAFFIC_PROFILES = {"bf16x3": ["r02_x3_pmc_conv_family.json"],
                     "fp32": ["r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json", "r01_j_pmc_conv_family.json"]}
@@ -61,7 +63,7 @@ def parse():
     ap.add_argument("--network", default="resnet-50", choices=["resnet-50", "vgg16_reduced", "inceptionv3"],
                     help="backbone preset; the headline workload is resnet-50 (the other BASELINE.json configs: "
                          "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
-    ap.add_argument("--math", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
+    ap.add_argument("--math", default="bf16x3", choices=["bf16x3", "f16x2", "fp32", "bf16"],
                     help="convolution math on float tensors: bf16x3 = fp32 results from six exact bf16 products per "
                          "multiply on the bf16 MFMA (default), fp32 = fp32 MFMA, bf16 = operands rounded to bf16")
     ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],

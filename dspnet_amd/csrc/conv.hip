@@ -72,6 +72,39 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, b
   p2 = to_bf16x4(r2);
 }
 
+// DSPN_MATH_F32_F16X2 ("two-piece" mode, float tensors): every float operand x, scaled by a power of two s chosen per tensor
+// (include/dspn_nn.h), is cut into TWO fp16 pieces, h0 = fp16(s x), h1 = fp16(s x - h0) (round to nearest even; 11 + 11 bits
+// and a sign: h0 + h1 = s x to within 2^-24 |s x|, the rounding of the float itself), and a product is the sum of THREE
+// exact partial products h0 g0 + h0 g1 + h1 g0 (11 x 11 bits fit the fp32 accumulator input); the dropped h1 g1 is below
+// 2^-24 |x w|.  Half the MFMAs of the three-piece bf16 split for the same fp32-level result -- what it costs is RANGE: fp16
+// holds 2^-24 .. 65504, so the scale must put the tensor's largest magnitude below 2^15; elements more than 2^17 below
+// that maximum keep an ABSOLUTE error of 2^-25 / s (2^-40 of the maximum) instead of a relative one.
+// the power of two that maps a largest magnitude m into [2^14, 2^15) (1 for m = 0 / non-finite m; exponent kept within +-60
+// so that the product of two scales and its reciprocal stay finite floats)
+constexpr int kAbsmaxSlots = 64;    // a magnitude "scalar" is 64 partial maxima (see absmax_kernel): one per lane here
+__device__ __forceinline__ float operand_scale(const float *absmax) {
+  if (!absmax) return 1.f;
+  float m = absmax[threadIdx.x & 63];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1  ->  m * 2^(15 - e) < 2^15
+  e = 15 - e;
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  return __uint_as_float((unsigned)(127 + e) << 23);
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(const float4 v, const float s, bf16x4 &p0, bf16x4 &p1) {
+  const float4 u = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+  const f16x4 h0 = {(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w};
+  const f16x4 h1 = {(_Float16)(u.x - (float)h0[0]), (_Float16)(u.y - (float)h0[1]), (_Float16)(u.z - (float)h0[2]),
+                    (_Float16)(u.w - (float)h0[3])};
+  p0 = __builtin_bit_cast(bf16x4, h0);     // (the piece registers / LDS images are typed bf16x4: 4 x 16 bits either way)
+  p1 = __builtin_bit_cast(bf16x4, h1);
+}
+
 constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
 constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
 constexpr int kBKF = 32;                       // ... of its fp32-MFMA path
@@ -113,6 +146,11 @@ struct ConvGeom {
   // optional BatchNorm statistics of the OUTPUT, per row tile: stats[(mt*2 + 0)*Cout + c] = mean over the tile's
   // rows, stats[(mt*2 + 1)*Cout + c] = sum of squared deviations from that mean (merged by dspn_bn_stats_from_tiles_f32)
   float *stats;
+  // optional (two-piece math, with stats): minmax[(mt*2 + 0)*Cout + c] = smallest, [(mt*2 + 1)*Cout + c] = largest stored value
+  // of the tile's rows in column c.  A BatchNorm(+ReLU) of the output is monotone per channel, so the magnitude of what the
+  // NEXT convolution's loader forms from this tensor is the largest |f_c(extreme)| over this small table
+  // (dspn_absmax_f32 on it, with the affine) -- instead of a pass over the whole tensor
+  float *minmax;
   // optional BatchNorm-backward sums of the OUTPUT (a data gradient dy of a BatchNorm(+ReLU) output whose input was
   // bn_x, same layout as out): per row tile t, bn_sums[((tile_base + t)*2 + 0)*Cout + c] = sum of dy' and
   // [... + 1 ...] = sum of dy' * xhat, with dy' = dy where (bn_x*bn_scale + bn_shift > 0 or no ReLU) else 0 and
@@ -121,6 +159,10 @@ struct ConvGeom {
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   float *bn_sums;
   int bn_relu, bn_tile_base;
+  // DSPN_MATH_F32_F16X2: device scalars holding the largest magnitude of the A operand (the gathered tensor AFTER its input
+  // affine) and of the B operand (the weights); the kernel derives the power-of-two scales that put them just below 2^15
+  // (operand_scale) and undoes both in the epilogue.  NULL = scale 1 (the caller vouches for |operand| < 65504).
+  const float *a_absmax, *b_absmax;
   // host side only: the weight operand as three bf16 piece planes [Cout][WTAPS][Cin / 32][3][32] (split mode, Cin % 32 == 0:
   // dspn_conv2d_weight_planes_f32); the kernel then receives this pointer in place of the float weights
   const void *w_planes;
@@ -151,12 +193,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
     const int ksteps_per_split, float *__restrict__ slab, const st_t *__restrict__ residual) {
   constexpr bool BF16 = MATH != 0;      // the bf16 matrix instruction
-  constexpr bool SPLIT = MATH == 2;     // ... fed with the three bf16 pieces of every float operand (kMathSplit)
+  constexpr bool SPLIT = MATH >= 2;     // ... fed with the pieces of every float operand: 2 = three bf16, 3 = two fp16 pieces
+  constexpr int NPC = MATH == 3 ? 2 : 3;   // pieces per operand
   static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
-  constexpr bool PRE = SPLIT && UNIFORM_TAP;            // the weight operand is three bf16 piece planes (see above)
+  constexpr bool PRE = MATH == 2 && UNIFORM_TAP;        // the weight operand is three bf16 piece planes (see above)
   // 16-B loads per thread per k-step
   constexpr int A_LD = BM / RSTEP;
   constexpr int B_LD = PRE ? 3 * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
@@ -164,7 +207,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
-  constexpr int ROWH = SPLIT ? kLdsRowS : kLdsRowH;   // LDS row (bf16 elements) of the bf16 images
+  constexpr int ROWH = SPLIT ? NPC * 32 + 8 : kLdsRowH;   // LDS row (16-bit elements) of the 16-bit images: 208 / 144 / 80 B
   constexpr int STAGES = SPLIT ? 1 : 2;               // the three-piece image is single-buffered (two barriers per k-step)
   __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
   __bf16 *hB = hA + STAGES * BM * ROWH;
@@ -184,6 +227,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int k_begin = slab ? blockIdx.y * ksteps_per_split : 0;
   const int nk = slab ? max(0, min(nk_all - k_begin, ksteps_per_split)) : nk_all;
 
+  // two-piece mode: operand scales (wave-uniform, read once), and their exact inverse for the epilogue
+  const float sc_a = MATH == 3 ? operand_scale(g.a_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.b_absmax) : 1.f;
+  const float sc_o = MATH == 3 ? 1.f / (sc_a * sc_b) : 1.f;
   const int chunk = tid & 7, row0 = tid >> 3;
   // 8-wave kernels only (measured: +3..4 % there; on 4 waves the doubled store count costs more than the reads gain)
   constexpr bool LDS_SHIFT = NTHR == 512;
@@ -365,10 +411,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     if constexpr (SPLIT) {
       affine_tiles();
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i) split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+      for (int i = 0; i < A_LD; ++i) {
+        if constexpr (MATH == 3) split2h(ra[i], sc_a, pa[i][0], pa[i][1]);
+        else split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+      }
       if constexpr (!PRE) {
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+        for (int i = 0; i < B_LD; ++i) {
+          if constexpr (MATH == 3) split2h(rb[i], sc_b, pb[i][0], pb[i][1]);
+          else split3(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+        }
       }
     }
   };
@@ -409,7 +461,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int i = 0; i < A_LD; ++i) {
         __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
+        for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
       }
       if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
 #pragma unroll
@@ -426,7 +478,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int i = 0; i < B_LD; ++i) {
         __bf16 *d = b + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pb[i][pc];
+        for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pb[i][pc];
       }
       }
     } else if constexpr (BF16) {
@@ -493,9 +545,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
       auto block = [&](const int kk) __attribute__((always_inline)) {
-        bf16x8 fa[3][TM], fb[3][TN];
+        bf16x8 fa[NPC][TM], fb[NPC][TN];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPC; ++p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
             fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
@@ -503,15 +555,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           for (int j = 0; j < TN; ++j)
             fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
         }
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        // piece pairs, smallest terms first: three-piece bf16 (p + q <= 2), two-piece fp16 (p + q <= 1)
+        constexpr int NPROD = MATH == 3 ? 3 : 6;
+        constexpr int PA[6] = {MATH == 3 ? 1 : 2, 0, MATH == 3 ? 0 : 1, 1, 0, 0}, PB[6] = {0, MATH == 3 ? 1 : 2, MATH == 3 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6) {
-          if ((dbg & 64) && t6 > 0) break;     // timing-only ablation: one of the six products
+        for (int t6 = 0; t6 < NPROD; ++t6) {
+          if ((dbg & 64) && t6 > 0) break;     // timing-only ablation: one of the products
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (MATH == 3)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[PA[t6]][i]),
+                                                                   __builtin_bit_cast(f16x8, fb[PB[t6]][j]), acc[i][j], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+            }
         }
       };
       block(0);
@@ -525,18 +584,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pa[i][pc]));
+        for (int pc = 0; pc < NPC; ++pc) asm volatile("" : "+v"(pa[i][pc]));
       if constexpr (!PRE) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pb[i][pc]));
+        for (int pc = 0; pc < NPC; ++pc) asm volatile("" : "+v"(pb[i][pc]));
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NPC * (TM + TN), 0);
 #pragma unroll
-      for (int m = 0; m < 6 * TM * TN; ++m) {
+      for (int m = 0; m < (MATH == 3 ? 3 : 6) * TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (kSplitValuPerMfma + 1) / 2 : kSplitValuPerMfma, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (kSplitValuPerMfma + 1) / 2 : (MATH == 3 ? 2 * kSplitValuPerMfma : kSplitValuPerMfma), 0);
       }
     } else if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of each 16-wide MFMA k block
@@ -635,7 +694,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              if (m < M) o[(long long)m * g.Cout + co] = acc[i][j][r];
+              if (m < M) o[(long long)m * g.Cout + co] = MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];
             }
         }
       } else if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
@@ -696,7 +755,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+              st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] =
+                  MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];      // (two-piece mode: undo the operand scales, exact)
         rows_bn_x();   // requested once the accumulators are staged (their registers are free), ahead of the barrier
         __syncthreads();
         float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -716,6 +776,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         // BatchNorm statistics of the stored values (g.stats): shifted sums about the thread's first row
         float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         int scnt = 0;
+        constexpr bool MINMAX = EPI == 1 && MATH == 3;     // per-tile extremes of the stored values (g.minmax)
+        constexpr float kInf = __builtin_huge_valf();
+        float vmn[4] = {kInf, kInf, kInf, kInf}, vmx[4] = {-kInf, -kInf, -kInf, -kInf};
 #pragma unroll (NTHR == 512 && EPI != 0 && !(EPI == 1 && INTF) ? 1 : NP / RC)
         for (int ch = 0; ch < NP / RC; ++ch) {
           if (ch > 0) { rows_begin(ch); rows_bn_x(); }
@@ -754,6 +817,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
                 ++scnt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = v[e] - sK[e]; s1[e] += d; s2[e] += d * d; }
+                if constexpr (MINMAX) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { vmn[e] = fminf(vmn[e], v[e]); vmx[e] = fmaxf(vmx[e], v[e]); }
+                }
               }
             } else {
 #pragma unroll
@@ -802,6 +869,29 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
             const long long mt_ = m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
+          }
+          if constexpr (MINMAX) {
+            if (g.minmax) {              // (kernel-uniform) the same two-stage reduction for the extremes
+              __syncthreads();           // the (mean, M2) table has been merged
+              if (vec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  red[((er0 * BN) + c4 * 4 + e) * 2] = vmn[e];
+                  red[((er0 * BN) + c4 * 4 + e) * 2 + 1] = vmx[e];
+                }
+              }
+              __syncthreads();
+              if (tid < BN && n0 + tid < g.Cout) {
+                const int lim = min(M - m0, BM);
+                float mn = kInf, mx = -kInf;
+                for (int er = 0; er < RPP && er < lim; ++er) {      // row groups past the tile's last row hold nothing
+                  mn = fminf(mn, red[(er * BN + tid) * 2]); mx = fmaxf(mx, red[(er * BN + tid) * 2 + 1]);
+                }
+                const long long mt_ = m0 / BM;
+                g.minmax[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mn;
+                g.minmax[(mt_ * 2 + 1) * g.Cout + n0 + tid] = mx;
+              }
+            }
           }
         }
         if constexpr (EPI == 2) {
@@ -870,6 +960,7 @@ struct WgradGeom {
   const float *in_scale, *in_shift;   // optional affine (+ReLU) on x, as in ConvGeom
   int in_relu;
   int bf16;                           // host side only: math mode of this call
+  const float *dy_absmax, *x_absmax;  // DSPN_MATH_F32_F16X2: device scalars, largest magnitude of dy / of x after its affine (ConvGeom)
 };
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
@@ -881,7 +972,8 @@ template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool INTF>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
     const st_t *__restrict__ x, const st_t *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
-  constexpr bool BF16 = MATH != 0, SPLIT = MATH == 2;   // as in conv_nt_kernel
+  constexpr bool BF16 = MATH != 0, SPLIT = MATH >= 2;   // as in conv_nt_kernel
+  constexpr int NPC = MATH == 3 ? 2 : 3;
   static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;   // BM over cout, BN over (tap,c)
   constexpr int NTHR = WAVES_M * WAVES_N * 64;                     // 4 waves, or 8 (4 waves per SIMD with two workgroups per CU)
@@ -991,7 +1083,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
   // split mode: three piece planes per operand, single-buffered: [3][kPK][RAB] then [3][kPK][RBB]
-  constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? 3 : 1;
+  constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? NPC : 1;
+  const float sc_a = MATH == 3 ? operand_scale(g.dy_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.x_absmax) : 1.f;
+  const float sc_o = MATH == 3 ? 1.f / (sc_a * sc_b) : 1.f;
   char *hA = reinterpret_cast<char *>(smem);            // [2][kPK][RAB]
   char *hB = hA + STAGES * PLANES * kPK * RAB;          // [2][kPK][RBB]
   // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
@@ -1039,20 +1133,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         bf16x4 p0, p1, p2;
-        split3(ra[i], p0, p1, p2);
+        if constexpr (MATH == 3) split2h(ra[i], sc_a, p0, p1);
+        else split3(ra[i], p0, p1, p2);
         char *d = hA + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
         *reinterpret_cast<bf16x4 *>(d + kPK * RAB) = p1;
-        *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RAB) = p2;
+        if constexpr (MATH != 3) *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RAB) = p2;
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         bf16x4 p0, p1, p2;
-        split3(rb[i], p0, p1, p2);
+        if constexpr (MATH == 3) split2h(rb[i], sc_b, p0, p1);
+        else split3(rb[i], p0, p1, p2);
         char *d = hB + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
         *reinterpret_cast<bf16x4 *>(d + kPK * RBB) = p1;
-        *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RBB) = p2;
+        if constexpr (MATH != 3) *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RBB) = p2;
       }
     } else if constexpr (BF16) {
       char *a = hA + buf * kPK * RAB, *b = hB + buf * kPK * RBB;
@@ -1103,22 +1199,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       };
 #pragma unroll
       for (int kk = 0; kk < kPK / 16; ++kk) {
-        bf16x8 fa[3][TM], fb[3][TN];
+        bf16x8 fa[NPC][TM], fb[NPC][TN];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPC; ++p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[p][i] = frag(a + p * kPK * RAB + kk * 16 * RAB + i * 64, RAB);
 #pragma unroll
           for (int j = 0; j < TN; ++j) fb[p][j] = frag(b + p * kPK * RBB + kk * 16 * RBB + j * 64, RBB);
         }
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NPROD = MATH == 3 ? 3 : 6;     // piece pairs as in conv_nt_kernel
+        constexpr int PA[6] = {MATH == 3 ? 1 : 2, 0, MATH == 3 ? 0 : 1, 1, 0, 0}, PB[6] = {0, MATH == 3 ? 1 : 2, MATH == 3 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
+        for (int t6 = 0; t6 < NPROD; ++t6)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (MATH == 3)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[PA[t6]][i]),
+                                                                   __builtin_bit_cast(f16x8, fb[PB[t6]][j]), acc[i][j], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t6]][i], fb[PB[t6]][j], acc[i][j], 0, 0, 0);
+            }
       }
     } else if constexpr (BF16) {
       // transposed-read addressing: 16-lane group gl = lane >> 4 covers channels 16*(gl&1) .. +15 of a 32-channel
@@ -1198,7 +1300,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r];
+        st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] =
+            MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];
   __syncthreads();
   constexpr int C4 = BN / 4, RPP = NTHR / C4;
   const int c4 = tid % C4, er0 = tid / C4;
@@ -1443,6 +1546,74 @@ long long weight_planes_tiles(int K, int T, int C, int cols_t, bool with_t) {
   return (long long)((std::max(K, with_t ? cols_t : K) + 31) / 32) * T * ((C + 31) / 32);
 }
 
+// Largest magnitude of a float tensor, for the operand scales of DSPN_MATH_F32_F16X2: u = x or (relu)(x * scale[c] + shift[c])
+// (the operand a convolution with a folded BatchNorm actually multiplies).  The result is kAbsmaxSlots = 64 PARTIAL maxima:
+// workgroup b folds its maximum into out[b & 63] with one integer atomicMax (non-negative floats order like their bit
+// patterns; max is order independent: deterministic), and the consuming kernels take the maximum of the 64 with one
+// coalesced load and a wave reduction.  (One shared word instead of 64: 16 000 same-address atomics per launch serialise
+// in L2 -- 140 us per launch whatever the tensor's size, measured.)  The caller zeroes the 64 words once per step.
+// NaNs are skipped (fmaxf), infinities propagate.
+__device__ __forceinline__ float absmax4(const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ void absmax_commit(float m, unsigned *out, int slot) {
+  __shared__ float sm[4];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    unsigned *o = out + (slot & (kAbsmaxSlots - 1));
+    // (a plain look first: once a few workgroups have published, most maxima are not news and need no atomic at all)
+    if (m > 0.f && __float_as_uint(m) > __builtin_nontemporal_load(o)) atomicMax(o, __float_as_uint(m));
+  }
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float4 *__restrict__ x, long long n4, int C4,
+                                                     const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                     int relu, unsigned *__restrict__ out) {
+  float m = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!scale) {
+    for (long long i = i0; i < n4; i += stride) m = fmaxf(m, absmax4(x[i]));
+  } else if (stride % C4 == 0) {            // every element of this thread lies in one channel group: coefficients loaded once
+    const float4 a = scale[(int)(i0 % C4)], b = shift[(int)(i0 % C4)];
+    for (long long i = i0; i < n4; i += stride) {
+      const float4 t = x[i];
+      float4 v = make_float4(fmaf(t.x, a.x, b.x), fmaf(t.y, a.y, b.y), fmaf(t.z, a.z, b.z), fmaf(t.w, a.w, b.w));   // the loaders' fmaf
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      m = fmaxf(m, absmax4(v));
+    }
+  } else {
+    for (long long i = i0; i < n4; i += stride) {
+      const int c4 = (int)(i % C4);
+      const float4 t = x[i], a = scale[c4], b = shift[c4];
+      float4 v = make_float4(fmaf(t.x, a.x, b.x), fmaf(t.y, a.y, b.y), fmaf(t.z, a.z, b.z), fmaf(t.w, a.w, b.w));
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      m = fmaxf(m, absmax4(v));
+    }
+  }
+  absmax_commit(m, out, blockIdx.x);
+}
+// many small tensors (every weight of a graph) in one launch: chunk = 1024 float4 per workgroup, rows sorted by `begin` (chunks)
+struct AmDesc { const float4 *x; unsigned *out; long long n4; long long begin; };
+__global__ __launch_bounds__(256) void absmax_batch_kernel(const AmDesc *__restrict__ d, int n) {
+  const long long chunk = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].begin <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const AmDesc e = d[lo];
+  const long long base = (chunk - e.begin) * 1024;
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < e.n4) m = fmaxf(m, absmax4(e.x[i]));
+  }
+  absmax_commit(m, e.out, (int)(chunk - e.begin));
+}
+
 // out[m*ldc + co] (+)= relu(sum_s slab[s][m][co] + bias[co])   (dense outputs only)
 __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bias,
                                        st_t *__restrict__ out, long long M, int Cout, int ldc, int splits,
@@ -1474,7 +1645,8 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-  const size_t lds = std::max<size_t>(MATH == 2   ? sizeof(__bf16) * (BM + BN) * kLdsRowS
+  const size_t lds = std::max<size_t>(MATH == 3   ? sizeof(__bf16) * (BM + BN) * (2 * 32 + 8)
+                                      : MATH == 2 ? sizeof(__bf16) * (BM + BN) * kLdsRowS
                                       : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
                                                   : sizeof(float) * 2 * (BM + BN) * kLdsRow,
                                       sizeof(float) * BM * (BN + 4));
@@ -1518,10 +1690,12 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
 #ifdef DSPN_HALF
 #define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E))
 #elif defined(DSPN_DEV_X3ONLY)   /* development builds: only the split-mode kernels are instantiated (compile time) */
-#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
-                                         : dspn::fail(DSPN_ERR_ARG_, "development build: DSPN_MATH_F32_BF16X3 only"))
+#define DSPN_NT_UB_(T, E) (g.bf16 == 3   ? (uni ? DSPN_NT_(true, 3, T, E) : DSPN_NT_(false, 3, T, E)) \
+                           : g.bf16 == 2 ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
+                                         : dspn::fail(DSPN_ERR_ARG_, "development build: split math modes only"))
 #else
-#define DSPN_NT_UB_(T, E) (g.bf16 == 2   ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
+#define DSPN_NT_UB_(T, E) (g.bf16 == 3   ? (uni ? DSPN_NT_(true, 3, T, E) : DSPN_NT_(false, 3, T, E)) \
+                           : g.bf16 == 2 ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
                            : g.bf16 == 1 ? (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E)) \
                                          : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
@@ -1611,7 +1785,7 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // bf16 tensors: the main loop is ~3x shorter, the fused epilogues cost relatively more, and the 8-wave form wins for
   // every epilogue (measured on the resnet-50 step: 28.6 -> 26.1 ms)
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
-  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 == 2) ? true
+  const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 >= 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
@@ -1697,8 +1871,9 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 #endif
 
 struct InAffine { const float *scale, *shift; int relu; };
+struct OpScales { const float *a, *b; };   // device scalars: largest magnitudes of the two operands (DSPN_MATH_F32_F16X2)
 
-static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats, const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
+static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine tf, float *stats, float *minmax, const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                             int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
@@ -1723,8 +1898,10 @@ static int conv2d_forward_one(int math, const st_t *x, InAffine tf, float *stats
   g.flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (accumulate ? 4 : 0) | (residual ? 8 : 0) | ((tf.scale && tf.relu) ? 32 : 0);
   g.in_scale = tf.scale; g.in_shift = tf.shift;
   g.stats = stats;
+  g.minmax = (stats && !kHalf && math == DSPN_MATH_F32_F16X2) ? minmax : nullptr;
   g.bf16 = kHalf ? 1 : math;
   g.w_planes = w_planes;
+  g.a_absmax = scales.a; g.b_absmax = scales.b;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -1751,10 +1928,11 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
                                const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
                                int dil, int Ho, int Wo, long long y_batch_stride, int y_ldc,
-                               int relu, int accumulate, float *out_stats, size_t out_stats_bytes, int math,
+                               int relu, int accumulate, float *out_stats, size_t out_stats_bytes, float *out_minmax,
+                               int math, const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_forward: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_forward: math is one of DSPN_MATH_*");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   if (out_stats) {
     int tile_rows = 0;
@@ -1768,7 +1946,7 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, w, w_planes, bias,
+    const int rc = conv2d_forward_one(math, OpScales{x_absmax, w_absmax}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, out_minmax, w, w_planes, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
@@ -1784,8 +1962,8 @@ int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, c
                             int relu, int accumulate, void *workspace, size_t workspace_bytes,
                             void *stream) {
   return dspn_conv2d_forward_bn_f32(x, nullptr, nullptr, 0, w, nullptr, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad_h,
-                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, DSPN_MATH_FP32,
-                                    workspace, workspace_bytes, stream);
+                                    pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu, accumulate, nullptr, 0, nullptr,
+                                    DSPN_MATH_FP32, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
@@ -1824,6 +2002,27 @@ int dspn_conv2d_weight_planes_f32(const float *w, void *planes, void *planes_t, 
 long long dspn_conv2d_weight_planes_tiles(int Cout, int taps, int Cin, int cols_t, int with_transposed) {
   if (Cout <= 0 || taps <= 0 || Cin <= 0) return 0;
   return weight_planes_tiles(Cout, taps, Cin, cols_t, with_transposed != 0);
+}
+
+/* operand magnitudes for DSPN_MATH_F32_F16X2 (include/dspn_nn.h) */
+int dspn_absmax_f32(const float *x, long long rows, int C, const float *scale, const float *shift, int relu,
+                    float *out_dev, void *stream) {
+  DSPN_REQUIRE(x && out_dev && rows > 0 && C > 0 && C % 4 == 0, "absmax: bad argument (C must be a multiple of 4)");
+  DSPN_REQUIRE((scale == nullptr) == (shift == nullptr), "absmax: scale and shift go together");
+  const long long n4 = rows * (C / 4);
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);     // (an even count: 512 float4 channel groups divide it)
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(x), n4,
+                     C / 4, reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), relu,
+                     reinterpret_cast<unsigned *>(out_dev));
+  return dspn::check_launch("absmax");
+}
+
+int dspn_absmax_batch_f32(const void *table, int n, long long total_chunks, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_chunks > 0 && total_chunks < (1ll << 31), "absmax_batch: bad argument");
+  static_assert(sizeof(AmDesc) == 32, "table row layout: 2 pointers, 2 int64");
+  hipLaunchKernelGGL(absmax_batch_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const AmDesc *>(table), n);
+  return dspn::check_launch("absmax_batch");
 }
 
 int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_tiles, void *stream) {
@@ -1875,7 +2074,7 @@ static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class 
   return total;
 }
 
-static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, const void *wt_planes, st_t *dx, int N, int H, int W,
+static int conv2d_dgrad_one(int math, OpScales scales, const st_t *dy, const st_t *wt, const void *wt_planes, st_t *dx, int N, int H, int W,
                           int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int dx_ldc, int accumulate, BnBwd bn, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -1893,6 +2092,7 @@ static int conv2d_dgrad_one(int math, const st_t *dy, const st_t *wt, const void
   g.flags = accumulate ? 4 : 0;
   g.bf16 = kHalf ? 1 : math;
   g.w_planes = wt_planes;
+  g.a_absmax = scales.a; g.b_absmax = scales.b;
   g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
   g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
   int class_tiles[4] = {0, 0, 0, 0};
@@ -1941,9 +2141,10 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt
                              int Wo, int dx_ldc, int accumulate,
                              const st_t *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
                              const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, int math,
-                             void *workspace, size_t workspace_bytes, void *stream) {
+                             const float *dy_absmax, const float *w_absmax, void *workspace, size_t workspace_bytes,
+                             void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_dgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_dgrad: math is one of DSPN_MATH_*");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy);
   if (bn_sums) {
@@ -1955,7 +2156,7 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt
   }
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_dgrad_one(math, dy + (long long)n0 * Ho * Wo * ldy, wt, wt_planes, dx + (long long)n0 * H * W * ldc, n, H,
+    const int rc = conv2d_dgrad_one(math, OpScales{dy_absmax, w_absmax}, dy + (long long)n0 * Ho * Wo * ldy, wt, wt_planes, dx + (long long)n0 * H * W * ldc, n, H,
                                     W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate,
                                     BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums}, workspace,
                                     workspace_bytes, stream);
@@ -1971,7 +2172,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
                           void *stream) {
   return dspn_conv2d_dgrad_bn_f32(dy, wt, nullptr, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
                                   accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, DSPN_MATH_FP32,
-                                  workspace, workspace_bytes, stream);
+                                  nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 size_t dspn_conv2d_input_sum_grad_workspace_bytes(int Ho, int Wo, int ldy, int R, int S) {
@@ -2011,7 +2212,7 @@ size_t dspn_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cou
 }
 #endif
 
-static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy, float *dw, int N, int H, int W, int Cin,
+static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine tf, const st_t *dy, float *dw, int N, int H, int W, int Cin,
                           int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -2022,6 +2223,7 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
   g.sh = stride; g.sw = stride; g.ph = pad_h; g.pw = pad_w; g.dh = dil; g.dw = dil; g.R = R; g.S = S;
   g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
   g.bf16 = kHalf ? 1 : math;
+  g.dy_absmax = scales.a; g.x_absmax = scales.b;
   {
     const long long xb = (long long)sizeof(st_t) * N * H * W * Cin, yb = (long long)sizeof(st_t) * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -2060,11 +2262,13 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
     if (g.in_scale) {                                                                                    \
-      if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, true)                                     \
+      if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, true)                                     \
+      else if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, true)                                \
       else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, true)                                     \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, true)                                                 \
     } else {                                                                                             \
-      if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, false)                                    \
+      if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, false)                                    \
+      else if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, false)                               \
       else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, false)                                    \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, false)                                                \
     }                                                                                                    \
@@ -2100,16 +2304,16 @@ static int conv2d_wgrad_one(int math, const st_t *x, InAffine tf, const st_t *dy
 int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
                              const st_t *dy, float *dw, int N, int H, int W, int Cin,
                              int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                             int Wo, int accumulate, int math, void *workspace, size_t workspace_bytes,
-                             void *stream) {
+                             int Wo, int accumulate, int math, const float *x_absmax, const float *dy_absmax,
+                             void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_wgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   const int nb = std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                           batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_wgrad_one(math, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
+    const int rc = conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
                                     dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
                                     Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, accumulate || n0 > 0,
                                     workspace, workspace_bytes, stream);
@@ -2133,14 +2337,14 @@ int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, in
 int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu,
                                 const st_t *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                                int Wo, int math, void *stream) {
+                                int Wo, int math, const float *x_absmax, const float *dy_absmax, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  DSPN_REQUIRE(math == DSPN_MATH_FP32 || math == DSPN_MATH_BF16 || math == DSPN_MATH_F32_BF16X3, "conv2d_wgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                         batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");
-  return conv2d_wgrad_one(math, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
+  return conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax}, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
                           pad_h, pad_w, dil, Ho, Wo, 0, slabs, slabs_bytes, stream);
 }
 
@@ -2162,7 +2366,7 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, int N, int
                           int Wo, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   return dspn_conv2d_wgrad_bn_f32(x, nullptr, nullptr, 0, dy, dw, N, H, W, Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil,
-                                  Ho, Wo, accumulate, DSPN_MATH_FP32, workspace, workspace_bytes, stream);
+                                  Ho, Wo, accumulate, DSPN_MATH_FP32, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 #endif

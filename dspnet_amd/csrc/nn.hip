@@ -290,10 +290,14 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
   }
 }
 
+// absmax (optional, float tensors): 64 partial maxima of |dx| as stored -- the magnitude of the gradient the producing
+// convolution's data / weight gradient multiply next in the two-piece fp16 math (include/dspn_nn.h dspn_absmax_f32); this
+// kernel is HBM-bound and has the vector slots to spare, a separate pass would read dx again
 __global__ void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
                                     const float4 *__restrict__ shift, const CA4Ptr dy,
                                     const float4 *__restrict__ coef, const A4Ptr dx,
-                                    long long n4, int C4, int relu, int accumulate) {
+                                    long long n4, int C4, int relu, int accumulate, unsigned *__restrict__ absmax) {
+  float mx = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
@@ -309,6 +313,19 @@ __global__ void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ s
                            a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);
     if (accumulate) { const float4 d = dx[i]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
     dx[i] = o;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  }
+  if (absmax) {          // (kernel-uniform)
+    __shared__ float sm[kT / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < kT / 64; ++w) mx = fmaxf(mx, sm[w]);
+      unsigned *o = absmax + (blockIdx.x & 63);
+      if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(o)) atomicMax(o, __float_as_uint(mx));   // (look before the atomic)
+    }
   }
 }
 
@@ -1231,7 +1248,7 @@ int DSPN_FN(dspn_bn_apply)(const st_t *x, const float *scale, const float *shift
 int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                          const float *mean, const float *rstd, const float *gamma, st_t *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
-                         void *workspace, size_t workspace_bytes, void *stream) {
+                         float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace, "bn_backward: null pointer");
   DSPN_REQUIRE(!relu || (scale && shift), "bn_backward: relu needs the forward scale/shift");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward: C must be a positive multiple of 4");
@@ -1261,7 +1278,7 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
-                     accumulate);
+                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax));
   return dspn::check_launch("bn_backward");
 }
 
@@ -1270,7 +1287,7 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
 int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+                                   int accumulate, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
   DSPN_REQUIRE(!relu || (scale && shift), "bn_backward_from_sums: relu needs the forward scale/shift");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward_from_sums: C must be a positive multiple of 4");
@@ -1302,7 +1319,7 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
-                     accumulate);
+                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax));
   return dspn::check_launch("bn_backward_from_sums");
 }
 

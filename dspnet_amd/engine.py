@@ -123,6 +123,13 @@ class Graph:
         # created: a later functional.set_conv_math() does not change what an existing graph computes
         self.math = fn.get_conv_math()
         self.wp_table = None       # split math: descriptor table of every piece-plane weight operand (one launch per step)
+        # "f16x2" math: one float per operand magnitude (functional.absmax), all in one arena zeroed at the top of forward();
+        # slots are handed out while the graph is built (new_scalar) and become views of the arena in finalize()
+        self._nscal = 0
+        self.scalars = None
+        self.am_table = None       # descriptor table of the weight magnitudes (one launch per step)
+        self._am_x = {}            # (id of the raw input tensor, id of its affine scale) -> slot shared by its readers
+        self._am_done = set()      # slots already computed in the current step
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -142,6 +149,14 @@ class Graph:
     def add(self, node):
         self.nodes.append(node)
         return node
+
+    def new_scalar(self):
+        """index of a fresh slot of the operand-magnitude arena ("f16x2" math)"""
+        self._nscal += 1
+        return self._nscal - 1
+
+    def scalar(self, i):
+        return None if (i is None or self.scalars is None) else self.scalars[i * fn.ABSMAX_SLOTS:(i + 1) * fn.ABSMAX_SLOTS]
 
     def _resolve_auto_deferred(self):
         """BatchNorm(defer_apply="auto"): keep the output virtual only if every reader is a plain convolution input;
@@ -201,10 +216,27 @@ class Graph:
             n.bwd_sums = (fn.zeros(tiles, 2, last.x.shape[3], device=self.device), tiles)
             last.bn_bwd_node = n
 
+    def _plan_gradient_magnitudes(self):
+        """"f16x2" math: a BatchNorm whose backward is the LAST writer of its input's gradient (backward runs the nodes in
+        reverse: the reader with the smallest index) stores the complete gradient, so its apply kernel can also take the
+        magnitude the producing convolution needs (BatchNorm.completes_x_grad)."""
+        first_reader = {}
+        for idx, m in enumerate(self.nodes):
+            for k, v in vars(m).items():
+                if k == "out":
+                    continue
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, Tensor):
+                        first_reader.setdefault(id(t), idx)
+        for idx, n in enumerate(self.nodes):
+            if isinstance(n, BatchNorm):
+                n.completes_x_grad = first_reader.get(id(n.x)) == idx
+
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._resolve_auto_deferred()
         self._plan_bn_backward_fusion()
+        self._plan_gradient_magnitudes()
         self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and (n.wt is not None or n.wh is not None)]
         off = 0
         for p in self.param_order:
@@ -235,6 +267,11 @@ class Graph:
                 self.wt_table = fn.weight_transpose_table([(n.w.data, n.wt, n.wh) for n in pairs], self.device)
                 self.half_operands = self.wt_table[3]
         if self.device.type == "cuda":
+            if self.math == "f16x2" and self._nscal:
+                self.scalars = torch.zeros(self._nscal * fn.ABSMAX_SLOTS, dtype=torch.float32, device=self.device)
+                pairs = [(n.w.data, self.scalar(n.am_w)) for n in self.nodes if isinstance(n, Conv) and n.am_w is not None]
+                if pairs:
+                    self.am_table = fn.absmax_table(pairs, self.device)
             planes = [(n.w.data, n.wp, n.wtp) for n in self.nodes
                       if isinstance(n, Conv) and (n.wp is not None or n.wtp is not None)]
             if planes:
@@ -278,6 +315,11 @@ class Graph:
             self.wt_batched = True
         if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands)
             fn.weight_planes_batch(*self.wp_table)
+        if self.scalars is not None:   # "f16x2" math: every operand magnitude of the step starts from zero; the weights' now
+            self.scalars.zero_()
+            self._am_done = set()
+            if self.am_table is not None:
+                fn.absmax_batch(*self.am_table)
         for f in self.pre_forward:
             f()
         for n in self.nodes:
@@ -460,6 +502,10 @@ class BatchNorm(Node):
                                      # still gather this BatchNorm's backward reductions in its epilogue)
         self.bwd_sums = None         # (buffer, tiles) written by the LAST data gradient into self.out.grad
         self.bwd_sums_ready = False
+        self._g = g
+        # True when this node's backward is the LAST writer of x's gradient (set by Graph.finalize): only then is the dx it
+        # stores the complete gradient whose magnitude the producing convolution may use
+        self.completes_x_grad = False
 
     def forward(self):
         if self.tile_stats is not None:
@@ -477,8 +523,17 @@ class BatchNorm(Node):
     def backward(self):
         if not self.out._gw:
             return
+        am = None
         if self.x.requires_grad:
             dx, acc = self.x.grad_target()
+            # "f16x2" math: dx is the output gradient of the convolution that produced x; when this call completes it (a
+            # tensor read by this BatchNorm alone, or the residual stream, whose last writer in backward order is the next
+            # unit's first BatchNorm), its magnitude comes out of the apply kernel instead of a pass of its own
+            prod, g = getattr(self.x, "producer", None), self._g
+            if (isinstance(prod, Conv) and prod.am_dy is not None and g.scalars is not None and dx.dtype == torch.float32
+                    and self.completes_x_grad):
+                am = g.scalar(prod.am_dy)
+                g._am_done.add(prod.am_dy)
         else:  # parameters still need their gradients; dx goes to scratch
             dx, acc = self.out.grad, False
         if self.bwd_sums_ready:      # the two reductions came out of the data-gradient kernel's epilogue
@@ -486,12 +541,12 @@ class BatchNorm(Node):
             fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                                      None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
                                      relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
-                                     dbeta=self.beta.grad, accumulate=acc)
+                                     dbeta=self.beta.grad, accumulate=acc, dx_absmax=am)
             return
         fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
-                       accumulate=acc)
+                       accumulate=acc, dx_absmax=am)
 
 
 class Conv(Node):
@@ -530,6 +585,7 @@ class Conv(Node):
         self.out.producer = self
         self.slabs, self.slabs_fresh = None, False     # deferred split-K slab reduction (Graph.flush_slabs)
         self.out_stats = None      # (buffer, tiles, rows per tile) once a BatchNorm asked for them
+        self.out_minmax = None     # "f16x2" math: (tiles, 2, Cout) smallest / largest output value per tile (with out_stats)
         self._g = g
         # residual: a tensor of the output's shape added in the conv epilogue (`conv3 + shortcut`,
         # symbol/resnet.py:51); its gradient is the output gradient itself
@@ -542,6 +598,14 @@ class Conv(Node):
         # split math: piece planes of the weight (forward operand) and of its transpose (data-gradient operand), cut once
         # per step by Graph.forward for the whole graph instead of once per tile inside the kernels
         self.math = g.math
+        # "f16x2" math: slots of the operand magnitudes.  Readers of one (raw tensor, affine) pair share the input's slot
+        # (act1 feeds conv1 and the projection shortcut); the gradient's and the weight's belong to this node.
+        self.am_x = self.am_dy = self.am_w = None
+        if g.math == "f16x2" and self.out.dtype == torch.float32:
+            key = (id(self.x_raw), None if self.in_affine is None else id(self.in_affine[0]))
+            if key not in g._am_x:
+                g._am_x[key] = g.new_scalar()
+            self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(), g.new_scalar()
         self.wp = self.wtp = None
         if g.device.type == "cuda":
             if fn.needs_planes(self.out.dtype, Cin, g.math):
@@ -582,20 +646,42 @@ class Conv(Node):
             if tiles == 0:
                 return None
             self.out_stats = (fn.zeros(tiles, 2, self.cout, device=self._g.device), tiles, tile_rows)
+            if self.math == "f16x2" and self.out.dtype == torch.float32:
+                # per-tile extremes of the output next to its statistics: the magnitude of BatchNorm(+ReLU)(out), which
+                # the next convolution multiplies, is then read off this table instead of off the whole tensor
+                self.out_minmax = fn.zeros(tiles, 2, self.cout, device=self._g.device)
         return self.out_stats
 
+    def _magnitudes(self, which):
+        """device scalars of this node's operand magnitudes ("f16x2" math; None otherwise).  `x`: computed by the first
+        reader of the (tensor, affine) pair in a step; `dy`: by backward(); `w`: by Graph.forward for all weights."""
+        g = self._g
+        if self.am_x is None or g.scalars is None:
+            return None
+        if which == "x" and self.am_x not in g._am_done:
+            prod = getattr(self.x_raw, "producer", None)
+            table = getattr(prod, "out_minmax", None) if self.in_affine is not None else None
+            if table is not None:    # monotone per channel: the extremes of (relu)(scale x + shift) sit at the extremes of x
+                fn.absmax(table.view(-1, table.shape[-1]), self.in_affine, out=g.scalar(self.am_x))
+            else:
+                fn.absmax(self.x_raw.data, self.in_affine, out=g.scalar(self.am_x))
+            g._am_done.add(self.am_x)
+        return g.scalar({"x": self.am_x, "dy": self.am_dy, "w": self.am_w}[which])
+
     def forward(self):
+        xa, wa = self._magnitudes("x"), self._magnitudes("w")
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
             fn.conv2d_forward(self.x.data, self.wop().view(cout * kh * kw, 1, 1, cin), None, 1, 0, 1, out=self.z,
-                              w_planes=self.wp, math=self.math)     # (the planes of [Cout][taps][..] ARE those of the view)
+                              w_planes=self.wp, math=self.math,     # (the planes of [Cout][taps][..] ARE those of the view)
+                              x_absmax=xa, w_absmax=wa)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
         fn.conv2d_forward(self.x_raw.data, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
                           residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine,
                           out_stats=None if self.out_stats is None else self.out_stats[0], w_planes=self.wp,
-                          math=self.math)
+                          math=self.math, x_absmax=xa, w_absmax=wa, out_minmax=self.out_minmax)
 
     def backward(self):
         if not self.out._gw:
@@ -609,20 +695,26 @@ class Conv(Node):
             self.residual.give_grad(dy)
         if self.b is not None and not self.relu:
             fn.colsum(dy, self.cout, out=self.b.grad)
+        # "f16x2" math: the gradient's magnitude once (after the in-place ReLU mask above), for both of its readers
+        xa, dya, wa = self._magnitudes("x"), self._magnitudes("dy"), self._magnitudes("w")
+        if dya is not None and self.am_dy not in self._g._am_done:       # (else: the BatchNorm backward that completed dy took it)
+            fn.absmax(dy, out=dya)
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
             fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
+            # (the weight gradient multiplies the SPREAD gradient z: its magnitude is taken on the fly, these are small layers)
             if self.slabs is not None:
-                fn.conv2d_wgrad_slabs(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), self.slabs, 1, 0, 1, math=self.math)
+                fn.conv2d_wgrad_slabs(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), self.slabs, 1, 0, 1, math=self.math,
+                                      x_absmax=xa)
             else:
                 fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
-                                out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math)
+                                out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math, x_absmax=xa)
         elif self.slabs is not None:
             fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
-                                  in_affine=self.in_affine, math=self.math)
+                                  in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya)
         else:
             fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
-                            in_affine=self.in_affine, math=self.math)
+                            in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya)
         self.slabs_fresh = self.slabs is not None
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
@@ -639,7 +731,7 @@ class Conv(Node):
                 bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
                 bn.bwd_sums_ready = True
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
-                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math)
+                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa)
 
 
 class BilinearConcatConv(Node):

@@ -23,7 +23,9 @@ _lib.register({
     "dspn_conv2d_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                      _ll, _i, _i, _i, _vp, _sz, _vp]),
     "dspn_conv2d_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                        _i, _ll, _i, _i, _i, _vp, _sz, _i, _vp, _sz, _vp]),
+                                        _i, _ll, _i, _i, _i, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dspn_absmax_f32": (_i, [_vp, _ll, _i, _vp, _vp, _i, _vp, _vp]),
+    "dspn_absmax_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_weight_planes_tiles": (_ll, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
@@ -31,10 +33,10 @@ _lib.register({
     "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      _i, _i, _vp, _sz, _vp]),
+                                      _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dspn_conv2d_wgrad_slabs_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                         _i, _i, _i, _vp]),
+                                         _i, _i, _i, _vp, _vp, _vp]),
     "dspn_conv2d_slab_reduce_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -42,9 +44,9 @@ _lib.register({
                                    _sz, _vp]),
     "dspn_conv2d_dgrad_bn_tiles": (_i, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp, _sz, _vp]),
+                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
-                                            _vp, _sz, _vp]),
+                                            _vp, _vp, _sz, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                             _vp, _sz, _vp]),
@@ -54,7 +56,7 @@ _lib.register({
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
-    "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _sz,
+    "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _sz,
                                   _vp]),
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
@@ -195,7 +197,7 @@ def act_empty(*shape, device=None):
 
 
 # ------------------------------------------------------------------ convolution
-_MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}      # include/dspn_nn.h DSPN_MATH_*
+_MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}      # include/dspn_nn.h DSPN_MATH_*
 # this module's default for the `math` argument it passes on every convolution call (float tensors); DSPN_CONV_MATH
 # overrides it for a whole process (the test suite is run once per mode)
 DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "bf16x3")
@@ -209,6 +211,8 @@ def set_conv_math(mode):
       "bf16x3"  fp32 results on the bf16 MFMA: every float operand cut into three bf16 pieces on its way into LDS, six
                 exact partial products per multiply, fp32 accumulate (default: as accurate as "fp32", ~1.3x faster)
       "fp32"    fp32 MFMA (v_mfma_f32_32x32x2_f32)
+      "f16x2"   fp32 results on the fp16 MFMA with half the matrix work of "bf16x3": two fp16 pieces per operand after a
+                per-tensor power-of-two scale, three exact products per multiply (include/dspn_nn.h DSPN_MATH_F32_F16X2)
       "bf16"    operands ROUNDED to bf16 (2^-9 relative), fp32 accumulate: BASELINE.json configs[3]
     Host-side default only: the C ABI takes the mode per call, the library itself has no state."""
     global _MATH
@@ -216,7 +220,7 @@ def set_conv_math(mode):
 
 
 def get_conv_math():
-    return ("fp32", "bf16", "bf16x3")[_MATH]
+    return ("fp32", "bf16", "bf16x3", "f16x2")[_MATH]
 
 
 def conv_stats_layout(out_pixels, cout):
@@ -231,6 +235,41 @@ def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta,
     check(L().dspn_bn_stats_from_tiles_f32(ptr(tile_stats), tiles, tile_rows, rows, C, eps, ptr(gamma), ptr(beta), ptr(mean),
                                            ptr(rstd), ptr(scale), ptr(shift), ptr(ws), ws.numel(), stream()),
           "bn_stats_from_tiles")
+
+
+ABSMAX_SLOTS = 64      # include/dspn_nn.h DSPN_ABSMAX_SLOTS: a magnitude is 64 partial maxima
+
+
+def absmax(x, in_affine=None, out=None):
+    """largest magnitude of the float32 tensor x (last dimension = channels, a multiple of 4) -- of (relu)(x * scale + shift)
+    when in_affine = (scale, shift, relu) is given -- as 64 partial maxima in device memory: the `*_absmax` operand of the
+    "f16x2" math (`.max()` of the result is the magnitude).  out: an existing 64-element float32 tensor to take the maxima
+    INTO (it is not zeroed here)"""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0
+    if out is None:
+        out = zeros(ABSMAX_SLOTS, device=x.device)
+    assert out.numel() == ABSMAX_SLOTS and out.dtype == torch.float32
+    sc, sh, relu = in_affine if in_affine is not None else (None, None, False)
+    C = x.shape[-1]
+    check(L().dspn_absmax_f32(ptr(x), x.numel() // C, C, ptr(sc), ptr(sh), int(bool(relu)), ptr(out), stream()), "absmax")
+    return out
+
+
+def absmax_table(pairs, device):
+    """pairs: [(float32 tensor, 64-element float32 output)] -> (device table, rows, total chunks) for absmax_batch"""
+    import numpy as np
+    rows = np.zeros(len(pairs), dtype=[("x", "<u8"), ("out", "<u8"), ("n4", "<i8"), ("begin", "<i8")])
+    total = 0
+    for i, (t, o) in enumerate(pairs):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 and o.numel() == ABSMAX_SLOTS
+        rows[i] = (t.data_ptr(), o.data_ptr(), t.numel() // 4, total)
+        total += (t.numel() // 4 + 1023) // 1024
+    assert rows.dtype.itemsize == 32
+    return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(pairs), total
+
+
+def absmax_batch(table, n, total):
+    check(L().dspn_absmax_batch_f32(ptr(table), n, total, stream()), "absmax_batch")
 
 
 def _math_code(math):
@@ -286,7 +325,8 @@ def weight_planes_batch(table, n, total):
 
 
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
-                   in_affine=None, out_stats=None, w_planes=None, math=None):
+                   in_affine=None, out_stats=None, w_planes=None, math=None, x_absmax=None, w_absmax=None,
+                   out_minmax=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
     in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x.
     math: "fp32" / "bf16" / "bf16x3" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split math when
@@ -300,6 +340,12 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
             w_planes = weight_planes(w)
     else:
         w_planes = None
+    assert out_minmax is None or (out_stats is not None and out_minmax.numel() == out_stats.numel())
+    if math == 3 and x.dtype == torch.float32:     # "f16x2": operand magnitudes (made here when the caller keeps none)
+        x_absmax = absmax(x, in_affine) if x_absmax is None else x_absmax
+        w_absmax = absmax(w) if w_absmax is None else w_absmax
+    else:
+        x_absmax = w_absmax = None
     ph, pw = _hw(pad)
     Ho, Wo = conv_out_size(H, R, stride, ph, dil), conv_out_size(W, S, stride, pw, dil)
     if out is None:
@@ -314,7 +360,8 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
                                          ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
-                                         math, ptr(ws), ws.numel(), stream()), "conv2d_forward")
+                                         ptr(out_minmax), math, ptr(x_absmax), ptr(w_absmax), ptr(ws), ws.numel(), stream()),
+          "conv2d_forward")
     return out
 
 
@@ -371,7 +418,7 @@ def conv_dgrad_bn_tiles(x_shape, stride):
 
 
 def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None, wt_planes=None,
-                 math=None):
+                 math=None, dy_absmax=None, w_absmax=None):
     """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin).
     bn_bwd = (bn_x, scale, shift, mean, rstd, relu, sums): dx is the complete gradient of a BatchNorm(+ReLU) output
     whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin).
@@ -386,6 +433,11 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
             wt_planes = weight_planes(wt)        # planes of the matrix wt itself: rows = Cin, cols = ldy
     else:
         wt_planes = None
+    if math == 3 and dy.dtype == torch.float32:
+        dy_absmax = absmax(dy) if dy_absmax is None else dy_absmax
+        w_absmax = absmax(wt) if w_absmax is None else w_absmax
+    else:
+        dy_absmax = w_absmax = None
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
         out = (zeros if Cx != Cin else empty)(N, H, W, Cx, device=dy.device, dtype=dy.dtype)
@@ -396,11 +448,18 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     check(_f("dspn_conv2d_dgrad_bn", dy)(ptr(dy), ptr(wt), ptr(wt_planes), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw,
                                        dil, Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
                                        ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
-                                       math, ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
+                                       math, ptr(dy_absmax), ptr(w_absmax), ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
     return out
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None, math=None):
+def _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax):
+    if math == 3 and x.dtype == torch.float32:
+        return (absmax(x, in_affine) if x_absmax is None else x_absmax, absmax(dy) if dy_absmax is None else dy_absmax)
+    return None, None
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None, math=None,
+                 x_absmax=None, dy_absmax=None):
     """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -413,9 +472,11 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     ph, pw = _hw(pad)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     assert x.dtype == dy.dtype and out.dtype == torch.float32
+    math = _math_code(math)
+    x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
-                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), _math_code(math), ptr(ws),
-                                       ws.numel(), stream()), "conv2d_wgrad")
+                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), math, ptr(x_absmax),
+                                       ptr(dy_absmax), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
     return out
 
 
@@ -445,7 +506,8 @@ def conv2d_wgrad_splits(x_shape, dy_shape, w_shape, stride):
     return L().dspn_conv2d_wgrad_splits(N, dy_shape[1], dy_shape[2], Cin, Cout, R, S, stride)
 
 
-def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None, math=None):
+def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None, math=None, x_absmax=None,
+                       dy_absmax=None):
     """the weight-gradient GEMM alone: split-K partial sums -> slabs (splits, Cout, R, S, Cin); see slab_reduce_batch"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -453,9 +515,11 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     ph, pw = _hw(pad)
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     assert x.dtype == dy.dtype and slabs.dtype == torch.float32
+    math = _math_code(math)
+    x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_slabs", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
-                                          dy.shape[2], _math_code(math), stream()), "conv2d_wgrad_slabs")
+                                          dy.shape[2], math, ptr(x_absmax), ptr(dy_absmax), stream()), "conv2d_wgrad_slabs")
 
 
 def slab_reduce_table(entries, device):
@@ -518,7 +582,8 @@ def bn_apply(x, scale, shift, relu=False, out=None):
 
 
 def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dgamma=None, dbeta=None,
-                accumulate=False):
+                accumulate=False, dx_absmax=None):
+    """dx_absmax: 64-float magnitude block that receives the partial maxima of |dx| as stored (see absmax)"""
     C = x.shape[-1]
     rows = _rows(x)
     dx = torch.empty_like(x) if dx is None else dx
@@ -528,13 +593,13 @@ def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dga
     ws = workspace(L().dspn_bn_workspace_bytes(rows, C), x.device, "bn")
     assert dy.dtype == x.dtype == dx.dtype
     check(_f("dspn_bn_backward", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
-                                   ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(ws),
+                                   ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(dx_absmax), ptr(ws),
                                    ws.numel(), stream()), "bn_backward")
     return dx, dgamma, dbeta
 
 
 def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=False, dx=None, dgamma=None,
-                          dbeta=None, accumulate=False):
+                          dbeta=None, accumulate=False, dx_absmax=None):
     """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...))"""
     C = x.shape[-1]
     rows = _rows(x)
@@ -546,7 +611,8 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     assert dy.dtype == x.dtype == dx.dtype
     check(_f("dspn_bn_backward_from_sums", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
-                                             int(accumulate), ptr(ws), ws.numel(), stream()), "bn_backward_from_sums")
+                                             int(accumulate), ptr(dx_absmax), ptr(ws), ws.numel(), stream()),
+          "bn_backward_from_sums")
     return dx, dgamma, dbeta
 
 

@@ -58,10 +58,25 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                         of cutting the float weights again in every tile of every call; the float operand may then be
  *                         NULL.  Other channel counts (3 -> 4, 20, 36 ...) read the float operand and ignore the planes.
  *                         Non-finite operands: +-inf and |x| > 3.39e38 give NaN / inf pieces (x - bf16(x) is inf - inf).
+ *   DSPN_MATH_F32_F16X2   fp32 RESULTS on the fp16 MFMA (v_mfma_f32_32x32x16_f16) with HALF the matrix work of the mode above:
+ *                         each float operand x, multiplied by a power of two s chosen per TENSOR, is cut into two fp16
+ *                         pieces (h0 = fp16(s x), h1 = fp16(s x - h0): 11 + 11 bits and a sign, equal to s x within 2^-24)
+ *                         and a product is h0 g0 + h0 g1 + h1 g0 (three exact partial products, fp32 accumulate; the
+ *                         dropped h1 g1 is below 2^-24 |x w|); the accumulators are multiplied by 1 / (s_x s_w) -- exact --
+ *                         in the epilogue.  Error against float64: the fp32 MFMA's (rms 1.15x, largest error lower;
+ *                         tests/test_nn_gpu.py).  What it needs that the bf16 split does not is RANGE (fp16: 2^-24 .. 65504):
+ *                         the caller passes, per operand, the operand's largest magnitude in device memory
+ *                         (`*_absmax` arguments: DSPN_ABSMAX_SLOTS partial maxima; dspn_absmax_f32 / dspn_absmax_batch_f32
+ *                         compute them, for a folded input affine of the tensor AFTER the affine); the kernel scales that
+ *                         maximum into [2^14, 2^15).
+ *                         Elements more than 2^17 below the tensor's maximum keep an absolute error of 2^-39 of that
+ *                         maximum instead of a relative one.  A NULL magnitude means scale 1 (caller vouches for
+ *                         |operand| < 65504); one that UNDERSTATES the maximum by more than 2x overflows to inf.
  * The *_bf16 entry points (bf16 tensors in HBM) ignore the argument: their operands are bf16 already. */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
 #define DSPN_MATH_F32_BF16X3 2
+#define DSPN_MATH_F32_F16X2 3
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
@@ -79,9 +94,16 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                long long y_batch_stride, int y_ldc, int relu, int accumulate,
-                               float *out_stats, size_t out_stats_bytes, int math,
+                               float *out_stats, size_t out_stats_bytes, float *out_minmax, int math,
+                               const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream);
-/* out_stats (optional): BatchNorm statistics of y gathered in the convolution's epilogue, one (mean, M2) pair per
+/* out_minmax (optional; written in DSPN_MATH_F32_F16X2 together with out_stats, same size and tiling): per row tile and
+ * channel the smallest [(t*2 + 0)*Cout + c] and largest [(t*2 + 1)*Cout + c] stored value.  A BatchNorm(+ReLU) of y is
+ * monotone per channel, so the magnitude of what the next convolution multiplies is dspn_absmax_f32 over THIS table
+ * (tiles*2 rows of Cout values) with that BatchNorm's scale / shift -- a few KB instead of a pass over y.
+ * x_absmax / w_absmax: DSPN_MATH_F32_F16X2 only (ignored otherwise): magnitudes (DSPN_ABSMAX_SLOTS floats each, see
+ * dspn_absmax_f32) of the input AFTER its affine and of the weights.
+ * out_stats (optional): BatchNorm statistics of y gathered in the convolution's epilogue, one (mean, M2) pair per
  * channel and row tile: out_stats[(t*2 + 0)*Cout + c] = mean of tile t's rows, [(t*2 + 1)*Cout + c] = their sum of
  * squared deviations.  dspn_conv2d_stats_layout() gives the number of tiles (0: not available, Cout % 4 != 0) and
  * the rows per tile for an output of out_pixels x Cout; dspn_bn_stats_from_tiles_f32 merges them.  Requires a dense
@@ -130,7 +152,8 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, const void *wt_pl
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                              int accumulate, const float *bn_x, const float *bn_scale, const float *bn_shift,
                              const float *bn_mean, const float *bn_rstd, int bn_relu, float *bn_sums,
-                             size_t bn_sums_bytes, int math, void *workspace, size_t workspace_bytes, void *stream);
+                             size_t bn_sums_bytes, int math, const float *dy_absmax, const float *w_absmax,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
  * from per-tap sums of dy without forming the gradient (the first convolution's input only feeds the
@@ -152,7 +175,8 @@ int dspn_conv2d_wgrad_f32(const float *x, const float *dy, float *dw,
 int dspn_conv2d_wgrad_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                              const float *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
-                             int accumulate, int math, void *workspace, size_t workspace_bytes, void *stream);
+                             int accumulate, int math, const float *x_absmax, const float *dy_absmax,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* The two halves of the weight gradient separately, so that a training step can run ONE slab reduction for many
  * layers (82 launches of a few microseconds each otherwise): dspn_conv2d_wgrad_slabs_f32 leaves the split-K partial
@@ -163,8 +187,23 @@ int dspn_conv2d_wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int R, in
 int dspn_conv2d_wgrad_slabs_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu,
                                 const float *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                 int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                                int Wo, int math, void *stream);
+                                int Wo, int math, const float *x_absmax, const float *dy_absmax, void *stream);
 int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4, void *stream);
+
+/* Operand magnitudes for DSPN_MATH_F32_F16X2.  A magnitude is DSPN_ABSMAX_SLOTS = 64 floats in device memory whose maximum is
+ * the largest |u| of the operand (64 partial maxima instead of one word: thousands of atomics on one address serialise);
+ * every `*_absmax` argument of the convolution entries points at such a block.  dspn_absmax_f32: out_dev[0..63] =
+ * max(out_dev[..], partial maxima of |u|) over a (rows, C) float tensor, u = x or (relu)(x * scale[c] + shift[c]) when scale /
+ * shift are given (the operand a convolution with a folded BatchNorm multiplies; the same fmaf as the loaders).  The caller
+ * zeroes the block (once per step is enough for a whole array of them); integer atomic max on the floats' bits:
+ * deterministic.  C % 4 == 0.
+ * Batch form (every weight of a graph in one launch): table of n 32-byte rows in DEVICE memory { const float *x; float *out
+ * (64 floats); int64 n4 (= elements / 4); int64 begin (= sum of ceil(n4 / 1024) over the preceding rows) }; total_chunks =
+ * that sum. */
+#define DSPN_ABSMAX_SLOTS 64
+int dspn_absmax_f32(const float *x, long long rows, int C, const float *scale, const float *shift, int relu,
+                    float *out_dev, void *stream);
+int dspn_absmax_batch_f32(const void *table, int n, long long total_chunks, void *stream);
 
 /* ---- bfloat16 TENSORS in HBM: the `*_bf16` twins (BASELINE.json configs[3] "bf16 MFMA convs" with the operands stored
  * as they are multiplied).  Same arguments and semantics as the `*_f32` entry of the same name, with every ACTIVATION
@@ -185,22 +224,24 @@ int dspn_conv2d_forward_bn_bf16(const dspn_bf16 *x, const float *in_scale, const
                                 int N, int H, int W, int Cin, int Cout, int R, int S,
                                 int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                                 long long y_batch_stride, int y_ldc, int relu, int accumulate,
-                                float *out_stats, size_t out_stats_bytes, int math,
+                                float *out_stats, size_t out_stats_bytes, float *out_minmax_unused, int math,
+                                const float *absmax_unused_a, const float *absmax_unused_b,
                                 void *workspace, size_t workspace_bytes, void *stream);
 int dspn_conv2d_dgrad_bn_bf16(const dspn_bf16 *dy, const dspn_bf16 *wt, const void *wt_planes_unused, dspn_bf16 *dx, int N, int H, int W, int Cin,
                               int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                               int dx_ldc, int accumulate, const dspn_bf16 *bn_x, const float *bn_scale,
                               const float *bn_shift, const float *bn_mean, const float *bn_rstd, int bn_relu,
-                              float *bn_sums, size_t bn_sums_bytes, int math, void *workspace, size_t workspace_bytes,
-                              void *stream);
+                              float *bn_sums, size_t bn_sums_bytes, int math, const float *absmax_unused_a,
+                              const float *absmax_unused_b, void *workspace, size_t workspace_bytes, void *stream);
 int dspn_conv2d_wgrad_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
                               const dspn_bf16 *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
                               int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
-                              int accumulate, int math, void *workspace, size_t workspace_bytes, void *stream);
+                              int accumulate, int math, const float *absmax_unused_a, const float *absmax_unused_b,
+                              void *workspace, size_t workspace_bytes, void *stream);
 int dspn_conv2d_wgrad_slabs_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
                                  const dspn_bf16 *dy, float *slabs, size_t slabs_bytes, int N, int H, int W, int Cin,
                                  int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
-                                 int Wo, int math, void *stream);
+                                 int Wo, int math, const float *absmax_unused_a, const float *absmax_unused_b, void *stream);
 int dspn_conv2d_input_sum_grad_bf16(const dspn_bf16 *dy, const float *w, float *out, int N, int H, int W,
                                     int Cin, int Cout, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil,
                                     int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream);
@@ -241,15 +282,18 @@ int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, fl
 /* Backward of the fused op.  If relu != 0, dy is first masked with (x*scale + shift > 0), i.e. the
  * forward output's sign recomputed from x (the forward output itself is not read).
  * dx (+)= gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); dgamma = sum dy*xhat; dbeta = sum dy.
- * dgamma may be NULL (fix_gamma).  accumulate != 0: dx += . */
+ * dgamma may be NULL (fix_gamma).  accumulate != 0: dx += .
+ * dx_absmax (optional, float tensors): DSPN_ABSMAX_SLOTS floats that receive the partial maxima of |dx| AS STORED (after
+ * the accumulation), i.e. dspn_absmax_f32(dx) without its pass over dx: the magnitude the convolution that produced x
+ * needs for its data / weight gradient in DSPN_MATH_F32_F16X2.  The caller zeroes it, as for dspn_absmax_f32. */
 int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift, const float *dy,
                          const float *mean, const float *rstd, const float *gamma, float *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream);
 int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+                                   int accumulate, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- element-wise / layout --------------------------------------------------------------- */
 int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream);      /* out = a + b */
@@ -409,11 +453,12 @@ int dspn_bn_apply_bf16(const dspn_bf16 *x, const float *scale, const float *shif
 int dspn_bn_backward_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
                          const float *mean, const float *rstd, const float *gamma, dspn_bf16 *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         float *dx_absmax_unused, void *workspace, size_t workspace_bytes, void *stream);
 int dspn_bn_backward_from_sums_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, dspn_bf16 *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+                                   int accumulate, float *dx_absmax_unused, void *workspace, size_t workspace_bytes,
+                                   void *stream);
 int dspn_add_bf16(const dspn_bf16 *a, const dspn_bf16 *b, dspn_bf16 *out, long long n, void *stream);
 int dspn_relu_backward_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long n, int accumulate, void *stream);
 int dspn_relu_backward_colsum_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long rows, int C, int ld,

@@ -24,8 +24,10 @@ def timeit(f, reps=5):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-fn.set_conv_math("bf16x3")
-print("halo:", "off" if os.environ.get("DSPN_NT_NOHALO") else "on")
+WG_MODE = os.environ.get("X3_WG_MODE", os.environ.get("X3_MODE", "bf16x3"))
+MODE = os.environ.get("X3_MODE", "bf16x3")      # bf16x3 | f16x2
+fn.set_conv_math(MODE)
+print("math:", MODE)
 print("%-11s %7s | %-22s | %-22s | %-22s | %-22s" % ("layer", "GFLOP", "fwd ms  TF  frac", "fwd+affine+stats", "dgrad", "wgrad"))
 tot = [0.0] * 4; totf = 0.0
 for name, H, W, Cin, Cout, k, stride, pad in LAYERS:
@@ -37,14 +39,14 @@ for name, H, W, Cin, Cout, k, stride, pad in LAYERS:
     dy = torch.randn(B, Ho, Wo, Cout, device="cuda")
     y = torch.empty(B, Ho, Wo, Cout, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w)
     wt = fn.weight_transpose(w)
-    wp, wtp = fn.weight_planes(w), fn.weight_planes(w, transposed=True, cols=Cout)
+    wp, wtp = (fn.weight_planes(w), fn.weight_planes(w, transposed=True, cols=Cout)) if MODE == 'bf16x3' else (None, None)
     sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda")
     tiles, _ = fn.conv_stats_layout(B * Ho * Wo, Cout)
     st = torch.empty(tiles, 2, Cout, device="cuda")
     ts = [timeit(lambda: fn.conv2d_forward(x, w, None, stride, pad, 1, out=y, w_planes=wp)),
           timeit(lambda: fn.conv2d_forward(x, w, None, stride, pad, 1, out=y, w_planes=wp, in_affine=(sc, sh, True), out_stats=st)),
           timeit(lambda: fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=dx, wt_planes=wtp)),
-          timeit(lambda: fn.conv2d_wgrad(x, dy, tuple(w.shape), stride, pad, 1, out=dw))]
+          timeit(lambda: fn.conv2d_wgrad(x, dy, tuple(w.shape), stride, pad, 1, out=dw, math=WG_MODE))]
     for i in range(4): tot[i] += ts[i]
     totf += fl
     print("%-11s %7.1f | %s" % (name, fl / 1e9, " | ".join("%7.3f %6.1f %5.2f  " % (t, fl / t / 1e9, fl / t / 1e9 / 416.7) for t in ts)))

@@ -78,13 +78,13 @@ def test_convolution_argument_validation_without_gpu():
 
     def fwd(N=1, H=8, W=8, Cin=4, math=0, in_scale=None, in_shift=None):
         return lib.dspn_conv2d_forward_bn_f32(p, in_scale, in_shift, 0, p, None, None, None, p, N, H, W, Cin, 8, 3, 3, 1, 1, 1, 1,
-                                              8, 8, 8 * 8 * 8, 8, 0, 0, None, 0, math, None, 0, None)
+                                              8, 8, 8 * 8 * 8, 8, 0, 0, None, 0, None, math, None, None, None, 0, None)
 
     assert fwd(N=0) == -1 and b"bad geometry" in lib.dspn_last_error()
-    assert fwd(math=3) == -1 and b"DSPN_MATH" in lib.dspn_last_error()
+    assert fwd(math=4) == -1 and b"DSPN_MATH" in lib.dspn_last_error()
     assert fwd(math=-1) == -1
     assert fwd(in_scale=p) == -1 and b"go together" in lib.dspn_last_error()
-    for math in (0, 1, 2):          # DSPN_MATH_FP32, DSPN_MATH_BF16, DSPN_MATH_F32_BF16X3 are the accepted values
+    for math in (0, 1, 2, 3):       # DSPN_MATH_FP32, DSPN_MATH_BF16, DSPN_MATH_F32_BF16X3, DSPN_MATH_F32_F16X2 are the accepted values
         assert fwd(N=0, math=math) == -1 and b"bad geometry" in lib.dspn_last_error()
     # the split math reads whole 32-channel blocks from piece planes: without them the call is rejected (before any launch)
     assert fwd(Cin=64, math=2) == -1 and b"piece planes" in lib.dspn_last_error()
@@ -92,6 +92,8 @@ def test_convolution_argument_validation_without_gpu():
     assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 8, 9, 64, 48, None) == -1    # transposed planes: cols_t % 32
     assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 40, 9, 64, 32, None) == -1   # ... and cols_t >= Cout
     assert lib.dspn_conv2d_weight_planes_f32(p, None, None, 8, 9, 64, 0, None) == -1  # nothing to write
+    assert lib.dspn_absmax_f32(p, 8, 6, None, None, 0, p, None) == -1                # C % 4
+    assert lib.dspn_absmax_f32(p, 8, 8, p, None, 0, p, None) == -1                   # scale without shift
     assert lib.dspn_conv2d_weight_planes_tiles(64, 9, 64, 64, 1) == 2 * 9 * 2 and lib.dspn_conv2d_weight_planes_tiles(40, 1, 64, 64, 1) == 4
 
 

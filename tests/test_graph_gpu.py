@@ -16,7 +16,7 @@ from oracle import multibox as om
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bf16x3", "fp32"])
+@pytest.fixture(params=["bf16x3", "fp32", "f16x2"])
 def conv_math(request):
     """both fp32-result math modes of the float-tensor convolutions (functional.set_conv_math), same tolerances"""
     from dspnet_amd import functional as fn

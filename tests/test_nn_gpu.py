@@ -41,7 +41,7 @@ def close(got, exp, tol=1e-4):
     assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
 
 
-@pytest.fixture(params=["bf16x3", "fp32"])
+@pytest.fixture(params=["bf16x3", "fp32", "f16x2"])
 def conv_math(request):
     """the two math modes of float-tensor convolutions that promise fp32 results -- DSPN_MATH_F32_BF16X3 (three-piece bf16
     split, six exact products per multiply, fp32 accumulate: the default) and DSPN_MATH_FP32 (fp32 MFMA) -- held to the same
@@ -145,7 +145,7 @@ def test_split_math_needs_planes_at_the_c_abi(gpu_device):
     x = torch.zeros(1, 8, 16, 64, device="cuda"); w = torch.zeros(64, 3, 3, 64, device="cuda"); y = torch.zeros(1, 8, 16, 64, device="cuda")
     L = fn.L()
     rc = L.dspn_conv2d_forward_bn_f32(fn.ptr(x), 0, 0, 0, fn.ptr(w), 0, 0, 0, fn.ptr(y), 1, 8, 16, 64, 64, 3, 3, 1, 1, 1, 1, 8, 16,
-                                      0, 64, 0, 0, 0, 0, 2, 0, 0, fn.stream())
+                                      0, 64, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, fn.stream())
     assert rc != 0 and b"piece planes" in L.dspn_last_error()
     with pytest.raises(DspnError):
         fn.check(rc, "conv2d_forward")
@@ -604,7 +604,22 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_re
     tiles, tile_rows = fn.conv_stats_layout(N * Ho * Wo, Cout)
     assert tiles > 0
     st = torch.full((tiles, 2, Cout), float("nan"), device="cuda")
-    y = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, residual=res, out_stats=st)
+    mm = torch.full((tiles, 2, Cout), float("nan"), device="cuda") if conv_math == "f16x2" else None
+    y = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, residual=res, out_stats=st, out_minmax=mm)
+    if mm is not None:
+        # two-piece math: per-tile extremes of the stored output beside the statistics.  Exact (they are selections), and
+        # the magnitude of a BatchNorm(+ReLU) of y read off the table equals the one taken over the whole tensor
+        yt = y.view(-1, Cout)
+        assert torch.equal(mm[:, 0].min(0).values, yt.min(0).values) and torch.equal(mm[:, 1].max(0).values, yt.max(0).values)
+        rows = N * Ho * Wo
+        for t in (0, tiles - 1):
+            blk = yt[t * tile_rows:min(rows, (t + 1) * tile_rows)]
+            assert torch.equal(mm[t, 0], blk.min(0).values) and torch.equal(mm[t, 1], blk.max(0).values)
+        sc = torch.randn(Cout, generator=g).cuda(); sh = torch.randn(Cout, generator=g).cuda()
+        for relu_ in (True, False):
+            a = fn.absmax(mm.view(-1, Cout), (sc, sh, relu_)).max()
+            b = fn.absmax(y, (sc, sh, relu_)).max()
+            assert float(a) == float(b) and float(b) > 0
     y_plain = fn.conv2d_forward(xd, wd_, bd, stride=stride, pad=pad, residual=res)
     # (not bit-equal in general: small grids take the split-K path without out_stats, a different summation order)
     assert float((y - y_plain).abs().max()) <= 1e-5 * float(y_plain.abs().max())
