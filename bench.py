@@ -9,17 +9,18 @@ BASELINE.json's scaling target is quoted on).  Weak scaling: every rank holds a 
 32-image shard; the only collective is the gradient all-reduce.
 
 fp32 here means fp32 tensors, fp32 accumulation and fp32-accurate products.  The default convolution
-math (--math bf16x3, DSPN_MATH_F32_BF16X3) forms every product from six exact bf16 x bf16 partial
-products of a three-piece split of both fp32 operands on the bf16 MFMA -- its error against float64 is
-the same as the fp32 MFMA's (tests/test_nn_gpu.py::test_split_bf16_math_is_as_accurate_as_the_fp32_mfma,
-and every graph parity test runs in both modes at one tolerance); --math fp32 runs v_mfma_f32_32x32x2_f32
-and is reported beside the headline under other_configs.
+math (--math f16x2, DSPN_MATH_F32_F16X2, round 3) forms every product from three exact fp16 x fp16
+partial products of a two-piece split of both fp32 operands (after a per-tensor power-of-two scale that
+puts the operand inside fp16's range) on the fp16 MFMA -- its error against float64 is the fp32 MFMA's
+(tests/test_nn_gpu.py::test_split_math_is_as_accurate_as_the_fp32_mfma, and every graph parity test runs
+in all three fp32-result modes at one tolerance); --math bf16x3 (six bf16 products, round 2's default) and
+--math fp32 (v_mfma_f32_32x32x2_f32) are reported beside the headline under other_configs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline     - the implicit-GEMM convolution family: algorithmic conv FLOPs executed per step / conv
                  kernel time per step, the latter measured live with HIP events on the launch stream
-                 over the timed region; peak = the instruction that bounds the mode (bf16x3: bf16 MFMA
-                 2500 TFLOP/s / 6 products per multiply-add = 416.7; fp32: 157.3; bf16: 2500);
+                 over the timed region; peak = the instruction that bounds the mode (f16x2: 16-bit MFMA
+                 2500 TFLOP/s / 3 products per multiply-add = 833.3; bf16x3: 2500 / 6 = 416.7; fp32: 157.3; bf16: 2500);
   math_accuracy_check - one backbone layer in the three math modes against float64 (N = 1): the default math's error next
                  to the fp32 MFMA's and the bf16 mode's, measured in this run;
   roofline_ops - the HBM-bound operators SURVEY.md 8(d) names (MultiBoxTarget, MultiBoxDetection, the BatchNorm backward
@@ -47,7 +48,8 @@ MATH_LABEL = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (operands rounded to bf16)
               "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)",
               "f16x2": "fp32 on the fp16 MFMA (2-piece split after a per-tensor power-of-two scale, 3 products)"}
 # committed rocprofv3 --pmc passes of the headline workload per math mode, newest first (roofline.traffic is read from these)
-TRAFFIC_PROFILES = {"bf16x3": ["r02_x3_pmc_conv_family.json"],
+TRAFFIC_PROFILES = {"f16x2": ["r03_f16x2_pmc_conv_family.json"],
+                    "bf16x3": ["r03_x3_pmc_conv_family.json", "r02_x3_pmc_conv_family.json"],
                     "fp32": ["r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json", "r01_j_pmc_conv_family.json"]}
 PROF_STEPS = 2   # steps of the timed region whose convolution launches are bracketed by HIP events (roofline.achieved)
 
@@ -63,9 +65,10 @@ def parse():
     ap.add_argument("--network", default="resnet-50", choices=["resnet-50", "vgg16_reduced", "inceptionv3"],
                     help="backbone preset; the headline workload is resnet-50 (the other BASELINE.json configs: "
                          "vgg16_reduced --batch 16; inceptionv3 --size 512 --width 1024 --batch 8 --math bf16)")
-    ap.add_argument("--math", default="bf16x3", choices=["bf16x3", "f16x2", "fp32", "bf16"],
-                    help="convolution math on float tensors: bf16x3 = fp32 results from six exact bf16 products per "
-                         "multiply on the bf16 MFMA (default), fp32 = fp32 MFMA, bf16 = operands rounded to bf16")
+    ap.add_argument("--math", default="f16x2", choices=["f16x2", "bf16x3", "fp32", "bf16"],
+                    help="convolution math on float tensors: f16x2 = fp32 results from three exact fp16 products per "
+                         "multiply (two fp16 pieces per operand after a per-tensor power-of-two scale; default), bf16x3 = "
+                         "six exact bf16 products per multiply, fp32 = fp32 MFMA, bf16 = operands rounded to bf16")
     ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"],
                     help="storage type of activation tensors and convolution operands in HBM: float32 (default) or "
                          "bfloat16 (the *_bf16 kernels: bf16 MFMA, fp32 accumulate, fp32 master weights)")
@@ -298,7 +301,7 @@ def math_accuracy_check(dev):
     out = {"layer": "3x3 conv 256->256, 8x32x32, K = 2304; max |err| / max |ref| against float64"}
     prev = fn.get_conv_math()
     try:
-        for mode in ("bf16x3", "fp32", "bf16"):
+        for mode in ("f16x2", "bf16x3", "fp32", "bf16"):
             fn.set_conv_math(mode)
             y = fn.conv2d_forward(xd, wd, None, 1, 1, 1)
             dx = fn.conv2d_dgrad(dyd, wt, tuple(xd.shape), 1, 1, 1)
@@ -352,11 +355,12 @@ def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, tr
            "nt_ms_per_step": round(nt_ms / steps, 3), "wgrad_ms_per_step": round(wg_ms / steps, 3),
            "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
            "share_of_step_time": round(conv_s / step_s, 3)}
-    if math == "bf16x3":
-        # the same work priced two other ways: against the fp32 MFMA it replaces, and as issued bf16 MFMA flops
-        out["peak_note"] = "2500 TFLOP/s bf16 MFMA / 6 bf16 products per fp32 multiply-add"
+    if math in ("bf16x3", "f16x2"):
+        # the same work priced two other ways: against the fp32 MFMA it replaces, and as issued 16-bit MFMA flops
+        k = 6.0 if math == "bf16x3" else 3.0
+        out["peak_note"] = "2500 TFLOP/s 16-bit MFMA / %d products per fp32 multiply-add" % k
         out["achieved_vs_fp32_mfma_peak"] = round(ach / FP32_MATRIX_PEAK_TFLOPS, 4)
-        out["issued_bf16_mfma_tflops"] = round(6.0 * ach, 1)
+        out["issued_16bit_mfma_tflops"] = round(k * ach, 1)
     return out
 
 
@@ -600,12 +604,13 @@ def main():
     # the other BASELINE.json configs beside the headline workload: short side measurements OUTSIDE the timed region
     # above (never part of `value`), N=1 only, each with its own roofline block
     other = None
-    headline = (args.network, S, Wd, B, args.math, args.store) == ("resnet-50", 512, 512, 32, "bf16x3", "fp32")
+    headline = (args.network, S, Wd, B, args.math, args.store) == ("resnet-50", 512, 512, 32, "f16x2", "fp32")
     if rank == 0 and world == 1 and headline and not args.no_other_configs and not args.no_cpu_baseline:
         del solver
         other = {}
         for key, f in (("headline shape, fp32 MFMA", lambda: side_train("resnet-50", 512, 512, 32, "fp32", 6, 2, dev)),
-                       ("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "bf16x3", 5, 2, dev)),
+                       ("headline shape, bf16x3 (round-2 default)", lambda: side_train("resnet-50", 512, 512, 32, "bf16x3", 6, 2, dev)),
+                       ("configs[1]", lambda: side_train("vgg16_reduced", 512, 512, 16, "f16x2", 5, 2, dev)),
                        ("configs[3]", lambda: side_train("inceptionv3", 512, 1024, 8, "bf16", 8, 3, dev, store="bf16")),
                        ("headline shape, bf16 tensors", lambda: side_train("resnet-50", 512, 512, 32, "bf16", 8, 3, dev, store="bf16")),
                        ("configs[4]", lambda: side_infer(64, 512, 100, 10, dev))):

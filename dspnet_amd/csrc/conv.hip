@@ -79,8 +79,9 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, b
 // 2^-24 |x w|.  Half the MFMAs of the three-piece bf16 split for the same fp32-level result -- what it costs is RANGE: fp16
 // holds 2^-24 .. 65504, so the scale must put the tensor's largest magnitude below 2^15; elements more than 2^17 below
 // that maximum keep an ABSOLUTE error of 2^-25 / s (2^-40 of the maximum) instead of a relative one.
-// the power of two that maps a largest magnitude m into [2^14, 2^15) (1 for m = 0 / non-finite m; exponent kept within +-60
-// so that the product of two scales and its reciprocal stay finite floats)
+// the power of two that maps a largest magnitude m into [2^14, 2^15) (1 for m = 0 / non-finite m).  Exponent kept within
+// +-100, i.e. magnitudes from 2^-85 to 2^115 are scaled exactly into place (beyond that the pieces underflow / overflow);
+// the epilogues undo the two operand scales one after the other, so no product of scales is ever formed
 constexpr int kAbsmaxSlots = 64;    // a magnitude "scalar" is 64 partial maxima (see absmax_kernel): one per lane here
 __device__ __forceinline__ float operand_scale(const float *absmax) {
   if (!absmax) return 1.f;
@@ -91,7 +92,7 @@ __device__ __forceinline__ float operand_scale(const float *absmax) {
   int e;
   (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1  ->  m * 2^(15 - e) < 2^15
   e = 15 - e;
-  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return __uint_as_float((unsigned)(127 + e) << 23);
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -208,7 +209,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
   constexpr int ROWH = SPLIT ? NPC * 32 + 8 : kLdsRowH;   // LDS row (16-bit elements) of the 16-bit images: 208 / 144 / 80 B
-  constexpr int STAGES = SPLIT ? 1 : 2;               // the three-piece image is single-buffered (two barriers per k-step)
+  // the three-piece image is single-buffered (two barriers per k-step: two stages of 208-B rows do not leave two workgroups
+  // per CU); the two-piece image (144-B rows) fits twice: one barrier per k-step, as in the unsplit modes
+#ifdef DSPN_F16X2_ONE_STAGE
+  constexpr int STAGES = SPLIT ? 1 : 2;
+#else
+  constexpr int STAGES = MATH == 2 ? 1 : 2;
+#endif
   __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
   __bf16 *hB = hA + STAGES * BM * ROWH;
 
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 
   // two-piece mode: operand scales (wave-uniform, read once), and their exact inverse for the epilogue
   const float sc_a = MATH == 3 ? operand_scale(g.a_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.b_absmax) : 1.f;
-  const float sc_o = MATH == 3 ? 1.f / (sc_a * sc_b) : 1.f;
+  const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;      // (exact: powers of two)
   const int chunk = tid & 7, row0 = tid >> 3;
   // 8-wave kernels only (measured: +3..4 % there; on 4 waves the doubled store count costs more than the reads gain)
   constexpr bool LDS_SHIFT = NTHR == 512;
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              if (m < M) o[(long long)m * g.Cout + co] = MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];
+              if (m < M) o[(long long)m * g.Cout + co] = MATH == 3 ? acc[i][j][r] * inv_a * inv_b : acc[i][j][r];
             }
         }
       } else if (dbg & 32) {   // timing-only ablation: no epilogue (the impossible compare keeps the MFMAs alive)
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] =
-                  MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];      // (two-piece mode: undo the operand scales, exact)
+                  MATH == 3 ? acc[i][j][r] * inv_a * inv_b : acc[i][j][r];      // (two-piece mode: undo the operand scales, exact)
         rows_bn_x();   // requested once the accumulators are staged (their registers are free), ahead of the barrier
         __syncthreads();
         float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1085,7 +1092,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // split mode: three piece planes per operand, single-buffered: [3][kPK][RAB] then [3][kPK][RBB]
   constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? NPC : 1;
   const float sc_a = MATH == 3 ? operand_scale(g.dy_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.x_absmax) : 1.f;
-  const float sc_o = MATH == 3 ? 1.f / (sc_a * sc_b) : 1.f;
+  const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
   char *hA = reinterpret_cast<char *>(smem);            // [2][kPK][RAB]
   char *hB = hA + STAGES * PLANES * kPK * RAB;          // [2][kPK][RBB]
   // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
@@ -1301,7 +1308,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] =
-            MATH == 3 ? acc[i][j][r] * sc_o : acc[i][j][r];
+            MATH == 3 ? acc[i][j][r] * inv_a * inv_b : acc[i][j][r];
   __syncthreads();
   constexpr int C4 = BN / 4, RPP = NTHR / C4;
   const int c4 = tid % C4, er0 = tid / C4;
@@ -1645,7 +1652,12 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-  const size_t lds = std::max<size_t>(MATH == 3   ? sizeof(__bf16) * (BM + BN) * (2 * 32 + 8)
+#ifdef DSPN_F16X2_ONE_STAGE
+  constexpr int kStages3 = 1;
+#else
+  constexpr int kStages3 = 2;
+#endif
+  const size_t lds = std::max<size_t>(MATH == 3   ? sizeof(__bf16) * kStages3 * (BM + BN) * (2 * 32 + 8)
                                       : MATH == 2 ? sizeof(__bf16) * (BM + BN) * kLdsRowS
                                       : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
                                                   : sizeof(float) * 2 * (BM + BN) * kLdsRow,

@@ -200,7 +200,7 @@ def act_empty(*shape, device=None):
 _MATH_CODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}      # include/dspn_nn.h DSPN_MATH_*
 # this module's default for the `math` argument it passes on every convolution call (float tensors); DSPN_CONV_MATH
 # overrides it for a whole process (the test suite is run once per mode)
-DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "bf16x3")
+DEFAULT_CONV_MATH = os.environ.get("DSPN_CONV_MATH", "f16x2")
 if DEFAULT_CONV_MATH not in _MATH_CODES:
     raise ValueError("DSPN_CONV_MATH=%r: expected one of %s" % (DEFAULT_CONV_MATH, ", ".join(sorted(_MATH_CODES))))
 _MATH = _MATH_CODES[DEFAULT_CONV_MATH]
@@ -208,8 +208,10 @@ _MATH = _MATH_CODES[DEFAULT_CONV_MATH]
 
 def set_conv_math(mode):
     """math of the float-tensor convolution calls made through this module from now on (include/dspn_nn.h DSPN_MATH_*):
+      "f16x2"   (default since round 3) fp32 results on the fp16 MFMA: two fp16 pieces per operand after a per-tensor
+                power-of-two scale, three exact products per multiply -- see below
       "bf16x3"  fp32 results on the bf16 MFMA: every float operand cut into three bf16 pieces on its way into LDS, six
-                exact partial products per multiply, fp32 accumulate (default: as accurate as "fp32", ~1.3x faster)
+                exact partial products per multiply, fp32 accumulate (the default of round 2; needs no operand magnitudes)
       "fp32"    fp32 MFMA (v_mfma_f32_32x32x2_f32)
       "f16x2"   fp32 results on the fp16 MFMA with half the matrix work of "bf16x3": two fp16 pieces per operand after a
                 per-tensor power-of-two scale, three exact products per multiply (include/dspn_nn.h DSPN_MATH_F32_F16X2)

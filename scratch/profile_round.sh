@@ -8,9 +8,10 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 COMMON="--no-cpu-baseline --no-other-configs"
-# x3 = the default math (fp32 results on the bf16 MFMA, DSPN_MATH_F32_BF16X3), fp32 = fp32 MFMA, bf16 = bf16 tensors in HBM
-for MODE in x3 fp32 bf16; do
-  ST=""; [ $MODE = bf16 ] && ST="--store bf16"; [ $MODE = fp32 ] && ST="--math fp32"
+# f16x2 = the default math (fp32 results from two fp16 pieces, DSPN_MATH_F32_F16X2), x3 = three bf16 pieces (round 2's default),
+# fp32 = fp32 MFMA, bf16 = bf16 tensors in HBM
+for MODE in f16x2 x3 fp32 bf16; do
+  ST=""; [ $MODE = bf16 ] && ST="--store bf16"; [ $MODE = fp32 ] && ST="--math fp32"; [ $MODE = x3 ] && ST="--math bf16x3"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python3 bench.py --steps 6 --warmup 2 $COMMON $ST > $OUT/bench_$MODE.log 2>&1
   grep '^{"metric"' $OUT/bench_$MODE.log > profiles/${TAG}_${MODE}_bench_line.json
   S=$(ls $OUT/kt_$MODE/*kernel_stats.csv 2>/dev/null | head -1)
@@ -22,8 +23,8 @@ for MODE in x3 fp32 bf16; do
   python3 scratch/pmc_traffic2.py $OUT/pmc_fetch_$MODE $OUT/pmc_write_$MODE 3 profiles/${TAG}_${MODE}_pmc_hbm_traffic.csv profiles/${TAG}_${MODE}_pmc_conv_family.json > $OUT/pmc_$MODE.txt 2>&1
   cat $OUT/pmc_$MODE.txt
 done
-for MODE in x3 fp32; do
-  ST=""; [ $MODE = fp32 ] && ST="--math fp32"
+for MODE in f16x2 x3 fp32; do
+  ST=""; [ $MODE = fp32 ] && ST="--math fp32"; [ $MODE = x3 ] && ST="--math bf16x3"
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_$MODE -o p -- python3 bench.py --steps 2 --warmup 1 --no-roofline $COMMON $ST > $OUT/pmc_mfma_$MODE.log 2>&1
   python3 scratch/pmc_mfma2.py $OUT/pmc_mfma_$MODE > profiles/${TAG}_${MODE}_pmc_mfma_busy.csv 2>$OUT/pmc_mfma_$MODE.err
 done

@@ -740,12 +740,13 @@ def test_conv_full_size_properties(gpu_device, conv_math, case):
 
 @pytest.mark.parametrize("case", [(8, 32, 32, 256, 256, 3, 1, 1), (8, 64, 64, 128, 512, 1, 1, 0), (8, 64, 64, 64, 64, 3, 1, 1),
                                   (4, 64, 64, 256, 128, 1, 2, 0), (2, 32, 32, 36, 40, 3, 1, 1)])
-def test_split_bf16_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
-    """DSPN_MATH_F32_BF16X3 against DSPN_MATH_FP32, both against float64, on operands with full 24-bit mantissas: forward,
-    data gradient and weight gradient (plain, and with the fused input affine + output statistics).  The split mode's
-    root-mean-square error may not exceed 1.25x the fp32 MFMA's on any of them and its largest error 2x (measured: rms
-    0.85 .. 1.05x, largest 0.8 .. 1.6x), and both stay below 1e-5 of the tensor's scale -- i.e. the six-product bf16 evaluation
-    is an fp32 convolution, not a reduced-precision one."""
+def test_split_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
+    """DSPN_MATH_F32_F16X2 (two fp16 pieces, three products, the default) and DSPN_MATH_F32_BF16X3 (three bf16 pieces, six
+    products) against DSPN_MATH_FP32, all against float64, on operands with full 24-bit mantissas: forward, data gradient and
+    weight gradient (plain, and with the fused input affine + output statistics).  A split mode's root-mean-square error
+    may not exceed 1.25x the fp32 MFMA's on any of them and its largest error 2x (measured: bf16x3 rms 0.85 .. 1.05x, largest
+    0.8 .. 1.6x; f16x2 rms 1.1 .. 1.2x, largest 0.6 .. 0.9x), and all stay below 1e-5 of the tensor's scale -- i.e. both are
+    fp32 convolutions, not reduced-precision ones."""
     N, H, W, Cin, Cout, k, stride, pad = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64).float().double().requires_grad_()
@@ -767,7 +768,7 @@ def test_split_bf16_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
         return float(d.abs().max() / exp.abs().max()), float((d * d).mean().sqrt() / exp.abs().max())
 
     errs = {}
-    for mode in ("fp32", "bf16x3"):
+    for mode in ("fp32", "bf16x3", "f16x2"):
         fn.set_conv_math(mode)
         try:
             y = fn.conv2d_forward(xd, wd_, None, stride=stride, pad=pad)
@@ -780,14 +781,61 @@ def test_split_bf16_math_is_as_accurate_as_the_fp32_mfma(gpu_device, case):
         errs[mode] = dict(fwd=rel(nchw(y, Cout), y_ref.detach()), dgrad=rel(nchw(dx, Cin), x.grad),
                           wgrad=rel(dw.permute(0, 3, 1, 2)[:, :Cin], w.grad), fwd_affine=rel(nchw(yu, Cout), yu_ref),
                           wgrad_affine=rel(dwu.permute(0, 3, 1, 2)[:, :Cin], dwu_ref))
-    print(case, {k: "max %.2f rms %.2f of fp32's" % (errs["bf16x3"][k][0] / errs["fp32"][k][0], errs["bf16x3"][k][1] / errs["fp32"][k][1])
-                 for k in errs["fp32"]})
-    for key in errs["fp32"]:
-        (mx, rx), (mf, rf) = errs["bf16x3"][key], errs["fp32"][key]
-        assert mx < 1e-5 and mf < 1e-5, (key, errs)
-        # the root-mean-square error is the stable statistic (the largest of 10^5 .. 10^7 errors fluctuates by tens of percent
-        # between two evaluations of equal quality): within 1.25x; the largest error within 2x
-        assert rx <= 1.25 * rf + 1e-9 and mx <= 2.0 * mf + 1e-8, (key, errs)
+    for split in ("bf16x3", "f16x2"):
+        print(case, split, {k: "max %.2f rms %.2f of fp32's" % (errs[split][k][0] / errs["fp32"][k][0], errs[split][k][1] / errs["fp32"][k][1])
+                            for k in errs["fp32"]})
+        for key in errs["fp32"]:
+            (mx, rx), (mf, rf) = errs[split][key], errs["fp32"][key]
+            assert mx < 1e-5 and mf < 1e-5, (split, key, errs)
+            # the root-mean-square error is the stable statistic (the largest of 10^5 .. 10^7 errors fluctuates by tens of
+            # percent between two evaluations of equal quality): within 1.25x; the largest error within 2x
+            assert rx <= 1.25 * rf + 1e-9 and mx <= 2.0 * mf + 1e-8, (split, key, errs)
+
+
+@pytest.mark.parametrize("xs,ws", [(1.0, 1.0), (1e-20, 1e-12), (1e20, 1e12), (3e-30, 1.0), (1.0, 1e25)])
+def test_two_piece_math_scales_any_float_magnitude_into_fp16_range(gpu_device, xs, ws):
+    """DSPN_MATH_F32_F16X2: the per-tensor power-of-two scales make the result independent of the operands' magnitudes --
+    the same convolution with x scaled by xs and w by ws gives exactly (xs * ws) times the unit-scale result when both are
+    powers of two, and the fp32 accuracy otherwise; forward, data gradient and weight gradient."""
+    fn.set_conv_math("f16x2")
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 32, 32, 64, generator=g).cuda(); w = (torch.randn(96, 3, 3, 64, generator=g) / 24).cuda()
+        dy = torch.randn(4, 32, 32, 96, generator=g).cuda()
+        y0 = fn.conv2d_forward(x, w, None, 1, 1, 1)
+        dx0 = fn.conv2d_dgrad(dy, fn.weight_transpose(w), tuple(x.shape), 1, 1, 1)
+        dw0 = fn.conv2d_wgrad(x, dy, tuple(w.shape), 1, 1, 1)
+        y = fn.conv2d_forward(x * xs, w * ws, None, 1, 1, 1)
+        dx = fn.conv2d_dgrad(dy * xs, fn.weight_transpose(w * ws), tuple(x.shape), 1, 1, 1)
+        dw = fn.conv2d_wgrad(x * xs, dy * ws, tuple(w.shape), 1, 1, 1)
+        for got, ref in ((y, y0), (dx, dx0), (dw, dw0)):
+            assert torch.isfinite(got).all()
+            exp = ref.double() * xs * ws
+            assert float((got.double() - exp).abs().max()) <= 2e-6 * float(exp.abs().max())
+    finally:
+        fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+
+
+def test_two_piece_math_with_a_wide_dynamic_range_inside_one_tensor(gpu_device):
+    """DSPN_MATH_F32_F16X2's documented limit: elements more than 2^17 below their tensor's largest magnitude keep an ABSOLUTE
+    error (2^-39 of that maximum) instead of a relative one.  One outlier of 2^20 in an otherwise unit-scale input: the
+    outputs it does not touch still agree with float64 to 1e-5 of the unit-scale output (the outlier's own outputs to 2e-6 of
+    theirs), where the three-piece bf16 split and the fp32 MFMA give 2e-6 everywhere."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 16, 64, generator=g, dtype=torch.float64).float()
+    w = (torch.randn(64, 3, 3, 64, generator=g, dtype=torch.float64) / 24).float()
+    x[0, 2, 2, 5] = 2.0 ** 20
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    far = torch.ones(2, 16, 16, dtype=torch.bool); far[0, 1:4, 1:4] = False          # outputs the outlier does not reach
+    unit = float(ref[far].abs().max())
+    for mode, tol in (("f16x2", 1e-5), ("bf16x3", 2e-6), ("fp32", 2e-6)):
+        fn.set_conv_math(mode)
+        try:
+            y = fn.conv2d_forward(x.cuda(), w.cuda(), None, 1, 1, 1).double().cpu()
+        finally:
+            fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+        assert float((y - ref)[far].abs().max()) <= tol * unit, mode
+        assert float((y - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), mode
 
 
 @pytest.mark.parametrize("k,cout", [(1, 64), (3, 32)])
