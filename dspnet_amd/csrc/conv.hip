@@ -200,10 +200,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NTHR = WAVES_M * WAVES_N * 64;          // 4 waves, or 8 (two workgroups then put 4 waves on every SIMD)
   constexpr int RSTEP = NTHR / 8;                       // tile rows covered by one pass of 16-byte loads (8 chunks per row)
-  constexpr bool PRE = MATH == 2 && UNIFORM_TAP;        // the weight operand is three bf16 piece planes (see above)
+  constexpr bool PRE = SPLIT && UNIFORM_TAP;            // the weight operand arrives as NPC piece planes (see above)
+  constexpr int PB = NPC * 32;                          // 16-bit elements of one (row, tap, 32-channel block) of the planes
   // 16-B loads per thread per k-step
   constexpr int A_LD = BM / RSTEP;
-  constexpr int B_LD = PRE ? 3 * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
+  constexpr int B_LD = PRE ? NPC * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
   constexpr bool B_EXACT = (4 * BN) % NTHR == 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // PRE: thread (row = tid >> 2, part = tid & 3) moves chunks 3 * part .. 3 * part + 2 of the 12 chunks (192 B) of tile
   // row `row` (+ NTHR / 4 per pass): one address register per pass, the three chunks at immediate offsets
   constexpr int B_PASS = PRE ? (4 * BN + NTHR - 1) / NTHR : 1;
-  static_assert(!PRE || B_LD == 3 * B_PASS || (4 * BN) % NTHR != 0, "chunk count of the piece-plane loader");
+  static_assert(!PRE || B_LD == NPC * B_PASS, "chunk count of the piece-plane loader");
   const int CB = g.Cin >> 5;                 // PRE: 32-channel blocks per tap
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int ps = 0; ps < B_PASS; ++ps) {
         const int br = (tid >> 2) + ps * (NTHR / 4), k = ld_n0 + br;
-        b_eoff[ps] = ((B_EXACT || br < BN) && k < g.Cout) ? k * (g.WTAPS * CB * kPlaneBlk) + (tid & 3) * 24 : -1;
+        b_eoff[ps] = ((B_EXACT || br < BN) && k < g.Cout) ? k * (g.WTAPS * CB * PB) + (tid & 3) * (NPC * 8) : -1;
       }
     } else {
 #pragma unroll
@@ -373,13 +374,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
     if constexpr (PRE) {
       // piece planes: the 192 bytes of (row, tap, block of 32 channels) are contiguous; 12 chunks per row
-      const int boff = (wtap * CB + (cq0 >> 3)) * kPlaneBlk;
+      const int boff = (wtap * CB + (cq0 >> 3)) * PB;
 #pragma unroll
       for (int ps = 0; ps < B_PASS; ++ps) {
         const bool v = qv && b_eoff[ps] >= 0;
         const unsigned off = ((unsigned)(b_eoff[ps] + boff) * 2u) | (v ? 0u : kOOB);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) hb[3 * ps + c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off + 16 * c, 0, 0);
+        for (int c = 0; c < NPC; ++c) hb[NPC * ps + c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off + 16 * c, 0, 0);
       }
     } else {
     const int b_off = wtap * g.Cin + cq * kEPC;
@@ -475,9 +476,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         for (int ps = 0; ps < B_PASS; ++ps) {
           const int br = (tid >> 2) + ps * (NTHR / 4);
           if (B_EXACT || br < BN) {
-            __bf16 *d = hB + br * ROWH + (tid & 3) * 24;
+            __bf16 *d = b + br * ROWH + (tid & 3) * (NPC * 8);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4_t *>(d + 8 * c) = hb[3 * ps + c];
+            for (int c = 0; c < NPC; ++c) *reinterpret_cast<u32x4_t *>(d + 8 * c) = hb[NPC * ps + c];
           }
         }
       } else {
@@ -1500,8 +1501,13 @@ __global__ void weight_transpose_batch_kernel(const WtDesc *__restrict__ d, int 
 // transposed ones go through a 6-KB LDS image and leave the same way -- both operands of a layer from ONE read of its
 // weights, every access a full line (the first version, one thread per element with 2-byte stores, took 0.51 ms per step;
 // the float transpose it replaced 0.27).  Table rows sorted by `begin` (tile index), found by binary search per workgroup.
-struct WpDesc { const float *w; __bf16 *planes; __bf16 *planes_t; int K, T, C, cols_t; long long begin; };
+// npc = 3: bf16 pieces (DSPN_MATH_F32_BF16X3); npc = 2: fp16 pieces of w * 2^e, the scale operand_scale() derives from the
+// weight's magnitude block `absmax` -- the same function of the same 64 floats the convolution kernels evaluate, so the planes
+// and the kernels' epilogue agree on it by construction
+struct WpDesc { const float *w; __bf16 *planes; __bf16 *planes_t; int K, T, C, cols_t; long long begin; const float *absmax; int npc, pad_; };
 __device__ __forceinline__ void weight_planes_tile(const WpDesc &e, long long tile, __bf16 (*sm)[32][36]) {
+  const int pb = e.npc * 32;
+  const float scale = e.npc == 2 ? operand_scale(e.absmax) : 1.f;
   const int cblocks = (e.C + 31) >> 5;
   const int cb = (int)(tile % cblocks);
   const long long kt = tile / cblocks;
@@ -1511,11 +1517,13 @@ __device__ __forceinline__ void weight_planes_tile(const WpDesc &e, long long ti
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (k < e.K && c < e.C) v = *reinterpret_cast<const float4 *>(e.w + ((long long)k * e.T + t) * e.C + c);   // C % 4 == 0
   bf16x4 p[3];
-  split3(v, p[0], p[1], p[2]);
+  if (e.npc == 2) { split2h(v, scale, p[0], p[1]); p[2] = p[1]; }
+  else split3(v, p[0], p[1], p[2]);
   if (e.planes && k < e.K && c < e.C) {      // (C % 32 == 0 whenever the forward planes exist)
-    __bf16 *d = e.planes + (((long long)k * e.T + t) * (e.C >> 5) + cb) * kPlaneBlk + 4 * q;
+    __bf16 *d = e.planes + (((long long)k * e.T + t) * (e.C >> 5) + cb) * pb + 4 * q;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = p[pc];
+    for (int pc = 0; pc < 3; ++pc)
+      if (pc < e.npc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = p[pc];
   }
   if (!e.planes_t) return;                    // block-uniform
 #pragma unroll
@@ -1525,9 +1533,10 @@ __device__ __forceinline__ void weight_planes_tile(const WpDesc &e, long long ti
   __syncthreads();
   const int cc = cb * 32 + r;                 // this thread's row of the transposed operand, columns k = 4q .. 4q+3 of the block
   if (cc < e.C && kb * 32 < e.cols_t) {
-    __bf16 *d = e.planes_t + (((long long)cc * e.T + t) * (e.cols_t >> 5) + kb) * kPlaneBlk + 4 * q;
+    __bf16 *d = e.planes_t + (((long long)cc * e.T + t) * (e.cols_t >> 5) + kb) * pb + 4 * q;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
+      if (pc >= e.npc) break;
       bf16x4 o = {sm[pc][r][4 * q], sm[pc][r][4 * q + 1], sm[pc][r][4 * q + 2], sm[pc][r][4 * q + 3]};
       *reinterpret_cast<bf16x4 *>(d + 32 * pc) = o;
     }
@@ -1761,12 +1770,12 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   const long long M = (long long)g.N * g.Hg * g.Wg;
   if (M <= 0) return 0;
   // split mode with whole 32-channel blocks per tap: the kernels read the weights as piece planes
-  const bool pre = !kHalf && g.bf16 == 2 && ((g.Cin / kEPC) & 7) == 0;
+  const bool pre = !kHalf && g.bf16 >= 2 && ((g.Cin / kEPC) & 7) == 0;
   if (pre) {
     if (!g.w_planes)
-      return dspn::fail(DSPN_ERR_ARG_, "conv: DSPN_MATH_F32_BF16X3 with a multiple of 32 input channels (%d) needs the weight operand as piece planes (dspn_conv2d_weight_planes_f32)", g.Cin);
+      return dspn::fail(DSPN_ERR_ARG_, "conv: the split math modes with a multiple of 32 input channels (%d) need the weight operand as piece planes (dspn_conv2d_weight_planes_f32)", g.Cin);
     w = static_cast<const st_t *>(g.w_planes);
-    g.w_bytes = (unsigned)(6ll * g.Cout * g.WTAPS * g.Cin);
+    g.w_bytes = (unsigned)((g.bf16 == 3 ? 4ll : 6ll) * g.Cout * g.WTAPS * g.Cin);
   }
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
   const int cfg = nt_config(M, g.Cout);
@@ -2000,11 +2009,12 @@ int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long t
 
 /* piece planes of a weight operand (DSPN_MATH_F32_BF16X3, include/dspn_nn.h) */
 int dspn_conv2d_weight_planes_f32(const float *w, void *planes, void *planes_t, int Cout, int taps, int Cin, int cols_t,
-                                  void *stream) {
+                                  int pieces, const float *w_absmax, void *stream) {
   DSPN_REQUIRE(w && (planes || planes_t) && Cout > 0 && taps > 0 && Cin > 0 && Cin % 4 == 0, "weight_planes: bad argument");
+  DSPN_REQUIRE(pieces == 3 || (pieces == 2 && w_absmax), "weight_planes: pieces is 3 (bf16) or 2 (fp16, with the weight's magnitude block)");
   DSPN_REQUIRE(!planes || Cin % 32 == 0, "weight_planes: the forward planes need Cin %% 32 == 0, got %d", Cin);
   DSPN_REQUIRE(!planes_t || (cols_t % 32 == 0 && cols_t >= Cout), "weight_planes: cols_t is the padded Cout, a multiple of 32");
-  WpDesc e{w, static_cast<__bf16 *>(planes), static_cast<__bf16 *>(planes_t), Cout, taps, Cin, planes_t ? cols_t : 0, 0};
+  WpDesc e{w, static_cast<__bf16 *>(planes), static_cast<__bf16 *>(planes_t), Cout, taps, Cin, planes_t ? cols_t : 0, 0, w_absmax, pieces, 0};
   const long long tiles = weight_planes_tiles(Cout, taps, Cin, cols_t, planes_t != nullptr);
   DSPN_REQUIRE(tiles < (1ll << 31), "weight_planes: too many tiles");
   hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, e);
@@ -2039,7 +2049,7 @@ int dspn_absmax_batch_f32(const void *table, int n, long long total_chunks, void
 
 int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_tiles, void *stream) {
   DSPN_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "weight_planes_batch: bad argument");
-  static_assert(sizeof(WpDesc) == 48, "table row layout: 3 pointers, 4 ints, 1 int64");
+  static_assert(sizeof(WpDesc) == 64, "table row layout: 3 pointers, 4 ints, 1 int64, 1 pointer, 2 ints");
   hipLaunchKernelGGL(weight_planes_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WpDesc *>(table), n);
   return dspn::check_launch("weight_planes_batch");

@@ -272,8 +272,8 @@ class Graph:
                 pairs = [(n.w.data, self.scalar(n.am_w)) for n in self.nodes if isinstance(n, Conv) and n.am_w is not None]
                 if pairs:
                     self.am_table = fn.absmax_table(pairs, self.device)
-            planes = [(n.w.data, n.wp, n.wtp) for n in self.nodes
-                      if isinstance(n, Conv) and (n.wp is not None or n.wtp is not None)]
+            planes = [(n.w.data, n.wp, n.wtp) + ((self.scalar(n.am_w),) if self.math == "f16x2" else ())
+                      for n in self.nodes if isinstance(n, Conv) and (n.wp is not None or n.wtp is not None)]
             if planes:
                 self.wp_table = fn.weight_planes_table(planes, self.device)
         if self.device.type == "cuda":
@@ -313,13 +313,13 @@ class Graph:
         if self.half_operands:         # bf16 copies (forward) and transposes (data gradient) of every weight, one launch
             fn.weight_transpose_batch(*self.wt_table)
             self.wt_batched = True
-        if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands)
-            fn.weight_planes_batch(*self.wp_table)
         if self.scalars is not None:   # "f16x2" math: every operand magnitude of the step starts from zero; the weights' now
             self.scalars.zero_()
             self._am_done = set()
             if self.am_table is not None:
                 fn.absmax_batch(*self.am_table)
+        if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands;
+            fn.weight_planes_batch(*self.wp_table)     # "f16x2": cut relative to the magnitudes just taken)
         for f in self.pre_forward:
             f()
         for n in self.nodes:
@@ -608,10 +608,11 @@ class Conv(Node):
             self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(), g.new_scalar()
         self.wp = self.wtp = None
         if g.device.type == "cuda":
+            npc = fn.plane_pieces(g.math)
             if fn.needs_planes(self.out.dtype, Cin, g.math):
-                self.wp = fn.zeros(num_filter, kh * kw, Cin // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
+                self.wp = fn.zeros(num_filter, kh * kw, Cin // 32, npc, 32, device=g.device, dtype=torch.bfloat16)
             if x.requires_grad and fn.needs_planes(self.out.dtype, ldc, g.math):
-                self.wtp = fn.zeros(Cin, kh * kw, ldc // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
+                self.wtp = fn.zeros(Cin, kh * kw, ldc // 32, npc, 32, device=g.device, dtype=torch.bfloat16)
         # tap-expanded evaluation (few output channels, stride 1): 1x1 convolution to Cout*kh*kw channels
         # on the same weight buffer + shifted sum over taps (include/dspn_nn.h, dspn_tap_sum_f32)
         self.tap_expand = bool(tap_expand) and kh * kw > 1
@@ -721,7 +722,8 @@ class Conv(Node):
                                      out=self.input_sum_grad.grad)
         if self.x.requires_grad:
             if self.wtp is not None and self._g.wp_table is None:
-                fn.weight_planes(self.w.data, transposed=True, cols=self.wtp.shape[2] * 32, out=self.wtp)
+                fn.weight_planes(self.w.data, transposed=True, cols=self.wtp.shape[2] * 32, out=self.wtp, math=self.math,
+                                 w_absmax=wa)
             elif self.wtp is None and not self._g.wt_batched:
                 fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
             dx, acc = self.x.grad_target()
@@ -780,7 +782,7 @@ class BilinearConcatConv(Node):
             self.wch.append(fn.act_zeros(T, 1, 1, t.shape[3], device=g.device) if half else None)   # bf16 forward operand
             self.dwc.append(fn.zeros(T, 1, 1, t.shape[3], device=g.device))
             # split math: piece planes of W_c (the forward operand), refreshed after every gather of the slices
-            self.wcp.append(fn.zeros(T, 1, t.shape[3] // 32, 3, 32, device=g.device, dtype=torch.bfloat16)
+            self.wcp.append(fn.zeros(T, 1, t.shape[3] // 32, fn.plane_pieces(g.math), 32, device=g.device, dtype=torch.bfloat16)
                             if g.device.type == "cuda" and fn.needs_planes(self.zc[-1].dtype, t.shape[3], g.math) else None)
         self.sources = None           # fn.SamplerSources over zc, made at the first forward
         self.out = g.tensor((N, Ht, Wt, fn.padc(num_filter)), name + "_out")
@@ -802,10 +804,11 @@ class BilinearConcatConv(Node):
         for c, t in enumerate(self.inputs):
             if self.wch[c] is not None:      # bf16 operands of this slice: copy + transpose in one launch
                 fn.weight_transpose(self.wc[c], out=self.wct[c], copy=self.wch[c])
+            wa = fn.absmax(self.wc[c]) if self.math == "f16x2" and self.wch[c] is None else None
             if self.wcp[c] is not None:
-                fn.weight_planes(self.wc[c], out=self.wcp[c])
+                fn.weight_planes(self.wc[c], out=self.wcp[c], math=self.math, w_absmax=wa)
             fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c],
-                              w_planes=self.wcp[c], math=self.math)
+                              w_planes=self.wcp[c], math=self.math, w_absmax=wa)
         if self.sources is None:
             self.sources = fn.SamplerSources([(z, 0) for z in self.zc])
         fn.affine_sampler_forward(self.sources, self.theta.data, self.z)       # z = sum_c U_c(theta)(W_c x_c), one pass

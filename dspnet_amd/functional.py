@@ -26,7 +26,7 @@ _lib.register({
                                         _i, _ll, _i, _i, _i, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_absmax_f32": (_i, [_vp, _ll, _i, _vp, _vp, _i, _vp, _vp]),
     "dspn_absmax_batch_f32": (_i, [_vp, _i, _ll, _vp]),
-    "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dspn_conv2d_weight_planes_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "dspn_conv2d_weight_planes_tiles": (_ll, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
@@ -280,45 +280,60 @@ def _math_code(math):
 
 def needs_planes(t_dtype, k_channels, math=None):
     """True when a forward / data-gradient call contracting over k_channels per tap reads its weight operand as piece
-    planes (include/dspn_nn.h: DSPN_MATH_F32_BF16X3, float tensors, whole 32-channel blocks)"""
-    return t_dtype == torch.float32 and _math_code(math) == 2 and k_channels % 32 == 0
+    planes (include/dspn_nn.h: the split math modes, float tensors, whole 32-channel blocks)"""
+    return t_dtype == torch.float32 and _math_code(math) in (2, 3) and k_channels % 32 == 0
 
 
-def weight_planes(w, transposed=False, cols=None, out=None):
-    """piece planes (rows, taps, cols / 32, 3, 32) bfloat16 of the float32 master w (Cout, R, S, Cin): of w itself
-    (rows = Cout, cols = Cin: `w_planes` of conv2d_forward) or, transposed, of its transpose (rows = Cin, cols >= Cout zero
-    padded: `wt_planes` of conv2d_dgrad)"""
+def plane_pieces(math=None):
+    """pieces per element of a piece-plane operand: 3 bfloat16 ("bf16x3") or 2 float16 of the scaled value ("f16x2")"""
+    return 2 if _math_code(math) == 3 else 3
+
+
+def weight_planes(w, transposed=False, cols=None, out=None, math=None, w_absmax=None):
+    """piece planes (rows, taps, cols / 32, pieces, 32) of the float32 master w (Cout, R, S, Cin): of w itself (rows = Cout,
+    cols = Cin: `w_planes` of conv2d_forward) or, transposed, of its transpose (rows = Cin, cols >= Cout zero padded:
+    `wt_planes` of conv2d_dgrad).  "bf16x3": 3 bfloat16 pieces.  "f16x2": 2 float16 pieces (16-bit containers, dtype
+    bfloat16 only names the width) of w scaled by the power of two that w_absmax (absmax(w), the block the convolution
+    is later given as its weight magnitude) implies."""
     Cout, R, S, Cin = w.shape
     assert w.dtype == torch.float32 and w.is_contiguous()
+    npc = plane_pieces(math)
+    assert npc == 3 or w_absmax is not None, "f16x2 planes are cut relative to the weight's magnitude block"
     rows, cols = (Cin, cols or (Cout + 31) // 32 * 32) if transposed else (Cout, Cin)
     assert cols % 32 == 0
     if out is None:
-        out = empty(rows, R * S, cols // 32, 3, 32, device=w.device, dtype=torch.bfloat16)
-    assert out.numel() == rows * R * S * cols * 3 and out.dtype == torch.bfloat16
+        out = empty(rows, R * S, cols // 32, npc, 32, device=w.device, dtype=torch.bfloat16)
+    assert out.numel() == rows * R * S * cols * npc and out.dtype == torch.bfloat16
     check(L().dspn_conv2d_weight_planes_f32(ptr(w), 0 if transposed else ptr(out), ptr(out) if transposed else 0, Cout,
-                                            R * S, Cin, cols if transposed else 0, stream()), "weight_planes")
+                                            R * S, Cin, cols if transposed else 0, npc,
+                                            ptr(w_absmax) if npc == 2 else 0, stream()), "weight_planes")
     return out
 
 
 def weight_planes_table(entries, device):
-    """entries: [(w float32 [Cout,R,S,Cin], planes or None, planes_t or None)] -> (device table, rows, total tiles) for
-    weight_planes_batch: every piece-plane operand of a graph refreshed from the float masters by ONE launch"""
+    """entries: [(w float32 [Cout,R,S,Cin], planes or None, planes_t or None[, w_absmax])] -> (device table, rows, total
+    tiles) for weight_planes_batch: every piece-plane operand of a graph refreshed from the float masters by ONE launch.
+    With w_absmax (the weight's magnitude block, filled before the launch) the row's planes are the two float16 pieces."""
     import numpy as np
     rows = np.zeros(len(entries), dtype=[("w", "<u8"), ("planes", "<u8"), ("planes_t", "<u8"), ("K", "<i4"), ("T", "<i4"),
-                                         ("C", "<i4"), ("cols_t", "<i4"), ("begin", "<i8")])
+                                         ("C", "<i4"), ("cols_t", "<i4"), ("begin", "<i8"), ("absmax", "<u8"),
+                                         ("npc", "<i4"), ("pad", "<i4")])
     total = 0
-    for i, (w, pl, plt) in enumerate(entries):
+    for i, e in enumerate(entries):
+        w, pl, plt = e[:3]
+        am = e[3] if len(e) > 3 else None
+        npc = 3 if am is None else 2
         Cout, R, S, Cin = w.shape
         assert w.dtype == torch.float32 and w.is_contiguous() and (pl is not None or plt is not None)
-        assert pl is None or (pl.dtype == torch.bfloat16 and pl.shape == (Cout, R * S, Cin // 32, 3, 32) and Cin % 32 == 0)
+        assert pl is None or (pl.dtype == torch.bfloat16 and pl.shape == (Cout, R * S, Cin // 32, npc, 32) and Cin % 32 == 0)
         cols_t = 0
         if plt is not None:
             cols_t = plt.shape[2] * 32
-            assert plt.dtype == torch.bfloat16 and plt.shape == (Cin, R * S, cols_t // 32, 3, 32) and cols_t >= Cout
+            assert plt.dtype == torch.bfloat16 and plt.shape == (Cin, R * S, cols_t // 32, npc, 32) and cols_t >= Cout
         rows[i] = (w.data_ptr(), 0 if pl is None else pl.data_ptr(), 0 if plt is None else plt.data_ptr(), Cout, R * S, Cin,
-                   cols_t, total)
+                   cols_t, total, 0 if am is None else am.data_ptr(), npc, 0)
         total += int(L().dspn_conv2d_weight_planes_tiles(Cout, R * S, Cin, cols_t, int(plt is not None)))
-    assert rows.dtype.itemsize == 48
+    assert rows.dtype.itemsize == 64
     return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(entries), total
 
 
@@ -331,23 +346,24 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
                    out_minmax=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
     in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x.
-    math: "fp32" / "bf16" / "bf16x3" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split math when
-    Cin % 32 == 0 (made here, one extra launch, when the caller keeps none)."""
+    math: "fp32" / "bf16" / "bf16x3" / "f16x2" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split
+    math modes when Cin % 32 == 0 (made here, one extra launch, when the caller keeps none)."""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
     math = _math_code(math)
-    if needs_planes(x.dtype, Cin, math):
-        if w_planes is None:
-            w_planes = weight_planes(w)
-    else:
-        w_planes = None
     assert out_minmax is None or (out_stats is not None and out_minmax.numel() == out_stats.numel())
     if math == 3 and x.dtype == torch.float32:     # "f16x2": operand magnitudes (made here when the caller keeps none)
+        assert w_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
         x_absmax = absmax(x, in_affine) if x_absmax is None else x_absmax
         w_absmax = absmax(w) if w_absmax is None else w_absmax
     else:
         x_absmax = w_absmax = None
+    if needs_planes(x.dtype, Cin, math):
+        if w_planes is None:
+            w_planes = weight_planes(w, math=math, w_absmax=w_absmax)
+    else:
+        w_planes = None
     ph, pw = _hw(pad)
     Ho, Wo = conv_out_size(H, R, stride, ph, dil), conv_out_size(W, S, stride, pw, dil)
     if out is None:
@@ -430,16 +446,17 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     Cin, R, S, ldy = wt.shape
     assert dy.shape[3] == ldy, (dy.shape, wt.shape)
     math = _math_code(math)
-    if needs_planes(dy.dtype, ldy, math):
-        if wt_planes is None:
-            wt_planes = weight_planes(wt)        # planes of the matrix wt itself: rows = Cin, cols = ldy
-    else:
-        wt_planes = None
     if math == 3 and dy.dtype == torch.float32:
+        assert wt_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
         dy_absmax = absmax(dy) if dy_absmax is None else dy_absmax
         w_absmax = absmax(wt) if w_absmax is None else w_absmax
     else:
         dy_absmax = w_absmax = None
+    if needs_planes(dy.dtype, ldy, math):
+        if wt_planes is None:                    # planes of the matrix wt itself: rows = Cin, cols = ldy
+            wt_planes = weight_planes(wt, math=math, w_absmax=w_absmax)
+    else:
+        wt_planes = None
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
         out = (zeros if Cx != Cin else empty)(N, H, W, Cx, device=dy.device, dtype=dy.dtype)

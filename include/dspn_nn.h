@@ -110,18 +110,22 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
  * output (y_ldc == Cout or 0). */
 int dspn_conv2d_stats_layout(long long out_pixels, int Cout, int *tile_rows);
 
-/* Piece planes of a weight operand for DSPN_MATH_F32_BF16X3, from the float master w [Cout][taps][Cin] (Cin % 4 == 0):
+/* Piece planes of a weight operand for the split math modes, from the float master w [Cout][taps][Cin] (Cin % 4 == 0):
  *   planes   (optional, needs Cin % 32 == 0): of w itself, [Cout][taps][Cin / 32][piece][32]
  *                                             -> `w_planes` of dspn_conv2d_forward_bn_f32,
  *   planes_t (optional, cols_t % 32 == 0, cols_t >= Cout): of w^T zero padded, [Cin][taps][cols_t / 32][piece][32]
  *                                             -> `wt_planes` of dspn_conv2d_dgrad_bn_f32 (cols_t = ldy),
- * bfloat16, every element x cut into p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even):
- * rows * taps * cols * 6 bytes each.  Either pointer may be NULL.  One read of w serves both.
- * Batch form (every weight of a training step in one launch): table of n 48-byte rows in DEVICE memory
- * { const float *w; void *planes; void *planes_t; int32 Cout, taps, Cin, cols_t; int64 begin } with begin = the sum of
- * dspn_conv2d_weight_planes_tiles() over the preceding rows; total_tiles = that sum over all rows. */
+ * 16-bit elements, rows * taps * cols * 2 * pieces bytes each.  Either pointer may be NULL.  One read of w serves both.
+ *   pieces = 3 (DSPN_MATH_F32_BF16X3): bfloat16 p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round to nearest even;
+ *   pieces = 2 (DSPN_MATH_F32_F16X2):  float16 p0 = f16(s x), p1 = f16(s x - p0) with s the power of two the convolution
+ *              kernels derive from `w_absmax` (the weight's magnitude block, dspn_absmax_f32 of w -- filled BEFORE this call
+ *              on the same stream, and the block later passed as the convolution's `w_absmax`).
+ * Batch form (every weight of a training step in one launch): table of n 64-byte rows in DEVICE memory
+ * { const float *w; void *planes; void *planes_t; int32 Cout, taps, Cin, cols_t; int64 begin; const float *w_absmax;
+ *   int32 pieces, 0 } with begin = the sum of dspn_conv2d_weight_planes_tiles() over the preceding rows; total_tiles = that
+ * sum over all rows. */
 int dspn_conv2d_weight_planes_f32(const float *w, void *planes, void *planes_t, int Cout, int taps, int Cin, int cols_t,
-                                  void *stream);
+                                  int pieces, const float *w_absmax, void *stream);
 long long dspn_conv2d_weight_planes_tiles(int Cout, int taps, int Cin, int cols_t, int with_transposed);
 int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long total_tiles, void *stream);
 

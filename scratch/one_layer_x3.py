@@ -11,7 +11,7 @@ fn.set_conv_math("bf16x3")
 x = torch.randn(B, H, H, Cin, device="cuda"); w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05
 dy = torch.randn(B, H, H, Cout, device="cuda"); y = torch.empty(B, H, H, Cout, device="cuda"); dx = torch.empty_like(x)
 dw = torch.empty_like(w)
-wt = fn.weight_transpose(w); wp = fn.weight_planes(w); wtp = fn.weight_planes(w, transposed=True, cols=Cout)
+wt = fn.weight_transpose(w); wp = fn.weight_planes(w, math="bf16x3"); wtp = fn.weight_planes(w, transposed=True, cols=Cout, math="bf16x3")
 sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda")
 tiles, _ = fn.conv_stats_layout(B * H * H, Cout)
 st = torch.empty(tiles, 2, Cout, device="cuda")

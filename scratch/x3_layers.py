@@ -39,7 +39,7 @@ for name, H, W, Cin, Cout, k, stride, pad in LAYERS:
     dy = torch.randn(B, Ho, Wo, Cout, device="cuda")
     y = torch.empty(B, Ho, Wo, Cout, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w)
     wt = fn.weight_transpose(w)
-    wp, wtp = (fn.weight_planes(w), fn.weight_planes(w, transposed=True, cols=Cout)) if MODE == 'bf16x3' else (None, None)
+    wp, wtp = (fn.weight_planes(w, math=MODE), fn.weight_planes(w, transposed=True, cols=Cout, math=MODE)) if MODE == "bf16x3" else (None, None)
     sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda")
     tiles, _ = fn.conv_stats_layout(B * Ho * Wo, Cout)
     st = torch.empty(tiles, 2, Cout, device="cuda")

@@ -88,10 +88,13 @@ def test_convolution_argument_validation_without_gpu():
         assert fwd(N=0, math=math) == -1 and b"bad geometry" in lib.dspn_last_error()
     # the split math reads whole 32-channel blocks from piece planes: without them the call is rejected (before any launch)
     assert fwd(Cin=64, math=2) == -1 and b"piece planes" in lib.dspn_last_error()
-    assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 48, 0, None) == -1     # forward planes: Cin % 32
-    assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 8, 9, 64, 48, None) == -1    # transposed planes: cols_t % 32
-    assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 40, 9, 64, 32, None) == -1   # ... and cols_t >= Cout
-    assert lib.dspn_conv2d_weight_planes_f32(p, None, None, 8, 9, 64, 0, None) == -1  # nothing to write
+    assert fwd(Cin=64, math=3) == -1
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 64, 0, 2, None, None) == -1 and b"magnitude" in lib.dspn_last_error()
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 64, 0, 4, None, None) == -1     # pieces: 2 or 3
+    assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 48, 0, 3, None, None) == -1     # forward planes: Cin % 32
+    assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 8, 9, 64, 48, 3, None, None) == -1    # transposed planes: cols_t % 32
+    assert lib.dspn_conv2d_weight_planes_f32(p, None, p, 40, 9, 64, 32, 3, None, None) == -1   # ... and cols_t >= Cout
+    assert lib.dspn_conv2d_weight_planes_f32(p, None, None, 8, 9, 64, 0, 3, None, None) == -1  # nothing to write
     assert lib.dspn_absmax_f32(p, 8, 6, None, None, 0, p, None) == -1                # C % 4
     assert lib.dspn_absmax_f32(p, 8, 8, p, None, 0, p, None) == -1                   # scale without shift
     assert lib.dspn_conv2d_weight_planes_tiles(64, 9, 64, 64, 1) == 2 * 9 * 2 and lib.dspn_conv2d_weight_planes_tiles(40, 1, 64, 64, 1) == 4

@@ -6,6 +6,7 @@ checked here are the documented MXNet ones restated in oracle/dspnet_torch.py.  
 MFMA path is an exact fmaf chain, so |err| <= 2e-6 * sum|a*b| is expected; tests use 1e-4 relative to
 the output scale (BASELINE.json: fp32 losses within 1e-4)."""
 import numpy as np
+import math
 import pytest
 import torch
 import torch.nn.functional as F
@@ -123,12 +124,12 @@ def test_weight_planes_layout_and_pieces(gpu_device, shape):
         rows, taps, cols = m.shape
         return st.view(3, rows, taps, cols // 32, 32).permute(1, 2, 3, 0, 4).contiguous()
 
-    fwd = fn.weight_planes(w)
+    fwd = fn.weight_planes(w, math="bf16x3")
     assert torch.equal(fwd.view(torch.int16), pieces(w.view(Cout, R * S, Cin)).view(torch.int16))
     cols = (Cout + 31) // 32 * 32
     wt = torch.zeros(Cin, R * S, cols, device="cuda")
     wt[:, :, :Cout] = w.view(Cout, R * S, Cin).permute(2, 1, 0)
-    bwd = fn.weight_planes(w, transposed=True, cols=cols)
+    bwd = fn.weight_planes(w, transposed=True, cols=cols, math="bf16x3")
     assert torch.equal(bwd.view(torch.int16), pieces(wt).view(torch.int16))
     # p0 + p1 + p2 reproduces the float to half an fp32 ulp
     back = fwd.float().sum(dim=3).view(Cout, R * S, Cin)
@@ -137,6 +138,29 @@ def test_weight_planes_layout_and_pieces(gpu_device, shape):
     fn.weight_planes_batch(*fn.weight_planes_table([(w, a, b), (w, None, torch.zeros_like(b)), (w, torch.zeros_like(a), None)],
                                                    w.device))
     assert torch.equal(a.view(torch.int16), fwd.view(torch.int16)) and torch.equal(b.view(torch.int16), bwd.view(torch.int16))
+
+    # DSPN_MATH_F32_F16X2: two float16 pieces of w * 2^e, 2^e the power of two that puts max |w| into [2^14, 2^15)
+    am = fn.absmax(w)
+    e = 15 - math.frexp(float(w.abs().max()))[1]
+    assert float(am.max()) == float(w.abs().max())
+
+    def pieces2(m):
+        u = m * 2.0 ** e
+        h0 = u.half(); h1 = (u - h0.float()).half()
+        rows, taps, cols_ = m.shape
+        return torch.stack([h0, h1], dim=0).view(2, rows, taps, cols_ // 32, 32).permute(1, 2, 3, 0, 4).contiguous()
+
+    fwd2 = fn.weight_planes(w, math="f16x2", w_absmax=am)
+    assert fwd2.shape == (Cout, R * S, Cin // 32, 2, 32)
+    assert torch.equal(fwd2.view(torch.int16), pieces2(w.view(Cout, R * S, Cin)).view(torch.int16))
+    bwd2 = fn.weight_planes(w, transposed=True, cols=cols, math="f16x2", w_absmax=am)
+    assert torch.equal(bwd2.view(torch.int16), pieces2(wt).view(torch.int16))
+    a2, b2 = torch.zeros_like(fwd2), torch.zeros_like(bwd2)
+    fn.weight_planes_batch(*fn.weight_planes_table([(w, a2, b2, am), (w, a, None)], w.device))
+    assert torch.equal(a2.view(torch.int16), fwd2.view(torch.int16)) and torch.equal(b2.view(torch.int16), bwd2.view(torch.int16))
+    assert torch.equal(a.view(torch.int16), fwd.view(torch.int16))          # a three-piece row beside a two-piece one
+    with pytest.raises(AssertionError):
+        fn.weight_planes(w, math="f16x2")                                   # no magnitude block
 
 
 def test_split_math_needs_planes_at_the_c_abi(gpu_device):
