@@ -121,8 +121,10 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(
 __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     const float *__restrict__ ts, int tiles, int tile_rows, long long rows, int C, float eps,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ mean,
-    float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift) {
+    float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift,
+    const float *__restrict__ mm, int mm_tiles, int relu, unsigned *__restrict__ absmax) {
   __shared__ double sA[64][17], sB[64][17];
+  __shared__ float sLo[64][17], sHi[64][17];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const long long last_n = rows - (long long)(tiles - 1) * tile_rows;
@@ -137,6 +139,17 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     }
   }
   sA[sl][cl] = A; sB[sl][cl] = B;
+  if (mm) {      // the extremes of the tensor, per channel, from the (min, max) pairs its producer wrote beside the statistics
+    float lo = INFINITY, hi = -INFINITY;
+    if (c < C) {
+#pragma unroll 8
+      for (int t = sl; t < mm_tiles; t += 64) {
+        lo = fminf(lo, mm[((long long)t * 2 + 0) * C + c]);
+        hi = fmaxf(hi, mm[((long long)t * 2 + 1) * C + c]);
+      }
+    }
+    sLo[sl][cl] = lo; sHi[sl][cl] = hi;
+  }
   __syncthreads();
   if (sl == 0 && c < C) {
     for (int k = 1; k < 64; ++k) { A += sA[k][cl]; B += sB[k][cl]; }
@@ -147,8 +160,17 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = mu; rstd[c] = rs;
     const float sc = (gamma ? gamma[c] : 1.f) * rs;
+    const float sh = beta[c] - mu * sc;
     scale[c] = sc;
-    shift[c] = beta[c] - mu * sc;
+    shift[c] = sh;
+    if (mm) {    // largest |(relu)(x * scale + shift)|: the affine is monotone per channel, so it sits at an extreme of x
+      float lo = sLo[0][cl], hi = sHi[0][cl];
+      for (int k = 1; k < 64; ++k) { lo = fminf(lo, sLo[k][cl]); hi = fmaxf(hi, sHi[k][cl]); }
+      float a = fmaf(lo, sc, sh), b = fmaf(hi, sc, sh);        // the same fmaf as the loaders that apply this affine
+      if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+      const float v = fmaxf(fabsf(a), fabsf(b));
+      if (v == v) atomicMax(absmax + (c & 63), __float_as_uint(v));    // non-negative floats order as their bit patterns
+    }
   }
 }
 
@@ -1209,10 +1231,13 @@ size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) { return bn_tiles_workspa
 #ifndef DSPN_HALF
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, void *workspace, size_t workspace_bytes, void *stream) {
+                                 float *shift, const float *tile_minmax, int relu, float *out_absmax,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
                "bn_stats_from_tiles: bad argument");
+  DSPN_REQUIRE((tile_minmax != nullptr) == (out_absmax != nullptr), "bn_stats_from_tiles: tile_minmax and out_absmax go together");
+  const int mm_tiles = tiles;
   if (tiles >= 1024 && workspace && workspace_bytes >= bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = static_cast<float *>(workspace);
@@ -1221,7 +1246,8 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
     tile_stats = grouped; tiles = groups; tile_rows *= kTileGroup;
   }
   hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
-                     tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift);
+                     tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift, tile_minmax, mm_tiles, relu,
+                     reinterpret_cast<unsigned *>(out_absmax));
   return dspn::check_launch("bn_stats_from_tiles");
 }
 #endif

@@ -220,7 +220,7 @@ class Graph:
         """"f16x2" math: a BatchNorm whose backward is the LAST writer of its input's gradient (backward runs the nodes in
         reverse: the reader with the smallest index) stores the complete gradient, so its apply kernel can also take the
         magnitude the producing convolution needs (BatchNorm.completes_x_grad)."""
-        first_reader = {}
+        first_reader, readers = {}, {}
         for idx, m in enumerate(self.nodes):
             for k, v in vars(m).items():
                 if k == "out":
@@ -228,9 +228,19 @@ class Graph:
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
                     if isinstance(t, Tensor):
                         first_reader.setdefault(id(t), idx)
+                        readers.setdefault(id(t), set()).add(idx)
         for idx, n in enumerate(self.nodes):
             if isinstance(n, BatchNorm):
                 n.completes_x_grad = first_reader.get(id(n.x)) == idx
+        # a convolution read by nothing but another convolution's residual add (the projection shortcut of a unit) receives
+        # that convolution's output gradient itself (Tensor.give_grad aliases it): one magnitude slot serves both
+        for idx, n in enumerate(self.nodes):
+            r = getattr(n, "residual", None)
+            if isinstance(n, Conv) and n.am_dy is not None and r is not None and r.requires_grad:
+                prod = getattr(r, "producer", None)
+                if (isinstance(prod, Conv) and prod.am_dy is not None and prod.out is r and readers.get(id(r)) == {idx}
+                        and not prod.relu and prod.b is None):
+                    prod.am_dy = n.am_dy
 
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
@@ -511,9 +521,17 @@ class BatchNorm(Node):
         if self.tile_stats is not None:
             buf, tiles, tile_rows = self.tile_stats
             rows = int(np.prod(self.x.shape[:-1]))
+            # "f16x2" math: the convolutions that fold this BatchNorm into their loaders multiply (relu)(x * scale + shift);
+            # its magnitude comes out of this finalize kernel, from the extremes the producer wrote beside the statistics
+            g, mm, am = self._g, getattr(self.x.producer, "out_minmax", None), None
+            slot = g._am_x.get((id(self.x), id(self.scale))) if (mm is not None and g.scalars is not None) else None
+            if slot is not None:
+                am = g.scalar(slot)
+                g._am_done.add(slot)
             fn.bn_stats_from_tiles(buf, tiles, tile_rows, rows, self.x.shape[-1], self.eps,
                                    None if self.gamma is None else self.gamma.data, self.beta.data,
-                                   self.mean, self.rstd, self.scale, self.shift)
+                                   self.mean, self.rstd, self.scale, self.shift,
+                                   tile_minmax=mm if am is not None else None, relu=self.relu, out_absmax=am)
         else:
             fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                         self.mean, self.rstd, self.scale, self.shift)

@@ -276,7 +276,12 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
  * double (Chan et al.), fixed order */
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, void *workspace, size_t workspace_bytes, void *stream);
+                                 float *shift, const float *tile_minmax, int relu, float *out_absmax,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+/* tile_minmax + out_absmax (both or neither; DSPN_MATH_F32_F16X2): the (min, max) pairs the same convolution wrote beside
+ * its statistics (out_minmax).  The largest |(relu)(x * scale + shift)| over the tensor -- the magnitude of what the next
+ * convolution multiplies when it folds this BatchNorm into its loader -- is then max-ed INTO the magnitude block
+ * out_absmax (DSPN_ABSMAX_SLOTS floats, zeroed by the caller at the start of the step), with no pass over the tensor. */
 /* optional scratch for long tile tables (>= 1024 tiles are first merged in groups of 32 by many workgroups);
  * dspn_bn_backward_from_sums_f32 uses 3*C floats + this many bytes the same way */
 size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);

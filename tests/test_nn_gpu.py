@@ -650,6 +650,15 @@ def test_conv_epilogue_batchnorm_statistics(gpu_device, conv_math, case, with_re
     gamma = (torch.rand(Cout, generator=g) + 0.5).cuda(); beta = torch.randn(Cout, generator=g).cuda()
     outs = [torch.empty(Cout, device="cuda") for _ in range(4)]
     fn.bn_stats_from_tiles(st, tiles, tile_rows, N * Ho * Wo, Cout, 2e-5, gamma, beta, *outs)
+    if mm is not None:
+        # ... and the finalize kernel takes that magnitude itself, for the affine it has just computed (no pass of its own)
+        for relu_ in (True, False):
+            outs2 = [torch.empty(Cout, device="cuda") for _ in range(4)]
+            am = torch.zeros(fn.ABSMAX_SLOTS, device="cuda")
+            fn.bn_stats_from_tiles(st, tiles, tile_rows, N * Ho * Wo, Cout, 2e-5, gamma, beta, *outs2, tile_minmax=mm,
+                                   relu=relu_, out_absmax=am)
+            assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+            assert float(am.max()) == float(fn.absmax(y, (outs2[2], outs2[3], relu_)).max()) > 0
     yd = y.double().view(-1, Cout)
     mean_ref = yd.mean(0); var_ref = yd.var(0, unbiased=False)
     rstd_ref = 1.0 / torch.sqrt(var_ref + 2e-5)
