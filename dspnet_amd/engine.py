@@ -130,6 +130,7 @@ class Graph:
         self.am_table = None       # descriptor table of the weight magnitudes (one launch per step)
         self._am_x = {}            # (id of the raw input tensor, id of its affine scale) -> slot shared by its readers
         self._am_done = set()      # slots already computed in the current step
+        self._am_bwd_slots, self._am_bwd_ran = set(), False
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -150,13 +151,27 @@ class Graph:
         self.nodes.append(node)
         return node
 
-    def new_scalar(self):
-        """index of a fresh slot of the operand-magnitude arena ("f16x2" math)"""
+    def new_scalar(self, backward=False):
+        """index of a fresh slot of the operand-magnitude arena ("f16x2" math).  backward=True: the magnitude of a gradient;
+        a second backward pass after one forward pass takes those again (begin_backward)"""
         self._nscal += 1
+        if backward:
+            self._am_bwd_slots.add(self._nscal - 1)
         return self._nscal - 1
 
     def scalar(self, i):
         return None if (i is None or self.scalars is None) else self.scalars[i * fn.ABSMAX_SLOTS:(i + 1) * fn.ABSMAX_SLOTS]
+
+    def magnitude(self, slot, tensor):
+        """"f16x2" math: the magnitude block of `tensor` in slot `slot` (a node-owned index from new_scalar), taken by a pass
+        over the tensor the first time a step asks for it and reused afterwards; None in the other math modes"""
+        if slot is None or self.scalars is None or tensor.dtype != torch.float32:
+            return None
+        out = self.scalar(slot)
+        if slot not in self._am_done:
+            fn.absmax(tensor, out=out)
+            self._am_done.add(slot)
+        return out
 
     def _resolve_auto_deferred(self):
         """BatchNorm(defer_apply="auto"): keep the output virtual only if every reader is a plain convolution input;
@@ -326,6 +341,7 @@ class Graph:
         if self.scalars is not None:   # "f16x2" math: every operand magnitude of the step starts from zero; the weights' now
             self.scalars.zero_()
             self._am_done = set()
+            self._am_bwd_ran = False
             if self.am_table is not None:
                 fn.absmax_batch(*self.am_table)
         if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands;
@@ -340,6 +356,12 @@ class Graph:
         for t in self.all_tensors:
             t._gw = False
             t.grad = None
+        if self.scalars is not None:
+            if self._am_bwd_ran:       # a second backward pass on the same forward pass: new gradients, new magnitudes
+                for slot in self._am_bwd_slots & self._am_done:
+                    self.scalar(slot).zero_()
+                self._am_done -= self._am_bwd_slots
+            self._am_bwd_ran = True
         if self.half_operands:
             return                     # prepared by forward(); the weights have not changed since
         self.wt_batched = self.wt_table is not None
@@ -623,7 +645,7 @@ class Conv(Node):
             key = (id(self.x_raw), None if self.in_affine is None else id(self.in_affine[0]))
             if key not in g._am_x:
                 g._am_x[key] = g.new_scalar()
-            self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(), g.new_scalar()
+            self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(backward=True), g.new_scalar()
         self.wp = self.wtp = None
         if g.device.type == "cuda":
             npc = fn.plane_pieces(g.math)
@@ -790,6 +812,11 @@ class BilinearConcatConv(Node):
         self.z = fn.act_zeros(N, Ht, Wt, Tp, device=g.device)        # tap-expanded map at the target size (dz in backward)
         self.zc, self.wc, self.wct, self.dwc, self.wch, self.wcp = [], [], [], [], [], []
         self.math = g.math
+        self._g = g
+        # "f16x2" math: per component, slots for the magnitudes of its input, its weight slice and its output gradient --
+        # each taken once per step and shared by the forward, weight-gradient and data-gradient calls that multiply it
+        f16 = g.math == "f16x2"
+        self.am = [(g.new_scalar(), g.new_scalar(), g.new_scalar(backward=True)) if f16 else (None, None, None) for _ in inputs]
         for t in inputs:
             # W_c . x_c at the component's own resolution (its gradient in backward).  Every component goes through
             # the sampler, also the ones that already have the target size: once the optimizer has moved
@@ -822,11 +849,11 @@ class BilinearConcatConv(Node):
         for c, t in enumerate(self.inputs):
             if self.wch[c] is not None:      # bf16 operands of this slice: copy + transpose in one launch
                 fn.weight_transpose(self.wc[c], out=self.wct[c], copy=self.wch[c])
-            wa = fn.absmax(self.wc[c]) if self.math == "f16x2" and self.wch[c] is None else None
+            xa, wa = self._g.magnitude(self.am[c][0], t.data), self._g.magnitude(self.am[c][1], self.wc[c])
             if self.wcp[c] is not None:
                 fn.weight_planes(self.wc[c], out=self.wcp[c], math=self.math, w_absmax=wa)
             fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c],
-                              w_planes=self.wcp[c], math=self.math, w_absmax=wa)
+                              w_planes=self.wcp[c], math=self.math, x_absmax=xa, w_absmax=wa)
         if self.sources is None:
             self.sources = fn.SamplerSources([(z, 0) for z in self.zc])
         fn.affine_sampler_forward(self.sources, self.theta.data, self.z)       # z = sum_c U_c(theta)(W_c x_c), one pass
@@ -841,13 +868,17 @@ class BilinearConcatConv(Node):
         Cin = self.offsets[-1]
         for c, t in enumerate(self.inputs):
             dz = fn.affine_sampler_backward_data(self.z, self.theta.data, self.zc[c].shape, 0, dx=self.zc[c])
-            fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c], math=self.math)
+            xa, wa = self._g.magnitude(self.am[c][0], t.data), self._g.magnitude(self.am[c][1], self.wc[c])
+            dza = self._g.magnitude(self.am[c][2], dz)
+            fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c], math=self.math, x_absmax=xa,
+                            dy_absmax=dza)
             fn.copy_block(self.dwc[c], self.w.grad, 1, self.T, t.shape[3], 0, t.shape[3], 0, 0, Cin, self.offsets[c])
             if t.requires_grad:
                 if self.wch[c] is None:
                     fn.weight_transpose(self.wc[c], out=self.wct[c])
                 dx, acc = t.grad_target()
-                fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc, math=self.math)
+                fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc, math=self.math, dy_absmax=dza,
+                                w_absmax=wa)
 
 
 class Deconv4x4s2(Node):
@@ -864,22 +895,29 @@ class Deconv4x4s2(Node):
         self.out = g.tensor((N, 2 * H, 2 * W, Cp), name + "_out")
         self.out.channels = channels
         self.math = g.math
+        self._g = g
+        self.am = (g.new_scalar(), g.new_scalar(), g.new_scalar(backward=True)) if g.math == "f16x2" else (None, None, None)   # x, w, dy
         self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
         fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
-        fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data, math=self.math)
+        g = self._g
+        xa, wa = g.magnitude(self.am[0], self.x.data), g.magnitude(self.am[1], self.w.data)
+        fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data, math=self.math, dy_absmax=xa,
+                        w_absmax=wa)
 
     def backward(self):
         if not self.out._gw:
             return
         dy = self.out.grad
-        fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad, math=self.math)
+        g = self._g
+        xa, wa, dya = g.magnitude(self.am[0], self.x.data), g.magnitude(self.am[1], self.w.data), g.magnitude(self.am[2], dy)
+        fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad, math=self.math, x_absmax=dya, dy_absmax=xa)
         if self.x.requires_grad:
             dx, acc = self.x.grad_target()
             fn.conv2d_forward(dy, self.w.data if self.wh is None else self.wh, None, 2, 1, 1, out=dx, accumulate=acc,
-                              math=self.math)
+                              math=self.math, x_absmax=dya, w_absmax=wa)
 
 
 class Add(Node):
