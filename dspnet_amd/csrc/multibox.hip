@@ -445,7 +445,9 @@ struct DetWs {
   int *nms_count;              // [B] rows that take part in sort+NMS (0 = none)
   float *temp;                 // [B*A*7] pre-sort copy of the compacted rows
   unsigned long long *keys;    // [B*n2] sort keys when they do not fit LDS
-  unsigned long long *mask;    // [B*A*nwords] suppression bit matrix
+  unsigned long long *mask;    // [B*A*nwords] suppression bit matrix, over GROUPED positions (see det_decode_sort_kernel)
+  int *perm;                   // [B*A] grouped position -> output row: the valid rows ordered by (class id, row)
+  int *gcls;                   // [B*A] class id of each grouped position (ascending)
 };
 
 __device__ __forceinline__ unsigned ordered_bits(float s) {
@@ -455,11 +457,28 @@ __device__ __forceinline__ unsigned ordered_bits(float s) {
 }
 __device__ __forceinline__ float clip01(float v) { return fmaxr(0.f, fminr(1.f, v)); }
 
+// in-place ascending bitonic sort of n2 (a power of two) 64-bit keys by one workgroup; ends behind a barrier
+__device__ __forceinline__ void bitonic_sort_keys(unsigned long long *keys, int n2, int tid) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += kTB) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool asc = (i & k) == 0;
+          if ((x > y) == asc) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <bool kLdsKeys>
 __global__ __launch_bounds__(kTB) void det_decode_sort_kernel(
     const float *__restrict__ cls_prob, const float *__restrict__ loc_pred,
     const float4 *__restrict__ anchors, int A, int C, float threshold, int clip,
-    float vx, float vy, float vw, float vh, int nms_enabled, int nms_topk, int n2cap,
+    float vx, float vy, float vw, float vh, int nms_enabled, int nms_topk, int force, int n2cap,
     DetWs ws, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_w[kTB / 64];
@@ -519,25 +538,38 @@ __global__ __launch_bounds__(kTB) void det_decode_sort_kernel(
   while (n2 < V) n2 <<= 1;
   for (int i = V + tid; i < n2; i += kTB) keys[i] = ~0ull;
   __syncthreads();
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n2; i += kTB) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long x = keys[i], y = keys[ixj];
-          const bool asc = (i & k) == 0;
-          if ((x > y) == asc) { keys[i] = y; keys[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  bitonic_sort_keys(keys, n2, tid);
   int nkeep = V;
   if (nms_topk > 0 && nms_topk < nkeep) nkeep = nms_topk;
   for (int e = tid; e < nkeep * 7; e += kTB) {
     const int i = e / 7, q = e - i * 7;
     const unsigned src = (unsigned)(keys[i] & 0xffffffffull);
     po[e] = pt[(size_t)src * 7 + q];
+  }
+  // Suppression only ever relates rows of ONE class (multibox_detection.cc:159; every pair under force_suppress), and a row's
+  // fate depends only on the earlier rows of its class: the greedy pass over all rows is C - 1 independent greedy passes.
+  // perm = the valid rows ordered by (class id, row) -- a second sort of (class, row) keys: the suppression matrix and the
+  // scan work on these GROUPED positions, where a class is a contiguous segment (A^2 / 2 -> sum_c n_c^2 / 2 box pairs, and
+  // a chain of n_c / 64 dependent blocks per scan instead of A / 64).
+  int *perm = ws.perm + (size_t)b * A, *gcls = ws.gcls + (size_t)b * A;
+  if (force) {
+    for (int i = tid; i < V; i += kTB) { perm[i] = i; gcls[i] = 0; }
+    return;
+  }
+  for (int i = tid; i < n2; i += kTB) {     // (entry i is read and rewritten by the same thread)
+    unsigned long long k2 = ~0ull;
+    if (i < V) {
+      // the class of output row i: that of its source row (rows past nms_topk keep their pre-sort contents)
+      const unsigned src = i < nkeep ? (unsigned)(keys[i] & 0xffffffffull) : (unsigned)i;
+      k2 = ((unsigned long long)(unsigned)(int)pt[(size_t)src * 7] << 32) | (unsigned)i;
+    }
+    keys[i] = k2;
+  }
+  __syncthreads();
+  bitonic_sort_keys(keys, n2, tid);
+  for (int i = tid; i < V; i += kTB) {
+    perm[i] = (int)(unsigned)(keys[i] & 0xffffffffull);
+    gcls[i] = (int)(keys[i] >> 32);
   }
 }
 
@@ -549,36 +581,44 @@ __device__ __forceinline__ float nms_iou(const float *a, const float *b) {
   return u <= 0.f ? 0.f : i / u;
 }
 
-// 64x64 tiles of the upper-triangular suppression matrix:
-// bit (i,j), j>i: row i would suppress row j (multibox_detection.cc:153-167).
-// One single-wave workgroup per (64-row tile, sample) walks the column tiles to its right: (A / 64) x B long-lived waves
-// instead of (A / 64)^2 x B short ones.  The kernel runs on MultiBoxDetection's side stream beside the training step, and
-// the dispatcher hands out the workgroups of ONE queue's kernel at a time: with 295 000 tiny workgroups (96 x 96 tiles x
-// 32 samples) every main-stream kernel that became ready meanwhile waited for the whole dispatch (a 7-us BatchNorm table
-// merge took 0.46 ms, rocprofv3 kernel trace of the step); 3072 workgroups are handed out in microseconds and the main
-// stream's kernels then slot in beside them.
+// 64x64 tiles of the upper-triangular suppression matrix over the GROUPED positions (ws.perm: rows ordered by class, then
+// row): bit (i,j), j>i: grouped row i would suppress grouped row j (multibox_detection.cc:153-167).
+// One single-wave workgroup per (64-row tile, sample, chunk of kMaskChunk column tiles).  A row tile only meets the column
+// tiles up to the end of its last row's class segment; the others are never read by the scan.
+// The kernel runs on MultiBoxDetection's side stream beside the training step, and the dispatcher hands out the workgroups
+// of ONE queue's kernel at a time: with 295 000 tiny workgroups (96 x 96 tiles x 32 samples, the first version) every
+// main-stream kernel that became ready meanwhile waited for the whole dispatch (a 7-us BatchNorm table merge took 0.46 ms,
+// rocprofv3 kernel trace of the step); a few thousand longer-lived ones are handed out in microseconds.
+constexpr int kMaskChunk = 16;
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ out, int A,
                                                       int nwords, float nms_threshold,
                                                       int force, DetWs ws) {
   const int rt = blockIdx.x, b = blockIdx.y;
   const int V = ws.nms_count[b];
-  if (rt * 64 >= V) return;
+  const int ntile = (V + 63) >> 6;
+  const int ct0 = rt + blockIdx.z * kMaskChunk;
+  if (rt * 64 >= V || ct0 >= ntile) return;
   __shared__ float s_box[64][5];
   const float *po = out + (size_t)b * A * 7;
+  const int *perm = ws.perm + (size_t)b * A;
   const int lane = threadIdx.x;
   const int i = rt * 64 + lane;
   float bi[4] = {0.f, 0.f, 0.f, 0.f}, idi = -1.f;
   if (i < V) {
-    const float *ri = po + (size_t)i * 7;
+    const float *ri = po + (size_t)perm[i] * 7;
     bi[0] = ri[2]; bi[1] = ri[3]; bi[2] = ri[4]; bi[3] = ri[5];
     idi = ri[0];
   }
-  const int ntile = (V + 63) >> 6;
-  for (int ct = rt; ct < ntile; ++ct) {
+  // class of this tile's last row: grouped positions ascend in class, so a column tile that starts above it has no pair
+  const int *gcls = ws.gcls + (size_t)b * A;
+  const int c_hi = gcls[min(V, rt * 64 + 64) - 1];
+  const int ct1 = min(ntile, ct0 + kMaskChunk);
+  for (int ct = ct0; ct < ct1; ++ct) {
+    if (gcls[ct * 64] > c_hi) break;      // (wave-uniform) this and every later column tile hold other classes only
     __syncthreads();                      // the previous column tile has been read by every lane
     const int jc = ct * 64 + lane;
     if (jc < V) {
-      const float *r = po + (size_t)jc * 7;
+      const float *r = po + (size_t)perm[jc] * 7;
       s_box[lane][0] = r[2]; s_box[lane][1] = r[3]; s_box[lane][2] = r[4]; s_box[lane][3] = r[5];
       s_box[lane][4] = r[0];
     }
@@ -597,26 +637,48 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
   }
 }
 
-// One wave per sample walks the rows in order and ORs the masks of surviving rows.
-// Greedy scan over the suppression bit matrix, one 16-wave workgroup per sample.  Rows are resolved in blocks of 64:
-// wave 0 walks the block's 64x64 diagonal word by word with lane shuffles (the only inherently serial part); the
-// surviving rows then OR their mask words into the `removed` words of all later blocks -- 64 rows x up to 128 words,
-// one (row, word phase) pair per thread, LDS atomics (OR is order independent, so the result is deterministic).
+// Greedy scan over the suppression bit matrix, one 16-wave workgroup per (sample, class): the grouped positions [s, e) of
+// class blockIdx.y (every valid row under force_suppress).  Rows are resolved in blocks of 64 grouped positions: wave 0
+// walks the block's 64x64 diagonal word by word with lane shuffles (the only inherently serial part); the surviving rows
+// then OR their mask words into the `removed` words of all later blocks of the segment -- 64 rows x up to 128 words, one
+// (row, word phase) pair per thread, LDS atomics (OR is order independent, so the result is deterministic).
 // The mask words a block needs do not depend on which rows survive, so they are requested one block AHEAD and are in
 // registers by the time the diagonal is resolved: per block the critical path is the 64-step shuffle chain plus two
 // barriers instead of a chain of dependent global loads (the one-wave version took 1.4 ms for 6132 rows).
+// The first and last block of a segment also hold rows of the neighbouring classes: no mask bit relates them to this
+// class's rows, so whatever this workgroup concludes about them is ignored (only rows of [s, e) are written).
 constexpr int kScanThreads = 1024, kScanPhases = kScanThreads / 64, kScanPre = 8;   // 8 x 16 = 128 words ahead per row
-__global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restrict__ out, int A, int nwords,
+__global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restrict__ out, int A, int nwords, int force,
                                                                 DetWs ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *removed = reinterpret_cast<unsigned long long *>(smem);
   __shared__ unsigned long long s_alive;
+  __shared__ int s_seg[2];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = ws.nms_count[b];
   if (V == 0) return;
-  const int nw = (V + 63) >> 6;
+  float *po = out + (size_t)b * A * 7;
+  const int *perm = ws.perm + (size_t)b * A;
+  if (tid == 0) {
+    int s0 = 0, e0 = V;
+    if (!force) {      // lower bounds of class c and c + 1 among the grouped positions (ascending in class)
+      const int *gcls = ws.gcls + (size_t)b * A;
+      const int c = (int)blockIdx.y;
+      int lo = 0, hi = V;
+      while (lo < hi) { const int m = (lo + hi) >> 1; if (gcls[m] < c) lo = m + 1; else hi = m; }
+      s0 = lo; hi = V;
+      while (lo < hi) { const int m = (lo + hi) >> 1; if (gcls[m] <= c) lo = m + 1; else hi = m; }
+      e0 = lo;
+    }
+    s_seg[0] = s0; s_seg[1] = e0;
+  }
+  __syncthreads();
+  const int seg_s = s_seg[0], seg_e = s_seg[1];
+  if (seg_e <= seg_s) return;
+  const int wb = seg_s >> 6;                    // first block of the segment
+  const int nw = ((seg_e - 1) >> 6) + 1;        // one past its last block
   const unsigned long long *mask = ws.mask + (size_t)b * A * nwords;
-  for (int w = tid; w < nw; w += kScanThreads) removed[w] = 0;
+  for (int w = wb + tid; w < nw; w += kScanThreads) removed[w] = 0;
   const int r = tid / kScanPhases, ph = tid % kScanPhases;     // propagation role: row r of the block, words ph, ph+16, ...
   unsigned long long v[kScanPre], vn[kScanPre];
   auto preload = [&](int w0, unsigned long long *dst) {
@@ -624,17 +686,17 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restric
 #pragma unroll
     for (int k = 0; k < kScanPre; ++k) {
       const int w = w0 + 1 + ph + kScanPhases * k;
-      dst[k] = (w < nw && row < V) ? mask[(size_t)row * nwords + w] : 0ull;
+      dst[k] = (w < nw && row >= seg_s && row < seg_e) ? mask[(size_t)row * nwords + w] : 0ull;
     }
   };
   auto load_diag = [&](int w0) {
     const int row = w0 * 64 + lane;
-    return (wave == 0 && row < V) ? mask[(size_t)row * nwords + w0] : 0ull;
+    return (wave == 0 && row >= seg_s && row < seg_e) ? mask[(size_t)row * nwords + w0] : 0ull;
   };
-  preload(0, v);
-  unsigned long long diag = load_diag(0), diag_n = 0;
+  preload(wb, v);
+  unsigned long long diag = load_diag(wb), diag_n = 0;
   __syncthreads();
-  for (int w0 = 0; w0 < nw; ++w0) {
+  for (int w0 = wb; w0 < nw; ++w0) {
     if (w0 + 1 < nw) { preload(w0 + 1, vn); diag_n = load_diag(w0 + 1); }   // in flight while this block is resolved
     if (wave == 0) {
       unsigned long long cur = removed[w0];
@@ -642,8 +704,9 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restric
         const unsigned long long d = __shfl(diag, t, 64);
         if (!((cur >> t) & 1ull)) cur |= d;
       }
-      const int rows_here = min(64, V - w0 * 64);
-      const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+      const int lo = max(seg_s - w0 * 64, 0), hi = min(seg_e - w0 * 64, 64);     // this segment's rows of the block
+      const unsigned long long below = hi == 64 ? ~0ull : ((1ull << hi) - 1ull);
+      const unsigned long long valid = below & ~((1ull << lo) - 1ull);
       if (lane == 0) { removed[w0] = cur; s_alive = ~cur & valid; }
     }
     __syncthreads();
@@ -663,9 +726,8 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restric
     for (int k = 0; k < kScanPre; ++k) v[k] = vn[k];
     diag = diag_n;
   }
-  float *po = out + (size_t)b * A * 7;
-  for (int i = tid; i < V; i += kScanThreads)
-    if ((removed[i >> 6] >> (i & 63)) & 1ull) po[(size_t)i * 7] = -1.f;
+  for (int i = seg_s + tid; i < seg_e; i += kScanThreads)
+    if ((removed[i >> 6] >> (i & 63)) & 1ull) po[(size_t)perm[i] * 7] = -1.f;
 }
 
 struct TargetLayout { size_t err, ngt, row_iou, row_gt, bgkey, flag, total; };
@@ -684,7 +746,7 @@ TargetLayout target_layout(int B, int A) {
 
 constexpr int kLdsKeyCap = 16384;  // 128 KiB of 64-bit keys
 int next_pow2(int v) { int n = 1; while (n < v) n <<= 1; return n; }
-struct DetLayout { size_t cnt, temp, keys, mask, total; int n2cap, nwords; bool lds_keys; };
+struct DetLayout { size_t cnt, temp, keys, mask, perm, gcls, total; int n2cap, nwords; bool lds_keys; };
 DetLayout det_layout(int B, int A) {
   DetLayout l;
   l.n2cap = next_pow2(A);
@@ -695,6 +757,8 @@ DetLayout det_layout(int B, int A) {
   l.temp = o; o = dspn::align_up(o + sizeof(float) * (size_t)B * A * 7, 256);
   l.keys = o; if (!l.lds_keys) o = dspn::align_up(o + 8 * (size_t)B * l.n2cap, 256);
   l.mask = o; o = dspn::align_up(o + 8 * (size_t)B * A * l.nwords, 256);
+  l.perm = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
+  l.gcls = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
   l.total = o;
   return l;
 }
@@ -829,6 +893,8 @@ int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred
   ws.temp = reinterpret_cast<float *>(w + l.temp);
   ws.keys = reinterpret_cast<unsigned long long *>(w + l.keys);
   ws.mask = reinterpret_cast<unsigned long long *>(w + l.mask);
+  ws.perm = reinterpret_cast<int *>(w + l.perm);
+  ws.gcls = reinterpret_cast<int *>(w + l.gcls);
   hipStream_t s = (hipStream_t)stream;
   const float4 *an = reinterpret_cast<const float4 *>(anchors_dev);
   const int nms_enabled = !(nms_threshold <= 0 || nms_threshold > 1);
@@ -842,20 +908,21 @@ int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred
     }
     hipLaunchKernelGGL(det_decode_sort_kernel<true>, dim3(batch), dim3(kTB), lds, s, cls_prob_dev,
                        loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
-                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, l.n2cap,
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap,
                        ws, out_dev);
   } else {
     hipLaunchKernelGGL(det_decode_sort_kernel<false>, dim3(batch), dim3(kTB), 0, s, cls_prob_dev,
                        loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
-                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, l.n2cap,
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap,
                        ws, out_dev);
   }
   if (nms_enabled) {
     const int nt = l.nwords;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, batch), dim3(64), 0, s, out_dev, num_anchors,
-                       l.nwords, nms_threshold, force_suppress, ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(kScanThreads), 8 * (size_t)l.nwords, s, out_dev,
-                       num_anchors, l.nwords, ws);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, batch, (nt + kMaskChunk - 1) / kMaskChunk), dim3(64), 0, s, out_dev,
+                       num_anchors, l.nwords, nms_threshold, force_suppress != 0, ws);
+    // one scan per (sample, class id 0 .. num_classes - 2); a single one per sample under force_suppress
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(batch, (force_suppress || num_classes < 3) ? 1 : num_classes - 1), dim3(kScanThreads),
+                       8 * (size_t)l.nwords, s, out_dev, num_anchors, l.nwords, force_suppress != 0, ws);
   }
   return dspn::check_launch("multibox_detection");
 }

@@ -185,6 +185,19 @@ def test_detection_dspnet_shape(gpu_device, peaky):
     assert ((got[..., 0] >= 0).sum(axis=1) > 10).all()
 
 
+@pytest.mark.parametrize("num_classes,absent", [(21, ()), (81, (3, 40)), (3, (1,))])
+def test_detection_many_classes_segments(gpu_device, num_classes, absent):
+    """the suppression matrix and the greedy scan run per class segment of the class-grouped rows: many classes (segments
+    far from 64-row aligned, some shorter than one block), classes that never win (empty segments), nms_topk leaving stale
+    rows whose class is the pre-sort row's"""
+    anc = mc.r50_anchors(512, 512)
+    prob, loc = mc.detection_inputs(anc, batch=3, num_classes=num_classes, seed=77 + num_classes, peaky=False)
+    for c in absent:
+        prob[:, c] = 0.0
+    for kw in (dict(nms_threshold=.5, nms_topk=400), dict(nms_threshold=.3), dict(nms_threshold=.5, nms_topk=5000)):
+        run_detection(anc, prob, loc, **kw)
+
+
 def test_detection_cityscapes_shape_force_suppress(gpu_device):
     anc = mc.r50_anchors(512, 1024)
     prob, loc = mc.detection_inputs(anc, batch=2, seed=32, peaky=True)
