@@ -51,7 +51,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *   DSPN_MATH_F32_BF16X3  fp32 RESULTS on the bf16 MFMA: each float operand is cut into three bf16 pieces on the way into
  *                         LDS (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)) and a product is the sum of the six
  *                         exact partial products x_p * w_q, p + q <= 2, accumulated in fp32.  Error against float64 equal
- *                         to DSPN_MATH_FP32's (tests/test_nn_gpu.py), ~1.3x its speed; what dspnet_amd passes by default.
+ *                         to DSPN_MATH_FP32's (tests/test_nn_gpu.py), ~1.3x its speed; dspnet_amd's default in round 2.
  *                         WEIGHT OPERANDS in this mode: a forward / data-gradient call whose contraction runs over a multiple
  *                         of 32 channels per tap (Cin % 32 == 0, resp. ldy % 32 == 0) reads the weights as PIECE PLANES
  *                         (`w_planes` / `wt_planes`, made by dspn_conv2d_weight_planes_f32 once per weight update) instead
@@ -64,7 +64,8 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                         and a product is h0 g0 + h0 g1 + h1 g0 (three exact partial products, fp32 accumulate; the
  *                         dropped h1 g1 is below 2^-24 |x w|); the accumulators are multiplied by 1 / (s_x s_w) -- exact --
  *                         in the epilogue.  Error against float64: the fp32 MFMA's (rms 1.15x, largest error lower;
- *                         tests/test_nn_gpu.py).  What it needs that the bf16 split does not is RANGE (fp16: 2^-24 .. 65504):
+ *                         tests/test_nn_gpu.py); ~1.45x its speed; what dspnet_amd passes by default (round 3).  WEIGHT
+ *                         OPERANDS as in the mode above (piece planes with pieces = 2, cut relative to `w_absmax`).  What it needs that the bf16 split does not is RANGE (fp16: 2^-24 .. 65504):
  *                         the caller passes, per operand, the operand's largest magnitude in device memory
  *                         (`*_absmax` arguments: DSPN_ABSMAX_SLOTS partial maxima; dspn_absmax_f32 / dspn_absmax_batch_f32
  *                         compute them, for a folded input affine of the tensor AFTER the affine); the kernel scales that
@@ -72,6 +73,8 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                         Elements more than 2^17 below the tensor's maximum keep an absolute error of 2^-39 of that
  *                         maximum instead of a relative one.  A NULL magnitude means scale 1 (caller vouches for
  *                         |operand| < 65504); one that UNDERSTATES the maximum by more than 2x overflows to inf.
+ *                         Non-finite operands: an infinite magnitude selects scale 1; +-inf elements then give NaN
+ *                         (h1 = inf - inf), NaN stays NaN.
  * The *_bf16 entry points (bf16 tensors in HBM) ignore the argument: their operands are bf16 already. */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
