@@ -994,10 +994,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   float *sB = smem + 2 * kPK * BM;       // [2][kPK][BN]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
+  // (tile, split) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest): taken as
+  // is, the tiles of one split -- which all stream the SAME pixel range of dy and x -- land on all eight L2s and every L2
+  // fetches that range for its four or five tiles.  xcd_remap gives each XCD a contiguous run of (split, tile) pairs
+  // instead: a pixel range is then read through ONE L2 and shared there by all the tiles of its split
+#ifdef DSPN_WG_NO_XCD
+  const int tile = blockIdx.x, split = blockIdx.y;
+#else
+  const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int split = lin / (int)gridDim.x, tile = lin - split * (int)gridDim.x;
+#endif
   const int kt_i = tile / j_tiles, jt_i = tile - kt_i * j_tiles;
   const int k0 = kt_i * BM, j0 = jt_i * BN;
-  const int split = blockIdx.y;
   const int P = g.N * g.Ho * g.Wo;
   const int J = g.R * g.S * g.Cin;
   const int p_begin = split * g.pix_per_split;
