@@ -8,7 +8,7 @@ from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
 from dspnet_amd.train.metric import MultiBoxMetric
 from dspnet_amd.train.solver import MultiTaskSolver
 dev = torch.device("cuda", 0)
-for math in ("bf16x3", "fp32"):
+for math in ("f16x2", "bf16x3", "fp32"):
     fn.set_conv_math(math)
     net = get_multi_symbol_train("resnet-50", 512, num_classes=8, batch_size=8, device=dev, seed=0)
     g = synthetic.rng(3)
