@@ -321,9 +321,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 
   float4 ra[A_LD], rb[B_LD];
   u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
+  // timing-only ablation (bits 4096 / 8192, split modes): the A side of a k-step -- loads, affine, pieces, LDS stores -- only
+  // every 3rd / 9th k-step: the upper bound of what an A tile kept in LDS across a kernel row's / all nine taps could save
+  int abl_phase = 0;
+  bool abl_a_on = true;
   auto load_tiles = [&]() __attribute__((always_inline)) {     // issues the global loads of k-step ld_kt of the tile set up last
     int tr, ts, cq, cq0 = 0;
     bool qv;
+    if (dbg & (4096 | 8192)) {
+      const int period = (dbg & 8192) ? 9 : 3;
+      abl_a_on = abl_phase == 0;
+      abl_phase = abl_phase + 1 == period ? 0 : abl_phase + 1;
+    }
     if constexpr (uniform_tap) {
       tr = u_tr; ts = u_ts; cq0 = u_cq; cq = u_cq + chunk; qv = u_cq < CQ && nk > 0 && !(dbg & 128);   // 128: timing-only, no loads
       ++u_ts;                                   // branch-free wave-uniform advance: taps inner, channels outer
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int ih = a_ih0[i] + dh, iw = a_iw0[i] + dw;
-      const bool v = qv && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      const bool v = qv && abl_a_on && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
       if constexpr (INTF) tf_mask |= v ? (1u << i) : 0u;
       // valid offsets are < 2^31; setting bit 31 pushes an invalid one past num_records
       const unsigned off = ((unsigned)(a_eoff[i] + a_off) * (unsigned)sizeof(st_t)) | (v ? 0u : kOOB);
@@ -417,11 +426,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   bf16x4 pa[SPLIT ? A_LD : 1][3], pb[(SPLIT && !PRE) ? B_LD : 1][3];
   auto split_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT) {
+      if (abl_a_on) {
       affine_tiles();
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         if constexpr (MATH == 3) split2h(ra[i], sc_a, pa[i][0], pa[i][1]);
         else split3(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+      }
       }
       if constexpr (!PRE) {
 #pragma unroll
@@ -465,11 +476,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     if constexpr (SPLIT) {
       // x = p0 + p1 + p2 (split_tiles): piece p of channel k of a row lies at row * ROWH + p * 32 + k
       __bf16 *a = hA + buf * BM * ROWH, *b = hB + buf * BN * ROWH;
+      if (abl_a_on) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
+      }
       }
       if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
 #pragma unroll

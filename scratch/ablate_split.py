@@ -34,7 +34,7 @@ for (N, H, W, Cin, Cout, k) in shapes:
     nprod = {"f16x2": 3, "bf16x3": 6}.get(mode, 1)
     res = []
     for bits, nm in ((0, "full"), (32, "no-epi"), (32 + 64, "no-epi,1 product"), (32 + 128, "no-epi,no-loads"), (32 + 2, "no-epi,no-lds-store"),
-                     (32 + 2 + 128, "no-epi,no-loads,no-store"), (32 + 2 + 4 + 128, "..+no-barrier"), (32 + 2 + 4 + 128 + 64, "..+1 product"), (256, "no piece arithmetic"), (32 + 256, "no-epi,no piece arithmetic")):
+                     (32 + 2 + 128, "no-epi,no-loads,no-store"), (32 + 2 + 4 + 128, "..+no-barrier"), (32 + 2 + 4 + 128 + 64, "..+1 product"), (256, "no piece arithmetic"), (32 + 256, "no-epi,no piece arithmetic"), (4096, "A side every 3rd k-step"), (8192, "A side every 9th k-step"), (32 + 4096, "no-epi, A every 3rd"), (32 + 8192, "no-epi, A every 9th")):
         fn.L().dspn_debug_set(bits)
         t = timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=out, **kw))
         res.append("%s %.3f" % (nm, t))
