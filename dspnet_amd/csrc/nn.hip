@@ -37,6 +37,13 @@ inline int grid_for(long long n, int per_block = kT, int cap = 8192) {
   return (int)std::max<long long>(1, std::min<long long>(b, cap));
 }
 
+// grid of a chunked streaming kernel (4 x kT consecutive elements per workgroup and step) over n elements of `groups`
+// channel groups per row; *fixed: kT % groups == 0, i.e. every element of a thread belongs to one channel group
+inline int grid_fixed_channel(long long n, int groups, int *fixed) {
+  *fixed = groups > 0 && kT % groups == 0;
+  return grid_for(n, 4 * kT, 4096);
+}
+
 // bias gradients are column sums of small, narrow tensors (20..54 channels): slabs of 64 rows keep a few
 // hundred workgroups busy instead of rows/512
 inline int colsum_slab_rows(long long rows) { return (int)std::max<long long>(64, (rows + 4095) / 4096); }
@@ -315,27 +322,61 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
 // absmax (optional, float tensors): 64 partial maxima of |dx| as stored -- the magnitude of the gradient the producing
 // convolution's data / weight gradient multiply next in the two-piece fp16 math (include/dspn_nn.h dspn_absmax_f32); this
 // kernel is HBM-bound and has the vector slots to spare, a separate pass would read dx again
-__global__ void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
+// Streaming form: the launcher picks a grid whose stride (gridDim.x * 256 float4) is a multiple of C4 whenever it can
+// (`fixed_c`), so a thread meets ONE channel group -- its five coefficient vectors are loaded once, no 64-bit modulo per
+// element -- and four elements per tensor are requested before the first is used (this kernel is 3 - 4 passes over HBM and
+// nothing else; one element at a time held it to 4.85 TB/s where a plain add reaches 6.1 on the same box).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
                                     const float4 *__restrict__ shift, const CA4Ptr dy,
                                     const float4 *__restrict__ coef, const A4Ptr dx,
-                                    long long n4, int C4, int relu, int accumulate, unsigned *__restrict__ absmax) {
+                                    long long n4, int C4, int relu, int accumulate, unsigned *__restrict__ absmax,
+                                    int fixed_c) {
   float mx = 0.f;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const float4 xv = x[i];
-    float4 g = dy[i];
+  auto one = [&](const float4 xv, float4 g, const float4 d, const float4 sa, const float4 sb, const float4 a,
+                 const float4 c1, const float4 c0) __attribute__((always_inline)) {
     if (relu) {
-      const float4 sa = scale[c4], sb = shift[c4];
       g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
       g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
     }
-    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
     float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
                            a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);
-    if (accumulate) { const float4 d = dx[i]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
-    dx[i] = o;
+    if (accumulate) { o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    return o;
+  };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // a workgroup walks chunks of 4 x 256 consecutive elements (16 KB per tensor): thread t takes t, t + 256, t + 512, t + 768
+  constexpr int U = 4;
+  const long long cstride = (long long)gridDim.x * (U * 256);
+  long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
+  if (fixed_c) {       // 256 % C4 == 0: all of a thread's elements belong to one channel group
+    const int c4 = (int)(base % C4);
+    const float4 sa = relu ? scale[c4] : zero, sb = relu ? shift[c4] : zero;
+    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
+    for (; base + (U - 1) * 256 < n4; base += cstride) {
+      float4 xv[U], g[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { xv[u] = x[base + u * 256]; g[u] = dy[base + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) d[u] = accumulate ? (float4)dx[base + u * 256] : zero;
+#pragma unroll
+      for (int u = 0; u < U; ++u) dx[base + u * 256] = one(xv[u], g[u], d[u], sa, sb, a, c1, c0);
+    }
+    for (int u = 0; u < U; ++u) {       // the last, partial chunk (at most one workgroup's)
+      const long long j = base + u * 256;
+      if (j < n4) dx[j] = one(x[j], dy[j], accumulate ? (float4)dx[j] : zero, sa, sb, a, c1, c0);
+    }
+  } else {
+    for (; base < n4; base += cstride) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long j = base + u * 256;
+        if (j >= n4) break;
+        const int c4 = (int)(j % C4);
+        dx[j] = one(x[j], dy[j], accumulate ? (float4)dx[j] : zero, relu ? scale[c4] : zero, relu ? shift[c4] : zero, coef[c4],
+                    coef[C4 + c4], coef[2 * C4 + c4]);
+      }
+    }
   }
   if (absmax) {          // (kernel-uniform)
     __shared__ float sm[kT / 64];
@@ -378,37 +419,73 @@ __global__ void bn_apply8_kernel(const dspn::u32x4_t *__restrict__ x, const floa
 }
 // the backward apply pass likewise: this kernel moves ~12 GB per resnet-50 step
 // and 8-byte lanes reach only ~4.4 TB/s
-__global__ void bn_bwd_apply8_kernel(const dspn::u32x4_t *__restrict__ x, const float4 *__restrict__ scale,
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const dspn::u32x4_t *__restrict__ x, const float4 *__restrict__ scale,
                                      const float4 *__restrict__ shift, const dspn::u32x4_t *__restrict__ dy,
                                      const float4 *__restrict__ coef, dspn::u32x4_t *__restrict__ dx,
-                                     long long n8, int C8, int relu, int accumulate) {
+                                     long long n8, int C8, int relu, int accumulate, int fixed_c) {
   const int C4 = C8 * 2;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    const dspn::u32x4_t xw = x[i], gw = dy[i];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one 16-byte element = 8 channels = two coefficient groups h
+  auto one = [&](const dspn::u32x4_t xw, const dspn::u32x4_t gw, const dspn::u32x4_t dw, const float4 (&sa)[2],
+                 const float4 (&sb)[2], const float4 (&a)[2], const float4 (&c1)[2], const float4 (&c0)[2])
+                 __attribute__((always_inline)) {
     dspn::u32x4_t ow;
-    dspn::u32x4_t dw = {0u, 0u, 0u, 0u};
-    if (accumulate) dw = dx[i];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int c4 = c8 * 2 + h;
       const dspn::u32x2_t xh = {xw[2 * h], xw[2 * h + 1]}, gh = {gw[2 * h], gw[2 * h + 1]}, dh = {dw[2 * h], dw[2 * h + 1]};
       const float4 xv = dspn::widen4(xh);
       float4 g = dspn::widen4(gh);
       if (relu) {
-        const float4 sa = scale[c4], sb = shift[c4];
-        g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
-        g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
+        g.x = fmaf(xv.x, sa[h].x, sb[h].x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa[h].y, sb[h].y) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sa[h].z, sb[h].z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa[h].w, sb[h].w) > 0.f ? g.w : 0.f;
       }
-      const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
-      float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
-                             a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);
+      float4 o = make_float4(a[h].x * g.x + c1[h].x * xv.x + c0[h].x, a[h].y * g.y + c1[h].y * xv.y + c0[h].y,
+                             a[h].z * g.z + c1[h].z * xv.z + c0[h].z, a[h].w * g.w + c1[h].w * xv.w + c0[h].w);
       if (accumulate) { const float4 d = dspn::widen4(dh); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
       const dspn::u32x2_t on = dspn::narrow4(o);
       ow[2 * h] = on[0]; ow[2 * h + 1] = on[1];
     }
-    dx[i] = ow;
+    return ow;
+  };
+  auto coefs = [&](const int c8, float4 (&sa)[2], float4 (&sb)[2], float4 (&a)[2], float4 (&c1)[2], float4 (&c0)[2])
+                   __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c4 = c8 * 2 + h;
+      sa[h] = relu ? scale[c4] : zero; sb[h] = relu ? shift[c4] : zero;
+      a[h] = coef[c4]; c1[h] = coef[C4 + c4]; c0[h] = coef[2 * C4 + c4];
+    }
+  };
+  const dspn::u32x4_t z4 = {0u, 0u, 0u, 0u};
+  float4 sa[2], sb[2], a[2], c1[2], c0[2];
+  constexpr int U = 4;                     // (chunks of 4 x 256 elements per workgroup, as in bn_bwd_apply_kernel)
+  const long long cstride = (long long)gridDim.x * (U * 256);
+  long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
+  if (fixed_c) {
+    coefs((int)(base % C8), sa, sb, a, c1, c0);
+    for (; base + (U - 1) * 256 < n8; base += cstride) {
+      dspn::u32x4_t xw[U], gw[U], dw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { xw[u] = x[base + u * 256]; gw[u] = dy[base + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) dw[u] = accumulate ? dx[base + u * 256] : z4;
+#pragma unroll
+      for (int u = 0; u < U; ++u) dx[base + u * 256] = one(xw[u], gw[u], dw[u], sa, sb, a, c1, c0);
+    }
+    for (int u = 0; u < U; ++u) {
+      const long long j = base + u * 256;
+      if (j < n8) dx[j] = one(x[j], dy[j], accumulate ? dx[j] : z4, sa, sb, a, c1, c0);
+    }
+  } else {
+    for (; base < n8; base += cstride) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long j = base + u * 256;
+        if (j >= n8) break;
+        coefs((int)(j % C8), sa, sb, a, c1, c0);
+        dx[j] = one(x[j], dy[j], accumulate ? dx[j] : z4, sa, sb, a, c1, c0);
+      }
+    }
   }
 }
 #endif
@@ -1292,19 +1369,23 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
-    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid_for(n4 / 2)), dim3(kT), 0, S_(stream),
+    int fixed8 = 0;
+    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8);
+    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid8), dim3(kT), 0, S_(stream),
                        reinterpret_cast<const dspn::u32x4_t *>(x), reinterpret_cast<const float4 *>(scale),
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<const dspn::u32x4_t *>(dy),
                        reinterpret_cast<const float4 *>(coef), reinterpret_cast<dspn::u32x4_t *>(dx), n4 / 2, C / 8, relu,
-                       accumulate);
+                       accumulate, fixed8);
     return dspn::check_launch("bn_backward");
   }
 #endif
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+  int fixed4 = 0;
+  const int grid4 = grid_fixed_channel(n4, C4, &fixed4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid4), dim3(kT), 0, S_(stream),
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
-                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax));
+                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax), fixed4);
   return dspn::check_launch("bn_backward");
 }
 
@@ -1333,19 +1414,23 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
-    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid_for(n4 / 2)), dim3(kT), 0, S_(stream),
+    int fixed8 = 0;
+    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8);
+    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid8), dim3(kT), 0, S_(stream),
                        reinterpret_cast<const dspn::u32x4_t *>(x), reinterpret_cast<const float4 *>(scale),
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<const dspn::u32x4_t *>(dy),
                        reinterpret_cast<const float4 *>(coef), reinterpret_cast<dspn::u32x4_t *>(dx), n4 / 2, C / 8, relu,
-                       accumulate);
+                       accumulate, fixed8);
     return dspn::check_launch("bn_backward");
   }
 #endif
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
+  int fixed4 = 0;
+  const int grid4 = grid_fixed_channel(n4, C4, &fixed4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid4), dim3(kT), 0, S_(stream),
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
-                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax));
+                     accumulate, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax), fixed4);
   return dspn::check_launch("bn_backward_from_sums");
 }
 

@@ -740,6 +740,7 @@ class Conv(Node):
         xa, dya, wa = self._magnitudes("x"), self._magnitudes("dy"), self._magnitudes("w")
         if dya is not None and self.am_dy not in self._g._am_done:       # (else: the BatchNorm backward that completed dy took it)
             fn.absmax(dy, out=dya)
+            self._g._am_done.add(self.am_dy)      # (a projection shortcut that shares this slot reads the same gradient)
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
             fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
