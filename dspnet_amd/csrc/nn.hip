@@ -186,10 +186,13 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
 // single-workgroup-per-16-channels finalize kernels below read 32x fewer entries.
 //   MODE 0: (mean, M2) pairs  -> (mean_g, M2_g) by the one-sweep double formula;  MODE 1: plain sums
 constexpr int kTileGroup = 32;
+// mm / mm_out (MODE 0, optional): the per-tile (min, max) table of the same tiles, merged into one pair per group
 template <int MODE>
 __global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict__ ts, int tiles, int tile_rows,
-                                                         long long rows, int C, float *__restrict__ out) {
+                                                         long long rows, int C, float *__restrict__ out,
+                                                         const float *__restrict__ mm, float *__restrict__ mm_out) {
   __shared__ double sA[4][64], sB[4][64];
+  __shared__ float sLo[4][64], sHi[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const int t0 = blockIdx.x * kTileGroup, t1 = min(tiles, t0 + kTileGroup);
@@ -208,7 +211,24 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict
     }
   }
   sA[sl][cl] = A; sB[sl][cl] = B;
+  if (MODE == 0 && mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    if (c < C) {
+#pragma unroll 8
+      for (int t = t0 + sl; t < t1; t += 4) {
+        lo = fminf(lo, mm[((long long)t * 2 + 0) * C + c]);
+        hi = fmaxf(hi, mm[((long long)t * 2 + 1) * C + c]);
+      }
+    }
+    sLo[sl][cl] = lo; sHi[sl][cl] = hi;
+  }
   __syncthreads();
+  if (MODE == 0 && mm && sl == 0 && c < C) {
+    float lo = sLo[0][cl], hi = sHi[0][cl];
+    for (int k = 1; k < 4; ++k) { lo = fminf(lo, sLo[k][cl]); hi = fmaxf(hi, sHi[k][cl]); }
+    mm_out[((long long)blockIdx.x * 2 + 0) * C + c] = lo;
+    mm_out[((long long)blockIdx.x * 2 + 1) * C + c] = hi;
+  }
   if (sl == 0 && c < C) {
     for (int k = 1; k < 4; ++k) { A += sA[k][cl]; B += sB[k][cl]; }
     if (MODE == 0) {
@@ -1279,7 +1299,7 @@ static size_t bn_workspace_bytes(long long rows, int C) {
 }
 static size_t bn_tiles_workspace_bytes(int tiles, int C) {
   if (tiles <= 0 || C <= 0) return 0;
-  return sizeof(float) * 2 * (size_t)((tiles + kTileGroup - 1) / kTileGroup) * C;
+  return sizeof(float) * 4 * (size_t)((tiles + kTileGroup - 1) / kTileGroup) * C;     // grouped statistics + grouped (min, max)
 }
 #ifndef DSPN_HALF
 size_t dspn_bn_workspace_bytes(long long rows, int C) { return bn_workspace_bytes(rows, C); }
@@ -1314,13 +1334,15 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
                "bn_stats_from_tiles: bad argument");
   DSPN_REQUIRE((tile_minmax != nullptr) == (out_absmax != nullptr), "bn_stats_from_tiles: tile_minmax and out_absmax go together");
-  const int mm_tiles = tiles;
+  int mm_tiles = tiles;
   if (tiles >= 1024 && workspace && workspace_bytes >= bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = static_cast<float *>(workspace);
+    float *grouped_mm = tile_minmax ? grouped + 2 * (size_t)groups * C : nullptr;
     hipLaunchKernelGGL(tile_group_kernel<0>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_stats, tiles,
-                       tile_rows, rows, C, grouped);
+                       tile_rows, rows, C, grouped, tile_minmax, grouped_mm);
     tile_stats = grouped; tiles = groups; tile_rows *= kTileGroup;
+    if (tile_minmax) { tile_minmax = grouped_mm; mm_tiles = groups; }
   }
   hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
                      tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift, tile_minmax, mm_tiles, relu,
@@ -1406,7 +1428,7 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = coef + 3 * (size_t)C;
     hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
-                       (long long)tiles, C, grouped);
+                       (long long)tiles, C, grouped, static_cast<const float *>(nullptr), static_cast<float *>(nullptr));
     tile_sums = grouped; tiles = groups;
   }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), tile_sums, tiles, C,
