@@ -37,11 +37,13 @@ inline int grid_for(long long n, int per_block = kT, int cap = 8192) {
   return (int)std::max<long long>(1, std::min<long long>(b, cap));
 }
 
-// grid of a chunked streaming kernel (4 x kT consecutive elements per workgroup and step) over n elements of `groups`
-// channel groups per row; *fixed: kT % groups == 0, i.e. every element of a thread belongs to one channel group
-inline int grid_fixed_channel(long long n, int groups, int *fixed) {
+// grid of a chunked streaming kernel (U x kT consecutive elements per workgroup and step) over n elements of `groups`
+// channel groups per row; *fixed: kT % groups == 0, i.e. every element of a thread belongs to one channel group; *u4: the
+// tensor is large enough for four elements per thread (>= 2048 workgroups either way)
+inline int grid_fixed_channel(long long n, int groups, int *fixed, int *u4) {
   *fixed = groups > 0 && kT % groups == 0;
-  return grid_for(n, 4 * kT, 4096);
+  *u4 = n >= 4ll * kT * 2048;
+  return grid_for(n, (*u4 ? 4 : 1) * kT, 4096);
 }
 
 // bias gradients are column sums of small, narrow tensors (20..54 channels): slabs of 64 rows keep a few
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
 // (`fixed_c`), so a thread meets ONE channel group -- its five coefficient vectors are loaded once, no 64-bit modulo per
 // element -- and four elements per tensor are requested before the first is used (this kernel is 3 - 4 passes over HBM and
 // nothing else; one element at a time held it to 4.85 TB/s where a plain add reaches 6.1 on the same box).
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
                                     const float4 *__restrict__ shift, const CA4Ptr dy,
                                     const float4 *__restrict__ coef, const A4Ptr dx,
@@ -365,8 +368,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const CA4Ptr x, const
     return o;
   };
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  // a workgroup walks chunks of 4 x 256 consecutive elements (16 KB per tensor): thread t takes t, t + 256, t + 512, t + 768
-  constexpr int U = 4;
+  // a workgroup walks chunks of U x 256 consecutive elements (U = 4: 16 KB per tensor; thread t takes t, t + 256, t + 512,
+  // t + 768); small tensors run U = 1 so that they still spread over a few thousand workgroups
   const long long cstride = (long long)gridDim.x * (U * 256);
   long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
   if (fixed_c) {       // 256 % C4 == 0: all of a thread's elements belong to one channel group
@@ -439,6 +442,7 @@ __global__ void bn_apply8_kernel(const dspn::u32x4_t *__restrict__ x, const floa
 }
 // the backward apply pass likewise: this kernel moves ~12 GB per resnet-50 step
 // and 8-byte lanes reach only ~4.4 TB/s
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const dspn::u32x4_t *__restrict__ x, const float4 *__restrict__ scale,
                                      const float4 *__restrict__ shift, const dspn::u32x4_t *__restrict__ dy,
                                      const float4 *__restrict__ coef, dspn::u32x4_t *__restrict__ dx,
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const dspn::u32x4_t 
   };
   const dspn::u32x4_t z4 = {0u, 0u, 0u, 0u};
   float4 sa[2], sb[2], a[2], c1[2], c0[2];
-  constexpr int U = 4;                     // (chunks of 4 x 256 elements per workgroup, as in bn_bwd_apply_kernel)
+  // (chunks of U x 256 elements per workgroup, as in bn_bwd_apply_kernel)
   const long long cstride = (long long)gridDim.x * (U * 256);
   long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
   if (fixed_c) {
@@ -1391,9 +1395,9 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
-    int fixed8 = 0;
-    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8);
-    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid8), dim3(kT), 0, S_(stream),
+    int fixed8 = 0, u4 = 0;
+    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8, &u4);
+    hipLaunchKernelGGL(u4 ? bn_bwd_apply8_kernel<4> : bn_bwd_apply8_kernel<1>, dim3(grid8), dim3(kT), 0, S_(stream),
                        reinterpret_cast<const dspn::u32x4_t *>(x), reinterpret_cast<const float4 *>(scale),
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<const dspn::u32x4_t *>(dy),
                        reinterpret_cast<const float4 *>(coef), reinterpret_cast<dspn::u32x4_t *>(dx), n4 / 2, C / 8, relu,
@@ -1401,9 +1405,9 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
     return dspn::check_launch("bn_backward");
   }
 #endif
-  int fixed4 = 0;
-  const int grid4 = grid_fixed_channel(n4, C4, &fixed4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid4), dim3(kT), 0, S_(stream),
+  int fixed4 = 0, u4 = 0;
+  const int grid4 = grid_fixed_channel(n4, C4, &fixed4, &u4);
+  hipLaunchKernelGGL(u4 ? bn_bwd_apply_kernel<4> : bn_bwd_apply_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
@@ -1436,9 +1440,9 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
-    int fixed8 = 0;
-    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8);
-    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(grid8), dim3(kT), 0, S_(stream),
+    int fixed8 = 0, u4 = 0;
+    const int grid8 = grid_fixed_channel(n4 / 2, C / 8, &fixed8, &u4);
+    hipLaunchKernelGGL(u4 ? bn_bwd_apply8_kernel<4> : bn_bwd_apply8_kernel<1>, dim3(grid8), dim3(kT), 0, S_(stream),
                        reinterpret_cast<const dspn::u32x4_t *>(x), reinterpret_cast<const float4 *>(scale),
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<const dspn::u32x4_t *>(dy),
                        reinterpret_cast<const float4 *>(coef), reinterpret_cast<dspn::u32x4_t *>(dx), n4 / 2, C / 8, relu,
@@ -1446,9 +1450,9 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     return dspn::check_launch("bn_backward");
   }
 #endif
-  int fixed4 = 0;
-  const int grid4 = grid_fixed_channel(n4, C4, &fixed4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid4), dim3(kT), 0, S_(stream),
+  int fixed4 = 0, u4 = 0;
+  const int grid4 = grid_fixed_channel(n4, C4, &fixed4, &u4);
+  hipLaunchKernelGGL(u4 ? bn_bwd_apply_kernel<4> : bn_bwd_apply_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
                      reinterpret_cast<const float4 *>(coef), A4Ptr(dx), n4, C4, relu,
