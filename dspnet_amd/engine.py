@@ -701,8 +701,10 @@ class Conv(Node):
             return None
         if which == "x" and self.am_x not in g._am_done:
             prod = getattr(self.x_raw, "producer", None)
-            table = getattr(prod, "out_minmax", None) if self.in_affine is not None else None
-            if table is not None:    # monotone per channel: the extremes of (relu)(scale x + shift) sit at the extremes of x
+            # the producer's per-tile extremes of x_raw (written when some BatchNorm reads it): with an affine, its extremes
+            # sit at the extremes of x (monotone per channel); without one, |x| is largest at one of them
+            table = getattr(prod, "out_minmax", None) if getattr(prod, "out", None) is self.x_raw else None
+            if table is not None:
                 fn.absmax(table.view(-1, table.shape[-1]), self.in_affine, out=g.scalar(self.am_x))
             else:
                 fn.absmax(self.x_raw.data, self.in_affine, out=g.scalar(self.am_x))
