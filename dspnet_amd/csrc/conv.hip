@@ -443,26 +443,32 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       }
     }
   };
+  // bf16 tensors: the input affine of this thread's A chunks, in registers -- widen, u = x * scale[c] + shift[c] (ReLU), zero
+  // outside the image, round back to bf16.  Called in the MIDDLE of a k-step's MFMAs (round 3; it used to sit in
+  // store_tiles, after them: ~100 vector instructions per k-step that nothing overlapped beside 8 MFMAs -- the fused 1x1
+  // forward took 3.4x the plain one)
+  auto half_affine = [&]() __attribute__((always_inline)) {
+    if constexpr (kHalf && INTF) {
+      const bool in_relu = g.flags & 32;
+      const float sc[8] = {tf_sc.x, tf_sc.y, tf_sc.z, tf_sc.w, tf_sc2.x, tf_sc2.y, tf_sc2.z, tf_sc2.w};
+      const float sh[8] = {tf_sh.x, tf_sh.y, tf_sh.z, tf_sh.w, tf_sh2.x, tf_sh2.y, tf_sh2.z, tf_sh2.w};
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        float f[8];
+        widen8(ha[i], f);
+        const bool v = (tf_mask >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float u = fmaf(f[e], sc[e], sh[e]);      // the same fmaf as every other evaluation of this affine
+          if (in_relu) u = fmaxf(u, 0.f);
+          f[e] = v ? u : 0.f;
+        }
+        ha[i] = narrow8(f);
+      }
+    }
+  };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if constexpr (kHalf) {
-      if constexpr (INTF) {   // widen, u = x * scale[c] + shift[c] (ReLU), zero outside the image, round back to bf16
-        const bool in_relu = g.flags & 32;
-        const float sc[8] = {tf_sc.x, tf_sc.y, tf_sc.z, tf_sc.w, tf_sc2.x, tf_sc2.y, tf_sc2.z, tf_sc2.w};
-        const float sh[8] = {tf_sh.x, tf_sh.y, tf_sh.z, tf_sh.w, tf_sh2.x, tf_sh2.y, tf_sh2.z, tf_sh2.w};
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-          float f[8];
-          widen8(ha[i], f);
-          const bool v = (tf_mask >> i) & 1u;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float u = fmaf(f[e], sc[e], sh[e]);      // the same fmaf as every other evaluation of this affine
-            if (in_relu) u = fmaxf(u, 0.f);
-            f[e] = v ? u : 0.f;
-          }
-          ha[i] = narrow8(f);
-        }
-      }
       __bf16 *a = hA + buf * BM * kLdsRowH, *b = hB + buf * BN * kLdsRowH;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
@@ -624,6 +630,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       const __bf16 *b = hB + buf * BN * kLdsRowH + (wn + frow) * kLdsRowH + (lane >> 5) * 8;
 #pragma unroll
       for (int hk = 0; hk < kBK / 32; ++hk) {     // 32 k values (two 16-deep MFMA blocks) at a time
+        if constexpr (kHalf && INTF) {
+          if (hk == kBK / 32 - 1) {   // the rows requested before this k-step have had the first half's MFMAs to arrive
+            __builtin_amdgcn_sched_barrier(0);
+            half_affine();
+          }
+        }
         bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -641,6 +653,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        if constexpr (kHalf && INTF) {
+          if (hk == kBK / 32 - 1) {   // pin the transformed chunks here (their only readers, the LDS stores, sit behind the barrier)
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ha[i]));
+#pragma unroll
+            for (int m = 0; m < 2 * TM * TN; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            }
+          }
+        }
       }
     } else {
       const float *a = sA + buf * BM * kLdsRow + (wm + frow) * kLdsRow + fk + lds_shift_r;
@@ -683,6 +706,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   setup_tile(t);
   load_tiles();
   split_tiles();
+  half_affine();
   store_tiles(0);
   __syncthreads();
   zero_acc();
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
     // (32 v_mov + a full MFMA drain per k-step, seen in the ISA of the non-INTF 8-wave variants)
     if (NTHR == 512 || nk > 0) mma_step(buf);
-    else split_tiles();   // (split mode forms the pieces of the rows just requested inside mma_step)
+    else { split_tiles(); half_affine(); }   // (the pieces / the affine of the rows just requested are otherwise formed inside mma_step)
     if (last) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
