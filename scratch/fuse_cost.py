@@ -21,10 +21,17 @@ for (N, H, W, Cin, Cout, k) in shapes:
     aff = (torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev), True)
     tiles, _ = fn.conv_stats_layout(N * H * W, Cout)
     st = torch.empty(tiles, 2, Cout, device=dev)
-    t = [timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o)),
-         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, in_affine=aff)),
-         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, out_stats=st)),
-         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, in_affine=aff, out_stats=st))]
+    kw, kwa, mm = {}, {}, {}
+    if DT == torch.float32 and fn.get_conv_math() == "f16x2":     # magnitudes / planes / min-max table as the graph passes them
+        wa = fn.absmax(w)
+        wp = fn.weight_planes(w, math="f16x2", w_absmax=wa) if Cin % 32 == 0 else None
+        kw = dict(x_absmax=fn.absmax(x), w_absmax=wa, w_planes=wp)
+        kwa = dict(x_absmax=fn.absmax(x, aff), w_absmax=wa, w_planes=wp)
+        mm = dict(out_minmax=torch.empty(tiles, 2, Cout, device=dev))
+    t = [timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, **kw)),
+         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, in_affine=aff, **kwa)),
+         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, out_stats=st, **kw, **mm)),
+         timeit(lambda: fn.conv2d_forward(x, w, None, 1, k // 2, 1, out=o, in_affine=aff, out_stats=st, **kwa, **mm))]
     for i in range(4): tot[i] += t[i]
     print((N, H, W, Cin, Cout, k), "plain %.3f | +affine %.3f (%+.0f%%) | +stats %.3f (%+.0f%%) | both %.3f (%+.0f%%)" % (
         t[0], t[1], 100 * (t[1] / t[0] - 1), t[2], 100 * (t[2] / t[0] - 1), t[3], 100 * (t[3] / t[0] - 1)))
