@@ -1180,6 +1180,10 @@ __global__ __launch_bounds__(kT) void seg_upsample_argmax_kernel(const float *__
 // ------------------------------------------------------------------ losses
 // logits and their gradient are activations (storage type); the probabilities are a float output
 constexpr int kMaxSoftmaxC = 64;
+// CMAX: compile-time bound of ld (the row length) -- the row lives in CMAX registers, every loop over it is unrolled with a
+// `c < C` / `c < ld` guard (a `float v[64]` indexed by a run-time C lived in scratch memory: 0.14 ms for the 524 288 x 19
+// segmentation rows of the bench step).  Same operations in the same order for every CMAX.
+template <int CMAX>
 __global__ void softmax_output_kernel(const CA1Ptr logits, const float *__restrict__ label,
                                       float *__restrict__ prob, const A1Ptr grad, long long rows,
                                       int C, int ld, float ignore_label, float grad_scale,
@@ -1189,21 +1193,29 @@ __global__ void softmax_output_kernel(const CA1Ptr logits, const float *__restri
   for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
        r += (long long)gridDim.x * blockDim.x) {
     const CA1Ptr p = logits + r * ld;
-    float v[kMaxSoftmaxC];
+    float v[CMAX];
     float mx = -INFINITY;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) { v[c] = p[c]; mx = v[c] > mx ? v[c] : mx; }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      v[c] = c < C ? (float)p[c] : -INFINITY;
+      mx = v[c] > mx ? v[c] : mx;
+    }
     float sum = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    }
     const float inv = 1.f / sum;
     const float lab = label ? label[r] : 0.f;
     const bool ign = label ? (lab == ignore_label) : true;
     const int li = (int)lab;
-    for (int c = 0; c < ld; ++c) {
-      const float pr = c < C ? v[c] * inv : 0.f;
-      prob[r * ld + c] = pr;
-      if (grad) grad[r * ld + c] = (ign || c >= C) ? 0.f : (pr - (c == li ? 1.f : 0.f)) * scale;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c < ld) {
+        const float pr = c < C ? v[c] * inv : 0.f;
+        prob[r * ld + c] = pr;
+        if (grad) grad[r * ld + c] = (ign || c >= C) ? 0.f : (pr - (c == li ? 1.f : 0.f)) * scale;
+      }
     }
   }
 }
@@ -1764,9 +1776,11 @@ int dspn_seg_upsample_argmax_f32(const float *prob, unsigned char *out, int N, i
 int DSPN_FN(dspn_softmax_output)(const st_t *logits, const float *label, float *prob, st_t *grad,
                             long long rows, int C, int ld, float ignore_label, float grad_scale,
                             const float *valid_count, void *stream) {
-  DSPN_REQUIRE(logits && prob && rows > 0 && C > 0 && C <= kMaxSoftmaxC && ld >= C, "softmax_output: bad argument (C <= 64)");
+  DSPN_REQUIRE(logits && prob && rows > 0 && C > 0 && C <= kMaxSoftmaxC && ld >= C && ld <= kMaxSoftmaxC,
+               "softmax_output: bad argument (C <= ld <= 64)");
   DSPN_REQUIRE(!grad || label, "softmax_output: gradient needs labels");
-  hipLaunchKernelGGL(softmax_output_kernel, dim3(grid_for(rows, 128)), dim3(128), 0, S_(stream), CA1Ptr(logits), label,
+  auto kern = ld <= 12 ? softmax_output_kernel<12> : ld <= 24 ? softmax_output_kernel<24> : softmax_output_kernel<kMaxSoftmaxC>;
+  hipLaunchKernelGGL(kern, dim3(grid_for(rows, 128)), dim3(128), 0, S_(stream), CA1Ptr(logits), label,
                      prob, A1Ptr(grad), rows, C, ld, ignore_label, grad_scale, valid_count);
   return dspn::check_launch("softmax_output");
 }
