@@ -658,6 +658,20 @@ __global__ void copy_block_kernel(const SRC src, const DST dst,
     dst[di] = old + v;
   }
 }
+// the same copy in 16-byte units (same storage type on both sides, no accumulation, every extent / offset / stride a whole
+// number of units): the channel-concat copies of inceptionv3 move 16 bytes per lane instead of one element after three
+// 64-bit divisions
+__global__ void copy_block_vec_kernel(const dspn::u32x4_t *__restrict__ src, dspn::u32x4_t *__restrict__ dst,
+                                      long long rows_per_sample, int C, long long sss, int lds, int soff,
+                                      long long dss, int ldd, int doff, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const long long s = r / rows_per_sample, rr = r - s * rows_per_sample;
+    dst[s * dss + rr * ldd + doff + c] = src[s * sss + rr * lds + soff + c];
+  }
+}
 #ifndef DSPN_HALF
 __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                      int N, int C, long long total) {
@@ -1559,6 +1573,15 @@ int DSPN_FN(dspn_copy_block)(const st_t *src, st_t *dst, int samples, long long 
                         int ldd, int doff, int accumulate, void *stream) {
   DSPN_REQUIRE(src && dst && samples > 0 && rows_per_sample > 0 && C > 0, "copy_block: bad argument");
   const long long total = (long long)samples * rows_per_sample * C;
+  constexpr int E = 16 / (int)sizeof(st_t);      // elements per 16-byte unit
+  if (!accumulate && C % E == 0 && lds % E == 0 && ldd % E == 0 && soff % E == 0 && doff % E == 0 &&
+      src_sample_stride % E == 0 && dst_sample_stride % E == 0 &&
+      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    hipLaunchKernelGGL(copy_block_vec_kernel, dim3(grid_for(total / E)), dim3(kT), 0, S_(stream),
+                       reinterpret_cast<const dspn::u32x4_t *>(src), reinterpret_cast<dspn::u32x4_t *>(dst), rows_per_sample,
+                       C / E, src_sample_stride / E, lds / E, soff / E, dst_sample_stride / E, ldd / E, doff / E, total / E);
+    return dspn::check_launch("copy_block");
+  }
   hipLaunchKernelGGL((copy_block_kernel<CA1Ptr, A1Ptr>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), CA1Ptr(src),
                      A1Ptr(dst), rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff,
                      total, accumulate);

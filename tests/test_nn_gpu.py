@@ -902,3 +902,23 @@ def test_conv_tensors_of_2_gib_and_more_run_in_batch_chunks(gpu_device, conv_mat
     assert yerr <= 1e-4 * ymax and dxerr <= 1e-4 * dxmax, (yerr, ymax, dxerr, dxmax)
     dwerr = float((dw.permute(0, 3, 1, 2).double() - dw_ref).abs().max())
     assert dwerr <= 2e-4 * float(dw_ref.abs().max()), (dwerr, float(dw_ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,soff,doff", [(64, 0, 96), (32, 16, 8), (24, 8, 0), (20, 4, 12)])
+def test_copy_block_in_16_byte_units_and_by_element(gpu_device, dtype, c, soff, doff):
+    """the channel-slice copy behind Concat / the SSD head packing: whole 16-byte units when every extent, offset and stride
+    allows (4 floats / 8 bf16), element by element otherwise -- both against torch slicing, forward (into a slice) and
+    backward (out of a slice), incl. untouched neighbours"""
+    N, H, W, Cs, Cd = 3, 5, 7, 96, 160
+    g = torch.Generator().manual_seed(c + soff + doff)
+    src = torch.randn(N, H, W, Cs, generator=g).to(dtype).cuda()
+    dst = torch.randn(N, H, W, Cd, generator=g).to(dtype).cuda()
+    ref = dst.clone(); ref[..., doff:doff + c] = src[..., soff:soff + c]
+    fn.copy_block(src, dst, N, H * W, c, H * W * Cs, Cs, soff, H * W * Cd, Cd, doff)
+    assert torch.equal(dst, ref)
+    back = torch.randn(N, H, W, Cs, generator=g).to(dtype).cuda()
+    ref2 = back.clone(); ref2[..., soff:soff + c] = dst[..., doff:doff + c]
+    fn.copy_block(dst, back, N, H * W, c, H * W * Cd, Cd, doff, H * W * Cs, Cs, soff)
+    assert torch.equal(back, ref2)
