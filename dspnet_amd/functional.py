@@ -39,6 +39,7 @@ _lib.register({
                                          _i, _i, _i, _vp, _vp, _vp]),
     "dspn_conv2d_slab_reduce_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_weight_transpose_batch_f32": (_i, [_vp, _i, _ll, _vp]),
+    "dspn_conv2d_weight_transpose_tiles": (_ll, [_i, _i, _i, _i]),
     "dspn_conv2d_weight_transpose_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dspn_conv2d_dgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                    _sz, _vp]),
@@ -390,7 +391,7 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
 
 
 def weight_transpose_table(triples, device):
-    """triples: [(w float32 [Cout,R,S,Cin], wt [Cin,R,S,Kp], wh or None)] -> (device table, rows, total elements, bf16?)
+    """triples: [(w float32 [Cout,R,S,Cin], wt [Cin,R,S,Kp], wh or None)] -> (device table, rows, total tiles, bf16?)
     for weight_transpose_batch.  float32 operands: wt float32, wh None.  bfloat16 operands: wt bfloat16 and wh = the
     bfloat16 copy of w itself (the forward operand), both refreshed from the float32 master by the one launch."""
     import numpy as np
@@ -403,7 +404,7 @@ def weight_transpose_table(triples, device):
         assert w.dtype == torch.float32 and wt.shape[:3] == (Cin, R, S) and w.is_contiguous() and wt.is_contiguous()
         assert (wt.dtype == torch.bfloat16) == half and (wh is None or (half and wh.shape == w.shape))
         rows[i] = (w.data_ptr(), wt.data_ptr(), Cout, R * S, Cin, wt.shape[3], total, 0 if wh is None else wh.data_ptr())
-        total += wt.numel()
+        total += int(L().dspn_conv2d_weight_transpose_tiles(Cout, R * S, Cin, wt.shape[3]))     # 32 x 32 tiles per tap
     assert rows.dtype.itemsize == 48
     table = torch.from_numpy(rows.view(np.uint8).copy()).to(device)
     return table, len(triples), total, half

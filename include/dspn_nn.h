@@ -135,10 +135,12 @@ int dspn_conv2d_weight_planes_batch_f32(const void *table, int n, long long tota
 /* wt[c][tap][k] = w[k][tap][c], k padded with zeros to Cout_pad (operand of dgrad). */
 int dspn_conv2d_weight_transpose_f32(const float *w, float *wt, int Cout, int taps, int Cin,
                                      int Cout_pad, void *stream);
-/* every weight transpose of a training step in one launch.  table: n rows of 48 bytes in DEVICE memory,
- * { const float *w; float *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin; void *reserved (NULL) } where begin = the sum of
- * Cin*taps*Cout_pad over the preceding rows (rows sorted by begin); total_elements = that sum over all rows. */
-int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_elements, void *stream);
+/* every weight transpose of a training step in one launch (one workgroup per 32 x 32 tile of a tap).  table: n rows of 48
+ * bytes in DEVICE memory, { const float *w; float *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin; void *reserved (NULL) }
+ * where begin = the sum of dspn_conv2d_weight_transpose_tiles() over the preceding rows (rows sorted by begin);
+ * total_tiles = that sum over all rows.  Cin % 4 == 0 and Cout_pad % 4 == 0. */
+long long dspn_conv2d_weight_transpose_tiles(int Cout, int taps, int Cin, int Cout_pad);
+int dspn_conv2d_weight_transpose_batch_f32(const void *table, int n, long long total_tiles, void *stream);
 
 /* Data gradient of the convolution above: dx (N,H,W,dx_ldc) from dy (N,Ho,Wo,ldy) and the
  * transposed weights wt [Cin][R*S][ldy].  stride 1 (any dilation) or stride 2 (dilation 1; runs
@@ -255,11 +257,11 @@ int dspn_conv2d_input_sum_grad_bf16(const dspn_bf16 *dy, const float *w, float *
 /* bf16 operands of a float master weight w [Cout][taps][Cin]: wt [Cin][taps][Cout_pad] (zero padded, Cout_pad % 8 == 0;
  * the data-gradient operand) and, when wh != NULL, the copy wh [Cout][taps][Cin] (the forward operand).  Batch form:
  * table of n 48-byte rows in DEVICE memory { const float *w; dspn_bf16 *wt; int32 Cout, taps, Cin, Cout_pad; int64 begin;
- * dspn_bf16 *wh } with begin = the sum of Cin*taps*Cout_pad over the preceding rows.  (dspn_conv2d_weight_transpose_
- * batch_f32 reads the same 48-byte rows with wh = NULL.) */
+ * dspn_bf16 *wh } with begin = the sum of dspn_conv2d_weight_transpose_tiles() over the preceding rows, total_tiles = over
+ * all rows.  (dspn_conv2d_weight_transpose_batch_f32 reads the same 48-byte rows with wh = NULL.) */
 int dspn_conv2d_weight_prepare_bf16(const float *w, dspn_bf16 *wh, dspn_bf16 *wt, int Cout, int taps, int Cin,
                                     int Cout_pad, void *stream);
-int dspn_conv2d_weight_prepare_batch_bf16(const void *table, int n, long long total_elements, void *stream);
+int dspn_conv2d_weight_prepare_batch_bf16(const void *table, int n, long long total_tiles, void *stream);
 
 /* ---- BatchNorm with batch statistics (+ fused ReLU) (mx.sym.BatchNorm eps=2e-5:
  * symbol/resnet.py:30-41,91,96; multitask_symbol_builder.py:545-585) ------------------ */

@@ -922,3 +922,27 @@ def test_copy_block_in_16_byte_units_and_by_element(gpu_device, dtype, c, soff, 
     ref2 = back.clone(); ref2[..., soff:soff + c] = dst[..., doff:doff + c]
     fn.copy_block(dst, back, N, H * W, c, H * W * Cd, Cd, doff, H * W * Cs, Cs, soff)
     assert torch.equal(back, ref2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_batched_weight_transposes_match_permute(gpu_device, half):
+    """dspn_conv2d_weight_transpose_batch_f32 / dspn_conv2d_weight_prepare_batch_bf16 (one 32 x 32 tile of a tap per
+    workgroup): wt[c][t][k] = w[k][t][c] zero padded to Kp, and the storage-type copy of w itself in the bf16 form -- shapes
+    with partial tiles in both directions, several rows in one table"""
+    dt = torch.bfloat16 if half else torch.float32
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 3, 3, 64, 64), (19, 1, 1, 128, 24), (40, 3, 3, 36, 40), (171, 1, 1, 2048, 176), (96, 1, 7, 160, 96), (8, 7, 7, 4, 8)]
+    trip = []
+    for (K, R, S, C, Kp) in shapes:
+        w = torch.randn(K, R, S, C, generator=g).cuda()
+        wt = torch.full((C, R, S, Kp), float("nan"), device="cuda").to(dt)
+        wh = torch.full((K, R, S, C), float("nan"), device="cuda").to(dt) if half else None
+        trip.append((w, wt, wh))
+    fn.weight_transpose_batch(*fn.weight_transpose_table(trip, torch.device("cuda")))
+    for (w, wt, wh), (K, R, S, C, Kp) in zip(trip, shapes):
+        ref = torch.zeros(C, R, S, Kp, device="cuda")
+        ref[..., :K] = w.permute(3, 1, 2, 0)
+        assert torch.equal(wt, ref.to(dt))
+        if half:
+            assert torch.equal(wh, w.to(dt))
