@@ -392,6 +392,41 @@ def test_training_reduces_losses_and_is_deterministic(gpu_device):
     assert torch.equal(net.g.arena, net2.g.arena)
 
 
+def test_two_backward_passes_on_one_forward_pass_give_the_same_gradients(gpu_device):
+    """default (two-piece) math: the operand magnitudes of a step live in per-graph slots that forward() clears; a SECOND
+    backward pass on the same forward pass takes the gradient magnitudes again (Graph.begin_backward) instead of trusting
+    slots the first one filled -- the gradients come out bit-identical, and a backward pass whose head gradients are 1000x
+    larger (the slots would understate them 1000-fold) stays finite and scales accordingly"""
+    net, solver, *_ = make(2, 128, 128)
+    # (affine_matrix is left out: BilinearConcatConv's backward reuses the buffers that hold its forward products for the
+    # gradients -- by design one backward pass per forward pass -- and d/d affine_matrix of a second pass reads those)
+    th = net.g.params["affine_matrix"]
+    keep = torch.ones_like(net.g.grad_arena, dtype=torch.bool); keep[th.offset:th.offset + th.size] = False
+
+    def grads():
+        return net.g.grad_arena[keep].clone()
+    solver.forward()
+    solver.backward()
+    g1 = grads()
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    solver.backward()
+    assert torch.equal(grads(), g1)
+    # a second pass whose head gradient is 1000x larger: magnitude slots left over from the first pass would understate the
+    # segmentation branch's gradients a thousandfold (fp16 overflow in the two-piece math); re-taken, the result is exactly what
+    # a single backward pass with that head gradient gives
+    seg = net.seg_out
+    solver.forward()
+    seg.gbuf.mul_(1000.0)
+    solver.backward()
+    ref = grads()
+    solver.forward()
+    solver.backward()
+    seg.gbuf.mul_(1000.0)
+    solver.backward()
+    assert bool(torch.isfinite(ref).all()) and torch.equal(grads(), ref)
+    assert float((ref - g1).abs().max()) > 10 * float(g1.abs().max())       # (the larger head gradient did arrive)
+
+
 def test_step_replayed_from_a_hip_graph_is_bit_identical(gpu_device):
     """MultiTaskSolver.capture(): the whole step (forward, backward incl. the side-stream MultiBoxDetection, SGD) recorded
     into one HIP graph after two eager steps and replayed -- every library call is capturable (explicit stream, no
