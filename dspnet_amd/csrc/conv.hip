@@ -177,15 +177,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
-// Split mode, round 3 -- PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand
-// arrives as three bf16 piece planes, [row][tap][Cin / 32][piece][32] (dspn_conv2d_weight_planes_*: cut once per step for
-// the whole graph), so the B tile goes global -> registers -> LDS as three 16-byte chunks per 32 channels with no
-// arithmetic: 9.5 -> 3.5 non-MFMA vector instructions per MFMA on the 3x3 layers.
+// Split modes, round 3 -- PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand
+// arrives as piece planes, [row][tap][Cin / 32][piece][32] with three bf16 or two fp16 pieces (dspn_conv2d_weight_planes_*: cut
+// once per step for the whole graph), so the B tile goes global -> registers -> LDS as 16-byte chunks with no arithmetic
+// (three-piece math: 9.5 -> 3.5 non-MFMA vector instructions per MFMA on the 3x3 layers).
 // (A halo-resident A tile for the 3x3 stride-1 layers -- the (8 + 2) x (16 + 2) input patch under an 8 x 16 output tile loaded,
-// affine-transformed and cut once per 32 channels for all nine taps -- was built on top of this and removed again: 2.2
-// instructions per MFMA and a 4 % higher clock, but 14 % more wave cycles (the image load is exposed once per nine k-steps
-// and its 30 registers do not fit beside the fused epilogues of the 128-register kernels): 630 against 675 images/s, DESIGN.md.)
-constexpr int kPlaneBlk = 3 * 32;      // bf16 elements of one (row, tap, 32-channel block) of a piece-plane operand
+// affine-transformed and cut once per 32 channels for all nine taps -- was built on top of this in the three-piece math and
+// removed again: 2.2 instructions per MFMA and a 4 % higher clock, but 14 % more wave cycles (the image load is exposed once
+// per nine k-steps and its 30 registers do not fit beside the fused epilogues of the 128-register kernels): 630 against 675
+// images/s.  Its one-dimensional form in the two-piece math -- scratch/row_resident_a_tile_experiment.patch -- lost as well;
+// DESIGN.md section 4.)
 
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
