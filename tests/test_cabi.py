@@ -97,6 +97,16 @@ def test_convolution_argument_validation_without_gpu():
     assert lib.dspn_conv2d_weight_planes_f32(p, None, None, 8, 9, 64, 0, 3, None, None) == -1  # nothing to write
     assert lib.dspn_absmax_f32(p, 8, 6, None, None, 0, p, None) == -1                # C % 4
     assert lib.dspn_absmax_f32(p, 8, 8, p, None, 0, p, None) == -1                   # scale without shift
+    # BatchNorm finalize from tile statistics: the per-tile extremes and the magnitude block they feed go together
+    import ctypes
+    f = ctypes.c_float(1e-5)
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 512, 8, f, None, p, p, p, p, p, p, 0, None, None, 0, None) == -1
+    assert b"go together" in lib.dspn_last_error()
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 9999, 8, f, None, p, p, p, p, p, None, 0, None, None, 0, None) == -1   # rows vs tiles
+    # batched weight transposes count 32 x 32 tiles of a tap
+    assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
+    assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout
+    assert lib.dspn_conv2d_weight_transpose_batch_f32(None, 1, 4, None) == -1
     assert lib.dspn_conv2d_weight_planes_tiles(64, 9, 64, 64, 1) == 2 * 9 * 2 and lib.dspn_conv2d_weight_planes_tiles(40, 1, 64, 64, 1) == 4
 
 
