@@ -188,9 +188,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // images/s.  Its one-dimensional form in the two-piece math -- scratch/row_resident_a_tile_experiment.patch -- lost as well;
 // DESIGN.md section 4.)
 
+#ifdef DSPN_ABLATE
+__device__ unsigned g_phase_stamps[8192 * 8];     // dspn_debug_set bit 16384: 8 words per wave (conv_nt_kernel), read by dspn_debug_read_stamps
+#endif
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_nt_kernel(
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && TM * TN <= 2) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
     const int ksteps_per_split, float *__restrict__ slab, const st_t *__restrict__ residual) {
@@ -205,9 +208,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int PB = NPC * 32;                          // 16-bit elements of one (row, tap, 32-channel block) of the planes
   // 16-B loads per thread per k-step
   constexpr int A_LD = BM / RSTEP;
-  constexpr int B_LD = PRE ? NPC * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
+  // Two-piece math with weight planes (round 4): the B tile is a PURE COPY of 128-byte (row, tap, 32-channel block) records,
+  // so it goes global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction: no VGPRs, no ds_write, no vector
+  // instruction besides one address add).  The LDS destination of such a load is lane-linear, so the image cannot be padded
+  // against bank conflicts; it is XOR-swizzled instead, on the SOURCE address here and on the fragment reads in mma_step:
+  // rows are 128 B, two per 256-B bank line, and the 16-byte slot s = (row & 1) * 8 + chunk of line L = row >> 1 holds what
+  // an unswizzled image would keep in slot s ^ (L & 7).  A 16-lane group of ds_read_b128 (rows {0-3, 12-15, 20-27} or
+  // {4-11, 16-19, 28-31} of a 32-row fragment, one chunk index) then covers all 16 slots of the bank line once.
+  constexpr bool DMA_B = PRE && MATH == 3;
+  constexpr int NWV = NTHR / 64;
+  constexpr int B_NI = DMA_B ? BN / (8 * NWV) : 1;      // 1-KiB pieces (8 rows of the B tile) per wave and k-step
+  static_assert(!DMA_B || (BN % (8 * NWV) == 0 && B_NI >= 1), "the B tile is a whole number of 1-KiB pieces per wave");
+  constexpr int B_LD = DMA_B ? 1 : PRE ? NPC * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
   constexpr bool B_EXACT = (4 * BN) % NTHR == 0;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(1024))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
   float *sB = smem + 2 * BM * kLdsRow;       // [2][BN][kLdsRow]
   constexpr int ROWH = SPLIT ? NPC * 32 + 8 : kLdsRowH;   // LDS row (16-bit elements) of the 16-bit images: 208 / 144 / 80 B
@@ -218,8 +232,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #else
   constexpr int STAGES = MATH == 2 ? 1 : 2;
 #endif
-  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH]
+  static_assert(!DMA_B || STAGES == 2, "the direct-to-LDS B tile is double buffered");
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH] (DMA_B: [STAGES][BN][64], swizzled)
   __bf16 *hB = hA + STAGES * BM * ROWH;
+  static_assert(!DMA_B || (STAGES * BM * ROWH * 2) % 256 == 0, "the B image starts on a bank line");
 
 #ifdef DSPN_ABLATE
   const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
@@ -240,6 +256,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const float sc_a = MATH == 3 ? operand_scale(g.a_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.b_absmax) : 1.f;
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;      // (exact: powers of two)
   const int chunk = tid & 7, row0 = tid >> 3;
+  // two-piece math: the A rows of a thread are those of row0 with bits 0 and 2 swapped.  A 16-lane group of the piece stores
+  // (ds_write_b64: rows r and r', 8 chunks each, 144-B rows = 36 dwords) then writes rows 4 apart -- banks 4r .. 4r+15 and
+  // 4r+16 .. 4r+31 -- instead of neighbours, whose 16-bank windows overlap in 12 (SQ_LDS_BANK_CONFLICT was 15 - 17 % of the
+  // LDS-active cycles of these kernels, all of it from these stores; profiles/r04_f16x2_coexec.csv)
+  const int arow0 = MATH == 3 ? ((row0 & ~5) | ((row0 & 1) << 2) | ((row0 >> 2) & 1)) : row0;
   // 8-wave kernels only (measured: +3..4 % there; on 4 waves the doubled store count costs more than the reads gain)
   constexpr bool LDS_SHIFT = NTHR == 512;
   const int lds_shift_w = LDS_SHIFT ? ((row0 >> 3) & 1) * 2 : 0;
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // PRE: thread (row = tid >> 2, part = tid & 3) moves chunks 3 * part .. 3 * part + 2 of the 12 chunks (192 B) of tile
   // row `row` (+ NTHR / 4 per pass): one address register per pass, the three chunks at immediate offsets
   constexpr int B_PASS = PRE ? (4 * BN + NTHR - 1) / NTHR : 1;
-  static_assert(!PRE || B_LD == NPC * B_PASS, "chunk count of the piece-plane loader");
+  static_assert(!PRE || DMA_B || B_LD == NPC * B_PASS, "chunk count of the piece-plane loader");
   const int CB = g.Cin >> 5;                 // PRE: 32-channel blocks per tap
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     ld_m0 = mt * BM; ld_n0 = nt * BN;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      const int m = ld_m0 + row0 + RSTEP * i;
+      const int m = ld_m0 + arow0 + RSTEP * i;
       const int hw = g.Hg * g.Wg;
       const int n = m / hw, rem = m - n * hw;
       const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
@@ -299,7 +320,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       a_iw0[i] = mv ? iw0 : 0;
       a_eoff[i] = mv ? ((n * g.Hin + ih0) * g.Win + iw0) * g.Cin : 0;
     }
-    if constexpr (PRE) {
+    if constexpr (DMA_B) {
+      // piece q = wave * B_NI + i of the B image (1 KiB = bank lines 4q .. 4q+3 = tile rows 8q .. 8q+7): lane l fills slot
+      // l & 15 of line 4q + (l >> 4), i.e. fetches chunk c of row r with (r & 1) * 8 + c = (l & 15) ^ (line & 7).  Rows past
+      // Cout read the last row instead (finite values; their output columns are never stored): no reliance on what an
+      // out-of-range LDS-DMA load leaves in LDS
+#pragma unroll
+      for (int i = 0; i < B_NI; ++i) {
+        const int line = 4 * (wave * B_NI + i) + (lane >> 4);
+        const int sl = (lane & 15) ^ (line & 7);
+        const int k = min(ld_n0 + 2 * line + (sl >> 3), g.Cout - 1);
+        b_eoff[i] = k * (g.WTAPS * CB * PB * 2) + (sl & 7) * 16;      // BYTES
+      }
+    } else if constexpr (PRE) {
 #pragma unroll
       for (int ps = 0; ps < B_PASS; ++ps) {
         const int br = (tid >> 2) + ps * (NTHR / 4), k = ld_n0 + br;
@@ -322,6 +355,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 
   float4 ra[A_LD], rb[B_LD];
   u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
+  int b_soff = 0;                // DMA_B: what load_tiles() worked out for issue_b()
+  bool b_qv = false;
   // timing-only ablation (bits 4096 / 8192, split modes): the A side of a k-step -- loads, affine, pieces, LDS stores -- only
   // every 3rd / 9th k-step: the upper bound of what an A tile kept in LDS across a kernel row's / all nine taps could save
   int abl_phase = 0;
@@ -382,7 +417,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
                                __uint_as_float(t[3]));
     }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
-    if constexpr (PRE) {
+    if constexpr (DMA_B) {
+      // (wave-uniform) byte offset of this k-step's (tap, 32-channel block) inside a row of the planes; issue_b() sends it
+      b_soff = (wtap * CB + (cq0 >> 3)) * (PB * 2);
+      b_qv = qv;
+    } else if constexpr (PRE) {
       // piece planes: the 192 bytes of (row, tap, block of 32 channels) are contiguous; 12 chunks per row
       const int boff = (wtap * CB + (cq0 >> 3)) * PB;
 #pragma unroll
@@ -403,6 +442,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       else rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
                                __uint_as_float(t[3]));
     }
+    }
+  };
+  // DMA_B: the B tile of the k-step load_tiles() addressed last goes straight into stage `dst` of the LDS image.  Not part of
+  // load_tiles(): at a tile's last k-step the A rows of the next tile are requested BEFORE the epilogue (they wait in
+  // registers), the B tile only after it -- the epilogue's staging area covers both stages
+  auto issue_b = [&](const int dst, const int soff, const bool qv) __attribute__((always_inline)) {
+    if constexpr (DMA_B) {
+      if (qv) {
+        char *base = reinterpret_cast<char *>(hB) + dst * (BN * 128) + (wave * B_NI) * 1024;
+#pragma unroll
+        for (int i = 0; i < B_NI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(base + i * 1024), 16,
+                                                   b_eoff[i], soff, 0, 0);
+      }
     }
   };
   // float tensors: the input affine of this thread's A rows, in registers
@@ -486,12 +539,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       if (abl_a_on) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        __bf16 *d = a + (row0 + RSTEP * i) * ROWH + chunk * 4;
+        __bf16 *d = a + (arow0 + RSTEP * i) * ROWH + chunk * 4;
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
       }
       }
-      if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
+      if constexpr (DMA_B) {   // (already on its way: issue_b)
+      } else if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
 #pragma unroll
         for (int ps = 0; ps < B_PASS; ++ps) {
           const int br = (tid >> 2) + ps * (NTHR / 4);
@@ -555,6 +609,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
   const unsigned long long stamp_c0 = (dbg & 2048) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long stamp_r0 = (dbg & 2048) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  // diagnostic build path (dspn_debug_set bit 16384, results WRONG): where the cycles of a k-step go, per wave -- s_memtime
+  // stamps between the phases of every k-step that is not a tile's last, summed per phase:
+  //   0 requests issued | 1 first MFMA block | 2 wait for the requested rows | 3 piece arithmetic | 4 second MFMA block |
+  //   5 LDS stores | 6 barrier;   slot 7 counts the k-steps.  Written over the head of `out` by lane 0 of every wave.
+  unsigned ph_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned ph_t = 0;
+  auto stamp = [&](const int slot) __attribute__((always_inline)) {
+    if (dbg & 16384) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+      if (slot >= 0) ph_acc[slot] += now - ph_t;
+      ph_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   f32x16 acc[TM][TN];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -572,6 +641,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
       const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
+      // DMA_B: row r = wn + 32 j + frow sits in bank line r >> 1; chunk c = 4 p + 2 kk + (lane >> 5) of it in slot
+      // ((r & 1) * 8 + c) ^ ((r >> 1) & 7) (see DMA_B above; wn + 32 j adds whole groups of 16 lines, so the row bits are frow's)
+      const char *bsw = reinterpret_cast<const char *>(hB) + buf * (BN * 128) + wn * 128 + (frow >> 1) * 256;
+      const int bslot = ((((frow & 1) << 3) | (lane >> 5)) ^ ((frow >> 1) & 7)) << 4;
       auto block = [&](const int kk) __attribute__((always_inline)) {
         bf16x8 fa[NPC][TM], fb[NPC][TN];
 #pragma unroll
@@ -580,8 +653,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
           for (int i = 0; i < TM; ++i)
             fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (DMA_B) fb[p][j] = *reinterpret_cast<const bf16x8 *>(bsw + j * 4096 + (bslot ^ ((4 * p + 2 * kk) << 4)));
+            else fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
+          }
         }
         // piece pairs, smallest terms first: three-piece bf16 (p + q <= 2), two-piece fp16 (p + q <= 1)
         constexpr int NPROD = MATH == 3 ? 3 : 6;
@@ -605,7 +680,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // the rows requested before this k-step have had the first block's MFMAs to arrive: their pieces are formed on the
       // vector ALU between the second block's MFMAs
       __builtin_amdgcn_sched_barrier(0);
+      if (dbg & 16384) {
+        stamp(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(2);
+      }
       if (!(dbg & 256)) split_tiles();
+      if (dbg & 16384) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+          for (int pc = 0; pc < NPC; ++pc) asm volatile("" : "+v"(pa[i][pc]));
+        stamp(3);
+      }
       block(1);
       // pin the pieces HERE: their only readers (the LDS stores) sit behind the barrier, and hipcc otherwise sinks the
       // whole piece arithmetic down there, next to them
@@ -706,9 +793,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   setup_tile(t);
   load_tiles();
+  issue_b(0, b_soff, b_qv);
+  if constexpr (DMA_B) {
+    // a K range without taps (parity class of a strided data gradient) runs its one k-step on zero operands: nothing is ever
+    // loaded into the B image then, so clear it (both stages) -- stale LDS bits could be NaNs
+    if (nk == 0)
+      for (int i = tid; i < STAGES * BN * 8; i += NTHR) reinterpret_cast<u32x4_t *>(hB)[i] = u32x4_t{0u, 0u, 0u, 0u};
+  }
   split_tiles();
   half_affine();
   store_tiles(0);
+  if constexpr (DMA_B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B tile has landed (the barrier below publishes it)
   __syncthreads();
   zero_acc();
   int m0 = ld_m0, n0 = ld_n0;
@@ -718,15 +813,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   while (true) {
     const bool last = kt == nk1 - 1;
     const bool has_next = tn < ntiles;
-    if (last && has_next) setup_tile(tn);
+    // (the tile transitions are marked unlikely: hipcc then places its spill code there -- 74 scalar registers of the fused
+    // data-gradient kernel live in lanes of a vector register -- instead of 24 v_readlane + 6 v_writelane per k-step)
+    if (__builtin_expect(last && has_next, 0)) setup_tile(tn);
+    stamp(-1);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
+    if (!last) issue_b(buf ^ 1, b_soff, b_qv);   // (DMA_B; at a tile's last k-step the epilogue's staging area is in the way: issued after it)
+    stamp(0);
     // nk == 0 (a parity class of a strided data gradient without taps): the loads return zeros, so the k-step may run
     // (accumulators stay 0) or be skipped.  The 8-wave build must NOT branch here: with the branch hipcc keeps the
     // loop-carried accumulators in other registers than the MFMA results and copies all 32 after every k-step
     // (32 v_mov + a full MFMA drain per k-step, seen in the ISA of the non-INTF 8-wave variants)
     if (NTHR == 512 || nk > 0) mma_step(buf);
     else { split_tiles(); half_affine(); }   // (the pieces / the affine of the rows just requested are otherwise formed inside mma_step)
-    if (last) {
+    if ((dbg & 16384) && !last) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+      stamp(4);
+    }
+    if (__builtin_expect(last, 0)) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
       if (slab) {   // raw partial sums, dense [split][M][Cout]; bias / relu / accumulate happen in the reduce
@@ -759,7 +866,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         // are the settings that compile without scratch (hipcc 7.2): INTF + statistics 1 row / unrolled, the other
         // fused epilogues 2 rows / rolled, the plain epilogue 4 rows / unrolled
         constexpr int RC8 = (EPI == 1 && INTF) ? 1 : (EPI != 0) ? 2 : 4;
-        constexpr int RC = NTHR == 512 ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
+        constexpr bool TIGHT = NTHR == 512 && TM * TN <= 2;     // the 128-register 8-wave kernels
+        constexpr int RC = TIGHT ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
         float *st = smem;
         const int c4 = tid % C4, er0 = tid / C4;
         const int co = n0 + c4 * 4;
@@ -825,7 +933,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         constexpr bool MINMAX = EPI == 1 && MATH == 3;     // per-tile extremes of the stored values (g.minmax)
         constexpr float kInf = __builtin_huge_valf();
         float vmn[4] = {kInf, kInf, kInf, kInf}, vmx[4] = {-kInf, -kInf, -kInf, -kInf};
-#pragma unroll (NTHR == 512 && EPI != 0 && !(EPI == 1 && INTF) ? 1 : NP / RC)
+#pragma unroll (TIGHT && EPI != 0 && !(EPI == 1 && INTF) ? 1 : NP / RC)
         for (int ch = 0; ch < NP / RC; ++ch) {
           if (ch > 0) { rows_begin(ch); rows_bn_x(); }
 #pragma unroll
@@ -962,6 +1070,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         }
       }
       if (!has_next) {
+        if ((dbg & 16384) && lane == 0 && blockIdx.y == 0) {
+#ifdef DSPN_ABLATE
+          unsigned *po = g_phase_stamps + ((blockIdx.x * (NTHR / 64) + wave) & 8191) * 8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) po[q] = ph_acc[q];
+#endif
+        }
         if ((dbg & 2048) && tid == 0 && blockIdx.y == 0) {
           const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
           // 4 words per workgroup: cycles, real-time ticks (100 MHz), start tick and end tick (low 32 bits, raw)
@@ -978,6 +1093,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       m0 = ld_m0; n0 = ld_n0;
       kt = -1;
       __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
+      issue_b(buf ^ 1, b_soff, b_qv);
     }
     if constexpr (STAGES == 1) {
       if (!last && !(dbg & 4)) __syncthreads();   // every wave has read the fragments of this k-step (the epilogue's barriers cover `last`)
@@ -985,7 +1101,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       if (!(dbg & 4)) __syncthreads();
     } else {
       if (!(dbg & 2)) store_tiles(buf ^ 1);
+      if constexpr (DMA_B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the B tile have landed
+      if ((dbg & 16384) && !last) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(5); }
       if (!(dbg & 4)) __syncthreads();
+      if ((dbg & 16384) && !last) { stamp(6); ph_acc[7] += 1u; }
       buf ^= 1;
     }
     ++kt;
@@ -1787,6 +1906,21 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
 #undef DSPN_NT_
 }
 
+// the two-piece kernels alone (uniform taps), for tile shapes that exist only in that math
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_nt_f16x2(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
+                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
+#ifdef DSPN_HALF
+  return dspn::fail(DSPN_ERR_ARG_, "conv: no two-piece kernels for bf16 tensors");
+#else
+#define DSPN_NT3_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 3, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+  if (g.bn_sums) return DSPN_NT3_(false, 2);
+  if (g.in_scale) return g.stats ? DSPN_NT3_(true, 1) : DSPN_NT3_(true, 0);
+  return g.stats ? DSPN_NT3_(false, 1) : DSPN_NT3_(false, 0);
+#undef DSPN_NT3_
+#endif
+}
+
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
 // leaves most of the chip idle and K is long, split K across workgroups (dense outputs only).
 #ifdef DSPN_ABLATE
@@ -1794,7 +1928,7 @@ int g_debug_bits = 0;       // timing experiments only (dspn_debug_set, csrc/dsp
 #else
 constexpr int g_debug_bits = 0;
 #endif
-static const int kNtBm[4] = {128, 128, 64, 256}, kNtBn[4] = {128, 64, 64, 32};
+static const int kNtBm[5] = {128, 128, 64, 256, 128}, kNtBn[5] = {128, 64, 64, 32, 256};
 // Tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 256x32) for an M x Cout output
 int nt_config(long long M, int Cout) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
@@ -1868,6 +2002,11 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 >= 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
+  // experiment (DSPN_NT_WIDE=<min tiles>): 128 x 256 tiles on 8 waves of 64 x 64 (one workgroup per CU, 256 registers) for
+  // the two-piece layers with >= 256 output columns: half the A-side loads / piece arithmetic / LDS stores per multiply-add
+  static const int wide_min = [] { const char *e = getenv("DSPN_NT_WIDE"); return e ? atoi(e) : 0; }();
+  if (wide_min > 0 && pre && g.bf16 == 3 && splits == 1 && cfg == 0 && g.Cout % 256 == 0 && tiles(128, 256) >= wide_min)
+    return launch_nt_f16x2<2, 4, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
@@ -1939,6 +2078,11 @@ extern "C" {
 int dspn_debug_set_bf16(int bits) { g_debug_bits = bits; return 0; }   // the bf16-tensor kernels have their own word
 #else
 int dspn_debug_set(int bits) { g_debug_bits = bits; return 0; }
+int dspn_debug_read_stamps(unsigned *host, int words, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_stamps), sizeof(unsigned) * (size_t)std::min(words, 8192 * 8)) != hipSuccess) return 1;
+  if (clear) { static unsigned z[8192 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stamps), z, sizeof(z)); }
+  return 0;
+}
 #endif
 #endif
 
