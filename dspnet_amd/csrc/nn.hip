@@ -247,9 +247,12 @@ __global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict
   }
 }
 
-__global__ void bn_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
+// absmax (optional, float tensors): 64 partial maxima of |y| as stored -- the magnitude block of the tensor for the
+// convolutions that multiply it in the two-piece fp16 math (dspn_absmax_f32), taken here instead of by a pass of its own
+__global__ __launch_bounds__(kT) void bn_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
                                 const float4 *__restrict__ shift, const A4Ptr y,
-                                long long n4, int C4, int relu) {
+                                long long n4, int C4, int relu, unsigned *__restrict__ absmax) {
+  float mx = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
@@ -260,6 +263,43 @@ __global__ void bn_apply_kernel(const CA4Ptr x, const float4 *__restrict__ scale
       o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
     y[i] = o;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  }
+  if (absmax) {          // (kernel-uniform)
+    __shared__ float sm[kT / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < kT / 64; ++w) mx = fmaxf(mx, sm[w]);
+      unsigned *o = absmax + (blockIdx.x & 63);
+      if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(o)) atomicMax(o, __float_as_uint(mx));
+    }
+  }
+}
+
+// a BOUND of the magnitude of (relu)(x * scale[c] + shift[c]) from the magnitude M of x alone: max over c of
+// |scale[c]| * M + |shift[c]| -- for a convolution that folds a BatchNorm into its loader and whose raw input has a known
+// magnitude but no per-channel extremes (a pooled tensor).  A bound that is too large by less than 2^17 costs the two-piece
+// math nothing (include/dspn_nn.h).  One workgroup.
+__global__ __launch_bounds__(256) void absmax_affine_bound_kernel(const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                  int C, const float *__restrict__ x_absmax,
+                                                                  unsigned *__restrict__ out) {
+  __shared__ float sm[4];
+  float m = x_absmax[threadIdx.x & 63];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float b = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) b = fmaxf(b, fabsf(scale[c]) * m + fabsf(shift[c]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    b = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (!(b == b)) b = INFINITY;                        // a NaN coefficient: no finite bound exists
+    if (b > 0.f) atomicMax(out, __float_as_uint(b));
   }
 }
 
@@ -1381,7 +1421,7 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
 }
 #endif
 int DSPN_FN(dspn_bn_apply)(const st_t *x, const float *scale, const float *shift, st_t *y, long long rows,
-                      int C, int relu, void *stream) {
+                      int C, int relu, float *out_absmax, void *stream) {
   DSPN_REQUIRE(x && scale && shift && y, "bn_apply: null pointer");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_apply: C must be a positive multiple of 4");
   const long long n4 = rows * (C / 4);
@@ -1396,9 +1436,19 @@ int DSPN_FN(dspn_bn_apply)(const st_t *x, const float *scale, const float *shift
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream),
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale),
                      reinterpret_cast<const float4 *>(shift), A4Ptr(y), n4, C / 4,
-                     relu);
+                     relu, dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(out_absmax));
   return dspn::check_launch("bn_apply");
 }
+
+#ifndef DSPN_HALF
+int dspn_absmax_affine_bound_f32(const float *scale, const float *shift, int C, const float *x_absmax, float *out,
+                                 void *stream) {
+  DSPN_REQUIRE(scale && shift && x_absmax && out && C > 0, "absmax_affine_bound: bad argument");
+  hipLaunchKernelGGL(absmax_affine_bound_kernel, dim3(1), dim3(256), 0, S_(stream), scale, shift, C, x_absmax,
+                     reinterpret_cast<unsigned *>(out));
+  return dspn::check_launch("absmax_affine_bound");
+}
+#endif
 
 int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                          const float *mean, const float *rstd, const float *gamma, st_t *dx,

@@ -52,6 +52,11 @@ class Tensor:
         # their tile loaders, see BatchNorm(defer_apply=True)); .data stays None so any other consumer fails loudly
         self.affine_src = None
         self.producer = None       # the Conv node that writes this tensor (it can emit BatchNorm tile statistics)
+        # "f16x2" math: index of a magnitude block that BOUNDS |values| once the producer has run in this step (a materialised
+        # BatchNorm takes it while it writes the tensor; pooled / aliased tensors inherit their source's -- a bound that is too
+        # large by less than 2^17 costs the two-piece math nothing), and the tensor whose values this one shares (BlockGrad)
+        self.am_slot = None
+        self.alias_of = None
         self.channels = None       # logical channel count when the last axis is padded (19 -> 20, 3 -> 4)
         self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device, dtype=self.dtype))
         self.grad = None
@@ -131,6 +136,7 @@ class Graph:
         self._am_x = {}            # (id of the raw input tensor, id of its affine scale) -> slot shared by its readers
         self._am_done = set()      # slots already computed in the current step
         self._am_bwd_slots, self._am_bwd_ran = set(), False
+        self._am_table_slots = set()   # weight magnitudes taken by the one batched launch at the top of forward()
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -162,11 +168,14 @@ class Graph:
     def scalar(self, i):
         return None if (i is None or self.scalars is None) else self.scalars[i * fn.ABSMAX_SLOTS:(i + 1) * fn.ABSMAX_SLOTS]
 
-    def magnitude(self, slot, tensor):
+    def magnitude(self, slot, tensor, src=None):
         """"f16x2" math: the magnitude block of `tensor` in slot `slot` (a node-owned index from new_scalar), taken by a pass
-        over the tensor the first time a step asks for it and reused afterwards; None in the other math modes"""
+        over the tensor the first time a step asks for it and reused afterwards; None in the other math modes.
+        src: the engine Tensor behind `tensor` -- if its producer has already left a bound of it this step, that block"""
         if slot is None or self.scalars is None or tensor.dtype != torch.float32:
             return None
+        if src is not None and src.am_slot is not None and src.am_slot in self._am_done:
+            return self.scalar(src.am_slot)
         out = self.scalar(slot)
         if slot not in self._am_done:
             fn.absmax(tensor, out=out)
@@ -294,7 +303,9 @@ class Graph:
         if self.device.type == "cuda":
             if self.math == "f16x2" and self._nscal:
                 self.scalars = torch.zeros(self._nscal * fn.ABSMAX_SLOTS, dtype=torch.float32, device=self.device)
-                pairs = [(n.w.data, self.scalar(n.am_w)) for n in self.nodes if isinstance(n, Conv) and n.am_w is not None]
+                wnodes = [n for n in self.nodes if getattr(n, "am_w", None) is not None and getattr(n, "w", None) is not None]
+                pairs = [(n.w.data, self.scalar(n.am_w)) for n in wnodes]
+                self._am_table_slots = {n.am_w for n in wnodes}
                 if pairs:
                     self.am_table = fn.absmax_table(pairs, self.device)
             planes = [(n.w.data, n.wp, n.wtp) + ((self.scalar(n.am_w),) if self.math == "f16x2" else ())
@@ -344,6 +355,7 @@ class Graph:
             self._am_bwd_ran = False
             if self.am_table is not None:
                 fn.absmax_batch(*self.am_table)
+                self._am_done |= self._am_table_slots
         if self.wp_table is not None:  # split math: the piece planes of every weight (forward and data-gradient operands;
             fn.weight_planes_batch(*self.wp_table)     # "f16x2": cut relative to the magnitudes just taken)
         for f in self.pre_forward:
@@ -529,6 +541,9 @@ class BatchNorm(Node):
         if defer_apply:
             self.out.affine_src = (x, self.scale, self.shift, relu)
         self.out.bn_node = self
+        # "f16x2" math: a MATERIALISED output leaves its magnitude as a by-product of the apply kernel
+        self.am_out = g.new_scalar() if (g.math == "f16x2" and self.out.dtype == torch.float32) else None
+        self.out.am_slot = self.am_out
         self.conv_consumers = []     # convolutions reading self.out (deferred apply), in forward order
         self.mat_consumers = []      # plain convolutions reading a MATERIALISED self.out (their last data gradient can
                                      # still gather this BatchNorm's backward reductions in its epilogue)
@@ -558,7 +573,10 @@ class BatchNorm(Node):
             fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                         self.mean, self.rstd, self.scale, self.shift)
         if not self.defer_apply:
-            fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data)
+            am = self._g.scalar(self.am_out)
+            fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data, out_absmax=am)
+            if am is not None:
+                self._g._am_done.add(self.am_out)
 
     def backward(self):
         if not self.out._gw:
@@ -700,12 +718,20 @@ class Conv(Node):
         if self.am_x is None or g.scalars is None:
             return None
         if which == "x" and self.am_x not in g._am_done:
-            prod = getattr(self.x_raw, "producer", None)
+            src = self.x_raw
+            while src.alias_of is not None:       # BlockGrad: the same values under another name
+                src = src.alias_of
+            prod = getattr(src, "producer", None)
             # the producer's per-tile extremes of x_raw (written when some BatchNorm reads it): with an affine, its extremes
             # sit at the extremes of x (monotone per channel); without one, |x| is largest at one of them
-            table = getattr(prod, "out_minmax", None) if getattr(prod, "out", None) is self.x_raw else None
+            table = getattr(prod, "out_minmax", None) if getattr(prod, "out", None) is src else None
             if table is not None:
                 fn.absmax(table.view(-1, table.shape[-1]), self.in_affine, out=g.scalar(self.am_x))
+            elif src.am_slot is not None and src.am_slot in g._am_done:
+                # round 4: a bound the producer left while it wrote the tensor (or the bound of what it was pooled from)
+                if self.in_affine is None:
+                    return g.scalar(src.am_slot)
+                fn.absmax_affine_bound(self.in_affine[0], self.in_affine[1], g.scalar(src.am_slot), g.scalar(self.am_x))
             else:
                 fn.absmax(self.x_raw.data, self.in_affine, out=g.scalar(self.am_x))
             g._am_done.add(self.am_x)
@@ -820,6 +846,10 @@ class BilinearConcatConv(Node):
         # each taken once per step and shared by the forward, weight-gradient and data-gradient calls that multiply it
         f16 = g.math == "f16x2"
         self.am = [(g.new_scalar(), g.new_scalar(), g.new_scalar(backward=True)) if f16 else (None, None, None) for _ in inputs]
+        # round 4: every weight slice is bounded by the magnitude of the whole weight, which the one batched launch at the top
+        # of forward() takes with all the others (Graph.am_table); the inputs are materialised BatchNorm outputs, which leave
+        # theirs while they are written; the sampler's data-gradient passes leave the gradients'
+        self.am_w = g.new_scalar() if f16 else None
         for t in inputs:
             # W_c . x_c at the component's own resolution (its gradient in backward).  Every component goes through
             # the sampler, also the ones that already have the target size: once the optimizer has moved
@@ -833,6 +863,7 @@ class BilinearConcatConv(Node):
             self.wcp.append(fn.zeros(T, 1, t.shape[3] // 32, fn.plane_pieces(g.math), 32, device=g.device, dtype=torch.bfloat16)
                             if g.device.type == "cuda" and fn.needs_planes(self.zc[-1].dtype, t.shape[3], g.math) else None)
         self.sources = None           # fn.SamplerSources over zc, made at the first forward
+        self.tpart = None             # (source pixels of all components, 6) float64: rows of the theta gradient
         self.out = g.tensor((N, Ht, Wt, fn.padc(num_filter)), name + "_out")
         self.out.channels = num_filter
         # multiply-adds actually executed (the direct form would be 2 * Cin * Cout * k * k * Ht * Wt * N)
@@ -852,7 +883,7 @@ class BilinearConcatConv(Node):
         for c, t in enumerate(self.inputs):
             if self.wch[c] is not None:      # bf16 operands of this slice: copy + transpose in one launch
                 fn.weight_transpose(self.wc[c], out=self.wct[c], copy=self.wch[c])
-            xa, wa = self._g.magnitude(self.am[c][0], t.data), self._g.magnitude(self.am[c][1], self.wc[c])
+            xa, wa = self._g.magnitude(self.am[c][0], t.data, src=t), self._g.scalar(self.am_w)
             if self.wcp[c] is not None:
                 fn.weight_planes(self.wc[c], out=self.wcp[c], math=self.math, w_absmax=wa)
             fn.conv2d_forward(t.data, self.wc[c] if self.wch[c] is None else self.wch[c], None, 1, 0, 1, out=self.zc[c],
@@ -866,12 +897,21 @@ class BilinearConcatConv(Node):
         if not self.out._gw:
             return
         fn.tap_spread(self.out.grad, self.cout, self.kh, self.kw, self.pad, out=self.z)
-        # d L / d affine_matrix needs the forward values W_c x_c: taken before zc is reused for the gradients
-        fn.affine_sampler_backward_theta(self.sources, self.theta.data, self.z, self.theta.grad)
+        # d L / d affine_matrix needs the forward values W_c x_c: every source's data-gradient pass reads them (its own
+        # pixel's, before it overwrites zc with the gradient) and leaves its share of the theta gradient as rows of tpart
+        if self.tpart is None:
+            rows = [z.shape[0] * z.shape[1] * z.shape[2] for z in self.zc]
+            self.tpart = torch.zeros(sum(rows), 6, dtype=torch.float64, device=self.z.device)
+            self.tpart_off = np.cumsum([0] + rows).tolist()
         Cin = self.offsets[-1]
         for c, t in enumerate(self.inputs):
-            dz = fn.affine_sampler_backward_data(self.z, self.theta.data, self.zc[c].shape, 0, dx=self.zc[c])
-            xa, wa = self._g.magnitude(self.am[c][0], t.data), self._g.magnitude(self.am[c][1], self.wc[c])
+            dza = self._g.scalar(self.am[c][2])
+            if dza is not None and self.zc[c].dtype == torch.float32:
+                self._g._am_done.add(self.am[c][2])
+            dz = fn.affine_sampler_backward_data_theta(self.z, self.theta.data, self.zc[c], 0,
+                                                       self.tpart[self.tpart_off[c]:self.tpart_off[c + 1]], dx=self.zc[c],
+                                                       dx_absmax=dza)
+            xa, wa = self._g.magnitude(self.am[c][0], t.data, src=t), self._g.scalar(self.am_w)
             dza = self._g.magnitude(self.am[c][2], dz)
             fn.conv2d_wgrad(t.data, dz, (self.T, 1, 1, t.shape[3]), 1, 0, 1, out=self.dwc[c], math=self.math, x_absmax=xa,
                             dy_absmax=dza)
@@ -882,6 +922,7 @@ class BilinearConcatConv(Node):
                 dx, acc = t.grad_target()
                 fn.conv2d_dgrad(dz, self.wct[c], t.shape, 1, 0, 1, out=dx, accumulate=acc, math=self.math, dy_absmax=dza,
                                 w_absmax=wa)
+        fn.affine_sampler_theta_reduce(self.tpart, self.theta.grad)
 
 
 class Deconv4x4s2(Node):
@@ -900,13 +941,14 @@ class Deconv4x4s2(Node):
         self.math = g.math
         self._g = g
         self.am = (g.new_scalar(), g.new_scalar(), g.new_scalar(backward=True)) if g.math == "f16x2" else (None, None, None)   # x, w, dy
+        self.am_w = self.am[1]      # (taken with every other weight's by the batched launch at the top of forward())
         self.flops_fwd = 2.0 * channels * channels * 16 * H * W * N
         self.flops_bwd = self.flops_fwd * (2 if x.requires_grad else 1)
 
     def forward(self):
         fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
         g = self._g
-        xa, wa = g.magnitude(self.am[0], self.x.data), g.magnitude(self.am[1], self.w.data)
+        xa, wa = g.magnitude(self.am[0], self.x.data, src=self.x), g.magnitude(self.am[1], self.w.data)
         fn.conv2d_dgrad(self.x.data, self.wt, self.out.shape, 2, 1, 1, out=self.out.data, math=self.math, dy_absmax=xa,
                         w_absmax=wa)
 
@@ -915,7 +957,7 @@ class Deconv4x4s2(Node):
             return
         dy = self.out.grad
         g = self._g
-        xa, wa, dya = g.magnitude(self.am[0], self.x.data), g.magnitude(self.am[1], self.w.data), g.magnitude(self.am[2], dy)
+        xa, wa, dya = g.magnitude(self.am[0], self.x.data, src=self.x), g.magnitude(self.am[1], self.w.data), g.magnitude(self.am[2], dy)
         fn.conv2d_wgrad(dy, self.x.data, self.w.shape, 2, 1, 1, out=self.w.grad, math=self.math, x_absmax=dya, dy_absmax=xa)
         if self.x.requires_grad:
             dx, acc = self.x.grad_target()
@@ -946,6 +988,7 @@ class BlockGrad(Node):
 
     def __init__(self, g, x, name):
         self.out = g.tensor(x.shape, name, requires_grad=False, data=x.data)
+        self.out.alias_of, self.out.am_slot, self.out.channels = x, x.am_slot, x.channels
 
     def forward(self):
         pass
@@ -964,6 +1007,7 @@ class MaxPool(Node):
                 return fn.conv_out_size(h, kernel, stride, pad)
             return -(-(h + 2 * pad - kernel) // stride) + 1
         self.out = g.tensor((N, osz(H), osz(W), C), name)
+        self.out.am_slot = x.am_slot        # |max over a window| <= the input's magnitude
         # one byte per output element: which window position held the maximum (read by backward
         # instead of x and y)
         self.argmax = (torch.zeros(self.out.shape, dtype=torch.uint8, device=g.device)
@@ -993,6 +1037,7 @@ class AvgPool(Node):
             self.out = x
         else:
             self.out = g.tensor((N, H // k, W // k, C), name)
+            self.out.am_slot = x.am_slot    # |mean over a window| <= the input's magnitude
 
     def forward(self):
         if self.k > 1:

@@ -56,7 +56,8 @@ _lib.register({
                                    _vp, _sz, _vp]),
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp]),
+    "dspn_absmax_affine_bound_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _sz,
                                   _vp]),
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
@@ -90,6 +91,10 @@ _lib.register({
     "dspn_affine_sampler_theta_workspace_bytes": (_sz, [_i, _i, _i]),
     "dspn_affine_sampler_backward_theta_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i,
                                                     _vp, _sz, _vp]),
+    "dspn_affine_sampler_backward_data_theta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp,
+                                                         _vp]),
+    "dspn_affine_sampler_theta_reduce_workspace_bytes": (_sz, [_ll]),
+    "dspn_affine_sampler_theta_reduce": (_i, [_vp, _ll, _vp, _i, _vp, _sz, _vp]),
     "dspn_softmax_output_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
     "dspn_count_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp]),
     "dspn_smooth_l1_forward_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
@@ -107,7 +112,8 @@ for _name in ("dspn_conv2d_forward_bn", "dspn_conv2d_dgrad_bn", "dspn_conv2d_wgr
               "dspn_nchw_to_nhwc", "dspn_copy_block", "dspn_tap_sum", "dspn_tap_spread", "dspn_maxpool_forward",
               "dspn_maxpool_backward_argmax", "dspn_maxpool_backward", "dspn_avgpool_forward", "dspn_avgpool_backward",
               "dspn_avgpool2d_forward", "dspn_avgpool2d_backward", "dspn_softmax_output", "dspn_affine_sampler_forward",
-              "dspn_affine_sampler_backward_data", "dspn_affine_sampler_backward_theta"):
+              "dspn_affine_sampler_backward_data", "dspn_affine_sampler_backward_theta",
+              "dspn_affine_sampler_backward_data_theta"):
     _lib.register({_name + "_bf16": _lib.SIGNATURES[_name + "_f32"]})
 _lib.register({
     "dspn_conv2d_weight_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -599,11 +605,21 @@ def bn_stats(x, eps, gamma, beta, mean=None, rstd=None, scale=None, shift=None):
     return mean, rstd, scale, shift
 
 
-def bn_apply(x, scale, shift, relu=False, out=None):
+def bn_apply(x, scale, shift, relu=False, out=None, out_absmax=None):
+    """out_absmax (float tensors): a 64-float magnitude block that receives the partial maxima of |out| (not zeroed here)"""
     out = torch.empty_like(x) if out is None else out
-    assert out.dtype == x.dtype
+    assert out.dtype == x.dtype and (out_absmax is None or out_absmax.numel() == ABSMAX_SLOTS)
     check(_f("dspn_bn_apply", x)(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
-                                stream()), "bn_apply")
+                                ptr(out_absmax if x.dtype == torch.float32 else None), stream()), "bn_apply")
+    return out
+
+
+def absmax_affine_bound(scale, shift, x_absmax, out):
+    """out (64-float magnitude block, not zeroed here) max= max_c |scale[c]| * M + |shift[c]|, M = the magnitude in x_absmax:
+    a bound of |(relu)(x * scale + shift)| without a pass over x"""
+    assert scale.numel() == shift.numel() and x_absmax.numel() == out.numel() == ABSMAX_SLOTS
+    check(L().dspn_absmax_affine_bound_f32(ptr(scale), ptr(shift), scale.numel(), ptr(x_absmax), ptr(out), stream()),
+          "absmax_affine_bound")
     return out
 
 
@@ -850,6 +866,32 @@ def affine_sampler_backward_data(dy, theta, x_shape, coff, dx=None, accumulate=F
                                                     dy.shape[3], coff, int(accumulate), stream()),
           "affine_sampler_backward_data")
     return dx
+
+
+def affine_sampler_backward_data_theta(dy, theta, x, coff, theta_partial, dx=None, accumulate=False, dx_absmax=None):
+    """affine_sampler_backward_data plus this source's rows of the theta gradient from the same pass: x = the source map
+    the forward call sampled (it may be the buffer dx when dx is overwritten), theta_partial = a float64 tensor
+    (N * Hin * Win, 6) that receives one row per source pixel (affine_sampler_theta_reduce sums the rows of all sources)"""
+    N, Hin, Win, C = x.shape
+    dx = empty(N, Hin, Win, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
+    assert dx.dtype == dy.dtype == x.dtype and theta_partial.dtype == torch.float64 and theta_partial.is_contiguous()
+    assert theta_partial.numel() >= 6 * N * Hin * Win
+    check(_f("dspn_affine_sampler_backward_data_theta", dy)(ptr(dy), ptr(theta), ptr(x), ptr(dx), N, Hin, Win, C, dy.shape[1],
+                                                          dy.shape[2], dy.shape[3], coff, int(accumulate), ptr(theta_partial),
+                                                          theta_partial.numel() * 8,
+                                                          ptr(dx_absmax if dy.dtype == torch.float32 else None), stream()),
+          "affine_sampler_backward_data_theta")
+    return dx
+
+
+def affine_sampler_theta_reduce(theta_partial, dtheta, accumulate=False):
+    """dtheta[6] (+)= fixed-order sum of the rows of theta_partial (rows, 6) float64"""
+    rows = theta_partial.numel() // 6
+    ws = workspace(L().dspn_affine_sampler_theta_reduce_workspace_bytes(rows), theta_partial.device, "theta_reduce")
+    assert theta_partial.dtype == torch.float64 and dtheta.dtype == torch.float32 and dtheta.numel() == 6
+    check(L().dspn_affine_sampler_theta_reduce(ptr(theta_partial), rows, ptr(dtheta), int(accumulate), ptr(ws), ws.numel(),
+                                               stream()), "affine_sampler_theta_reduce")
+    return dtheta
 
 
 def affine_sampler_backward_theta(sources, theta, dy, dtheta, accumulate=False):

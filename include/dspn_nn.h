@@ -213,6 +213,12 @@ int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4
 int dspn_absmax_f32(const float *x, long long rows, int C, const float *scale, const float *shift, int relu,
                     float *out_dev, void *stream);
 int dspn_absmax_batch_f32(const void *table, int n, long long total_chunks, void *stream);
+/* a BOUND instead of the magnitude (round 4): out_dev (+max)= max over c of |scale[c]| * M + |shift[c]|, M = the magnitude
+ * in x_absmax_dev -- an upper bound of |(relu)(x * scale[c] + shift[c])| for a convolution that folds a BatchNorm into its
+ * loader and whose raw input has a known magnitude but no per-channel extremes (a pooled tensor).  A magnitude that is too
+ * large by less than 2^17 costs the two-piece math nothing (see DSPN_MATH_F32_F16X2).  One tiny launch instead of a pass. */
+int dspn_absmax_affine_bound_f32(const float *scale, const float *shift, int C, const float *x_absmax_dev, float *out_dev,
+                                 void *stream);
 
 /* ---- bfloat16 TENSORS in HBM: the `*_bf16` twins (BASELINE.json configs[3] "bf16 MFMA convs" with the operands stored
  * as they are multiplied).  Same arguments and semantics as the `*_f32` entry of the same name, with every ACTIVATION
@@ -290,8 +296,11 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
 /* optional scratch for long tile tables (>= 1024 tiles are first merged in groups of 32 by many workgroups);
  * dspn_bn_backward_from_sums_f32 uses 3*C floats + this many bytes the same way */
 size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);
+/* out_absmax (optional, float tensors): DSPN_ABSMAX_SLOTS floats that receive the partial maxima of |y| as stored --
+ * dspn_absmax_f32(y) without its pass over y (round 4: the magnitude of a MATERIALISED BatchNorm output for the
+ * convolutions that multiply it in DSPN_MATH_F32_F16X2).  The caller zeroes it, as for dspn_absmax_f32. */
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
-                      int C, int relu, void *stream);
+                      int C, int relu, float *out_absmax, void *stream);
 
 /* Backward of the fused op.  If relu != 0, dy is first masked with (x*scale + shift > 0), i.e. the
  * forward output's sign recomputed from x (the forward output itself is not read).
@@ -399,6 +408,7 @@ int dspn_affine_sampler_forward_f32(const float *const *x, const int *Hin, const
  * weight * dy[..., coff:coff+C]; gather form, fixed summation order (no atomics) */
 int dspn_affine_sampler_backward_data_f32(const float *dy, const float *theta, float *dx, int N, int Hin, int Win, int C,
                                           int Ho, int Wo, int ldo, int coff, int accumulate, void *stream);
+/* (dspn_affine_sampler_backward_data_theta_f32 below also takes dx_absmax: the magnitude block of the dx it stores) */
 /* gradient with respect to theta, all sources of a forward call at once: dtheta[6] (+)= sum over batch, target
  * pixels, sources and channels (BilinearSampler's grid gradient contracted with GridGenerator's backward);
  * two-stage fixed-order reduction in double */
@@ -407,6 +417,21 @@ int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin
                                            const int *coff, int nsrc, const float *theta, const float *dy, int N, int Ho,
                                            int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
                                            size_t workspace_bytes, void *stream);
+/* the data gradient of ONE source map and that source's share of the theta gradient from the same pass (round 4): as
+ * dspn_affine_sampler_backward_data_f32, plus theta_partial[N * Hin * Win][6] (doubles, DEVICE, overwritten) -- per source
+ * pixel the sum over the target pixels that sample it of (d weight / d grid) . <dy[target], x[source pixel]> x (x_t, y_t, 1).
+ * x: the source map itself (N,Hin,Win,C), as the forward call sampled it; it MAY be the buffer dx when accumulate == 0
+ * (every workgroup reads its pixel before it writes it).  The sum over the rows of every source of one forward call is
+ * d L / d theta (GridGenerator's backward): dspn_affine_sampler_theta_reduce adds them in a fixed order, two levels, in
+ * double.  Equals dspn_affine_sampler_backward_theta_f32 up to the summation order.
+ * dx_absmax (optional, float tensors): DSPN_ABSMAX_SLOTS floats that receive the partial maxima of |dx| as stored. */
+int dspn_affine_sampler_backward_data_theta_f32(const float *dy, const float *theta, const float *x, float *dx, int N, int Hin,
+                                                int Win, int C, int Ho, int Wo, int ldo, int coff, int accumulate,
+                                                double *theta_partial, size_t theta_partial_bytes, float *dx_absmax,
+                                                void *stream);
+size_t dspn_affine_sampler_theta_reduce_workspace_bytes(long long rows);
+int dspn_affine_sampler_theta_reduce(const double *theta_partial, long long rows, float *dtheta, int accumulate, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* ---- Segmentation readouts (train/metric.py:100-133 CustomAccuracyMetric, evaluate/eval_metric.py:278-388
@@ -463,7 +488,7 @@ int dspn_bn_stats_bf16(const dspn_bf16 *x, long long rows, int C, float eps, con
                       const float *beta, float *mean, float *rstd, float *scale, float *shift,
                       void *workspace, size_t workspace_bytes, void *stream);
 int dspn_bn_apply_bf16(const dspn_bf16 *x, const float *scale, const float *shift, dspn_bf16 *y, long long rows,
-                      int C, int relu, void *stream);
+                      int C, int relu, float *out_absmax /* ignored */, void *stream);
 int dspn_bn_backward_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
                          const float *mean, const float *rstd, const float *gamma, dspn_bf16 *dx,
                          float *dgamma, float *dbeta, long long rows, int C, int relu, int accumulate,
@@ -505,6 +530,10 @@ int dspn_softmax_output_bf16(const dspn_bf16 *logits, const float *label, float 
                             const float *valid_count, void *stream);
 int dspn_affine_sampler_backward_data_bf16(const dspn_bf16 *dy, const float *theta, dspn_bf16 *dx, int N, int Hin, int Win, int C,
                                           int Ho, int Wo, int ldo, int coff, int accumulate, void *stream);
+int dspn_affine_sampler_backward_data_theta_bf16(const dspn_bf16 *dy, const float *theta, const dspn_bf16 *x, dspn_bf16 *dx, int N,
+                                                 int Hin, int Win, int C, int Ho, int Wo, int ldo, int coff, int accumulate,
+                                                 double *theta_partial, size_t theta_partial_bytes, float *dx_absmax /* ignored */,
+                                                 void *stream);
 int dspn_affine_sampler_forward_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
                                     int nsrc, const float *theta, dspn_bf16 *y, int N, int Ho, int Wo, int ldo, void *stream);
 int dspn_affine_sampler_backward_theta_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C,

@@ -351,6 +351,25 @@ def test_affine_sampler_matches_torch_grid_sample(gpu_device, theta, shapes):
         again = torch.zeros(6, device="cuda")
         fn.affine_sampler_backward_theta(src, th_dev, dyc, again)
         assert torch.equal(dth, again)                                   # fixed-order reductions
+        # round 4: the same gradient as a by-product of the data-gradient passes (one call per source, rows of float64
+        # partial sums, two-level fixed-order reduce) -- with the forward values read from the buffer dx overwrites
+        rows = [xdev.shape[0] * xdev.shape[1] * xdev.shape[2] for xdev in xd]
+        part = torch.full((sum(rows), 6), float("nan"), dtype=torch.float64, device="cuda")
+        r0 = 0
+        for x, xdev, off, r in zip(xs, xd, offs, rows):
+            buf = xdev.clone()
+            dx = fn.affine_sampler_backward_data_theta(dyc, th_dev, buf, off, part[r0:r0 + r], dx=buf)      # in place
+            assert torch.equal(dx, fn.affine_sampler_backward_data(dyc, th_dev, xdev.shape, off))
+            r0 += r
+        fused = torch.zeros(6, device="cuda")
+        fn.affine_sampler_theta_reduce(part, fused)
+        if not kink:
+            close(fused.cpu().double(), th.grad, 1e-4)
+        scale = float(dth.abs().max()) + 1e-6
+        assert float((fused - dth).abs().max()) <= 1e-4 * scale, (fused, dth)     # same sum, other order (kinks included)
+        again = torch.zeros(6, device="cuda")
+        fn.affine_sampler_theta_reduce(part, again)
+        assert torch.equal(fused, again)
 
 
 @pytest.mark.parametrize("hin,win", [(4, 4), (16, 16), (64, 64), (5, 9)])
