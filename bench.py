@@ -74,6 +74,9 @@ def parse():
                          "bfloat16 (the *_bf16 kernels: bf16 MFMA, fp32 accumulate, fp32 master weights)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: record the step into a HIP graph after the warm-up and replay it (single GPU; no roofline events)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="CUs the persistent convolution grids leave free for RCCL (dspn_conv_set_reserved_cus).  -1 (default): "
+                         "0 at N = 1; at N > 1 switched to 16 after warm-up iff the exposed all-reduce time exceeds 1 ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -463,15 +466,26 @@ def dry_run(args):
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    line = {"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
         dist.barrier()
         assert float(t.item()) == world * (world + 1) / 2
+        # the per-rank fields of the real N > 1 line, reduced the same way (rank r pretends to 10 + r ms per step and r / 10 ms
+        # of exposed all-reduce): min / max over ranks of the step time, max of the exposure, the group's own size
+        dt = torch.tensor([10.0 + rank], dtype=torch.float64)
+        tmax, tmin, texp = dt.clone(), dt.clone(), torch.tensor([rank / 10.0], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(texp, op=dist.ReduceOp.MAX)
+        line.update({"ms_per_step_min_over_ranks": float(tmin.item()), "ms_per_step_max_over_ranks": float(tmax.item()),
+                     "allreduce_exposed_ms_max_over_ranks": float(texp.item()), "dist_world_size": dist.get_world_size(),
+                     "rccl_version": "gloo (dry run)", "reserved_cus": max(args.reserve_cus, 0)})
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -550,17 +564,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = _lib.lib()
+    reserved = max(args.reserve_cus, 0)
+    lib.dspn_conv_set_reserved_cus(reserved)
+    if solver.reducer is not None:
+        solver.reducer.measure_exposed = True          # event records around the collective waits (and per bucket)
     for _ in range(args.warmup):
         solver.step()
     sync()
+    warm_exposed = solver.reducer.exposed_ms() if solver.reducer is not None else None
+    if solver.reducer is not None:
+        solver.reducer.bucket_latency_ms()             # (forget the warm-up's)
+    if args.reserve_cus < 0 and world > 1 and warm_exposed is not None:
+        # the persistent convolution kernels own every CU; if the warm-up shows the collectives are NOT hidden behind
+        # backward, give RCCL 16 CUs for the timed region.  Every rank must take the same decision: the largest exposure
+        t = torch.tensor([warm_exposed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t.item()) > 1.0:
+            reserved = 16
+            lib.dspn_conv_set_reserved_cus(reserved)
+            for _ in range(2):
+                solver.step()
+            sync()
+            solver.reducer.exposed_ms(); solver.reducer.bucket_latency_ms()
     graphed = bool(args.graph) and solver.capture(warmup=0)
-    lib = _lib.lib()
     prof = not args.no_roofline and not graphed
     # HIP events around every convolution launch cost ~2.5 ms of a 60 ms step (measured: 517 vs 539 images/s with every
     # step instrumented), so only PROF_STEPS steps of the timed region carry them; the other steps run as in production
     prof_steps = min(PROF_STEPS, args.steps) if prof else 0
-    if solver.reducer is not None:
-        solver.reducer.measure_exposed = True          # two event records per step around the collective waits
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == 0 and prof_steps:
@@ -572,11 +603,27 @@ def main():
     dt = time.perf_counter() - t0
     lib.dspn_profile_enable(0)
     exposed_ms = solver.reducer.exposed_ms() if solver.reducer is not None else None
+    bucket_ms = solver.reducer.bucket_latency_ms() if solver.reducer is not None else None
     n_buckets = len(solver.buckets)
+    range_rep = net.g.range_report()     # (one device -> host copy, after the timed region)
+    dt_rank = dt
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmin = t.clone()
+    texp = torch.tensor([exposed_ms if exposed_ms is not None else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(texp, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    dt_min = float(tmin.item())
+    world_dist = dist.get_world_size() if use_dist else 1
+    rccl_version = None
+    if use_dist:
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = "unknown"
+    exposed_max = float(texp.item()) if exposed_ms is not None else None
 
     roofline = None
     if prof:
@@ -659,6 +706,22 @@ def main():
             # the part of the bucketed collectives that backward did NOT hide
             line["allreduce_exposed_ms"] = round(exposed_ms, 4)
             line["allreduce_buckets"] = n_buckets
+            # max over ranks, and what the step saw per bucket (issue -> completion, release order, this rank)
+            line["allreduce_exposed_ms_max_over_ranks"] = round(exposed_max, 4)
+            if bucket_ms is not None:
+                line["allreduce_bucket_latency_ms"] = [round(v, 3) for v in bucket_ms]
+        if use_dist:
+            # per-rank skew of the timed region, the group as torch.distributed sees it, and the collective library
+            line["ms_per_step_min_over_ranks"] = round(dt_min / args.steps * 1e3, 3)
+            line["ms_per_step_max_over_ranks"] = round(dt / args.steps * 1e3, 3)
+            line["dist_world_size"] = world_dist
+            line["rccl_version"] = rccl_version
+        line["reserved_cus"] = reserved
+        if args.math == "f16x2" and args.store == "fp32":
+            # range monitor of the two-piece math (Graph.range_report): convolution inputs whose per-channel magnitudes were
+            # seen by a BatchNorm finalize, how many of them span more than 2^16, and the widest span in bits
+            line["config"]["f16x2_range_monitor"] = {"tensors": range_rep[0], "wider_than_2^16": range_rep[1],
+                                                     "widest_span_bits": round(range_rep[2], 1)}
         if other is not None:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

@@ -43,6 +43,11 @@ void prof_begin(int family, hipStream_t s) {
   g_prof.push_back(r);
 }
 void prof_end(hipStream_t s) { if (t_prof_end) (void)hipEventRecord(t_prof_end, s); t_prof_end = nullptr; }
+// A launch setting, not compute state (results are bit-identical under every value): how many CUs' worth of workgroup slots
+// the PERSISTENT convolution grids leave free for the kernels of other queues -- RCCL's all-reduce of the gradient buckets,
+// which otherwise only finds room between two convolution launches.
+static std::atomic<int> g_reserved_cus{0};
+int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
 extern "C" {
@@ -61,6 +66,11 @@ int dspn_profile_collect(int family, double *total_ms, long long *launches) {
   dspn::g_prof.swap(keep);
   if (total_ms) *total_ms = t;
   if (launches) *launches = n;
+  return 0;
+}
+int dspn_conv_set_reserved_cus(int cus) {
+  if (cus < 0 || cus > 128) return dspn::fail(DSPN_ERR_ARG_, "conv_set_reserved_cus: 0 .. 128 CUs, got %d", cus);
+  dspn::g_reserved_cus.store(cus);
   return 0;
 }
 const char *dspn_last_error(void) { return dspn::last_error_buf(); }

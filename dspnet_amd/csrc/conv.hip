@@ -83,20 +83,53 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, b
 // +-100, i.e. magnitudes from 2^-85 to 2^115 are scaled exactly into place (beyond that the pieces underflow / overflow);
 // the epilogues undo the two operand scales one after the other, so no product of scales is ever formed
 constexpr int kAbsmaxSlots = 64;    // a magnitude "scalar" is 64 partial maxima (see absmax_kernel): one per lane here
+// Non-finite elements (round 4): a partial maximum that is infinite only says "this tensor holds an inf" -- the scale comes
+// from the FINITE partial maxima (64 independent slots: the finite values still bound the rest of the tensor unless every
+// slot met an inf), so the finite elements keep their fp32 accuracy.  NaNs never enter a magnitude block (fmaxf skips them).
+// What an infinite ELEMENT becomes: in the weight-plane kernel and in the weight-gradient kernel its pieces are repaired
+// (repair_inf below; operand_nonfinite() says when) and every product is what fp32 gives.  In conv_nt_kernel's own loaders
+// (activations of the forward pass / output gradients of the data gradient) they are NOT: a wave-uniform branch around the
+// repair inside the k-loop cost the 128-register kernels 12 - 19 registers (scratch, -4 % on the training step), so an
+// infinite activation gives NaN (h1 = inf - inf) in every output it touches -- non-finite where fp32 is non-finite, but not
+// the signed infinity (include/dspn_nn.h; tests/test_nn_gpu.py::test_two_piece_math_propagates_non_finite_operands...).
 __device__ __forceinline__ float operand_scale(const float *absmax) {
   if (!absmax) return 1.f;
   float m = absmax[threadIdx.x & 63];
+  m = m < 3.0e38f ? m : 0.f;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+  if (!(m > 0.f)) return 1.f;
   int e;
   (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1  ->  m * 2^(15 - e) < 2^15
   e = 15 - e;
   e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return __uint_as_float((unsigned)(127 + e) << 23);
 }
+// wave-uniform: does the tensor behind this magnitude block hold an infinite element?
+__device__ __forceinline__ bool operand_nonfinite(const float *absmax) {
+  if (!absmax) return false;
+  const float m = absmax[threadIdx.x & 63];
+  return __ballot(!(m < 3.0e38f)) != 0ull;
+}
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// The two pieces of an infinite element come out of split2h as h0 = +-inf, h1 = NaN (inf - inf), and h0 g1 alone would be
+// NaN wherever the other operand's residual piece is 0.  Repaired (only in tensors whose magnitude block says so, in the
+// store path, outside the MFMA-interleaved piece arithmetic): h0 = +-65504, h1 = +-inf, so that x w = h0 g0 + h0 g1 + h1 g0
+// is +-inf with the sign of x w, or NaN where w is 0 -- what fp32 arithmetic gives.
+__device__ __forceinline__ void repair_inf(bf16x4 &p0, bf16x4 &p1) {
+  f16x4 h0 = __builtin_bit_cast(f16x4, p0), h1 = __builtin_bit_cast(f16x4, p1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float f = (float)h0[e];
+    if (f == __builtin_huge_valf() || f == -__builtin_huge_valf()) {
+      h1[e] = h0[e];
+      h0[e] = f > 0.f ? (_Float16)65504.f : (_Float16)-65504.f;
+    }
+  }
+  p0 = __builtin_bit_cast(bf16x4, h0);
+  p1 = __builtin_bit_cast(bf16x4, h1);
+}
 __device__ __forceinline__ void split2h(const float4 v, const float s, bf16x4 &p0, bf16x4 &p1) {
   const float4 u = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
   const f16x4 h0 = {(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w};
@@ -1259,6 +1292,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? NPC : 1;
   const float sc_a = MATH == 3 ? operand_scale(g.dy_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.x_absmax) : 1.f;
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
+  const bool nf_a = MATH == 3 && operand_nonfinite(g.dy_absmax), nf_b = MATH == 3 && operand_nonfinite(g.x_absmax);
   char *hA = reinterpret_cast<char *>(smem);            // [2][kPK][RAB]
   char *hB = hA + STAGES * PLANES * kPK * RAB;          // [2][kPK][RBB]
   // the input affine (+ReLU, zero outside the image) applied to the x rows in registers
@@ -1306,7 +1340,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         bf16x4 p0, p1, p2;
-        if constexpr (MATH == 3) split2h(ra[i], sc_a, p0, p1);
+        if constexpr (MATH == 3) { split2h(ra[i], sc_a, p0, p1); if (__builtin_expect(nf_a, 0)) repair_inf(p0, p1); }
         else split3(ra[i], p0, p1, p2);
         char *d = hA + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
@@ -1316,7 +1350,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         bf16x4 p0, p1, p2;
-        if constexpr (MATH == 3) split2h(rb[i], sc_b, p0, p1);
+        if constexpr (MATH == 3) { split2h(rb[i], sc_b, p0, p1); if (__builtin_expect(nf_b, 0)) repair_inf(p0, p1); }
         else split3(rb[i], p0, p1, p2);
         char *d = hB + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
@@ -1696,7 +1730,7 @@ __device__ __forceinline__ void weight_planes_tile(const WpDesc &e, long long ti
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (k < e.K && c < e.C) v = *reinterpret_cast<const float4 *>(e.w + ((long long)k * e.T + t) * e.C + c);   // C % 4 == 0
   bf16x4 p[3];
-  if (e.npc == 2) { split2h(v, scale, p[0], p[1]); p[2] = p[1]; }
+  if (e.npc == 2) { split2h(v, scale, p[0], p[1]); repair_inf(p[0], p[1]); p[2] = p[1]; }
   else split3(v, p[0], p[1], p[2]);
   if (e.planes && k < e.K && c < e.C) {      // (C % 32 == 0 whenever the forward planes exist)
     __bf16 *d = e.planes + (((long long)k * e.T + t) * (e.C >> 5) + cb) * pb + 4 * q;
@@ -1832,6 +1866,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 // caller-provided scratch for split-K partial tiles (set per call by the C entry points)
 struct SplitWs { float *ptr; size_t bytes; };
 
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
@@ -1853,7 +1888,7 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
-  static int slots = 0;
+  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
   if (!slots) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1861,13 +1896,18 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
     if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
       fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
               WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
   }
-  const int grid_x = (int)std::min<long long>((long long)mt * nt, slots);
+  // dspn_conv_set_reserved_cus(k): the persistent grid leaves k CUs' worth of workgroup slots free, so that the kernels of
+  // another queue (RCCL's all-reduce of the gradient buckets) find room beside a convolution instead of only between two
+  const int reserved = dspn::reserved_cus();
+  const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
+  const int grid_x = (int)std::min<long long>((long long)mt * nt, avail);
   {
     dspn::ProfScope prof(0, s);
     hipLaunchKernelGGL(kern, dim3(grid_x, splits), dim3(WAVES_M * WAVES_N * 64), lds, s, in, w, bias, out, g, mt, nt,
@@ -2005,8 +2045,13 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // experiment (DSPN_NT_WIDE=<min tiles>): 128 x 256 tiles on 8 waves of 64 x 64 (one workgroup per CU, 256 registers) for
   // the two-piece layers with >= 256 output columns: half the A-side loads / piece arithmetic / LDS stores per multiply-add
   static const int wide_min = [] { const char *e = getenv("DSPN_NT_WIDE"); return e ? atoi(e) : 0; }();
+#ifndef DSPN_DEV_FAST
   if (wide_min > 0 && pre && g.bf16 == 3 && splits == 1 && cfg == 0 && g.Cout % 256 == 0 && tiles(128, 256) >= wide_min)
     return launch_nt_f16x2<2, 4, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+#endif
+#ifdef DSPN_DEV_FAST   /* development: compile ONLY the 8-wave two-piece kernels (register / ISA inspection in under a minute) */
+  return launch_nt_f16x2<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+#else
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
@@ -2014,6 +2059,7 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
     case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
     default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   }
+#endif
 }
 
 struct WgradPlan { int bm; int bn; int splits; int pps; };
@@ -2157,7 +2203,11 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
                                int math, const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  math &= ~DSPN_MATH_UNSCALED_OK;
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_forward: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && w_absmax),
+               "conv2d_forward: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
   if (out_stats) {
     int tile_rows = 0;
@@ -2372,7 +2422,11 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt
                              const float *dy_absmax, const float *w_absmax, void *workspace, size_t workspace_bytes,
                              void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  math &= ~DSPN_MATH_UNSCALED_OK;
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_dgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (dy_absmax && w_absmax),
+               "conv2d_dgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   const int ldc = dx_ldc > 0 ? dx_ldc : Cin;
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy);
   if (bn_sums) {
@@ -2513,6 +2567,10 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     }                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
+#ifdef DSPN_DEV_FAST
+  if (g.bf16 == 3) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, false) }
+  else
+#endif
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64
@@ -2536,7 +2594,11 @@ int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const fl
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  math &= ~DSPN_MATH_UNSCALED_OK;
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
+               "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   const int nb = std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                           batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
@@ -2568,7 +2630,11 @@ int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const
                                 int Wo, int math, const float *x_absmax, const float *dy_absmax, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  math &= ~DSPN_MATH_UNSCALED_OK;
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
+               "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   DSPN_REQUIRE(std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                         batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");

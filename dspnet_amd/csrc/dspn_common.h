@@ -37,6 +37,9 @@ struct ProfScope {
   ~ProfScope() { if (on) prof_end(s); }
 };
 
+// CUs the persistent convolution grids leave free (dspn_conv_set_reserved_cus; a launch setting, results do not depend on it)
+int reserved_cus();
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

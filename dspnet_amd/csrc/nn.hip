@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     const float *__restrict__ ts, int tiles, int tile_rows, long long rows, int C, float eps,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ mean,
     float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift,
-    const float *__restrict__ mm, int mm_tiles, int relu, unsigned *__restrict__ absmax) {
+    const float *__restrict__ mm, int mm_tiles, int relu, unsigned *__restrict__ absmax, unsigned *__restrict__ absmin) {
   __shared__ double sA[64][17], sB[64][17];
   __shared__ float sLo[64][17], sHi[64][17];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -179,6 +179,10 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
       if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
       const float v = fmaxf(fabsf(a), fabsf(b));
       if (v == v) atomicMax(absmax + (c & 63), __float_as_uint(v));    // non-negative floats order as their bit patterns
+      // range monitor (optional): the SMALLEST non-zero per-channel magnitude of the same tensor.  A tensor whose channels
+      // span more than 2^17 leaves the two-piece math's relative-accuracy window for its small channels (include/dspn_nn.h);
+      // the caller compares the two blocks after the step (Graph.range_report)
+      if (absmin && v > 0.f && v < INFINITY) atomicMin(absmin, __float_as_uint(v));
     }
   }
 }
@@ -1398,7 +1402,7 @@ size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) { return bn_tiles_workspa
 #ifndef DSPN_HALF
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, const float *tile_minmax, int relu, float *out_absmax,
+                                 float *shift, const float *tile_minmax, int relu, float *out_absmax, float *out_absmin,
                                  void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
@@ -1416,7 +1420,7 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
   }
   hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
                      tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift, tile_minmax, mm_tiles, relu,
-                     reinterpret_cast<unsigned *>(out_absmax));
+                     reinterpret_cast<unsigned *>(out_absmax), reinterpret_cast<unsigned *>(tile_minmax ? out_absmin : nullptr));
   return dspn::check_launch("bn_stats_from_tiles");
 }
 #endif

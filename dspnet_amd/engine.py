@@ -137,6 +137,9 @@ class Graph:
         self._am_done = set()      # slots already computed in the current step
         self._am_bwd_slots, self._am_bwd_ran = set(), False
         self._am_table_slots = set()   # weight magnitudes taken by the one batched launch at the top of forward()
+        # range monitor of the "f16x2" math: per convolution-input slot the smallest non-zero per-channel magnitude, where a
+        # BatchNorm finalize sees the channels (range_report)
+        self.scalars_min = None
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -181,6 +184,21 @@ class Graph:
             fn.absmax(tensor, out=out)
             self._am_done.add(slot)
         return out
+
+    def range_report(self):
+        """"f16x2" math, after a step (one device -> host copy): (tensors seen, tensors whose channel magnitudes span more than
+        2^16, largest span in bits) over the convolution inputs whose BatchNorm finalize saw per-channel extremes.  The
+        two-piece math keeps fp32 relative accuracy for elements within 2^17 of their tensor's largest magnitude; channels
+        further below keep an absolute error of 2^-39 of that magnitude (include/dspn_nn.h)."""
+        if self.scalars is None:
+            return (0, 0, 0.0)
+        mx = self.scalars.view(-1, fn.ABSMAX_SLOTS).max(dim=1).values.cpu().numpy()
+        mn = self.scalars_min.cpu().numpy()
+        ok = np.isfinite(mn) & (mn > 0) & np.isfinite(mx) & (mx > 0)
+        if not ok.any():
+            return (0, 0, 0.0)
+        span = np.log2(mx[ok] / mn[ok])
+        return (int(ok.sum()), int((span > 16).sum()), float(span.max()))
 
     def _resolve_auto_deferred(self):
         """BatchNorm(defer_apply="auto"): keep the output virtual only if every reader is a plain convolution input;
@@ -303,6 +321,7 @@ class Graph:
         if self.device.type == "cuda":
             if self.math == "f16x2" and self._nscal:
                 self.scalars = torch.zeros(self._nscal * fn.ABSMAX_SLOTS, dtype=torch.float32, device=self.device)
+                self.scalars_min = torch.full((self._nscal,), float("inf"), dtype=torch.float32, device=self.device)
                 wnodes = [n for n in self.nodes if getattr(n, "am_w", None) is not None and getattr(n, "w", None) is not None]
                 pairs = [(n.w.data, self.scalar(n.am_w)) for n in wnodes]
                 self._am_table_slots = {n.am_w for n in wnodes}
@@ -351,6 +370,7 @@ class Graph:
             self.wt_batched = True
         if self.scalars is not None:   # "f16x2" math: every operand magnitude of the step starts from zero; the weights' now
             self.scalars.zero_()
+            self.scalars_min.fill_(float("inf"))
             self._am_done = set()
             self._am_bwd_ran = False
             if self.am_table is not None:
@@ -568,7 +588,8 @@ class BatchNorm(Node):
             fn.bn_stats_from_tiles(buf, tiles, tile_rows, rows, self.x.shape[-1], self.eps,
                                    None if self.gamma is None else self.gamma.data, self.beta.data,
                                    self.mean, self.rstd, self.scale, self.shift,
-                                   tile_minmax=mm if am is not None else None, relu=self.relu, out_absmax=am)
+                                   tile_minmax=mm if am is not None else None, relu=self.relu, out_absmax=am,
+                                   out_absmin=None if am is None else g.scalars_min[slot:slot + 1])
         else:
             fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                         self.mean, self.rstd, self.scale, self.shift)

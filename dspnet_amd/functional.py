@@ -30,7 +30,7 @@ _lib.register({
     "dspn_conv2d_weight_planes_tiles": (_ll, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
-    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -240,7 +240,7 @@ def conv_stats_layout(out_pixels, cout):
 
 
 def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift,
-                        tile_minmax=None, relu=False, out_absmax=None):
+                        tile_minmax=None, relu=False, out_absmax=None, out_absmin=None):
     """tile_minmax + out_absmax ("f16x2" math): also max the magnitude of (relu)(x * scale + shift) into the 64-slot block
     out_absmax, from the per-tile extremes the producing convolution wrote (conv2d_forward's out_minmax)"""
     ws = workspace(L().dspn_bn_tiles_workspace_bytes(tiles, C), tile_stats.device, "bn")
@@ -248,7 +248,7 @@ def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta,
     assert tile_minmax is None or (tile_minmax.numel() == tile_stats.numel() and out_absmax.numel() == ABSMAX_SLOTS)
     check(L().dspn_bn_stats_from_tiles_f32(ptr(tile_stats), tiles, tile_rows, rows, C, eps, ptr(gamma), ptr(beta), ptr(mean),
                                            ptr(rstd), ptr(scale), ptr(shift), ptr(tile_minmax), int(bool(relu)),
-                                           ptr(out_absmax), ptr(ws), ws.numel(), stream()),
+                                           ptr(out_absmax), ptr(out_absmin), ptr(ws), ws.numel(), stream()),
           "bn_stats_from_tiles")
 
 

@@ -48,16 +48,26 @@ class GradBucketReducer:
         # is what the step waits for the collectives AFTER backward has run out of kernels to overlap them with
         # (bench.py reports the mean as allreduce_exposed_ms)
         self.measure_exposed, self.exposed_events = False, []
+        # ... and per bucket, an event when it is handed to the collective and one when the compute stream has seen it
+        # complete: bucket_latency_ms() = issue -> completion as the step sees it (at world 1 that is the rest of backward;
+        # on a real node the first SCALE run can be read bucket by bucket)
+        self.bucket_events = []
 
     def begin(self):
         self.pending = list(self.buckets)
         self.works, self.launched = [], []
+        self._issue_ev = []
 
     def node_done(self, idx):
         import torch.distributed as dist
         while self.pending and self.pending[0][2] >= idx:
             lo, hi, _ = self.pending.pop(0)
             self.launched.append((lo, hi))
+            if self.measure_exposed and self.arena.is_cuda:
+                import torch
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self._issue_ev.append(ev)
             self.works.append(dist.all_reduce(self.arena[lo:hi], group=self.pg, async_op=True))
 
     def finish(self):
@@ -67,11 +77,18 @@ class GradBucketReducer:
             import torch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        done_ev = []
         for w in self.works:
             w.wait()
+            if timed and len(done_ev) < len(self._issue_ev):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                done_ev.append(ev)
         if timed:
             e1.record()
             self.exposed_events.append((e0, e1))
+            if len(done_ev) == len(self._issue_ev):
+                self.bucket_events.append(list(zip(self._issue_ev, done_ev)))
 
     def exposed_ms(self):
         """mean time per step the compute stream spent blocked in finish() (call after a device synchronize)"""
@@ -80,6 +97,16 @@ class GradBucketReducer:
         t = sum(a.elapsed_time(b) for a, b in self.exposed_events) / len(self.exposed_events)
         self.exposed_events = []
         return t
+
+    def bucket_latency_ms(self):
+        """per bucket (release order), mean over the measured steps: milliseconds from the all-reduce's issue to the point
+        where the compute stream has waited for it (call after a device synchronize)"""
+        if not self.bucket_events:
+            return None
+        n = len(self.bucket_events[0])
+        out = [sum(step[b][0].elapsed_time(step[b][1]) for step in self.bucket_events) / len(self.bucket_events) for b in range(n)]
+        self.bucket_events = []
+        return out
 
 
 class MultiTaskSolver:

@@ -47,6 +47,12 @@ int dspn_abi_version(void);
  * for one family and forgets them. */
 int dspn_profile_enable(int on);
 int dspn_profile_collect(int family, double *total_ms, long long *launches);
+/* Launch setting for data-parallel runs (round 4; not compute state -- every result is bit-identical under every value):
+ * the persistent convolution kernels size their grid to fill the chip, so the kernels of another queue (RCCL's all-reduce
+ * of a gradient bucket) only start between two convolution launches.  With cus > 0 those grids leave `cus` CUs' worth of
+ * workgroup slots free (0 .. 128; 0 = default).  bench.py --gpus N switches it on after warm-up only if the measured
+ * exposed all-reduce time says the collectives are not being hidden. */
+int dspn_conv_set_reserved_cus(int cus);
 
 /* Replaces MultiBoxPriorOp::Forward (operator/multibox_prior-inl.h:97-129) +
  * MultiBoxPriorForward (operator/multibox_prior.cc:30-71; GPU twin

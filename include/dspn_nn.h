@@ -71,15 +71,27 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  *                         compute them, for a folded input affine of the tensor AFTER the affine); the kernel scales that
  *                         maximum into [2^14, 2^15).
  *                         Elements more than 2^17 below the tensor's maximum keep an absolute error of 2^-39 of that
- *                         maximum instead of a relative one.  A NULL magnitude means scale 1 (caller vouches for
- *                         |operand| < 65504); one that UNDERSTATES the maximum by more than 2x overflows to inf.
- *                         Non-finite operands: an infinite magnitude selects scale 1; +-inf elements then give NaN
- *                         (h1 = inf - inf), NaN stays NaN.
+ *                         maximum instead of a relative one.  A NULL magnitude means scale 1 and needs DSPN_MATH_UNSCALED_OK
+ *                         (below); one that UNDERSTATES the maximum by more than 2x overflows to inf.
+ *                         Non-finite operands (round 4): NaN elements stay NaN and never enter a magnitude block; a
+ *                         block with an infinite partial maximum marks a tensor that holds +-inf: the scale then comes from
+ *                         the finite partial maxima, so every output no non-finite element touches keeps its accuracy.
+ *                         An infinite WEIGHT (piece planes) and infinite operands of the WEIGHT GRADIENT get the pieces
+ *                         (+-65504, +-inf): every output they touch is +-inf with the sign of x w, or NaN where the other
+ *                         factor is 0 or two infinite terms differ in sign -- the fp32 results.  An infinite ACTIVATION of
+ *                         the forward pass / infinite output gradient of the data gradient gives NaN in every output it
+ *                         touches (h1 = inf - inf): non-finite exactly where fp32 is non-finite, but NaN instead of the
+ *                         signed infinity (repairing it inside those kernels' k-loop cost 4 % of the training step).
  * The *_bf16 entry points (bf16 tensors in HBM) ignore the argument: their operands are bf16 already. */
 #define DSPN_MATH_FP32 0
 #define DSPN_MATH_BF16 1
 #define DSPN_MATH_F32_BF16X3 2
 #define DSPN_MATH_F32_F16X2 3
+/* OR-ed into `math`: with DSPN_MATH_F32_F16X2, a NULL magnitude block means "scale 1" and is only accepted with this flag --
+ * the caller vouches that every |operand| is below 65504 (round 4; without the flag a NULL block is DSPN_ERR_ARG: a silent
+ * fp16 overflow otherwise).  The C default for code that keeps no magnitudes is DSPN_MATH_FP32; dspnet_amd (Python) passes
+ * DSPN_MATH_F32_F16X2 with both blocks on every float-tensor call. */
+#define DSPN_MATH_UNSCALED_OK 0x100
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
@@ -287,12 +299,16 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
  * double (Chan et al.), fixed order */
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
-                                 float *shift, const float *tile_minmax, int relu, float *out_absmax,
+                                 float *shift, const float *tile_minmax, int relu, float *out_absmax, float *out_absmin,
                                  void *workspace, size_t workspace_bytes, void *stream);
 /* tile_minmax + out_absmax (both or neither; DSPN_MATH_F32_F16X2): the (min, max) pairs the same convolution wrote beside
  * its statistics (out_minmax).  The largest |(relu)(x * scale + shift)| over the tensor -- the magnitude of what the next
  * convolution multiplies when it folds this BatchNorm into its loader -- is then max-ed INTO the magnitude block
- * out_absmax (DSPN_ABSMAX_SLOTS floats, zeroed by the caller at the start of the step), with no pass over the tensor. */
+ * out_absmax (DSPN_ABSMAX_SLOTS floats, zeroed by the caller at the start of the step), with no pass over the tensor.
+ * out_absmin (optional, with tile_minmax; round 4): ONE float that receives, by atomic minimum on its bit pattern (the caller
+ * sets it to +inf first), the smallest non-zero PER-CHANNEL magnitude of the same tensor -- a range monitor: a tensor whose
+ * channel magnitudes span more than 2^17 leaves the two-piece math's window of relative accuracy for its small channels
+ * (DSPN_MATH_F32_F16X2 above), and the ratio of the two blocks says so without a pass over the tensor. */
 /* optional scratch for long tile tables (>= 1024 tiles are first merged in groups of 32 by many workgroups);
  * dspn_bn_backward_from_sums_f32 uses 3*C floats + this many bytes the same way */
 size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);

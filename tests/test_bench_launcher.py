@@ -35,7 +35,14 @@ def test_gpus_8_spawns_eight_ranks_and_prints_one_line():
     r = _run("--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "0")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
-    assert len(lines) == 1 and lines[0] == {"dry_run": True, "n_gpus": 8, "steps": 2, "warmup": 0}
+    assert len(lines) == 1
+    line = lines[0]
+    assert {k: line[k] for k in ("dry_run", "n_gpus", "steps", "warmup")} == {"dry_run": True, "n_gpus": 8, "steps": 2, "warmup": 0}
+    # round 4: the per-rank fields of the N > 1 line, reduced over the ranks the way the real run reduces them (rank r
+    # pretends to 10 + r ms per step and r / 10 ms of exposed all-reduce)
+    assert line["ms_per_step_min_over_ranks"] == 10.0 and line["ms_per_step_max_over_ranks"] == 17.0
+    assert abs(line["allreduce_exposed_ms_max_over_ranks"] - 0.7) < 1e-12
+    assert line["dist_world_size"] == 8 and line["rccl_version"] and line["reserved_cus"] == 0
 
 
 def test_gpus_1_runs_in_process():

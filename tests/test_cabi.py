@@ -89,6 +89,11 @@ def test_convolution_argument_validation_without_gpu():
     # the split math reads whole 32-channel blocks from piece planes: without them the call is rejected (before any launch)
     assert fwd(Cin=64, math=2) == -1 and b"piece planes" in lib.dspn_last_error()
     assert fwd(Cin=64, math=3) == -1
+    # round 4: the two-piece math without the operands' magnitude blocks is an error, not a silent scale of 1 ...
+    assert fwd(math=3) == -1 and b"DSPN_MATH_UNSCALED_OK" in lib.dspn_last_error()
+    # ... unless the caller vouches for |operand| < 65504 (the call then gets as far as the next check)
+    assert fwd(Cin=64, math=3 | 0x100) == -1 and b"piece planes" in lib.dspn_last_error()
+    assert fwd(math=4 | 0x100) == -1 and b"DSPN_MATH" in lib.dspn_last_error()
     assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 64, 0, 2, None, None) == -1 and b"magnitude" in lib.dspn_last_error()
     assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 64, 0, 4, None, None) == -1     # pieces: 2 or 3
     assert lib.dspn_conv2d_weight_planes_f32(p, p, None, 8, 9, 48, 0, 3, None, None) == -1     # forward planes: Cin % 32
@@ -100,9 +105,9 @@ def test_convolution_argument_validation_without_gpu():
     # BatchNorm finalize from tile statistics: the per-tile extremes and the magnitude block they feed go together
     import ctypes
     f = ctypes.c_float(1e-5)
-    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 512, 8, f, None, p, p, p, p, p, p, 0, None, None, 0, None) == -1
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 512, 8, f, None, p, p, p, p, p, p, 0, None, None, None, 0, None) == -1
     assert b"go together" in lib.dspn_last_error()
-    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 9999, 8, f, None, p, p, p, p, p, None, 0, None, None, 0, None) == -1   # rows vs tiles
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 9999, 8, f, None, p, p, p, p, p, None, 0, None, None, None, 0, None) == -1   # rows vs tiles
     # batched weight transposes count 32 x 32 tiles of a tap
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout

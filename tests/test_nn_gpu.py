@@ -868,6 +868,50 @@ def test_two_piece_math_scales_any_float_magnitude_into_fp16_range(gpu_device, x
         fn.set_conv_math(fn.DEFAULT_CONV_MATH)
 
 
+@pytest.mark.parametrize("cin", [64, 20])
+def test_two_piece_math_propagates_non_finite_operands_like_fp32(gpu_device, cin):
+    """Round 4: +-inf and NaN elements of either operand in DSPN_MATH_F32_F16X2 against the fp32 MFMA.
+    Everywhere: an output is non-finite exactly where fp32's is, NaN where fp32 has NaN, and the outputs no non-finite
+    element touches stay as accurate as before (the scale comes from the FINITE partial maxima of the magnitude block).
+    Signed infinities are reproduced where the pieces of an infinite element are repaired to (+-65504, +-inf): weights cut
+    by the piece-plane kernel (cin = 64) and both operands of the weight gradient.  conv_nt_kernel's own loaders do not
+    repair (include/dspn_nn.h says why): an infinite activation / output gradient -- and, with cin = 20, an infinite weight
+    cut inside the kernel -- gives NaN where fp32 gives +-inf."""
+    g = torch.Generator().manual_seed(17)
+    N, H, W, Cout = 2, 12, 12, 48
+    x = torch.randn(N, H, W, cin, generator=g); w = torch.randn(Cout, 3, 3, cin, generator=g) / 12
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    inf = float("inf")
+    x[0, 3, 3, 1] = inf; x[0, 8, 2, 5] = -inf; x[1, 5, 5, 2] = float("nan"); x[1, 9, 9, 7] = inf; x[1, 9, 10, 7] = -inf
+    w[5, 1, 1, 1] = 0.0                      # inf * 0 -> NaN at (0, 3, 3) of output channel 5
+    dy[0, 6, 6, 3] = inf; dy[1, 2, 9, 11] = float("nan")
+    w2 = w.clone(); w2[7, 0, 2, 3] = -inf    # an infinite WEIGHT (forward and data gradient)
+    x, w, w2, dy = x.cuda(), w.cuda(), w2.cuda(), dy.cuda()
+    res = {}
+    for mode in ("fp32", "f16x2"):
+        fn.set_conv_math(mode)
+        try:
+            res[mode] = dict(fwd=fn.conv2d_forward(x, w, None, 1, 1, 1), fwd_w=fn.conv2d_forward(x.nan_to_num(0, 0, 0), w2, None, 1, 1, 1),
+                             dgrad=fn.conv2d_dgrad(dy, fn.weight_transpose(w), tuple(x.shape), 1, 1, 1),
+                             dgrad_w=fn.conv2d_dgrad(dy.nan_to_num(0, 0, 0), fn.weight_transpose(w2), tuple(x.shape), 1, 1, 1),
+                             wgrad=fn.conv2d_wgrad(x, dy, tuple(w.shape), 1, 1, 1))
+        finally:
+            fn.set_conv_math(fn.DEFAULT_CONV_MATH)
+    # dgrad_w reads the TRANSPOSED weight: its contraction runs over Cout = 48 channels -- not a multiple of 32, cut in the kernel
+    exact_inf = {"wgrad"} | ({"fwd_w"} if cin % 32 == 0 else set())
+    for key, ref in res["fp32"].items():
+        got = res["f16x2"][key]
+        fin = torch.isfinite(ref)
+        assert 0 < int((~fin).sum()) < ref.numel() // 2, key            # the case does exercise both kinds of output
+        assert torch.equal(torch.isfinite(got), fin), (key, int((torch.isfinite(got) != fin).sum()))
+        assert bool(torch.isnan(got)[torch.isnan(ref)].all()), key        # NaN wherever fp32 has NaN
+        if key in exact_inf:
+            assert torch.equal(torch.isnan(got), torch.isnan(ref)), key
+            assert torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)]), key      # the same signed infinities
+        scale = float(ref[fin].abs().max())
+        assert float((got[fin] - ref[fin]).abs().max()) <= 1e-5 * scale, key
+
+
 def test_two_piece_math_with_a_wide_dynamic_range_inside_one_tensor(gpu_device):
     """DSPN_MATH_F32_F16X2's documented limit: elements more than 2^17 below their tensor's largest magnitude keep an ABSOLUTE
     error (2^-39 of that maximum) instead of a relative one.  One outlier of 2^20 in an otherwise unit-scale input: the
