@@ -25,6 +25,7 @@
 // fp32 MFMA is an exact fmaf chain (no reduced precision); peak 157 TFLOP/s.
 #include "dspn_common.h"
 #include "dspn_store.h"
+#include "dspn_pieces.h"
 #include <cstdlib>
 #include "../../include/dspn_nn.h"
 
@@ -42,7 +43,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using dspn::pieces::bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // bf16-MFMA math mode (per call: the `math` argument of the *_bn_f32 entry points): tensors stay fp32 in HBM, the loaders round to bf16 (RNE,
@@ -82,62 +83,9 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4 &p0, bf16x4 &p1, b
 // the power of two that maps a largest magnitude m into [2^14, 2^15) (1 for m = 0 / non-finite m).  Exponent kept within
 // +-100, i.e. magnitudes from 2^-85 to 2^115 are scaled exactly into place (beyond that the pieces underflow / overflow);
 // the epilogues undo the two operand scales one after the other, so no product of scales is ever formed
-constexpr int kAbsmaxSlots = 64;    // a magnitude "scalar" is 64 partial maxima (see absmax_kernel): one per lane here
-// Non-finite elements (round 4): a partial maximum that is infinite only says "this tensor holds an inf" -- the scale comes
-// from the FINITE partial maxima (64 independent slots: the finite values still bound the rest of the tensor unless every
-// slot met an inf), so the finite elements keep their fp32 accuracy.  NaNs never enter a magnitude block (fmaxf skips them).
-// What an infinite ELEMENT becomes: in the weight-plane kernel and in the weight-gradient kernel its pieces are repaired
-// (repair_inf below; operand_nonfinite() says when) and every product is what fp32 gives.  In conv_nt_kernel's own loaders
-// (activations of the forward pass / output gradients of the data gradient) they are NOT: a wave-uniform branch around the
-// repair inside the k-loop cost the 128-register kernels 12 - 19 registers (scratch, -4 % on the training step), so an
-// infinite activation gives NaN (h1 = inf - inf) in every output it touches -- non-finite where fp32 is non-finite, but not
-// the signed infinity (include/dspn_nn.h; tests/test_nn_gpu.py::test_two_piece_math_propagates_non_finite_operands...).
-__device__ __forceinline__ float operand_scale(const float *absmax) {
-  if (!absmax) return 1.f;
-  float m = absmax[threadIdx.x & 63];
-  m = m < 3.0e38f ? m : 0.f;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (!(m > 0.f)) return 1.f;
-  int e;
-  (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1  ->  m * 2^(15 - e) < 2^15
-  e = 15 - e;
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
-  return __uint_as_float((unsigned)(127 + e) << 23);
-}
-// wave-uniform: does the tensor behind this magnitude block hold an infinite element?
-__device__ __forceinline__ bool operand_nonfinite(const float *absmax) {
-  if (!absmax) return false;
-  const float m = absmax[threadIdx.x & 63];
-  return __ballot(!(m < 3.0e38f)) != 0ull;
-}
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// The two pieces of an infinite element come out of split2h as h0 = +-inf, h1 = NaN (inf - inf), and h0 g1 alone would be
-// NaN wherever the other operand's residual piece is 0.  Repaired (only in tensors whose magnitude block says so, in the
-// store path, outside the MFMA-interleaved piece arithmetic): h0 = +-65504, h1 = +-inf, so that x w = h0 g0 + h0 g1 + h1 g0
-// is +-inf with the sign of x w, or NaN where w is 0 -- what fp32 arithmetic gives.
-__device__ __forceinline__ void repair_inf(bf16x4 &p0, bf16x4 &p1) {
-  f16x4 h0 = __builtin_bit_cast(f16x4, p0), h1 = __builtin_bit_cast(f16x4, p1);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float f = (float)h0[e];
-    if (f == __builtin_huge_valf() || f == -__builtin_huge_valf()) {
-      h1[e] = h0[e];
-      h0[e] = f > 0.f ? (_Float16)65504.f : (_Float16)-65504.f;
-    }
-  }
-  p0 = __builtin_bit_cast(bf16x4, h0);
-  p1 = __builtin_bit_cast(bf16x4, h1);
-}
-__device__ __forceinline__ void split2h(const float4 v, const float s, bf16x4 &p0, bf16x4 &p1) {
-  const float4 u = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
-  const f16x4 h0 = {(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w};
-  const f16x4 h1 = {(_Float16)(u.x - (float)h0[0]), (_Float16)(u.y - (float)h0[1]), (_Float16)(u.z - (float)h0[2]),
-                    (_Float16)(u.w - (float)h0[3])};
-  p0 = __builtin_bit_cast(bf16x4, h0);     // (the piece registers / LDS images are typed bf16x4: 4 x 16 bits either way)
-  p1 = __builtin_bit_cast(bf16x4, h1);
-}
+// (operand_scale, operand_nonfinite, split2h, repair_inf: csrc/dspn_pieces.h, shared with the BatchNorm backward that writes
+// gradients as piece planes)
+using namespace dspn::pieces;
 
 constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
 constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
@@ -193,10 +141,14 @@ struct ConvGeom {
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   float *bn_sums;
   int bn_relu, bn_tile_base;
+  // optional, with bn_sums (round 4): 64 partial maxima of |dx| as stored -- the largest output gradient the following
+  // BatchNorm backward meets, from which it bounds the dx IT stores before it writes it as fp16 piece planes (dspn_nn.h)
+  unsigned *bn_dy_absmax;
   // DSPN_MATH_F32_F16X2: device scalars holding the largest magnitude of the A operand (the gathered tensor AFTER its input
   // affine) and of the B operand (the weights); the kernel derives the power-of-two scales that put them just below 2^15
   // (operand_scale) and undoes both in the epilogue.  NULL = scale 1 (the caller vouches for |operand| < 65504).
   const float *a_absmax, *b_absmax;
+  int a_planes;                    // host side only: the gathered tensor is fp16 piece planes (conv_nt_kernel, EPIX & 4)
   // host side only: the weight operand as three bf16 piece planes [Cout][WTAPS][Cin / 32][3][32] (split mode, Cin % 32 == 0:
   // dspn_conv2d_weight_planes_f32); the kernel then receives this pointer in place of the float weights
   const void *w_planes;
@@ -225,11 +177,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 __device__ unsigned g_phase_stamps[8192 * 8];     // dspn_debug_set bit 16384: 8 words per wave (conv_nt_kernel), read by dspn_debug_read_stamps
 #endif
 // EPI: 0 plain epilogue, 1 + BatchNorm statistics of the output (g.stats), 2 + BatchNorm-backward sums (g.bn_sums)
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
+// EPIX = EPI + 4: the A operand arrives as fp16 PIECE PLANES (two-piece math, round 4): [pixel][channels / 32][piece][32],
+// the same 4 bytes per element and the same byte address for chunk c of a (pixel, 32-channel block) as the float tensor has
+// -- only that the 128-byte record now IS the LDS row image (piece 0: 64 bytes, piece 1: 64 bytes), cut with the power of
+// two that operand_scale(g.a_absmax) gives: the loader copies 16-byte chunks, no arithmetic, one ds_write_b128 per chunk
+// instead of two ds_write_b64.  Written by dspn_bn_backward_from_sums_f32 (dx_planes): the output gradient a BatchNorm
+// backward hands to the convolution in front of it.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPIX>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && TM * TN <= 2) ? 4 : 2) void conv_nt_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
     const int ksteps_per_split, float *__restrict__ slab, const st_t *__restrict__ residual) {
+  constexpr int EPI = EPIX & 3;
+  constexpr bool A_PL = (EPIX & 4) != 0;
+  static_assert(!A_PL || (MATH == 3 && UNIFORM_TAP && !INTF && !kHalf), "piece-plane A operands: two-piece math, whole 32-channel blocks, no input affine");
   constexpr bool BF16 = MATH != 0;      // the bf16 matrix instruction
   constexpr bool SPLIT = MATH >= 2;     // ... fed with the pieces of every float operand: 2 = three bf16, 3 = two fp16 pieces
   constexpr int NPC = MATH == 3 ? 2 : 3;   // pieces per operand
@@ -513,7 +474,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   bf16x4 pa[SPLIT ? A_LD : 1][3], pb[(SPLIT && !PRE) ? B_LD : 1][3];
   auto split_tiles = [&]() __attribute__((always_inline)) {
     if constexpr (SPLIT) {
-      if (abl_a_on) {
+      if (abl_a_on && !A_PL) {
       affine_tiles();
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
@@ -569,7 +530,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
     if constexpr (SPLIT) {
       // x = p0 + p1 + p2 (split_tiles): piece p of channel k of a row lies at row * ROWH + p * 32 + k
       __bf16 *a = hA + buf * BM * ROWH, *b = hB + buf * BN * ROWH;
-      if (abl_a_on) {
+      if constexpr (A_PL) {       // chunk c of the 128-byte record = bytes 16 c .. 16 c + 15 of the row image
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+          *reinterpret_cast<float4 *>(a + (arow0 + RSTEP * i) * ROWH + chunk * 8) = ra[i];
+      } else if (abl_a_on) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         __bf16 *d = a + (arow0 + RSTEP * i) * ROWH + chunk * 4;
@@ -658,6 +623,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
     }
   };
   f32x16 acc[TM][TN];
+  float gmx_all = 0.f;       // EPI == 2, two-piece math: largest |dx| stored by this thread over all its tiles (g.bn_dy_absmax)
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -732,7 +698,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) asm volatile("" : "+v"(pa[i][pc]));
+        for (int pc = 0; pc < NPC; ++pc) { if constexpr (!A_PL) asm volatile("" : "+v"(pa[i][pc])); }
       if constexpr (!PRE) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i)
@@ -948,6 +914,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         __syncthreads();
         float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
         float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
+        float gmx = 0.f;         // largest |dx| this thread stores (EPI == 2, two-piece math: g.bn_dy_absmax)
         if (EPI == 2 && vec) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -998,6 +965,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
                   gs[e] += gd;
                   gss[e] += gd * ((xv[e] - bmu[e]) * brs[e]);
                 }
+                if constexpr (MATH == 3) gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
               }
               if constexpr (EPI == 1) {
                 if (scnt == 0) { sK[0] = v[0]; sK[1] = v[1]; sK[2] = v[2]; sK[3] = v[3]; }
@@ -1100,9 +1068,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
             g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + tid] = a;
             g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + tid] = b;
           }
+          if constexpr (MATH == 3) gmx_all = fmaxf(gmx_all, gmx);     // (published once, when the workgroup has run out of tiles)
         }
       }
       if (!has_next) {
+        if constexpr (EPI == 2 && MATH == 3) {
+          // g.bn_dy_absmax: the largest |dx| this workgroup stored, over ALL its tiles -- one atomic per workgroup and launch
+          // (per tile and wave, the dependent look at the end of every epilogue cost the short-K data gradients 30 - 50 us each)
+          if (g.bn_dy_absmax) {       // (kernel-uniform)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) gmx_all = fmaxf(gmx_all, __shfl_xor(gmx_all, o, 64));
+            __syncthreads();            // the epilogue's last LDS reads are done
+            if (lane == 0) smem[wave] = gmx_all;
+            __syncthreads();
+            if (tid == 0) {             // ONE atomic per workgroup: the waves of a launch all end together, every one of
+              float m = smem[0];        // them would find the slot still empty (4096 same-address atomics: +27 us per launch)
+              for (int q = 1; q < NTHR / 64; ++q) m = fmaxf(m, smem[q]);
+              if (m > 0.f) atomicMax(g.bn_dy_absmax + (blockIdx.x & 63u), __float_as_uint(m));
+            }
+          }
+        }
         if ((dbg & 16384) && lane == 0 && blockIdx.y == 0) {
 #ifdef DSPN_ABLATE
           unsigned *po = g_phase_stamps + ((blockIdx.x * (NTHR / 64) + wave) & 8191) * 8;
@@ -1159,6 +1144,7 @@ struct WgradGeom {
   int in_relu;
   int bf16;                           // host side only: math mode of this call
   const float *dy_absmax, *x_absmax;  // DSPN_MATH_F32_F16X2: device scalars, largest magnitude of dy / of x after its affine (ConvGeom)
+  int dy_planes;                      // host side only: dy is fp16 piece planes (MATHX = 4)
 };
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
@@ -1166,10 +1152,15 @@ struct WgradGeom {
 // consecutive pixels (= MFMA k) of its channel, two reads per 8-k fragment.
 constexpr int wg_row_bytes(int ch) { return ch == 32 ? 64 : ch * 2 + 64; }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool INTF>
+// MATHX = 4: the two-piece math (3) with dy as fp16 PIECE PLANES (conv_nt_kernel, EPIX & 4): chunk q of a pixel's BM output
+// channels -- the same byte address as the float chunk -- is 8 channels of ONE piece and goes to that piece's LDS plane as it is
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATHX, bool INTF>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
     const st_t *__restrict__ x, const st_t *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
+  constexpr int MATH = MATHX == 4 ? 3 : MATHX;
+  constexpr bool A_PL = MATHX == 4;
+  static_assert(!A_PL || !kHalf, "piece-plane gradients: float tensors");
   constexpr bool BF16 = MATH != 0, SPLIT = MATH >= 2;   // as in conv_nt_kernel
   constexpr int NPC = MATH == 3 ? 2 : 3;
   static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
@@ -1339,6 +1330,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     } else if constexpr (SPLIT) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
+        if constexpr (A_PL) {
+          // chunk q = a_chunk of the pixel's BM channels: 32-channel block q >> 3, piece (q >> 2) & 1, channels 8 (q & 3) .. + 7
+          char *d = hA + ((a_chunk >> 2) & 1) * (kPK * RAB) + (a_row0 + i * A_RSTEP) * RAB + ((a_chunk >> 3) * 32 + (a_chunk & 3) * 8) * 2;
+          *reinterpret_cast<float4 *>(d) = ra[i];
+          continue;
+        }
         bf16x4 p0, p1, p2;
         if constexpr (MATH == 3) { split2h(ra[i], sc_a, p0, p1); if (__builtin_expect(nf_a, 0)) repair_inf(p0, p1); }
         else split3(ra[i], p0, p1, p2);
@@ -1939,6 +1936,12 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
                            : g.bf16 == 1 ? (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E)) \
                                          : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
+#ifndef DSPN_HALF
+  if (g.a_planes) {      // (dispatch_nt has checked: two-piece math, uniform taps, no input affine, no statistics)
+    if (g.bn_sums) return DSPN_NT_(true, 3, false, 6);
+    return DSPN_NT_(true, 3, false, 4);
+  }
+#endif
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
   if (g.in_scale) return g.stats ? DSPN_NT_UB_(true, 1) : DSPN_NT_UB_(true, 0);
   return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
@@ -1954,6 +1957,7 @@ int launch_nt_f16x2(const st_t *in, const st_t *w, const float *bias, st_t *out,
   return dspn::fail(DSPN_ERR_ARG_, "conv: no two-piece kernels for bf16 tensors");
 #else
 #define DSPN_NT3_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 3, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
+  if (g.a_planes) return g.bn_sums ? DSPN_NT3_(false, 6) : DSPN_NT3_(false, 4);
   if (g.bn_sums) return DSPN_NT3_(false, 2);
   if (g.in_scale) return g.stats ? DSPN_NT3_(true, 1) : DSPN_NT3_(true, 0);
   return g.stats ? DSPN_NT3_(false, 1) : DSPN_NT3_(false, 0);
@@ -2017,6 +2021,8 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
   const int nk = (g.TR * g.TS * (g.Cin / kEPC) + 7) >> 3;
   int splits = 1, per = nk;
+  if (g.a_planes && !(pre && g.bf16 == 3 && !g.in_scale && !g.stats))
+    return dspn::fail(DSPN_ERR_ARG_, "conv: a piece-plane gradient operand needs DSPN_MATH_F32_F16X2, a multiple of 32 channels (%d) and no input affine / statistics", g.Cin);
   if (g.stats && (!g.dense || !(g.flags & 16) || g.Cout % 4 != 0))
     return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: output statistics need a dense, 16-byte aligned output with Cout %% 4 == 0");
   if (g.bn_sums && (g.in_scale || g.stats))
@@ -2142,7 +2148,7 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout) {
 #endif
 
 struct InAffine { const float *scale, *shift; int relu; };
-struct OpScales { const float *a, *b; };   // device scalars: largest magnitudes of the two operands (DSPN_MATH_F32_F16X2)
+struct OpScales { const float *a, *b; int a_planes = 0; };   // device scalars: largest magnitudes of the two operands (DSPN_MATH_F32_F16X2); a_planes: DSPN_MATH_DY_PLANES
 
 static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine tf, float *stats, float *minmax, const st_t *w, const void *w_planes, const float *bias, const st_t *residual, st_t *y, int N,
                             int H, int W, int Cin, int Cout, int R, int S, int stride, int pad_h, int pad_w,
@@ -2336,7 +2342,7 @@ int dspn_conv2d_weight_prepare_batch_bf16(const void *table, int n, long long to
 
 // dx (N,H,W,Cin_x) from dy (N,Ho,Wo,ldy) and wt = transposed weights [Cin_x][R*S][ldy].
 // Also the forward of a transposed convolution (x := dy).
-struct BnBwd { const st_t *x; const float *scale, *shift, *mean, *rstd; int relu; float *sums; };
+struct BnBwd { const st_t *x; const float *scale, *shift, *mean, *rstd; int relu; float *sums; float *dy_absmax; };
 
 // row tiles of the launches of one data gradient, in launch order (stride 2: up to 4 parity classes)
 static int dgrad_tiles(int N, int H, int W, int Cin, int stride, int *per_class /* [4] or NULL */) {
@@ -2373,6 +2379,8 @@ static int conv2d_dgrad_one(int math, OpScales scales, const st_t *dy, const st_
   g.a_absmax = scales.a; g.b_absmax = scales.b;
   g.bn_x = bn.x; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_rstd = bn.rstd;
   g.bn_relu = bn.relu; g.bn_sums = bn.sums; g.bn_tile_base = 0;
+  g.bn_dy_absmax = (bn.sums && !kHalf && math == DSPN_MATH_F32_F16X2) ? reinterpret_cast<unsigned *>(bn.dy_absmax) : nullptr;
+  g.a_planes = scales.a_planes;
   int class_tiles[4] = {0, 0, 0, 0};
   if (bn.sums) dgrad_tiles(N, H, W, Cin, stride, class_tiles);
   hipStream_t s = (hipStream_t)stream;
@@ -2418,12 +2426,14 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt
                              int Cin, int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho,
                              int Wo, int dx_ldc, int accumulate,
                              const st_t *bn_x, const float *bn_scale, const float *bn_shift, const float *bn_mean,
-                             const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, int math,
-                             const float *dy_absmax, const float *w_absmax, void *workspace, size_t workspace_bytes,
+                             const float *bn_rstd, int bn_relu, float *bn_sums, size_t bn_sums_bytes, float *bn_dy_absmax,
+                             int math, const float *dy_absmax, const float *w_absmax, void *workspace, size_t workspace_bytes,
                              void *stream) {
   DSPN_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_dgrad: bad geometry");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
-  math &= ~DSPN_MATH_UNSCALED_OK;
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, dy_planes = (math & DSPN_MATH_DY_PLANES) ? 1 : 0;
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES);
+  DSPN_REQUIRE(!dy_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy % 32 == 0 && dy_absmax),
+               "conv2d_dgrad: DSPN_MATH_DY_PLANES needs DSPN_MATH_F32_F16X2, ldy %% 32 == 0 and the block the planes were cut by (dy_absmax)");
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_dgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (dy_absmax && w_absmax),
                "conv2d_dgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
@@ -2438,9 +2448,9 @@ int DSPN_FN(dspn_conv2d_dgrad_bn)(const st_t *dy, const st_t *wt, const void *wt
   }
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_dgrad_one(math, OpScales{dy_absmax, w_absmax}, dy + (long long)n0 * Ho * Wo * ldy, wt, wt_planes, dx + (long long)n0 * H * W * ldc, n, H,
+    const int rc = conv2d_dgrad_one(math, OpScales{dy_absmax, w_absmax, dy_planes}, dy + (long long)n0 * Ho * Wo * ldy, wt, wt_planes, dx + (long long)n0 * H * W * ldc, n, H,
                                     W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc, accumulate,
-                                    BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums}, workspace,
+                                    BnBwd{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_relu, bn_sums, bn_dy_absmax}, workspace,
                                     workspace_bytes, stream);
     if (rc) return rc;
   }
@@ -2453,7 +2463,7 @@ int dspn_conv2d_dgrad_f32(const float *dy, const float *wt, float *dx, int N, in
                           int Wo, int dx_ldc, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream) {
   return dspn_conv2d_dgrad_bn_f32(dy, wt, nullptr, dx, N, H, W, Cin, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, dx_ldc,
-                                  accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, DSPN_MATH_FP32,
+                                  accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, DSPN_MATH_FP32,
                                   nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -2506,6 +2516,7 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
   g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
   g.bf16 = kHalf ? 1 : math;
   g.dy_absmax = scales.a; g.x_absmax = scales.b;
+  g.dy_planes = scales.a_planes;
   {
     const long long xb = (long long)sizeof(st_t) * N * H * W * Cin, yb = (long long)sizeof(st_t) * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -2544,12 +2555,14 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
     if (g.in_scale) {                                                                                    \
-      if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, true)                                     \
+      if (g.bf16 == 3 && g.dy_planes) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 4, true)                      \
+      else if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, true)                                \
       else if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, true)                                \
       else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, true)                                     \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, true)                                                 \
     } else {                                                                                             \
-      if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, false)                                    \
+      if (g.bf16 == 3 && g.dy_planes) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 4, false)                     \
+      else if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, false)                               \
       else if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, false)                               \
       else if (g.bf16) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 1, false)                                    \
       else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 0, false)                                                \
@@ -2568,7 +2581,8 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
 #ifdef DSPN_DEV_FAST
-  if (g.bf16 == 3) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, false) }
+  if (g.bf16 == 3 && g.dy_planes) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, false) }
+  else if (g.bf16 == 3) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, false) }
   else
 #endif
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
@@ -2594,8 +2608,10 @@ int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const fl
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
-  math &= ~DSPN_MATH_UNSCALED_OK;
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, dy_planes = (math & DSPN_MATH_DY_PLANES) ? 1 : 0;
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES);
+  DSPN_REQUIRE(!dy_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
+               "conv2d_wgrad: DSPN_MATH_DY_PLANES needs DSPN_MATH_F32_F16X2, ldy == Cout, Cout %% 32 == 0 and the block the planes were cut by (dy_absmax)");
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
@@ -2603,7 +2619,7 @@ int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const fl
                           batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy));
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
+    const int rc = conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax, dy_planes}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu},
                                     dy + (long long)n0 * Ho * Wo * ldy, dw, n, H, W,
                                     Cin, Cout, ldy, R, S, stride, pad_h, pad_w, dil, Ho, Wo, accumulate || n0 > 0,
                                     workspace, workspace_bytes, stream);
@@ -2630,15 +2646,17 @@ int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const
                                 int Wo, int math, const float *x_absmax, const float *dy_absmax, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
-  math &= ~DSPN_MATH_UNSCALED_OK;
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, dy_planes = (math & DSPN_MATH_DY_PLANES) ? 1 : 0;
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES);
+  DSPN_REQUIRE(!dy_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
+               "conv2d_wgrad: DSPN_MATH_DY_PLANES needs DSPN_MATH_F32_F16X2, ldy == Cout, Cout %% 32 == 0 and the block the planes were cut by (dy_absmax)");
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   DSPN_REQUIRE(std::min(batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin),
                         batch_chunk(N, (long long)sizeof(st_t) * Ho * Wo * ldy)) == N,
                "conv2d_wgrad_slabs: tensors of 2 GiB or more need dspn_conv2d_wgrad_f32");
-  return conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax}, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
+  return conv2d_wgrad_one(math, OpScales{dy_absmax, x_absmax, dy_planes}, x, InAffine{in_scale, in_shift, in_relu}, dy, nullptr, N, H, W, Cin, Cout, ldy, R, S, stride,
                           pad_h, pad_w, dil, Ho, Wo, 0, slabs, slabs_bytes, stream);
 }
 

@@ -9,6 +9,7 @@
 // atomics, so every result is bitwise reproducible run to run.
 #include "dspn_common.h"
 #include "dspn_store.h"
+#include "dspn_pieces.h"
 #include "../../include/dspn_nn.h"
 
 // Compiled twice (dspn_store.h): float activations -> `*_f32`, and through nn_h.hip with DSPN_HALF -> bfloat16
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     const float *__restrict__ ts, int tiles, int tile_rows, long long rows, int C, float eps,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ mean,
     float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift,
-    const float *__restrict__ mm, int mm_tiles, int relu, unsigned *__restrict__ absmax, unsigned *__restrict__ absmin) {
+    const float *__restrict__ mm, int mm_tiles, int relu, unsigned *__restrict__ absmax, unsigned *__restrict__ absmin,
+    float *__restrict__ chan_minmax) {
   __shared__ double sA[64][17], sB[64][17];
   __shared__ float sLo[64][17], sHi[64][17];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
     if (mm) {    // largest |(relu)(x * scale + shift)|: the affine is monotone per channel, so it sits at an extreme of x
       float lo = sLo[0][cl], hi = sHi[0][cl];
       for (int k = 1; k < 64; ++k) { lo = fminf(lo, sLo[k][cl]); hi = fmaxf(hi, sHi[k][cl]); }
+      if (chan_minmax) { chan_minmax[c] = lo; chan_minmax[C + c] = hi; }     // the tensor's extremes per channel (BatchNorm backward's bound)
       float a = fmaf(lo, sc, sh), b = fmaf(hi, sc, sh);        // the same fmaf as the loaders that apply this affine
       if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
       const float v = fmaxf(fabsf(a), fabsf(b));
@@ -357,9 +360,17 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
     const float *__restrict__ partial, int nslabs, int C, double inv_rows,
     const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
-    float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    const float *__restrict__ dy_absmax, const float *__restrict__ x_minmax, unsigned *__restrict__ dx_bound) {
   __shared__ double s_S[16][64];
   __shared__ double s_SS[16][64];
+  __shared__ float s_D;
+  if (dx_bound && threadIdx.x < 64) {      // D = the largest |dy'| the producing data gradient stored (finite partial maxima)
+    float m = dy_absmax[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) s_D = m;
+  }
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double S = 0, SS = 0;
@@ -381,7 +392,77 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
     const double c1 = -a * rs * (SS * inv_rows);
     coef[c] = (float)a;
     coef[C + c] = (float)c1;
-    coef[2 * C + c] = (float)(-a * (S * inv_rows) - c1 * mu);
+    const double c0 = -a * (S * inv_rows) - c1 * mu;
+    coef[2 * C + c] = (float)c0;
+    if (dx_bound) {
+      // |dx| = |a dy' + c1 x + c0| <= |a| D + max(|c1 lo + c0|, |c1 hi + c0|) over the channel's x in [lo, hi] (the affine
+      // part is monotone in x): the magnitude block of the dx the apply kernel is ABOUT to write as piece planes -- a bound,
+      // a few times the true maximum at most (the two-piece math tolerates 2^17)
+      const double lo = x_minmax[c], hi = x_minmax[C + c];
+      double b = fabs(a) * (double)s_D + fmax(fabs(c1 * lo + c0), fabs(c1 * hi + c0));
+      b *= 1.0 + 1e-6;
+      float bf = (float)b;
+      if (!(bf == bf)) bf = INFINITY;
+      if (bf > 0.f) atomicMax(dx_bound + (c & 63), __float_as_uint(bf));
+    }
+  }
+}
+
+// the apply pass of the BatchNorm backward with dx written as fp16 PIECE PLANES for the two-piece math (round 4):
+// [pixel][C / 32][piece][32], the same 4 bytes per element and the same byte offset for a float4's four channels as the
+// float tensor -- (h0, h1) = split2h(dx, s) with s = operand_scale(bound), the bound bn_bwd_final_kernel has just left in
+// the block the convolution in front of this BatchNorm reads as its dy magnitude.  That convolution's data gradient and
+// weight gradient then copy the records into LDS without any arithmetic (conv_nt_kernel EPIX & 4, conv_wgrad_kernel
+// MATHX = 4) instead of cutting every element once per (tap, column tile) that reads it.
+template <int U>
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
+                                    const float4 *__restrict__ shift, const CA4Ptr dy,
+                                    const float4 *__restrict__ coef, uint2 *__restrict__ planes,
+                                    long long n4, int C4, int relu, const float *__restrict__ bound, int fixed_c) {
+  const float s = dspn::pieces::operand_scale(bound);
+  auto one = [&](const long long j, const int c4, const float4 xv, float4 g, const float4 sa, const float4 sb, const float4 a,
+                 const float4 c1, const float4 c0) __attribute__((always_inline)) {
+    if (relu) {
+      g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
+    }
+    const float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
+                                 a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);     // (as bn_bwd_apply_kernel)
+    dspn::pieces::bf16x4 p0, p1;
+    dspn::pieces::split2h(o, s, p0, p1);
+    // float4 j = channels 4 c4 .. 4 c4 + 3 of pixel j / C4: 8-byte units -- pixel * (2 C4) + (c4 >> 3) * 16 + piece * 8 + (c4 & 7)
+    const long long u = (j - c4) * 2 + (c4 >> 3) * 16 + (c4 & 7);
+    planes[u] = __builtin_bit_cast(uint2, p0);
+    planes[u + 8] = __builtin_bit_cast(uint2, p1);
+  };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long cstride = (long long)gridDim.x * (U * 256);
+  long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
+  if (fixed_c) {
+    const int c4 = (int)(base % C4);
+    const float4 sa = relu ? scale[c4] : zero, sb = relu ? shift[c4] : zero;
+    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
+    for (; base + (U - 1) * 256 < n4; base += cstride) {
+      float4 xv[U], g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { xv[u] = x[base + u * 256]; g[u] = dy[base + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(base + u * 256, c4, xv[u], g[u], sa, sb, a, c1, c0);
+    }
+    for (int u = 0; u < U; ++u) {
+      const long long j = base + u * 256;
+      if (j < n4) one(j, c4, x[j], dy[j], sa, sb, a, c1, c0);
+    }
+  } else {
+    for (; base < n4; base += cstride) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long j = base + u * 256;
+        if (j >= n4) break;
+        const int c4 = (int)(j % C4);
+        one(j, c4, x[j], dy[j], relu ? scale[c4] : zero, relu ? shift[c4] : zero, coef[c4], coef[C4 + c4], coef[2 * C4 + c4]);
+      }
+    }
   }
 }
 
@@ -1403,7 +1484,7 @@ size_t dspn_bn_tiles_workspace_bytes(int tiles, int C) { return bn_tiles_workspa
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
                                  float *shift, const float *tile_minmax, int relu, float *out_absmax, float *out_absmin,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+                                 float *out_chan_minmax, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(tile_stats && beta && mean && rstd && scale && shift && tiles > 0 && tile_rows > 0 && C > 0 &&
                    rows > (long long)(tiles - 1) * tile_rows && rows <= (long long)tiles * tile_rows,
                "bn_stats_from_tiles: bad argument");
@@ -1420,7 +1501,8 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
   }
   hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), tile_stats, tiles,
                      tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift, tile_minmax, mm_tiles, relu,
-                     reinterpret_cast<unsigned *>(out_absmax), reinterpret_cast<unsigned *>(tile_minmax ? out_absmin : nullptr));
+                     reinterpret_cast<unsigned *>(out_absmax), reinterpret_cast<unsigned *>(tile_minmax ? out_absmin : nullptr),
+                     tile_minmax ? out_chan_minmax : nullptr);
   return dspn::check_launch("bn_stats_from_tiles");
 }
 #endif
@@ -1471,7 +1553,7 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
                      CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows));
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
-                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr);
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
@@ -1500,8 +1582,13 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
 int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream) {
+                                   int accumulate, float *dx_absmax, const float *dy_absmax, const float *x_chan_minmax,
+                                   int dx_planes, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
+  DSPN_REQUIRE(!dx_planes || (!dspn::kHalf && !accumulate && C % 32 == 0 && dx_absmax && dy_absmax && x_chan_minmax &&
+                              static_cast<const void *>(dx) != static_cast<const void *>(dy) && static_cast<const void *>(dx) != static_cast<const void *>(x)),
+               "bn_backward_from_sums: dx as piece planes needs float tensors, C %% 32 == 0, no accumulation, dx apart from x and dy, "
+               "and dx_absmax / dy_absmax / x_chan_minmax (the bound of dx is formed from the last two)");
   DSPN_REQUIRE(!relu || (scale && shift), "bn_backward_from_sums: relu needs the forward scale/shift");
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_backward_from_sums: C must be a positive multiple of 4");
   if (workspace_bytes < sizeof(float) * 3 * (size_t)C)
@@ -1516,8 +1603,19 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     tile_sums = grouped; tiles = groups;
   }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), tile_sums, tiles, C,
-                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta);
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, dx_planes ? dy_absmax : nullptr,
+                     dx_planes ? x_chan_minmax : nullptr, dx_planes ? reinterpret_cast<unsigned *>(dx_absmax) : nullptr);
   const long long n4 = rows * C4;
+#ifndef DSPN_HALF
+  if (dx_planes) {
+    int fixed4 = 0, u4 = 0;
+    const int grid4 = grid_fixed_channel(n4, C4, &fixed4, &u4);
+    hipLaunchKernelGGL(u4 ? bn_bwd_apply_planes_kernel<4> : bn_bwd_apply_planes_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
+                       CA4Ptr(x), reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
+                       reinterpret_cast<const float4 *>(coef), reinterpret_cast<uint2 *>(dx), n4, C4, relu, dx_absmax, fixed4);
+    return dspn::check_launch("bn_backward_from_sums");
+  }
+#endif
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
     int fixed8 = 0, u4 = 0;

@@ -57,6 +57,7 @@ class Tensor:
         # large by less than 2^17 costs the two-piece math nothing), and the tensor whose values this one shares (BlockGrad)
         self.am_slot = None
         self.alias_of = None
+        self.grad_planes = False   # this backward pass: .grad holds fp16 piece planes, not floats (BatchNorm.dx_planes)
         self.channels = None       # logical channel count when the last axis is padded (19 -> 20, 3 -> 4)
         self.data = None if virtual else (data if data is not None else fn.zeros(*self.shape, device=device, dtype=self.dtype))
         self.grad = None
@@ -284,11 +285,45 @@ class Graph:
                         and not prod.relu and prod.b is None):
                     prod.am_dy = n.am_dy
 
+    def _plan_gradient_planes(self):
+        """"f16x2" math, round 4: a BatchNorm whose backward (from the sums its consumer's data gradient gathered) is the ONLY
+        writer of its input's gradient, and whose input is the dense output of a plain convolution, writes that gradient as
+        fp16 piece planes -- same buffer, same bytes -- cut by a bound it forms beforehand (dspn_bn_backward_from_sums_f32,
+        dx_planes); the convolution's data gradient and weight gradient then copy their dy operand instead of cutting it
+        once per tap and column tile.  In the residual units: bn2 -> conv1 and bn3 -> conv2."""
+        if self.math != "f16x2" or self.device.type != "cuda":
+            return
+        readers = {}
+        for idx, m in enumerate(self.nodes):
+            for k, v in vars(m).items():
+                if k in ("out", "x_raw"):      # (x_raw: a convolution reading THROUGH a deferred BatchNorm; the gradient goes to the BatchNorm)
+                    continue
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, Tensor):
+                        readers.setdefault(id(t), set()).add(idx)
+        gatherer = {id(n.bn_bwd_node): n for n in self.nodes if isinstance(n, Conv) and getattr(n, "bn_bwd_node", None) is not None}
+        for idx, n in enumerate(self.nodes):
+            if not isinstance(n, BatchNorm) or n.bwd_sums is None or id(n) not in gatherer:
+                continue
+            prod, x = getattr(n.x, "producer", None), n.x
+            if not (isinstance(prod, Conv) and prod.out is x and readers.get(id(x)) == {idx} and x.requires_grad
+                    and x.dtype == torch.float32 and n.completes_x_grad and n.tile_stats is not None):
+                continue
+            if (prod.tap_expand or prod.relu or prod.b is not None or prod.residual is not None or prod.input_sum_grad is not None
+                    or prod.am_dy is None or x.shape[3] != prod.cout or prod.cout % 32 != 0 or prod.out_minmax is None
+                    or gatherer[id(n)].math != "f16x2"):
+                continue
+            n.dx_planes = True
+            n.x_ext = fn.zeros(2, x.shape[3], device=self.device)
+            n.am_dyin = self.new_scalar(backward=True)
+
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._resolve_auto_deferred()
         self._plan_bn_backward_fusion()
         self._plan_gradient_magnitudes()
+        if _os.environ.get("DSPN_DY_PLANES", "1") != "0":      # (A/B switch)
+            self._plan_gradient_planes()
         self._wt_pairs_nodes = [n for n in self.nodes if isinstance(n, Conv) and (n.wt is not None or n.wh is not None)]
         off = 0
         for p in self.param_order:
@@ -388,6 +423,7 @@ class Graph:
         for t in self.all_tensors:
             t._gw = False
             t.grad = None
+            t.grad_planes = False
         if self.scalars is not None:
             if self._am_bwd_ran:       # a second backward pass on the same forward pass: new gradients, new magnitudes
                 for slot in self._am_bwd_slots & self._am_done:
@@ -569,6 +605,9 @@ class BatchNorm(Node):
                                      # still gather this BatchNorm's backward reductions in its epilogue)
         self.bwd_sums = None         # (buffer, tiles) written by the LAST data gradient into self.out.grad
         self.bwd_sums_ready = False
+        # round 4 (Graph._plan_gradient_planes): dx leaves as fp16 piece planes; x_ext = per-channel extremes of x from the
+        # forward finalize, am_dyin = slot of the magnitude of this node's own output gradient (from the data gradient's epilogue)
+        self.dx_planes, self.x_ext, self.am_dyin = False, None, None
         self._g = g
         # True when this node's backward is the LAST writer of x's gradient (set by Graph.finalize): only then is the dx it
         # stores the complete gradient whose magnitude the producing convolution may use
@@ -589,7 +628,8 @@ class BatchNorm(Node):
                                    None if self.gamma is None else self.gamma.data, self.beta.data,
                                    self.mean, self.rstd, self.scale, self.shift,
                                    tile_minmax=mm if am is not None else None, relu=self.relu, out_absmax=am,
-                                   out_absmin=None if am is None else g.scalars_min[slot:slot + 1])
+                                   out_absmin=None if am is None else g.scalars_min[slot:slot + 1],
+                                   out_chan_minmax=self.x_ext if am is not None else None)
         else:
             fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                         self.mean, self.rstd, self.scale, self.shift)
@@ -598,6 +638,12 @@ class BatchNorm(Node):
             fn.bn_apply(self.x.data, self.scale, self.shift, relu=self.relu, out=self.out.data, out_absmax=am)
             if am is not None:
                 self._g._am_done.add(self.am_out)
+
+    def _x_ext_valid(self):
+        """the per-channel extremes of x were written by this step's forward finalize (the magnitude slot they come with is done)"""
+        g = self._g
+        slot = g._am_x.get((id(self.x), id(self.scale)))
+        return slot is not None and slot in g._am_done
 
     def backward(self):
         if not self.out._gw:
@@ -615,6 +661,16 @@ class BatchNorm(Node):
                 g._am_done.add(prod.am_dy)
         else:  # parameters still need their gradients; dx goes to scratch
             dx, acc = self.out.grad, False
+        if self.bwd_sums_ready and self.dx_planes and am is not None and not acc and self._x_ext_valid():
+            # the gradient leaves as fp16 piece planes (same buffer): `am` receives the BOUND it is cut by
+            self.bwd_sums_ready = False
+            fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
+                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
+                                     relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
+                                     dbeta=self.beta.grad, accumulate=False, dx_absmax=am,
+                                     dy_absmax=self._g.scalar(self.am_dyin), x_chan_minmax=self.x_ext, dx_planes=True)
+            self.x.grad_planes = True
+            return
         if self.bwd_sums_ready:      # the two reductions came out of the data-gradient kernel's epilogue
             self.bwd_sums_ready = False
             fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
@@ -777,6 +833,7 @@ class Conv(Node):
         if not self.out._gw:
             return
         dy = self.out.grad
+        planes = self.out.grad_planes            # fp16 piece planes from the BatchNorm behind this convolution (never with relu / bias / residual)
         if self.relu and self.b is not None:     # ReLU mask and bias gradient in one pass over dy
             fn.relu_backward_colsum(self.out.data, dy, self.cout, dx=dy, out=self.b.grad)
         elif self.relu:
@@ -802,10 +859,10 @@ class Conv(Node):
                                 out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math, x_absmax=xa)
         elif self.slabs is not None:
             fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
-                                  in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya)
+                                  in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya, dy_planes=planes)
         else:
             fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
-                            in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya)
+                            in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya, dy_planes=planes)
         self.slabs_fresh = self.slabs is not None
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
@@ -818,12 +875,15 @@ class Conv(Node):
                 fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
             dx, acc = self.x.grad_target()
             bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
-            bn_bwd = None
+            bn_bwd, bn_dya = None, None
             if bn is not None:
                 bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
                 bn.bwd_sums_ready = True
+                if bn.dx_planes:         # that BatchNorm's backward bounds its dx from the largest gradient stored here
+                    bn_dya = self._g.scalar(bn.am_dyin)
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
-                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa)
+                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa,
+                            bn_dy_absmax=bn_dya, dy_planes=planes)
 
 
 class BilinearConcatConv(Node):

@@ -30,7 +30,7 @@ _lib.register({
     "dspn_conv2d_weight_planes_tiles": (_ll, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_weight_planes_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_conv2d_stats_layout": (_i, [_ll, _i, _c.POINTER(_c.c_int)]),
-    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dspn_bn_stats_from_tiles_f32": (_i, [_vp, _i, _i, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "dspn_conv2d_wgrad_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -45,9 +45,9 @@ _lib.register({
                                    _sz, _vp]),
     "dspn_conv2d_dgrad_bn_tiles": (_i, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _vp, _sz, _vp]),
+                                      _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
-                                            _vp, _vp, _sz, _vp]),
+                                            _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                             _vp, _sz, _vp]),
@@ -240,7 +240,7 @@ def conv_stats_layout(out_pixels, cout):
 
 
 def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta, mean, rstd, scale, shift,
-                        tile_minmax=None, relu=False, out_absmax=None, out_absmin=None):
+                        tile_minmax=None, relu=False, out_absmax=None, out_absmin=None, out_chan_minmax=None):
     """tile_minmax + out_absmax ("f16x2" math): also max the magnitude of (relu)(x * scale + shift) into the 64-slot block
     out_absmax, from the per-tile extremes the producing convolution wrote (conv2d_forward's out_minmax)"""
     ws = workspace(L().dspn_bn_tiles_workspace_bytes(tiles, C), tile_stats.device, "bn")
@@ -248,7 +248,7 @@ def bn_stats_from_tiles(tile_stats, tiles, tile_rows, rows, C, eps, gamma, beta,
     assert tile_minmax is None or (tile_minmax.numel() == tile_stats.numel() and out_absmax.numel() == ABSMAX_SLOTS)
     check(L().dspn_bn_stats_from_tiles_f32(ptr(tile_stats), tiles, tile_rows, rows, C, eps, ptr(gamma), ptr(beta), ptr(mean),
                                            ptr(rstd), ptr(scale), ptr(shift), ptr(tile_minmax), int(bool(relu)),
-                                           ptr(out_absmax), ptr(out_absmin), ptr(ws), ws.numel(), stream()),
+                                           ptr(out_absmax), ptr(out_absmin), ptr(out_chan_minmax), ptr(ws), ws.numel(), stream()),
           "bn_stats_from_tiles")
 
 
@@ -448,8 +448,11 @@ def conv_dgrad_bn_tiles(x_shape, stride):
     return L().dspn_conv2d_dgrad_bn_tiles(N, H, W, C, stride)
 
 
+MATH_DY_PLANES = 0x200       # include/dspn_nn.h DSPN_MATH_DY_PLANES
+
+
 def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None, wt_planes=None,
-                 math=None, dy_absmax=None, w_absmax=None):
+                 math=None, dy_absmax=None, w_absmax=None, bn_dy_absmax=None, dy_planes=False):
     """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin).
     bn_bwd = (bn_x, scale, shift, mean, rstd, relu, sums): dx is the complete gradient of a BatchNorm(+ReLU) output
     whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin).
@@ -461,6 +464,7 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     math = _math_code(math)
     if math == 3 and dy.dtype == torch.float32:
         assert wt_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
+        assert not dy_planes or dy_absmax is not None, "piece-plane gradients come with the magnitude block they were cut by"
         dy_absmax = absmax(dy) if dy_absmax is None else dy_absmax
         w_absmax = absmax(wt) if w_absmax is None else w_absmax
     else:
@@ -480,18 +484,19 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     check(_f("dspn_conv2d_dgrad_bn", dy)(ptr(dy), ptr(wt), ptr(wt_planes), ptr(out), N, H, W, Cin, ldy, R, S, stride, ph, pw,
                                        dil, Ho, Wo, out.shape[3], int(accumulate), ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu),
                                        ptr(brs), int(brelu), ptr(bsums), 0 if bsums is None else bsums.numel() * 4,
-                                       math, ptr(dy_absmax), ptr(w_absmax), ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
+                                       ptr(bn_dy_absmax), math | (MATH_DY_PLANES if dy_planes else 0), ptr(dy_absmax),
+                                       ptr(w_absmax), ptr(ws), ws.numel(), stream()), "conv2d_dgrad")
     return out
 
 
 def _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax):
-    if math == 3 and x.dtype == torch.float32:
+    if math == 3 and x.dtype == torch.float32:      # (piece-plane gradients always come with their block: conv2d_wgrad's assert)
         return (absmax(x, in_affine) if x_absmax is None else x_absmax, absmax(dy) if dy_absmax is None else dy_absmax)
     return None, None
 
 
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None, math=None,
-                 x_absmax=None, dy_absmax=None):
+                 x_absmax=None, dy_absmax=None, dy_planes=False):
     """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -507,7 +512,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     math = _math_code(math)
     x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
-                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate), math, ptr(x_absmax),
+                                       R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate),
+                                       math | (MATH_DY_PLANES if dy_planes else 0), ptr(x_absmax),
                                        ptr(dy_absmax), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
     return out
 
@@ -539,7 +545,7 @@ def conv2d_wgrad_splits(x_shape, dy_shape, w_shape, stride):
 
 
 def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None, math=None, x_absmax=None,
-                       dy_absmax=None):
+                       dy_absmax=None, dy_planes=False):
     """the weight-gradient GEMM alone: split-K partial sums -> slabs (splits, Cout, R, S, Cin); see slab_reduce_batch"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -551,7 +557,8 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_slabs", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
-                                          dy.shape[2], math, ptr(x_absmax), ptr(dy_absmax), stream()), "conv2d_wgrad_slabs")
+                                          dy.shape[2], math | (MATH_DY_PLANES if dy_planes else 0), ptr(x_absmax),
+                                          ptr(dy_absmax), stream()), "conv2d_wgrad_slabs")
 
 
 def slab_reduce_table(entries, device):
@@ -641,8 +648,11 @@ def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dga
 
 
 def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=False, dx=None, dgamma=None,
-                          dbeta=None, accumulate=False, dx_absmax=None):
-    """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...))"""
+                          dbeta=None, accumulate=False, dx_absmax=None, dy_absmax=None, x_chan_minmax=None, dx_planes=False):
+    """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...)).
+    dx_planes ("f16x2" math): dx is written as fp16 piece planes (same bytes, same buffer shape) cut by the power of two of a
+    BOUND of |dx| that is formed from dy_absmax (the magnitude block of dy, conv2d_dgrad's bn_dy_absmax) and x_chan_minmax
+    (2 x C per-channel extremes of x, bn_stats_from_tiles' out_chan_minmax) and left in dx_absmax"""
     C = x.shape[-1]
     rows = _rows(x)
     dx = torch.empty_like(x) if dx is None else dx
@@ -653,7 +663,8 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     assert dy.dtype == x.dtype == dx.dtype
     check(_f("dspn_bn_backward_from_sums", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
-                                             int(accumulate), ptr(dx_absmax), ptr(ws), ws.numel(), stream()),
+                                             int(accumulate), ptr(dx_absmax), ptr(dy_absmax), ptr(x_chan_minmax),
+                                             int(bool(dx_planes)), ptr(ws), ws.numel(), stream()),
           "bn_backward_from_sums")
     return dx, dgamma, dbeta
 

@@ -92,6 +92,11 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  * fp16 overflow otherwise).  The C default for code that keeps no magnitudes is DSPN_MATH_FP32; dspnet_amd (Python) passes
  * DSPN_MATH_F32_F16X2 with both blocks on every float-tensor call. */
 #define DSPN_MATH_UNSCALED_OK 0x100
+/* OR-ed into `math` of dspn_conv2d_dgrad_bn_f32 / dspn_conv2d_wgrad_bn_f32 / dspn_conv2d_wgrad_slabs_f32 (with
+ * DSPN_MATH_F32_F16X2; round 4): dy is not a float tensor but the fp16 PIECE PLANES dspn_bn_backward_from_sums_f32 wrote
+ * (dx_planes), cut with the scale of the block passed as dy_absmax.  Needs ldy % 32 == 0 (and ldy == Cout for the weight
+ * gradient). */
+#define DSPN_MATH_DY_PLANES 0x200
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
@@ -173,8 +178,11 @@ int dspn_conv2d_dgrad_bn_f32(const float *dy, const float *wt, const void *wt_pl
                              int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo, int dx_ldc,
                              int accumulate, const float *bn_x, const float *bn_scale, const float *bn_shift,
                              const float *bn_mean, const float *bn_rstd, int bn_relu, float *bn_sums,
-                             size_t bn_sums_bytes, int math, const float *dy_absmax, const float *w_absmax,
+                             size_t bn_sums_bytes, float *bn_dy_absmax, int math, const float *dy_absmax, const float *w_absmax,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* bn_dy_absmax (optional, with bn_sums, DSPN_MATH_F32_F16X2; round 4): DSPN_ABSMAX_SLOTS floats (zeroed by the caller) that
+ * receive the partial maxima of |dx| as stored -- the `dy_absmax` of the dspn_bn_backward_from_sums_f32 call that finishes
+ * this BatchNorm's backward pass with dx_planes. */
 
 /* out[c] = sum over every input pixel of the data gradient of the convolution, c < Cin <= 8, computed
  * from per-tap sums of dy without forming the gradient (the first convolution's input only feeds the
@@ -258,8 +266,9 @@ int dspn_conv2d_dgrad_bn_bf16(const dspn_bf16 *dy, const dspn_bf16 *wt, const vo
                               int ldy, int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
                               int dx_ldc, int accumulate, const dspn_bf16 *bn_x, const float *bn_scale,
                               const float *bn_shift, const float *bn_mean, const float *bn_rstd, int bn_relu,
-                              float *bn_sums, size_t bn_sums_bytes, int math, const float *absmax_unused_a,
-                              const float *absmax_unused_b, void *workspace, size_t workspace_bytes, void *stream);
+                              float *bn_sums, size_t bn_sums_bytes, float *bn_dy_absmax_unused, int math,
+                              const float *absmax_unused_a, const float *absmax_unused_b, void *workspace,
+                              size_t workspace_bytes, void *stream);
 int dspn_conv2d_wgrad_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu,
                               const dspn_bf16 *dy, float *dw, int N, int H, int W, int Cin, int Cout, int ldy,
                               int R, int S, int stride, int pad_h, int pad_w, int dil, int Ho, int Wo,
@@ -300,7 +309,7 @@ int dspn_bn_stats_f32(const float *x, long long rows, int C, float eps, const fl
 int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_rows, long long rows, int C, float eps,
                                  const float *gamma, const float *beta, float *mean, float *rstd, float *scale,
                                  float *shift, const float *tile_minmax, int relu, float *out_absmax, float *out_absmin,
-                                 void *workspace, size_t workspace_bytes, void *stream);
+                                 float *out_chan_minmax, void *workspace, size_t workspace_bytes, void *stream);
 /* tile_minmax + out_absmax (both or neither; DSPN_MATH_F32_F16X2): the (min, max) pairs the same convolution wrote beside
  * its statistics (out_minmax).  The largest |(relu)(x * scale + shift)| over the tensor -- the magnitude of what the next
  * convolution multiplies when it folds this BatchNorm into its loader -- is then max-ed INTO the magnitude block
@@ -308,7 +317,9 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
  * out_absmin (optional, with tile_minmax; round 4): ONE float that receives, by atomic minimum on its bit pattern (the caller
  * sets it to +inf first), the smallest non-zero PER-CHANNEL magnitude of the same tensor -- a range monitor: a tensor whose
  * channel magnitudes span more than 2^17 leaves the two-piece math's window of relative accuracy for its small channels
- * (DSPN_MATH_F32_F16X2 above), and the ratio of the two blocks says so without a pass over the tensor. */
+ * (DSPN_MATH_F32_F16X2 above), and the ratio of the two blocks says so without a pass over the tensor.
+ * out_chan_minmax (optional, with tile_minmax; round 4): 2 x C floats, the smallest [c] and largest [C + c] value of channel c
+ * over the whole tensor -- what dspn_bn_backward_from_sums_f32 needs to bound the dx it writes as piece planes. */
 /* optional scratch for long tile tables (>= 1024 tiles are first merged in groups of 32 by many workgroups);
  * dspn_bn_backward_from_sums_f32 uses 3*C floats + this many bytes the same way */
 size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);
@@ -332,7 +343,18 @@ int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift,
 int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream);
+                                   int accumulate, float *dx_absmax, const float *dy_absmax, const float *x_chan_minmax,
+                                   int dx_planes, void *workspace, size_t workspace_bytes, void *stream);
+/* dx_planes != 0 (round 4; float tensors, C % 32 == 0, accumulate == 0): dx is written as fp16 PIECE PLANES for
+ * DSPN_MATH_F32_F16X2 instead of floats -- [row][C / 32][piece][32] 16-bit elements, the same 4 bytes per element and the
+ * same byte offset for every group of four channels as the float tensor, (p0, p1) = (f16(s dx), f16(s dx - p0)) -- so that
+ * the data gradient and the weight gradient of the convolution that produced x (DSPN_MATH_DY_PLANES) copy it into LDS
+ * without cutting every element once per tap and column tile.  The scale s has to be known BEFORE the pass that forms dx:
+ * it is the power of two of a BOUND, max over channels of |a| D + max(|c1 lo + c0|, |c1 hi + c0|) with dx = a dy' + c1 x + c0
+ * per channel, D = the magnitude in dy_absmax (of dy: e.g. `bn_dy_absmax` of the data gradient that produced it) and
+ * [lo, hi] = the channel's extremes of x in x_chan_minmax (2 x C floats: dspn_bn_stats_from_tiles_f32's out_chan_minmax).
+ * dx_absmax (zeroed by the caller) RECEIVES that bound and is the block the consuming convolutions are given as their dy
+ * magnitude -- a few times the true maximum at most, which the two-piece math does not feel (2^17). */
 
 /* ---- element-wise / layout --------------------------------------------------------------- */
 int dspn_add_f32(const float *a, const float *b, float *out, long long n, void *stream);      /* out = a + b */
@@ -512,8 +534,9 @@ int dspn_bn_backward_bf16(const dspn_bf16 *x, const float *scale, const float *s
 int dspn_bn_backward_from_sums_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, dspn_bf16 *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax_unused, void *workspace, size_t workspace_bytes,
-                                   void *stream);
+                                   int accumulate, float *dx_absmax_unused, const float *dy_absmax_unused,
+                                   const float *x_chan_minmax_unused, int dx_planes /* must be 0 */, void *workspace,
+                                   size_t workspace_bytes, void *stream);
 int dspn_add_bf16(const dspn_bf16 *a, const dspn_bf16 *b, dspn_bf16 *out, long long n, void *stream);
 int dspn_relu_backward_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long n, int accumulate, void *stream);
 int dspn_relu_backward_colsum_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long rows, int C, int ld,

@@ -105,9 +105,21 @@ def test_convolution_argument_validation_without_gpu():
     # BatchNorm finalize from tile statistics: the per-tile extremes and the magnitude block they feed go together
     import ctypes
     f = ctypes.c_float(1e-5)
-    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 512, 8, f, None, p, p, p, p, p, p, 0, None, None, None, 0, None) == -1
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 512, 8, f, None, p, p, p, p, p, p, 0, None, None, None, None, 0, None) == -1
     assert b"go together" in lib.dspn_last_error()
-    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 9999, 8, f, None, p, p, p, p, p, None, 0, None, None, None, 0, None) == -1   # rows vs tiles
+    assert lib.dspn_bn_stats_from_tiles_f32(p, 4, 128, 9999, 8, f, None, p, p, p, p, p, None, 0, None, None, None, None, 0, None) == -1   # rows vs tiles
+    # round 4: gradients as fp16 piece planes -- the flag needs the two-piece math, whole 32-channel blocks and the block the
+    # planes were cut by; the BatchNorm backward that writes them needs what it bounds dx from
+    def dgrad(math, ldy=64, dy_absmax=p):
+        return lib.dspn_conv2d_dgrad_bn_f32(p, p, None, p, 1, 8, 8, 32, ldy, 3, 3, 1, 1, 1, 1, 8, 8, 32, 0, None, None, None, None,
+                                            None, 0, None, 0, None, math, dy_absmax, p, None, 0, None)
+    assert dgrad(0 | 0x200) == -1 and b"DSPN_MATH_DY_PLANES" in lib.dspn_last_error()       # not the two-piece math
+    assert dgrad(3 | 0x200, ldy=48) == -1 and b"DSPN_MATH_DY_PLANES" in lib.dspn_last_error()
+    assert dgrad(3 | 0x200, dy_absmax=None) == -1
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 48, 1, 0, p, p, p, 1, p, 1 << 20, None) == -1
+    assert b"piece planes" in lib.dspn_last_error()                                         # C % 32
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 1, p, p, p, 1, p, 1 << 20, None) == -1   # accumulate
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 0, p, None, p, 1, p, 1 << 20, None) == -1  # no dy_absmax
     # batched weight transposes count 32 x 32 tiles of a tap
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout

@@ -722,6 +722,87 @@ def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, conv_math, case, acc
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), (float((a - r).abs().max()), float(r.abs().max()))
 
 
+def _decode_planes(planes, shape, block):
+    """fp16 piece planes [rows][C / 32][2][32] (stored in a float32 buffer of `shape`) -> float64 values (h0 + h1) / s with the
+    power of two s the kernels derive from the magnitude block (csrc/dspn_pieces.h operand_scale)"""
+    C = shape[-1]
+    h = planes.view(torch.float16).view(-1, C // 32, 2, 32).double()
+    m = float(block[torch.isfinite(block)].max())
+    e = 15 - (int(np.floor(np.log2(m))) + 1)          # frexp: m = f 2^e', 0.5 <= f < 1
+    e = max(-100, min(100, e))
+    return ((h[:, :, 0] + h[:, :, 1]) / 2.0 ** e).reshape(shape), 2.0 ** e
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 96, 3, 1, 1), (2, 24, 24, 128, 64, 1, 1, 0), (2, 25, 23, 64, 64, 3, 2, 1)])
+def test_gradient_as_piece_planes_from_batchnorm_backward(gpu_device, case):
+    """Round 4: the output gradient a BatchNorm backward hands to the convolution in front of it, written
+    as fp16 piece planes of the two-piece math instead of floats.  conv_b's data gradient gathers the BatchNorm-backward sums
+    and the largest gradient it stores (bn_dy_absmax); dspn_bn_backward_from_sums_f32(dx_planes) bounds its dx from that
+    and the per-channel extremes of x, cuts dx by the bound's power of two and writes the planes; conv_a's data gradient
+    and weight gradient read them with DSPN_MATH_DY_PLANES.  Checked: the bound IS a bound and within 2^6 of the true
+    maximum; the planes decode to the float dx within the rounding of the cut (2^-22 relative to the bound's scale); and
+    both consumers give the result of the float path fed the decoded values and the same block (to one ulp: see below)."""
+    N, H, W, Ca, Cb, k, stride, pad = case        # conv_a: Ca -> Cb (k x k, stride, pad) -> BatchNorm(+ReLU) -> conv_b: Cb -> 32 (1x1)
+    if fn.get_conv_math() != "f16x2":
+        pytest.skip("the two-piece math is not this process's default")
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xa = torch.randn(N, H, W, Ca, generator=g).cuda()
+    wa = (torch.randn(Cb, k, k, Ca, generator=g) / np.sqrt(Ca * k * k)).cuda()
+    gamma = (torch.rand(Cb, generator=g) * 1.5 + 0.25).cuda(); beta = (torch.randn(Cb, generator=g) * 0.3).cuda()
+    wb = (torch.randn(32, 1, 1, Cb, generator=g) / np.sqrt(Cb)).cuda()
+    dyb = torch.randn(N, Ho, Wo, 32, generator=g).cuda()
+    # forward of conv_a with the statistics / extremes epilogue, BatchNorm finalize with the per-channel extremes
+    tiles, tile_rows = fn.conv_stats_layout(N * Ho * Wo, Cb)
+    st = torch.zeros(tiles, 2, Cb, device="cuda"); mm = torch.zeros(tiles, 2, Cb, device="cuda")
+    x = fn.conv2d_forward(xa, wa, None, stride, pad, 1, out_stats=st, out_minmax=mm)
+    mean, rstd, scale, shift = (torch.zeros(Cb, device="cuda") for _ in range(4))
+    am_next = torch.zeros(64, device="cuda"); x_ext = torch.zeros(2, Cb, device="cuda")
+    fn.bn_stats_from_tiles(st, tiles, tile_rows, N * Ho * Wo, Cb, 2e-5, gamma, beta, mean, rstd, scale, shift,
+                           tile_minmax=mm, relu=True, out_absmax=am_next, out_chan_minmax=x_ext)
+    xr = x.view(-1, Cb)
+    assert torch.equal(x_ext[0], xr.min(0).values) and torch.equal(x_ext[1], xr.max(0).values)
+    # backward of conv_b: data gradient with the BatchNorm-backward sums and the magnitude of what it stores
+    bt = fn.conv_dgrad_bn_tiles(tuple(x.shape), 1)
+    sums = torch.zeros(bt, 2, Cb, device="cuda"); am_in = torch.zeros(64, device="cuda")
+    d = fn.conv2d_dgrad(dyb, fn.weight_transpose(wb), tuple(x.shape), 1, 0, 1, bn_bwd=(x, scale, shift, mean, rstd, True, sums),
+                        bn_dy_absmax=am_in)
+    assert float(am_in.max()) == float(d.abs().max())
+    # the BatchNorm backward: floats (reference) and piece planes
+    dx_ref, dg_ref, db_ref = fn.bn_backward_from_sums(x, scale, shift, d, mean, rstd, gamma, sums, bt, relu=True)
+    bound = torch.zeros(64, device="cuda")
+    pl, dg, db = fn.bn_backward_from_sums(x, scale, shift, d, mean, rstd, gamma, sums, bt, relu=True, dx=torch.empty_like(x),
+                                          dx_absmax=bound, dy_absmax=am_in, x_chan_minmax=x_ext, dx_planes=True)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    true_max, b = float(dx_ref.abs().max()), float(bound.max())
+    print(case, "bound / true maximum of dx: %.2f" % (b / true_max))
+    assert true_max <= b <= 64.0 * true_max
+    dec, s_dx = _decode_planes(pl, tuple(x.shape), bound)
+    assert float((dec - dx_ref.double()).abs().max()) <= 2.0 ** -21 * (2.0 ** 15 / s_dx), "the planes are the cut of dx"
+    # consumers: conv_a's data gradient and weight gradient on the planes == on the float tensor of the decoded values, same block
+    dec32 = dec.float()
+    assert torch.equal(dec32.double(), dec)           # h0 + h1 is a float (22 bits)
+    wat = fn.weight_transpose(wa)
+    dxa_p = fn.conv2d_dgrad(pl, wat, tuple(xa.shape), stride, pad, 1, dy_absmax=bound, dy_planes=True)
+    dxa_f = fn.conv2d_dgrad(dec32, wat, tuple(xa.shape), stride, pad, 1, dy_absmax=bound)
+    # (not bit for bit: where |h1| is exactly half an ulp of h0, cutting h0 + h1 again rounds the tie to the OTHER neighbour --
+    # the same value in two piece pairs whose dropped h1 g1-sized terms differ: a few outputs in a thousand move by one ulp)
+    def same(a, b):
+        return float((a - b).abs().max()) <= 2.0 ** -20 * float(b.abs().max())
+    assert same(dxa_p, dxa_f) and int((dxa_p != dxa_f).sum()) < dxa_f.numel() // 20
+    dwa_p = fn.conv2d_wgrad(xa, pl, tuple(wa.shape), stride, pad, 1, dy_absmax=bound, dy_planes=True)
+    dwa_f = fn.conv2d_wgrad(xa, dec32, tuple(wa.shape), stride, pad, 1, dy_absmax=bound)
+    assert same(dwa_p, dwa_f)
+    sc, sh = (torch.rand(Ca, generator=g) + 0.5).cuda(), torch.randn(Ca, generator=g).cuda()     # ... and with a folded input affine
+    am_x = fn.absmax(xa, (sc, sh, True))
+    dwa_p = fn.conv2d_wgrad(xa, pl, tuple(wa.shape), stride, pad, 1, in_affine=(sc, sh, True), x_absmax=am_x, dy_absmax=bound, dy_planes=True)
+    dwa_f = fn.conv2d_wgrad(xa, dec32, tuple(wa.shape), stride, pad, 1, in_affine=(sc, sh, True), x_absmax=am_x, dy_absmax=bound)
+    assert same(dwa_p, dwa_f)
+    # and against the exact float gradient
+    ref = fn.conv2d_dgrad(dx_ref, wat, tuple(xa.shape), stride, pad, 1)
+    assert float((dxa_p - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("rows,C,ld", [(1000, 64, 64), (70000, 30, 32), (5, 8, 8), (300000, 128, 128)])
 def test_relu_backward_colsum(gpu_device, rows, C, ld):
     g = torch.Generator().manual_seed(rows + C)
