@@ -727,7 +727,11 @@ class Conv(Node):
         self.residual = residual
         assert residual is None or residual.shape == self.out.shape
         half = self.out.dtype == torch.bfloat16
-        self.wt = None if not x.requires_grad else fn.zeros(Cin, kh, kw, ldc, device=g.device, dtype=self.out.dtype)
+        # data-gradient operand: the transposed weight -- as piece planes (wtp, below) where the split math contracts over whole
+        # 32-channel blocks, else as a tensor of the storage type (no float transpose is kept beside planes: ~100 MB on resnet-50)
+        self.wt_shape = (Cin, kh, kw, ldc)
+        planes_t = g.device.type == "cuda" and x.requires_grad and fn.needs_planes(self.out.dtype, ldc, g.math)
+        self.wt = None if (not x.requires_grad or planes_t) else fn.zeros(Cin, kh, kw, ldc, device=g.device, dtype=self.out.dtype)
         # bf16 operands: the copy of the float master the forward pass multiplies (refreshed once per step, Graph.forward)
         self.wh = fn.zeros(num_filter, kh, kw, Cin, device=g.device, dtype=torch.bfloat16) if half else None
         # split math: piece planes of the weight (forward operand) and of its transpose (data-gradient operand), cut once
@@ -883,7 +887,7 @@ class Conv(Node):
                     bn_dya = self._g.scalar(bn.am_dyin)
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
                             bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa,
-                            bn_dy_absmax=bn_dya, dy_planes=planes)
+                            bn_dy_absmax=bn_dya, dy_planes=planes, wt_shape=self.wt_shape)
 
 
 class BilinearConcatConv(Node):

@@ -452,15 +452,17 @@ MATH_DY_PLANES = 0x200       # include/dspn_nn.h DSPN_MATH_DY_PLANES
 
 
 def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None, wt_planes=None,
-                 math=None, dy_absmax=None, w_absmax=None, bn_dy_absmax=None, dy_planes=False):
+                 math=None, dy_absmax=None, w_absmax=None, bn_dy_absmax=None, dy_planes=False, wt_shape=None):
     """dy (N,Ho,Wo,ldy), wt (Cin,R,S,ldy) -> dx (N,H,W,ldc>=Cin).
     bn_bwd = (bn_x, scale, shift, mean, rstd, relu, sums): dx is the complete gradient of a BatchNorm(+ReLU) output
     whose input was bn_x; the two reductions of its backward pass are written to sums (tiles, 2, Cin).
     wt_planes: the piece planes of wt (weight_planes(w, transposed=True, cols=ldy)), used in the split math when
     ldy % 32 == 0 (made here from wt when the caller keeps none)."""
     N, H, W, Cx = x_shape
-    Cin, R, S, ldy = wt.shape
-    assert dy.shape[3] == ldy, (dy.shape, wt.shape)
+    # wt may be None when the call reads piece planes (wt_planes, split math with ldy % 32 == 0): wt_shape = (Cin, R, S, ldy)
+    Cin, R, S, ldy = wt.shape if wt is not None else wt_shape
+    assert dy.shape[3] == ldy, (dy.shape, (Cin, R, S, ldy))
+    assert wt is not None or wt_planes is not None
     math = _math_code(math)
     if math == 3 and dy.dtype == torch.float32:
         assert wt_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
@@ -477,7 +479,7 @@ def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=F
     Ho, Wo = dy.shape[1], dy.shape[2]
     if out is None:
         out = (zeros if Cx != Cin else empty)(N, H, W, Cx, device=dy.device, dtype=dy.dtype)
-    assert wt.dtype == dy.dtype == out.dtype, (dy.dtype, wt.dtype, out.dtype)
+    assert (wt is None or wt.dtype == dy.dtype) and dy.dtype == out.dtype, (dy.dtype, out.dtype)
     ws = workspace(L().dspn_conv2d_split_workspace_bytes(N * H * W, Cin), dy.device, "split")
     ph, pw = _hw(pad)
     bx, bsc, bsh, bmu, brs, brelu, bsums = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False, None)

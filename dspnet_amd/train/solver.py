@@ -221,7 +221,9 @@ class MultiTaskSolver:
         graph = torch.cuda.CUDAGraph()
         det = getattr(self.net, "det", None)
         try:
-            with torch.cuda.graph(graph):
+            # (captured on the solver's own high-priority stream when it has one: a replayed step then runs where an eager
+            # step runs, not on torch's normal-priority capture stream)
+            with torch.cuda.graph(graph, **({"stream": self.stream} if self.stream is not None else {})):
                 self.forward()
                 self.backward()
                 self.update()

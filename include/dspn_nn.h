@@ -117,7 +117,8 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                float *out_stats, size_t out_stats_bytes, float *out_minmax, int math,
                                const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream);
-/* out_minmax (optional; written in DSPN_MATH_F32_F16X2 together with out_stats, same size and tiling): per row tile and
+/* out_minmax (optional; written in DSPN_MATH_F32_F16X2 together with out_stats, SAME size and tiling -- the buffer must hold
+ * out_stats_bytes bytes, the one size argument covers both tables): per row tile and
  * channel the smallest [(t*2 + 0)*Cout + c] and largest [(t*2 + 1)*Cout + c] stored value.  A BatchNorm(+ReLU) of y is
  * monotone per channel, so the magnitude of what the next convolution multiplies is dspn_absmax_f32 over THIS table
  * (tiles*2 rows of Cout values) with that BatchNorm's scale / shift -- a few KB instead of a pass over y.

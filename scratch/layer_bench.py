@@ -41,7 +41,7 @@ for n in net.g.nodes:
     td = None
     if n.x.requires_grad:
         dx = n.x.own_grad()
-        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa))
+        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa, wt_shape=n.wt_shape))
     tot[0] += tf; tot[2] += tw; totf[0] += fl; totf[2] += fl
     if td: tot[1] += td; totf[1] += fl
     cnt[key] = cnt.get(key, 0) + 1
