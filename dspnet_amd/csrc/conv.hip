@@ -209,7 +209,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   // rows are 128 B, two per 256-B bank line, and the 16-byte slot s = (row & 1) * 8 + chunk of line L = row >> 1 holds what
   // an unswizzled image would keep in slot s ^ (L & 7).  A 16-lane group of ds_read_b128 (rows {0-3, 12-15, 20-27} or
   // {4-11, 16-19, 28-31} of a 32-row fragment, one chunk index) then covers all 16 slots of the bank line once.
+    // MEASURED (round 4, same box, twice each): 782 images/s with it, 785 - 787 with the register path it replaces (forward
+  // layers 1.5 % slower: at a tile's end the next tile's B piece can only be requested AFTER the epilogue has released the
+  // LDS, where the register path requests it before; data gradients 0.4 % faster).  In-kernel stamps say why neither
+  // matters much: a k-step spends ~600 of ~3100 cycles getting its four 1-KiB requests ACCEPTED by the texture path
+  // (64 B/clk per CU, 16 waves asking at once behind the barrier), whichever instruction carries them.  Kept as a build
+  // option (make DMA_B=1 -> -DDSPN_DMA_B), parity-green; the default build stages B through registers.
+#ifdef DSPN_DMA_B
   constexpr bool DMA_B = PRE && MATH == 3;
+#else
+  constexpr bool DMA_B = false;
+#endif
   constexpr int NWV = NTHR / 64;
   constexpr int B_NI = DMA_B ? BN / (8 * NWV) : 1;      // 1-KiB pieces (8 rows of the B tile) per wave and k-step
   static_assert(!DMA_B || (BN % (8 * NWV) == 0 && B_NI >= 1), "the B tile is a whole number of 1-KiB pieces per wave");
@@ -395,6 +405,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       }
     };
     if constexpr (INTF) {
+      // (Round 4, measured and not kept: these two 16-byte loads per thread and k-step are half as many texture-path requests
+      // again as the tiles themselves, and the same 16 bytes for the 64 threads of a chunk index -- fetched by 16 lanes of
+      // each wave and handed on by ds_swizzle: 799 against 808 - 810 images/s, the eight swizzles cost more than the 48 idle
+      // lanes save; fetched only at a block's first tap: eight registers more around the k-loop, scratch in the fused kernels)
       load_affine();
       tf_mask = 0;
     }
@@ -1280,7 +1294,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
   // split mode: three piece planes per operand, single-buffered: [3][kPK][RAB] then [3][kPK][RBB]
+  // LDS stages: the three-piece image is single-buffered (two barriers per k-step); the two-piece image of the 8-wave
+  // 128 x 128 tile fits TWICE in half a CU's LDS exactly (2 stages x 2 pieces x 32 pixels x (320 + 320) B = 80 KiB), which
+  // takes one of the two barriers out of every k-step (round 4, DSPN_WG_STAGES2: measured below before it became default)
+#ifdef DSPN_WG_STAGES2
+  constexpr int STAGES = (MATH == 2 || (MATH == 3 && WAVES_M * WAVES_N != 8)) ? 1 : 2, PLANES = SPLIT ? NPC : 1;
+#else
   constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? NPC : 1;
+#endif
   const float sc_a = MATH == 3 ? operand_scale(g.dy_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.x_absmax) : 1.f;
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
   const bool nf_a = MATH == 3 && operand_nonfinite(g.dy_absmax), nf_b = MATH == 3 && operand_nonfinite(g.x_absmax);
@@ -1328,18 +1349,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         if (b_row0 + i * B_RSTEP < kPK)
           *reinterpret_cast<u32x4_t *>(b + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 16) = hb[i];
     } else if constexpr (SPLIT) {
+      char *sA_ = hA + (STAGES == 1 ? 0 : buf) * (PLANES * kPK * RAB), *sB_ = hB + (STAGES == 1 ? 0 : buf) * (PLANES * kPK * RBB);
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         if constexpr (A_PL) {
           // chunk q = a_chunk of the pixel's BM channels: 32-channel block q >> 3, piece (q >> 2) & 1, channels 8 (q & 3) .. + 7
-          char *d = hA + ((a_chunk >> 2) & 1) * (kPK * RAB) + (a_row0 + i * A_RSTEP) * RAB + ((a_chunk >> 3) * 32 + (a_chunk & 3) * 8) * 2;
+          char *d = sA_ + ((a_chunk >> 2) & 1) * (kPK * RAB) + (a_row0 + i * A_RSTEP) * RAB + ((a_chunk >> 3) * 32 + (a_chunk & 3) * 8) * 2;
           *reinterpret_cast<float4 *>(d) = ra[i];
           continue;
         }
         bf16x4 p0, p1, p2;
         if constexpr (MATH == 3) { split2h(ra[i], sc_a, p0, p1); if (__builtin_expect(nf_a, 0)) repair_inf(p0, p1); }
         else split3(ra[i], p0, p1, p2);
-        char *d = hA + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8;
+        char *d = sA_ + (a_row0 + i * A_RSTEP) * RAB + a_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
         *reinterpret_cast<bf16x4 *>(d + kPK * RAB) = p1;
         if constexpr (MATH != 3) *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RAB) = p2;
@@ -1349,7 +1371,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         bf16x4 p0, p1, p2;
         if constexpr (MATH == 3) { split2h(rb[i], sc_b, p0, p1); if (__builtin_expect(nf_b, 0)) repair_inf(p0, p1); }
         else split3(rb[i], p0, p1, p2);
-        char *d = hB + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8;
+        char *d = sB_ + (b_row0 + i * B_RSTEP) * RBB + b_chunk * 8;
         *reinterpret_cast<bf16x4 *>(d) = p0;
         *reinterpret_cast<bf16x4 *>(d + kPK * RBB) = p1;
         if constexpr (MATH != 3) *reinterpret_cast<bf16x4 *>(d + 2 * kPK * RBB) = p2;
@@ -1393,8 +1415,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     if constexpr (SPLIT) {
       // the bf16 mode's transposed reads, once per piece plane; six MFMAs per accumulator and 16-pixel block (conv_nt_kernel)
       const int gl = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-      const char *a = hA + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
-      const char *b = hB + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *a = hA + buf * (PLANES * kPK * RAB) + (8 * (gl >> 1) + q) * RAB + (wm + 16 * (gl & 1) + 4 * pp) * 2;
+      const char *b = hB + buf * (PLANES * kPK * RBB) + (8 * (gl >> 1) + q) * RBB + (wn + 16 * (gl & 1) + 4 * pp) * 2;
       auto frag = [](const char *base, int row_bytes) {
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(base + 4 * row_bytes));
@@ -2541,9 +2563,14 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
   // mainloop buffers | staged output tile
   // (the float build sizes for its largest mode: float images 2 * kPK * (BM + BN) * 4 B; the three-piece bf16 image of the
   // split mode, single-buffered, 3 * kPK * row bytes, is smaller than the staged output tile for every tile shape but 32 x 128)
+#ifdef DSPN_WG_STAGES2
+  constexpr bool wg_two_stages = true;
+#else
+  constexpr bool wg_two_stages = false;
+#endif
   const size_t lds = kHalf ? std::max<size_t>(2 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)), sizeof(float) * BM * (BN + 4))
                            : std::max<size_t>(sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4)),
-                                              3 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)));
+                                              (wg_two_stages && g.bf16 == 3 && BM == 128 && BN == 128 ? 4 : 3) * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)));
   dspn::ProfScope prof(1, s);
 #ifdef DSPN_HALF
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \

@@ -76,9 +76,10 @@ def test_target_small_random(gpu_device, seed, ratio, thr, nthr):
                negative_mining_thresh=nthr)
 
 
-@pytest.mark.parametrize("hw,batch", [((512, 512), 8), ((512, 1024), 3)])
+@pytest.mark.parametrize("hw,batch", [((512, 512), 8), ((512, 1024), 3), ((512, 512), 32)])
 def test_target_dspnet_shape(gpu_device, hw, batch):
-    """the training configuration of symbol/multitask_symbol_builder.py:517-521"""
+    """the training configuration of symbol/multitask_symbol_builder.py:517-521 (round 4: also at the headline batch, 32 x 6132
+    anchors, against the oracle -- the greedy matching loop of target_match_kernel was rewritten this round)"""
     anc = mc.r50_anchors(*hw)
     lab, pred = mc.target_inputs(anc, batch=batch, seed=233)
     got = run_target(anc, lab, pred, overlap_threshold=.5, ignore_label=-1,
