@@ -112,7 +112,11 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
                                                                    const A4Ptr dx, int Hin, int Win, int C4,
                                                                    int Ho, int Wo, int ldo, int coff, int accumulate,
                                                                    const st_t *__restrict__ xfwd, double *__restrict__ tpart,
-                                                                   unsigned *__restrict__ absmax) {
+                                                                   unsigned *__restrict__ absmax, float4 *__restrict__ part) {
+  // part != NULL (small source maps, round 4): the rows of the pre-image box are cut into gridDim.y chunks, one workgroup
+  // each -- a 2 x 2 or 4 x 4 source otherwise leaves 128 / 512 workgroups walking ~4000 target pixels each (0.15 ms per map
+  // for a few KB of output) -- whose partial sums go to part[chunk][pixel][C4] and are added in chunk order by
+  // sampler_bwd_reduce_kernel; the theta rows become tpart[pixel * chunks + chunk]
   __shared__ float4 red[SL > 1 ? SL : 1][64];
   float mx = 0.f;       // largest |dx| this thread stores (absmax: the magnitude block of dx, two-piece math)
   __shared__ double tred[TH ? SL : 1][6];
@@ -146,6 +150,11 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
       wo_lo = (int)fmaxf(floorf(fw_lo) - 1.f, 0.f); wo_hi = (int)fminf(ceilf(fw_hi) + 1.f, (float)(Wo - 1));
       ho_lo = (int)fmaxf(floorf(fh_lo) - 1.f, 0.f); ho_hi = (int)fminf(ceilf(fh_hi) + 1.f, (float)(Ho - 1));
     }
+  }
+  if (part) {          // this workgroup's share of the box's rows
+    const int nch = (int)gridDim.y, per = (ho_hi - ho_lo + nch) / nch;
+    ho_lo += (int)blockIdx.y * per;
+    ho_hi = min(ho_hi, ho_lo + per - 1);
   }
   for (int cb = 0; cb < C4; cb += 64) {
     const int c4 = cb + lane;
@@ -190,13 +199,17 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
       }
     }
     if (sl == 0 && c4 < C4) {
-      if (accumulate) { const float4 p = dx[pix * C4 + c4]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
-      dx[pix * C4 + c4] = acc;
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+      if (part) {
+        part[((long long)blockIdx.y * gridDim.x + pix) * C4 + c4] = acc;
+      } else {
+        if (accumulate) { const float4 p = dx[pix * C4 + c4]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+        dx[pix * C4 + c4] = acc;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+      }
     }
     if (SL > 1) __syncthreads();
   }
-  if (absmax && sl == 0) {       // (kernel-uniform pointer; slice 0 = one wave holds every stored value)
+  if (absmax && !part && sl == 0) {       // (kernel-uniform pointers; slice 0 = one wave holds every stored value)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     unsigned *o = absmax + ((unsigned)pix & 63u);
@@ -214,7 +227,31 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
     if (sl == 0 && lane < 6) {
       double v = tred[0][lane];
       for (int q = 1; q < SL; ++q) v += tred[q][lane];
-      tpart[pix * 6 + lane] = v;
+      tpart[(part ? pix * gridDim.y + blockIdx.y : pix) * 6 + lane] = v;
+    }
+  }
+}
+
+// dx[pixel][C4] (+)= sum over the chunks of part[chunk][pixel][C4], in chunk order; optional magnitude block of the stored dx
+__global__ __launch_bounds__(256) void sampler_bwd_reduce_kernel(const float4 *__restrict__ part, const A4Ptr dx, long long n4,
+                                                                 int chunks, int accumulate, unsigned *__restrict__ absmax) {
+  float mx = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = part[i];
+    for (int c = 1; c < chunks; ++c) { const float4 v = part[(long long)c * n4 + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (accumulate) { const float4 p = dx[i]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+    dx[i] = a;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+  }
+  if (absmax) {
+    __shared__ float sm[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      if (mx > 0.f) atomicMax(absmax + (blockIdx.x & 63), __float_as_uint(mx));
     }
   }
 }
@@ -354,7 +391,7 @@ int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *thet
   const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
   hipStream_t s = (hipStream_t)stream;
 #define DSPN_SBD_(SL) hipLaunchKernelGGL((sampler_bwd_data_kernel<SL, false>), dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
-                                         A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, nullptr, nullptr, nullptr)
+                                         A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, nullptr, nullptr, nullptr, nullptr)
   if (rows >= 32) DSPN_SBD_(16);
   else if (rows >= 10) DSPN_SBD_(4);
   else DSPN_SBD_(1);
@@ -362,21 +399,51 @@ int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *thet
   return dspn::check_launch("affine_sampler_backward_data");
 }
 
+// chunks of the pre-image rows per source pixel (1: one workgroup per pixel does it all)
+static int sampler_chunks(int N, int Hin, int Win, int Ho) {
+  const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
+  return (rows >= 32 && (long long)N * Hin * Win <= 4096) ? 8 : 1;
+}
+#ifndef DSPN_HALF
+long long dspn_affine_sampler_theta_rows(int N, int Hin, int Win, int Ho) {
+  if (N <= 0 || Hin <= 0 || Win <= 0 || Ho <= 0) return 0;
+  return (long long)N * Hin * Win * sampler_chunks(N, Hin, Win, Ho);
+}
+size_t dspn_affine_sampler_backward_workspace_bytes(int N, int Hin, int Win, int C, int Ho) {
+  if (N <= 0 || Hin <= 0 || Win <= 0 || Ho <= 0 || C <= 0) return 0;
+  const int ch = sampler_chunks(N, Hin, Win, Ho);
+  return ch > 1 ? sizeof(float) * (size_t)ch * N * Hin * Win * C : 0;
+}
+#endif
+
 int DSPN_FN(dspn_affine_sampler_backward_data_theta)(const st_t *dy, const float *theta, const st_t *x, st_t *dx, int N, int Hin,
                                                 int Win, int C, int Ho, int Wo, int ldo, int coff, int accumulate,
-                                                double *theta_partial, size_t theta_partial_bytes, float *dx_absmax, void *stream) {
+                                                double *theta_partial, size_t theta_partial_bytes, float *dx_absmax,
+                                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(dy && theta && x && dx && theta_partial && N > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 &&
                    ldo % 4 == 0 && coff >= 0 && coff % 4 == 0 && coff + C <= ldo, "affine_sampler_backward_data_theta: bad argument");
   DSPN_REQUIRE(!accumulate || x != dx, "affine_sampler_backward_data_theta: x may alias dx only when dx is overwritten");
   const long long pix = (long long)N * Hin * Win;
   DSPN_REQUIRE(pix < (1ll << 31), "affine_sampler_backward_data_theta: too many source pixels");
-  if (theta_partial_bytes < sizeof(double) * 6 * (size_t)pix)
-    return dspn::fail(DSPN_ERR_WORKSPACE_, "affine_sampler_backward_data_theta: theta_partial holds N * Hin * Win rows of 6 doubles");
+  const int chunks = dspn::kHalf ? 1 : sampler_chunks(N, Hin, Win, Ho);
+  if (theta_partial_bytes < sizeof(double) * 6 * (size_t)pix * chunks)
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "affine_sampler_backward_data_theta: theta_partial holds dspn_affine_sampler_theta_rows() rows of 6 doubles");
   const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
   hipStream_t s = (hipStream_t)stream;
+  if (chunks > 1) {       // small source map: the pre-image rows of every pixel over `chunks` workgroups, then one reduce
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)chunks * pix * C)
+      return dspn::fail(DSPN_ERR_WORKSPACE_, "affine_sampler_backward_data_theta: workspace < dspn_affine_sampler_backward_workspace_bytes()");
+    float4 *part = static_cast<float4 *>(workspace);
+    hipLaunchKernelGGL((sampler_bwd_data_kernel<4, true>), dim3((unsigned)pix, chunks), dim3(64, 4), 0, s, dy, theta, A4Ptr(dx), Hin, Win,
+                       C / 4, Ho, Wo, ldo, coff, accumulate, x, theta_partial, nullptr, part);
+    const long long n4 = pix * (C / 4);
+    hipLaunchKernelGGL(sampler_bwd_reduce_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, part,
+                       A4Ptr(dx), n4, chunks, accumulate, reinterpret_cast<unsigned *>(dx_absmax));
+    return dspn::check_launch("affine_sampler_backward_data_theta");
+  }
 #define DSPN_SBD_(SL) hipLaunchKernelGGL((sampler_bwd_data_kernel<SL, true>), dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
                                          A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, x, theta_partial, \
-                                         dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax))
+                                         dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax), nullptr)
   if (rows >= 32) DSPN_SBD_(16);
   else if (rows >= 10) DSPN_SBD_(4);
   else DSPN_SBD_(1);

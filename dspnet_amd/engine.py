@@ -985,7 +985,7 @@ class BilinearConcatConv(Node):
         # d L / d affine_matrix needs the forward values W_c x_c: every source's data-gradient pass reads them (its own
         # pixel's, before it overwrites zc with the gradient) and leaves its share of the theta gradient as rows of tpart
         if self.tpart is None:
-            rows = [z.shape[0] * z.shape[1] * z.shape[2] for z in self.zc]
+            rows = [fn.affine_sampler_theta_rows(z.shape, self.z.shape[1], z.dtype) for z in self.zc]
             self.tpart = torch.zeros(sum(rows), 6, dtype=torch.float64, device=self.z.device)
             self.tpart_off = np.cumsum([0] + rows).tolist()
         Cin = self.offsets[-1]

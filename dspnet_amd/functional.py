@@ -92,7 +92,9 @@ _lib.register({
     "dspn_affine_sampler_backward_theta_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i,
                                                     _vp, _sz, _vp]),
     "dspn_affine_sampler_backward_data_theta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp,
-                                                         _vp]),
+                                                         _vp, _sz, _vp]),
+    "dspn_affine_sampler_theta_rows": (_ll, [_i, _i, _i, _i]),
+    "dspn_affine_sampler_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dspn_affine_sampler_theta_reduce_workspace_bytes": (_sz, [_ll]),
     "dspn_affine_sampler_theta_reduce": (_i, [_vp, _ll, _vp, _i, _vp, _sz, _vp]),
     "dspn_softmax_output_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),
@@ -888,13 +890,22 @@ def affine_sampler_backward_data_theta(dy, theta, x, coff, theta_partial, dx=Non
     N, Hin, Win, C = x.shape
     dx = empty(N, Hin, Win, C, device=dy.device, dtype=dy.dtype) if dx is None else dx
     assert dx.dtype == dy.dtype == x.dtype and theta_partial.dtype == torch.float64 and theta_partial.is_contiguous()
-    assert theta_partial.numel() >= 6 * N * Hin * Win
+    assert theta_partial.numel() >= 6 * affine_sampler_theta_rows(x.shape, dy.shape[1], x.dtype)
+    ws = workspace(L().dspn_affine_sampler_backward_workspace_bytes(N, Hin, Win, C, dy.shape[1]), dy.device, "sampler")
     check(_f("dspn_affine_sampler_backward_data_theta", dy)(ptr(dy), ptr(theta), ptr(x), ptr(dx), N, Hin, Win, C, dy.shape[1],
                                                           dy.shape[2], dy.shape[3], coff, int(accumulate), ptr(theta_partial),
                                                           theta_partial.numel() * 8,
-                                                          ptr(dx_absmax if dy.dtype == torch.float32 else None), stream()),
+                                                          ptr(dx_absmax if dy.dtype == torch.float32 else None),
+                                                          ptr(ws), ws.numel(), stream()),
           "affine_sampler_backward_data_theta")
     return dx
+
+
+def affine_sampler_theta_rows(x_shape, Ho, dtype=torch.float32):
+    """rows of the float64 (rows, 6) tensor affine_sampler_backward_data_theta fills for a source map of shape x_shape sampled
+    to Ho target rows (small float maps are split over several workgroups per pixel: one row each)"""
+    N, Hin, Win, _ = x_shape
+    return N * Hin * Win if dtype != torch.float32 else int(L().dspn_affine_sampler_theta_rows(N, Hin, Win, Ho))
 
 
 def affine_sampler_theta_reduce(theta_partial, dtheta, accumulate=False):

@@ -457,7 +457,7 @@ int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin
                                            int Wo, int ldo, float *dtheta, int accumulate, void *workspace,
                                            size_t workspace_bytes, void *stream);
 /* the data gradient of ONE source map and that source's share of the theta gradient from the same pass (round 4): as
- * dspn_affine_sampler_backward_data_f32, plus theta_partial[N * Hin * Win][6] (doubles, DEVICE, overwritten) -- per source
+ * dspn_affine_sampler_backward_data_f32, plus theta_partial[dspn_affine_sampler_theta_rows()][6] (doubles, DEVICE, overwritten) -- per source
  * pixel the sum over the target pixels that sample it of (d weight / d grid) . <dy[target], x[source pixel]> x (x_t, y_t, 1).
  * x: the source map itself (N,Hin,Win,C), as the forward call sampled it; it MAY be the buffer dx when accumulate == 0
  * (every workgroup reads its pixel before it writes it).  The sum over the rows of every source of one forward call is
@@ -467,7 +467,12 @@ int dspn_affine_sampler_backward_theta_f32(const float *const *x, const int *Hin
 int dspn_affine_sampler_backward_data_theta_f32(const float *dy, const float *theta, const float *x, float *dx, int N, int Hin,
                                                 int Win, int C, int Ho, int Wo, int ldo, int coff, int accumulate,
                                                 double *theta_partial, size_t theta_partial_bytes, float *dx_absmax,
-                                                void *stream);
+                                                void *workspace, size_t workspace_bytes, void *stream);
+/* rows of theta_partial one call writes (N * Hin * Win, times the number of workgroups a SMALL source map's pixels are split
+ * over: a 2 x 2 or 4 x 4 map would otherwise leave a few hundred workgroups walking thousands of target pixels each), and the
+ * scratch such a split call needs for the partial data gradients (0 for the others; `workspace` may then be NULL) */
+long long dspn_affine_sampler_theta_rows(int N, int Hin, int Win, int Ho);
+size_t dspn_affine_sampler_backward_workspace_bytes(int N, int Hin, int Win, int C, int Ho);
 size_t dspn_affine_sampler_theta_reduce_workspace_bytes(long long rows);
 int dspn_affine_sampler_theta_reduce(const double *theta_partial, long long rows, float *dtheta, int accumulate, void *workspace,
                                      size_t workspace_bytes, void *stream);
@@ -573,7 +578,7 @@ int dspn_affine_sampler_backward_data_bf16(const dspn_bf16 *dy, const float *the
 int dspn_affine_sampler_backward_data_theta_bf16(const dspn_bf16 *dy, const float *theta, const dspn_bf16 *x, dspn_bf16 *dx, int N,
                                                  int Hin, int Win, int C, int Ho, int Wo, int ldo, int coff, int accumulate,
                                                  double *theta_partial, size_t theta_partial_bytes, float *dx_absmax /* ignored */,
-                                                 void *stream);
+                                                 void *workspace /* unused */, size_t workspace_bytes, void *stream);
 int dspn_affine_sampler_forward_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C, const int *coff,
                                     int nsrc, const float *theta, dspn_bf16 *y, int N, int Ho, int Wo, int ldo, void *stream);
 int dspn_affine_sampler_backward_theta_bf16(const dspn_bf16 *const *x, const int *Hin, const int *Win, const int *C,

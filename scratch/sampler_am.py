@@ -14,7 +14,7 @@ th = torch.tensor([0.98, 0.03, -0.02, -0.04, 1.05, 0.01], device="cuda")
 dy = torch.randn(32, 64, 64, 172, device="cuda")
 for hw in (64, 32, 16, 8, 4, 2):
     x = torch.randn(32, hw, hw, 172, device="cuda")
-    part = torch.zeros(32 * hw * hw, 6, dtype=torch.float64, device="cuda")
+    part = torch.zeros(fn.affine_sampler_theta_rows(x.shape, 64), 6, dtype=torch.float64, device="cuda")
     am = torch.zeros(64, device="cuda")
     dx = torch.empty_like(x)
     t0 = timeit(lambda: fn.affine_sampler_backward_data(dy, th, x.shape, 0, dx=dx))

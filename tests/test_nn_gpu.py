@@ -353,7 +353,7 @@ def test_affine_sampler_matches_torch_grid_sample(gpu_device, theta, shapes):
         assert torch.equal(dth, again)                                   # fixed-order reductions
         # round 4: the same gradient as a by-product of the data-gradient passes (one call per source, rows of float64
         # partial sums, two-level fixed-order reduce) -- with the forward values read from the buffer dx overwrites
-        rows = [xdev.shape[0] * xdev.shape[1] * xdev.shape[2] for xdev in xd]
+        rows = [fn.affine_sampler_theta_rows(xdev.shape, Ho) for xdev in xd]
         part = torch.full((sum(rows), 6), float("nan"), dtype=torch.float64, device="cuda")
         r0 = 0
         for x, xdev, off, r in zip(xs, xd, offs, rows):
@@ -370,6 +370,34 @@ def test_affine_sampler_matches_torch_grid_sample(gpu_device, theta, shapes):
         again = torch.zeros(6, device="cuda")
         fn.affine_sampler_theta_reduce(part, again)
         assert torch.equal(fused, again)
+
+
+@pytest.mark.parametrize("hw", [(2, 2), (4, 4), (3, 5)])
+def test_affine_sampler_small_source_maps_split_over_workgroups(gpu_device, hw):
+    """Round 4: a 2 x 2 or 4 x 4 source sampled to 64 x 64 -- every source pixel gathers from thousands of target pixels -- runs
+    its data-gradient / theta pass as 8 workgroups per pixel and one fixed-order reduce; same dx (to rounding: other
+    summation order), same theta gradient, in place and accumulating, and bitwise reproducible"""
+    g = torch.Generator().manual_seed(21)
+    B, C, Ho, Wo = 3, 44, 64, 64
+    th = torch.tensor([0.97, 0.04, -0.03, -0.05, 1.04, 0.02], device="cuda")
+    x = torch.randn(B, hw[0], hw[1], C, generator=g).cuda()
+    dy = torch.randn(B, Ho, Wo, C + 4, generator=g).cuda()
+    assert fn.affine_sampler_theta_rows(x.shape, Ho) == 8 * B * hw[0] * hw[1]          # the split form is what runs
+    ref = fn.affine_sampler_backward_data(dy, th, x.shape, 4)
+    dth_ref = torch.zeros(6, device="cuda")
+    fn.affine_sampler_backward_theta(fn.SamplerSources([(x, 4)]), th, dy, dth_ref)
+    part = torch.full((fn.affine_sampler_theta_rows(x.shape, Ho), 6), float("nan"), dtype=torch.float64, device="cuda")
+    buf = x.clone(); am = torch.zeros(64, device="cuda")
+    dx = fn.affine_sampler_backward_data_theta(dy, th, buf, 4, part, dx=buf, dx_absmax=am)      # in place
+    assert float((dx - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(am.max()) == float(dx.abs().max())
+    dth = torch.zeros(6, device="cuda")
+    fn.affine_sampler_theta_reduce(part, dth)
+    assert float((dth - dth_ref).abs().max()) <= 1e-4 * float(dth_ref.abs().max())
+    acc = fn.affine_sampler_backward_data_theta(dy, th, x, 4, part, dx=ref.clone(), accumulate=True)
+    assert float((acc - 2 * ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    again = fn.affine_sampler_backward_data_theta(dy, th, x, 4, part)
+    assert torch.equal(again, dx)
 
 
 @pytest.mark.parametrize("hin,win", [(4, 4), (16, 16), (64, 64), (5, 9)])
