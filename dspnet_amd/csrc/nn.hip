@@ -869,13 +869,22 @@ __global__ void tap_spread_kernel_(const CA1Ptr dy, const A1Ptr dz, int H, int W
 // ------------------------------------------------------------------ pooling
 // optional argmax record: position r*k+s of the FIRST maximum of each window in (h, w) scan order, one
 // byte per element (255 = no finite maximum); the backward pass then needs neither x nor y
-template <bool IDX>
-__global__ void maxpool_fwd_kernel(const CA4Ptr x, const A4Ptr y,
+// AFF (round 4): the pooled tensor is (relu)(x * scale[c] + shift[c]) -- a BatchNorm(+ReLU) folded into the pooling pass
+// (symbol/resnet.py:96-98: bn0 -> relu0 -> pooling0): the normalised 32 x 256 x 256 x 64 tensor (537 MB at the bench shape) is
+// neither written nor read back; same fmaf as every other evaluation of the affine, so the ReLU mask the BatchNorm backward
+// recomputes from x is the one applied here.  absmax (optional): the magnitude block of the pooled output.
+template <bool IDX, bool AFF>
+__global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const CA4Ptr x, const A4Ptr y,
                                    uchar4 *__restrict__ argmax, int H, int W,
-                                   int C4, int k, int stride, int pad, int Ho, int Wo, long long total) {
+                                   int C4, int k, int stride, int pad, int Ho, int Wo, long long total,
+                                   const float4 *__restrict__ scale, const float4 *__restrict__ shift, int relu,
+                                   unsigned *__restrict__ absmax) {
+  float mx = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
+    float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (AFF) { sa = scale[c4]; sb = shift[c4]; }
     long long t = i / C4;
     const int wo = (int)(t % Wo); t /= Wo;
     const int ho = (int)(t % Ho);
@@ -888,7 +897,11 @@ __global__ void maxpool_fwd_kernel(const CA4Ptr x, const A4Ptr y,
       for (int s = 0; s < k; ++s) {
         const int w = wo * stride - pad + s;
         if ((unsigned)w >= (unsigned)W) continue;
-        const float4 v = x[((n * H + h) * W + w) * C4 + c4];
+        float4 v = x[((n * H + h) * W + w) * C4 + c4];
+        if constexpr (AFF) {
+          v = make_float4(fmaf(v.x, sa.x, sb.x), fmaf(v.y, sa.y, sb.y), fmaf(v.z, sa.z, sb.z), fmaf(v.w, sa.w, sb.w));
+          if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        }
         const int pos = r * k + s;
         if (v.x > m.x) { m.x = v.x; ix = pos; }
         if (v.y > m.y) { m.y = v.y; iy = pos; }
@@ -898,6 +911,20 @@ __global__ void maxpool_fwd_kernel(const CA4Ptr x, const A4Ptr y,
     }
     y[i] = m;
     if constexpr (IDX) argmax[i] = make_uchar4((unsigned char)ix, (unsigned char)iy, (unsigned char)iz, (unsigned char)iw);
+    if constexpr (AFF) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w))));
+  }
+  if constexpr (AFF) {
+    if (absmax) {          // (kernel-uniform)
+      __shared__ float sm[kT / 64];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < kT / 64; ++w) mx = fmaxf(mx, sm[w]);
+        if (mx > 0.f && mx < INFINITY) atomicMax(absmax + (blockIdx.x & 63), __float_as_uint(mx));
+      }
+    }
   }
 }
 
@@ -1797,14 +1824,33 @@ int DSPN_FN(dspn_maxpool_forward)(const st_t *x, st_t *y, unsigned char *argmax,
   DSPN_REQUIRE(!argmax || k * k < 255, "maxpool_forward: argmax record needs k*k < 255");
   const long long total = (long long)N * Ho * Wo * (C / 4);
   if (argmax)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+    hipLaunchKernelGGL((maxpool_fwd_kernel<true, false>), dim3(grid_for(total)), dim3(kT), 0, S_(stream),
                        CA4Ptr(x), A4Ptr(y),
-                       reinterpret_cast<uchar4 *>(argmax), H, W, C / 4, k, stride, pad, Ho, Wo, total);
+                       reinterpret_cast<uchar4 *>(argmax), H, W, C / 4, k, stride, pad, Ho, Wo, total, nullptr, nullptr, 0, nullptr);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+    hipLaunchKernelGGL((maxpool_fwd_kernel<false, false>), dim3(grid_for(total)), dim3(kT), 0, S_(stream),
                        CA4Ptr(x), A4Ptr(y),
-                       static_cast<uchar4 *>(nullptr), H, W, C / 4, k, stride, pad, Ho, Wo, total);
+                       static_cast<uchar4 *>(nullptr), H, W, C / 4, k, stride, pad, Ho, Wo, total, nullptr, nullptr, 0, nullptr);
   return dspn::check_launch("maxpool_forward");
+}
+
+/* max pooling of (relu)(x * in_scale[c] + in_shift[c]): the BatchNorm(+ReLU) in front of the pooling layer folded in */
+int DSPN_FN(dspn_maxpool_forward_bn)(const st_t *x, const float *in_scale, const float *in_shift, int in_relu, st_t *y,
+                                unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                                float *out_absmax, void *stream) {
+  DSPN_REQUIRE(x && y && in_scale && in_shift && C % 4 == 0 && N > 0, "maxpool_forward_bn: bad argument");
+  DSPN_REQUIRE(!argmax || k * k < 255, "maxpool_forward_bn: argmax record needs k*k < 255");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  unsigned *am = dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(out_absmax);
+  if (argmax)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<true, true>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), CA4Ptr(x), A4Ptr(y),
+                       reinterpret_cast<uchar4 *>(argmax), H, W, C / 4, k, stride, pad, Ho, Wo, total,
+                       reinterpret_cast<const float4 *>(in_scale), reinterpret_cast<const float4 *>(in_shift), in_relu, am);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<false, true>), dim3(grid_for(total)), dim3(kT), 0, S_(stream), CA4Ptr(x), A4Ptr(y),
+                       static_cast<uchar4 *>(nullptr), H, W, C / 4, k, stride, pad, Ho, Wo, total,
+                       reinterpret_cast<const float4 *>(in_scale), reinterpret_cast<const float4 *>(in_shift), in_relu, am);
+  return dspn::check_launch("maxpool_forward_bn");
 }
 int DSPN_FN(dspn_maxpool_backward_argmax)(const unsigned char *argmax, const st_t *dy, st_t *dx, int N, int H,
                                      int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream) {

@@ -1093,12 +1093,29 @@ class MaxPool(Node):
             return -(-(h + 2 * pad - kernel) // stride) + 1
         self.out = g.tensor((N, osz(H), osz(W), C), name)
         self.out.am_slot = x.am_slot        # |max over a window| <= the input's magnitude
+        # input produced by a deferred BatchNorm(+ReLU) (round 4: bn0 -> relu0 -> pooling0 of the resnet stem): the pooling pass
+        # reads the raw tensor and applies the affine itself, the normalised tensor is never written
+        self.x_raw, self.in_affine, self._g = x, None, g
+        self.am_out = None
+        if x.affine_src is not None:
+            raw, sc, sh, arelu = x.affine_src
+            self.x_raw, self.in_affine = raw, (sc, sh, arelu)
+            if g.math == "f16x2" and self.out.dtype == torch.float32:
+                self.am_out = g.new_scalar()
+                self.out.am_slot = self.am_out
         # one byte per output element: which window position held the maximum (read by backward
         # instead of x and y)
         self.argmax = (torch.zeros(self.out.shape, dtype=torch.uint8, device=g.device)
                        if x.requires_grad and kernel * kernel < 255 else None)
 
     def forward(self):
+        if self.in_affine is not None:
+            am = self._g.scalar(self.am_out)
+            fn.maxpool_forward(self.x_raw.data, self.k, self.s, self.p, out=self.out.data, argmax=self.argmax,
+                               in_affine=self.in_affine, out_absmax=am)
+            if am is not None:
+                self._g._am_done.add(self.am_out)
+            return
         fn.maxpool_forward(self.x.data, self.k, self.s, self.p, out=self.out.data, argmax=self.argmax)
 
     def backward(self):
@@ -1109,6 +1126,7 @@ class MaxPool(Node):
         if self.argmax is not None:
             fn.maxpool_backward_argmax(self.argmax, self.out.grad, self.x.shape, self.k, self.s, self.p, dx=dx)
         else:
+            assert self.in_affine is None, "a pooling layer behind a deferred BatchNorm keeps its argmax record"
             fn.maxpool_backward(self.x.data, self.out.data, self.out.grad, self.k, self.s, self.p, dx=dx)
 
 

@@ -79,6 +79,7 @@ _lib.register({
     "dspn_tap_sum_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_tap_spread_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_maxpool_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "dspn_maxpool_backward_argmax_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -111,7 +112,7 @@ _lib.register({
 for _name in ("dspn_conv2d_forward_bn", "dspn_conv2d_dgrad_bn", "dspn_conv2d_wgrad_bn", "dspn_conv2d_wgrad_slabs",
               "dspn_conv2d_input_sum_grad", "dspn_bn_stats", "dspn_bn_apply", "dspn_bn_backward",
               "dspn_bn_backward_from_sums", "dspn_add", "dspn_relu_backward", "dspn_relu_backward_colsum", "dspn_colsum",
-              "dspn_nchw_to_nhwc", "dspn_copy_block", "dspn_tap_sum", "dspn_tap_spread", "dspn_maxpool_forward",
+              "dspn_nchw_to_nhwc", "dspn_copy_block", "dspn_tap_sum", "dspn_tap_spread", "dspn_maxpool_forward", "dspn_maxpool_forward_bn",
               "dspn_maxpool_backward_argmax", "dspn_maxpool_backward", "dspn_avgpool_forward", "dspn_avgpool_backward",
               "dspn_avgpool2d_forward", "dspn_avgpool2d_backward", "dspn_softmax_output", "dspn_affine_sampler_forward",
               "dspn_affine_sampler_backward_data", "dspn_affine_sampler_backward_theta",
@@ -757,14 +758,22 @@ def transpose_bnc(src, out=None):
 
 
 # ------------------------------------------------------------------ pooling / sampler
-def maxpool_forward(x, k, stride, pad, out=None, argmax=None):
-    """argmax: optional uint8 tensor of the output's shape receiving the window position of each maximum"""
+def maxpool_forward(x, k, stride, pad, out=None, argmax=None, in_affine=None, out_absmax=None):
+    """argmax: optional uint8 tensor of the output's shape receiving the window position of each maximum.
+    in_affine = (scale, shift, relu): pool (relu)(x * scale + shift) instead of x (the BatchNorm in front folded in);
+    out_absmax then optionally receives the magnitude block of the pooled output (float tensors)"""
     N, H, W, C = x.shape
     if out is None:
         out = empty(N, conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad), C, device=x.device, dtype=x.dtype)
     Ho, Wo = out.shape[1], out.shape[2]     # a larger (pooling_convention='full') output is the caller's choice
     assert argmax is None or (argmax.dtype == torch.uint8 and argmax.shape == out.shape)
     assert out.dtype == x.dtype
+    if in_affine is not None:
+        sc, sh, relu = in_affine
+        check(_f("dspn_maxpool_forward_bn", x)(ptr(x), ptr(sc), ptr(sh), int(bool(relu)), ptr(out), ptr(argmax), N, H, W, C, k,
+                                             stride, pad, Ho, Wo, ptr(out_absmax if x.dtype == torch.float32 else None), stream()),
+              "maxpool_forward_bn")
+        return out
     check(_f("dspn_maxpool_forward", x)(ptr(x), ptr(out), ptr(argmax), N, H, W, C, k, stride, pad, Ho, Wo, stream()),
           "maxpool_forward")
     return out

@@ -53,7 +53,9 @@ def resnet(g, data, units, num_stages, filter_list, bottle_neck=True):
     bn_data = g.add(E.BatchNorm(g, x, "bn_data", fix_gamma=True, beta_grad_from_consumer=True))
     x = g.add(E.Conv(g, bn_data.out, "conv0", filter_list[0], 7, 2, 3, cin_logical=3,
                      input_sum_grad=bn_data.beta)).out
-    x = g.add(E.BatchNorm(g, x, "bn0", relu=True)).out
+    # bn0 -> relu0 -> pooling0 (symbol/resnet.py:96-98): the BatchNorm-apply + ReLU runs inside the pooling pass (round 4), the
+    # normalised 64-channel 256 x 256 tensor is never written (engine.FUSE_BATCHNORM = False materialises it again)
+    x = g.add(E.BatchNorm(g, x, "bn0", relu=True, defer_apply=True)).out
     body = g.add(E.MaxPool(g, x, "pooling0", 3, 2, 1)).out
     plus = 0
     for i in range(num_stages):

@@ -399,6 +399,13 @@ int dspn_tap_spread_f32(const float *dy, float *dz, int N, int H, int W, int Cou
  * scan order, 255 if none */
 int dspn_maxpool_forward_f32(const float *x, float *y, unsigned char *argmax, int N, int H, int W, int C, int k,
                              int stride, int pad, int Ho, int Wo, void *stream);
+/* the same pooling of (relu)(x * in_scale[c] + in_shift[c]) (round 4): the BatchNorm(+ReLU) in front of a pooling layer
+ * (symbol/resnet.py:96-98, bn0 -> relu0 -> pooling0) folded into the pooling pass -- the normalised tensor is never written.
+ * in_scale / in_shift: C floats each (dspn_bn_stats*'s scale / shift).  out_absmax (optional, float tensors): the magnitude
+ * block of y (DSPN_ABSMAX_SLOTS floats, zeroed by the caller). */
+int dspn_maxpool_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu, float *y,
+                                unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                                float *out_absmax, void *stream);
 /* gradient goes to the first maximum of each window in (h, w) scan order; from the argmax record ... */
 int dspn_maxpool_backward_argmax_f32(const unsigned char *argmax, const float *dy, float *dx, int N, int H,
                                      int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
@@ -559,6 +566,9 @@ int dspn_tap_spread_bf16(const dspn_bf16 *dy, dspn_bf16 *dz, int N, int H, int W
                         int S, int pad_h, int pad_w, void *stream);
 int dspn_maxpool_forward_bf16(const dspn_bf16 *x, dspn_bf16 *y, unsigned char *argmax, int N, int H, int W, int C, int k,
                              int stride, int pad, int Ho, int Wo, void *stream);
+int dspn_maxpool_forward_bn_bf16(const dspn_bf16 *x, const float *in_scale, const float *in_shift, int in_relu, dspn_bf16 *y,
+                                 unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                                 float *out_absmax_unused, void *stream);
 int dspn_maxpool_backward_argmax_bf16(const unsigned char *argmax, const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H,
                                      int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);
 int dspn_maxpool_backward_bf16(const dspn_bf16 *x, const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, int N, int H,

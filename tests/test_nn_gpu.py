@@ -267,6 +267,24 @@ def test_maxpool_3x3_s2_p1(gpu_device):
     assert torch.equal(fn.maxpool_backward_argmax(am, nhwc(dy), xd.shape, 3, 2, 1), dx)
 
 
+def test_maxpool_with_folded_batchnorm_relu(gpu_device):
+    """Round 4: dspn_maxpool_forward_bn_f32 -- max pooling of relu(x * scale + shift) without the normalised tensor -- gives
+    the values, the argmax record and the magnitude of bn_apply followed by the plain pooling, bit for bit (negative scales
+    included: the affine is applied per element before the comparison, not to the maximum)"""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(3, 37, 41, 24, generator=g).cuda()
+    sc = (torch.randn(24, generator=g)).cuda(); sh = (torch.randn(24, generator=g) * 0.5).cuda()
+    for relu in (True, False):
+        y = fn.bn_apply(x, sc, sh, relu=relu)
+        ref = fn.maxpool_forward(y, 3, 2, 1)
+        idx_ref = torch.zeros(ref.shape, dtype=torch.uint8, device="cuda"); fn.maxpool_forward(y, 3, 2, 1, argmax=idx_ref)
+        idx = torch.zeros_like(idx_ref); am = torch.zeros(64, device="cuda")
+        got = fn.maxpool_forward(x, 3, 2, 1, argmax=idx, in_affine=(sc, sh, relu), out_absmax=am)
+        assert torch.equal(got, ref) and torch.equal(idx, idx_ref)
+        assert float(am.max()) == float(ref.abs().max())
+        assert torch.equal(fn.maxpool_forward(x, 3, 2, 1, in_affine=(sc, sh, relu)), ref)
+
+
 @pytest.mark.parametrize("k", [1, 2, 4])
 def test_avgpool(gpu_device, k):
     g = torch.Generator().manual_seed(6)
