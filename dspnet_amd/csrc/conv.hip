@@ -1158,7 +1158,7 @@ struct WgradGeom {
   int in_relu;
   int bf16;                           // host side only: math mode of this call
   const float *dy_absmax, *x_absmax;  // DSPN_MATH_F32_F16X2: device scalars, largest magnitude of dy / of x after its affine (ConvGeom)
-  int dy_planes;                      // host side only: dy is fp16 piece planes (MATHX = 4)
+  int dy_planes, x_planes;            // host side only: dy / x are fp16 piece planes (MATHX = 4 / 5 / 6)
 };
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
@@ -1172,9 +1172,11 @@ template <int WAVES_M, int WAVES_N, int TM, int TN, int MATHX, bool INTF>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 4 : 2) void conv_wgrad_kernel(
     const st_t *__restrict__ x, const st_t *__restrict__ dy, float *__restrict__ slab,
     const WgradGeom g, const int k_tiles, const int j_tiles) {
-  constexpr int MATH = MATHX == 4 ? 3 : MATHX;
-  constexpr bool A_PL = MATHX == 4;
-  static_assert(!A_PL || !kHalf, "piece-plane gradients: float tensors");
+  // MATHX = 5: x as piece planes (a materialised BatchNorm output written by dspn_bn_apply_f32, y_planes), 6: both operands
+  constexpr int MATH = MATHX >= 4 ? 3 : MATHX;
+  constexpr bool A_PL = MATHX == 4 || MATHX == 6, B_PL = MATHX == 5 || MATHX == 6;
+  static_assert(!(A_PL || B_PL) || !kHalf, "piece-plane operands: float tensors");
+  static_assert(!B_PL || !INTF, "piece-plane x: the affine has been applied by the pass that wrote the planes");
   constexpr bool BF16 = MATH != 0, SPLIT = MATH >= 2;   // as in conv_nt_kernel
   constexpr int NPC = MATH == 3 ? 2 : 3;
   static_assert(!kHalf || MATH == 1, "bf16 tensors always run on the bf16 MFMA");
@@ -1368,6 +1370,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
+        if constexpr (B_PL) {       // (as A_PL above: chunk q = b_chunk of the tile row's BN columns)
+          char *d = sB_ + ((b_chunk >> 2) & 1) * (kPK * RBB) + (b_row0 + i * B_RSTEP) * RBB + ((b_chunk >> 3) * 32 + (b_chunk & 3) * 8) * 2;
+          *reinterpret_cast<float4 *>(d) = rb[i];
+          continue;
+        }
         bf16x4 p0, p1, p2;
         if constexpr (MATH == 3) { split2h(rb[i], sc_b, p0, p1); if (__builtin_expect(nf_b, 0)) repair_inf(p0, p1); }
         else split3(rb[i], p0, p1, p2);
@@ -1959,9 +1966,9 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
                                          : (uni ? DSPN_NT_(true, 0, T, E) : DSPN_NT_(false, 0, T, E)))
 #endif
 #ifndef DSPN_HALF
-  if (g.a_planes) {      // (dispatch_nt has checked: two-piece math, uniform taps, no input affine, no statistics)
+  if (g.a_planes) {      // (dispatch_nt has checked: two-piece math, uniform taps, no input affine)
     if (g.bn_sums) return DSPN_NT_(true, 3, false, 6);
-    return DSPN_NT_(true, 3, false, 4);
+    return g.stats ? DSPN_NT_(true, 3, false, 5) : DSPN_NT_(true, 3, false, 4);
   }
 #endif
   if (g.bn_sums) return DSPN_NT_UB_(false, 2);                       // data gradient feeding a BatchNorm backward
@@ -1979,7 +1986,7 @@ int launch_nt_f16x2(const st_t *in, const st_t *w, const float *bias, st_t *out,
   return dspn::fail(DSPN_ERR_ARG_, "conv: no two-piece kernels for bf16 tensors");
 #else
 #define DSPN_NT3_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 3, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
-  if (g.a_planes) return g.bn_sums ? DSPN_NT3_(false, 6) : DSPN_NT3_(false, 4);
+  if (g.a_planes) return g.bn_sums ? DSPN_NT3_(false, 6) : (g.stats ? DSPN_NT3_(false, 5) : DSPN_NT3_(false, 4));
   if (g.bn_sums) return DSPN_NT3_(false, 2);
   if (g.in_scale) return g.stats ? DSPN_NT3_(true, 1) : DSPN_NT3_(true, 0);
   return g.stats ? DSPN_NT3_(false, 1) : DSPN_NT3_(false, 0);
@@ -2043,8 +2050,8 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   const long long nblk = tiles(bm_[cfg], bn_[cfg]);
   const int nk = (g.TR * g.TS * (g.Cin / kEPC) + 7) >> 3;
   int splits = 1, per = nk;
-  if (g.a_planes && !(pre && g.bf16 == 3 && !g.in_scale && !g.stats))
-    return dspn::fail(DSPN_ERR_ARG_, "conv: a piece-plane gradient operand needs DSPN_MATH_F32_F16X2, a multiple of 32 channels (%d) and no input affine / statistics", g.Cin);
+  if (g.a_planes && !(pre && g.bf16 == 3 && !g.in_scale))
+    return dspn::fail(DSPN_ERR_ARG_, "conv: a piece-plane operand needs DSPN_MATH_F32_F16X2, a multiple of 32 channels (%d) and no input affine", g.Cin);
   if (g.stats && (!g.dense || !(g.flags & 16) || g.Cout % 4 != 0))
     return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: output statistics need a dense, 16-byte aligned output with Cout %% 4 == 0");
   if (g.bn_sums && (g.in_scale || g.stats))
@@ -2201,6 +2208,7 @@ static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine
   g.bf16 = kHalf ? 1 : math;
   g.w_planes = w_planes;
   g.a_absmax = scales.a; g.b_absmax = scales.b;
+  g.a_planes = scales.a_planes;
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }
@@ -2231,9 +2239,11 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
                                int math, const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0, "conv2d_forward: bad geometry");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
-  math &= ~DSPN_MATH_UNSCALED_OK;
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, x_planes = (math & DSPN_MATH_X_PLANES) ? 1 : 0;
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_X_PLANES);
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_forward: math is one of DSPN_MATH_*");
+  DSPN_REQUIRE(!x_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && Cin % 32 == 0 && x_absmax && !in_scale),
+               "conv2d_forward: DSPN_MATH_X_PLANES needs DSPN_MATH_F32_F16X2, Cin %% 32 == 0, no input affine and the block the planes were cut by (x_absmax)");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && w_absmax),
                "conv2d_forward: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_forward: in_scale and in_shift go together");
@@ -2249,7 +2259,7 @@ int DSPN_FN(dspn_conv2d_forward_bn)(const st_t *x, const float *in_scale, const 
   const int nb = batch_chunk(N, (long long)sizeof(st_t) * H * W * Cin);
   for (int n0 = 0; n0 < N; n0 += nb) {
     const int n = std::min(nb, N - n0);
-    const int rc = conv2d_forward_one(math, OpScales{x_absmax, w_absmax}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, out_minmax, w, w_planes, bias,
+    const int rc = conv2d_forward_one(math, OpScales{x_absmax, w_absmax, x_planes}, x + (long long)n0 * H * W * Cin, InAffine{in_scale, in_shift, in_relu}, out_stats, out_minmax, w, w_planes, bias,
                                       residual ? residual + (long long)n0 * ybs : nullptr, y + (long long)n0 * ybs, n, H, W,
                                       Cin, Cout, R, S, stride, pad_h, pad_w, dil, Ho, Wo, y_batch_stride, y_ldc, relu,
                                       accumulate, workspace, workspace_bytes, stream);
@@ -2538,7 +2548,7 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
   g.in_scale = tf.scale; g.in_shift = tf.shift; g.in_relu = tf.relu;
   g.bf16 = kHalf ? 1 : math;
   g.dy_absmax = scales.a; g.x_absmax = scales.b;
-  g.dy_planes = scales.a_planes;
+  g.dy_planes = scales.a_planes & 1; g.x_planes = (scales.a_planes >> 1) & 1;
   {
     const long long xb = (long long)sizeof(st_t) * N * H * W * Cin, yb = (long long)sizeof(st_t) * N * Ho * Wo * ldy;
     if (xb >= (1ll << 31) || yb >= (1ll << 31))
@@ -2581,7 +2591,10 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
 #else
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
   {                                                                                                      \
-    if (g.in_scale) {                                                                                    \
+    if (g.bf16 == 3 && g.x_planes) {                                                                     \
+      if (g.dy_planes) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 6, false)                                    \
+      else DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 5, false)                                                \
+    } else if (g.in_scale) {                                                                             \
       if (g.bf16 == 3 && g.dy_planes) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 4, true)                      \
       else if (g.bf16 == 3) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 3, true)                                \
       else if (g.bf16 == 2) DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, 2, true)                                \
@@ -2608,7 +2621,8 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
 #ifdef DSPN_DEV_FAST
-  if (g.bf16 == 3 && g.dy_planes) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, false) }
+  if (g.bf16 == 3 && g.x_planes) { if (g.dy_planes) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 6, false) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 5, false) }
+  else if (g.bf16 == 3 && g.dy_planes) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, false) }
   else if (g.bf16 == 3) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, false) }
   else
 #endif
@@ -2635,10 +2649,13 @@ int DSPN_FN(dspn_conv2d_wgrad_bn)(const st_t *x, const float *in_scale, const fl
                              void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, dy_planes = (math & DSPN_MATH_DY_PLANES) ? 1 : 0;
-  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES);
-  DSPN_REQUIRE(!dy_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  const int dy_planes = ((math & DSPN_MATH_DY_PLANES) ? 1 : 0) | ((math & DSPN_MATH_X_PLANES) ? 2 : 0);     // bit 0: dy, bit 1: x
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES | DSPN_MATH_X_PLANES);
+  DSPN_REQUIRE(!(dy_planes & 1) || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_DY_PLANES needs DSPN_MATH_F32_F16X2, ldy == Cout, Cout %% 32 == 0 and the block the planes were cut by (dy_absmax)");
+  DSPN_REQUIRE(!(dy_planes & 2) || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && Cin % 32 == 0 && x_absmax && !in_scale),
+               "conv2d_wgrad: DSPN_MATH_X_PLANES needs DSPN_MATH_F32_F16X2, Cin %% 32 == 0, no input affine and the block the planes were cut by (x_absmax)");
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");
@@ -2673,10 +2690,13 @@ int DSPN_FN(dspn_conv2d_wgrad_slabs)(const st_t *x, const float *in_scale, const
                                 int Wo, int math, const float *x_absmax, const float *dy_absmax, void *stream) {
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && ldy > 0, "conv2d_wgrad: bad geometry");
   DSPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-  const int math_vouch = math & DSPN_MATH_UNSCALED_OK, dy_planes = (math & DSPN_MATH_DY_PLANES) ? 1 : 0;
-  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES);
-  DSPN_REQUIRE(!dy_planes || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
+  const int math_vouch = math & DSPN_MATH_UNSCALED_OK;
+  const int dy_planes = ((math & DSPN_MATH_DY_PLANES) ? 1 : 0) | ((math & DSPN_MATH_X_PLANES) ? 2 : 0);     // bit 0: dy, bit 1: x
+  math &= ~(DSPN_MATH_UNSCALED_OK | DSPN_MATH_DY_PLANES | DSPN_MATH_X_PLANES);
+  DSPN_REQUIRE(!(dy_planes & 1) || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && ldy == Cout && Cout % 32 == 0 && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_DY_PLANES needs DSPN_MATH_F32_F16X2, ldy == Cout, Cout %% 32 == 0 and the block the planes were cut by (dy_absmax)");
+  DSPN_REQUIRE(!(dy_planes & 2) || (!dspn::kHalf && math == DSPN_MATH_F32_F16X2 && Cin % 32 == 0 && x_absmax && !in_scale),
+               "conv2d_wgrad: DSPN_MATH_X_PLANES needs DSPN_MATH_F32_F16X2, Cin %% 32 == 0, no input affine and the block the planes were cut by (x_absmax)");
   DSPN_REQUIRE(math >= DSPN_MATH_FP32 && math <= DSPN_MATH_F32_F16X2, "conv2d_wgrad: math is one of DSPN_MATH_*");
   DSPN_REQUIRE(dspn::kHalf || math != DSPN_MATH_F32_F16X2 || math_vouch || (x_absmax && dy_absmax),
                "conv2d_wgrad: DSPN_MATH_F32_F16X2 needs the magnitude block of both operands (dspn_absmax_f32); a caller who knows that every |operand| < 65504 passes math | DSPN_MATH_UNSCALED_OK");

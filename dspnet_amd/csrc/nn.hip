@@ -286,6 +286,34 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const CA4Ptr x, const floa
   }
 }
 
+// (relu)(x * scale[c] + shift[c]) written as fp16 PIECE PLANES (the layout of bn_bwd_apply_planes_kernel below), cut by
+// the scale of `block` -- the magnitude the statistics finalize formed from the producer's per-channel extremes BEFORE this
+// pass (dspn_bn_stats_from_tiles_f32 out_absmax).  For a BatchNorm in front of a multi-tap convolution: that convolution's
+// forward and weight gradient copy the records (conv_nt_kernel EPIX & 4, conv_wgrad_kernel MATHX = 5 / 6) instead of
+// applying the affine and cutting every element once per (tap, column tile).
+__global__ __launch_bounds__(kT) void bn_apply_planes_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+                                const float4 *__restrict__ shift, uint2 *__restrict__ planes,
+                                long long n4, int C4, int relu, const float *__restrict__ block) {
+  const float s = dspn::pieces::operand_scale(block);
+  const bool nf = dspn::pieces::operand_nonfinite(block);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const float4 v = x[i], a = scale[c4], b = shift[c4];
+    float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+    if (relu) {
+      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+    }
+    dspn::pieces::bf16x4 p0, p1;
+    dspn::pieces::split2h(o, s, p0, p1);
+    if (__builtin_expect(nf, 0)) dspn::pieces::repair_inf(p0, p1);
+    const long long u = (i - c4) * 2 + (c4 >> 3) * 16 + (c4 & 7);
+    planes[u] = __builtin_bit_cast(uint2, p0);
+    planes[u + 8] = __builtin_bit_cast(uint2, p1);
+  }
+}
+
 // a BOUND of the magnitude of (relu)(x * scale[c] + shift[c]) from the magnitude M of x alone: max over c of
 // |scale[c]| * M + |shift[c]| -- for a convolution that folds a BatchNorm into its loader and whose raw input has a known
 // magnitude but no per-channel extremes (a pooled tensor).  A bound that is too large by less than 2^17 costs the two-piece
@@ -1606,6 +1634,20 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
 
 // BatchNorm backward whose two reductions (sum dy', sum dy' xhat) were gathered per row tile by the data-gradient
 // kernel that produced dy (bn_sums of dspn_conv2d_dgrad_bn_f32): finalize + apply only
+#ifndef DSPN_HALF
+int dspn_bn_apply_planes_f32(const float *x, const float *scale, const float *shift, void *y_planes, long long rows, int C,
+                             int relu, const float *y_absmax, void *stream) {
+  DSPN_REQUIRE(x && scale && shift && y_planes && y_absmax, "bn_apply_planes: null pointer (y_absmax is the block the planes are cut by)");
+  DSPN_REQUIRE(rows > 0 && C > 0 && C % 32 == 0, "bn_apply_planes: C must be a positive multiple of 32");
+  DSPN_REQUIRE(static_cast<const void *>(x) != y_planes, "bn_apply_planes: in place is not supported");
+  const long long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream), reinterpret_cast<const float4 *>(x),
+                     reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
+                     static_cast<uint2 *>(y_planes), n4, C / 4, relu, y_absmax);
+  return dspn::check_launch("bn_apply_planes");
+}
+#endif
+
 int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,

@@ -317,9 +317,34 @@ class Graph:
             n.x_ext = fn.zeros(2, x.shape[3], device=self.device)
             n.am_dyin = self.new_scalar(backward=True)
 
+    def _plan_input_planes(self):
+        """"f16x2" math, round 4: a deferred BatchNorm with a MULTI-TAP convolution among its readers also writes
+        (relu)(x * scale + shift) as fp16 piece planes (dspn_bn_apply_planes_f32), cut by the magnitude its statistics finalize
+        has just formed; that convolution's forward and weight gradient then copy their x operand into LDS instead of applying
+        the affine and cutting every element once per (tap, column tile) -- 9 x Cout / 128 times for a 3 x 3.  The 1 x 1 readers
+        (and the BatchNorm backward) keep reading the raw tensor.  In the residual units: bn2 -> conv2."""
+        if self.math != "f16x2" or self.device.type != "cuda":
+            return
+        for n in self.nodes:
+            if not isinstance(n, BatchNorm) or n.defer_apply is not True or n.tile_stats is None:
+                continue
+            x = n.x
+            if (x.dtype != torch.float32 or x.shape[3] % 32 != 0 or x.data is None
+                    or getattr(getattr(x, "producer", None), "out_minmax", None) is None):
+                continue
+            cons = [c for c in n.conv_consumers
+                    if c.w.shape[1] * c.w.shape[2] > 1 and c.math == "f16x2" and c.wp is not None and c.x_raw is x]
+            if not cons:
+                continue
+            n.planes = fn.zeros(*x.shape, device=self.device)
+            for c in cons:
+                c.x_planes_bn = n
+
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._resolve_auto_deferred()
+        if _os.environ.get("DSPN_X_PLANES", "1") != "0":       # (A/B switch)
+            self._plan_input_planes()
         self._plan_bn_backward_fusion()
         self._plan_gradient_magnitudes()
         if _os.environ.get("DSPN_DY_PLANES", "1") != "0":      # (A/B switch)
@@ -608,6 +633,9 @@ class BatchNorm(Node):
         # round 4 (Graph._plan_gradient_planes): dx leaves as fp16 piece planes; x_ext = per-channel extremes of x from the
         # forward finalize, am_dyin = slot of the magnitude of this node's own output gradient (from the data gradient's epilogue)
         self.dx_planes, self.x_ext, self.am_dyin = False, None, None
+        # round 4 (Graph._plan_input_planes): the output as fp16 piece planes for the multi-tap convolutions behind a DEFERRED
+        # apply; planes_ready: written by this step's forward (the magnitude they are cut by came out of the finalize)
+        self.planes, self.planes_ready = None, False
         self._g = g
         # True when this node's backward is the LAST writer of x's gradient (set by Graph.finalize): only then is the dx it
         # stores the complete gradient whose magnitude the producing convolution may use
@@ -630,6 +658,9 @@ class BatchNorm(Node):
                                    tile_minmax=mm if am is not None else None, relu=self.relu, out_absmax=am,
                                    out_absmin=None if am is None else g.scalars_min[slot:slot + 1],
                                    out_chan_minmax=self.x_ext if am is not None else None)
+            self.planes_ready = self.planes is not None and am is not None
+            if self.planes_ready:
+                fn.bn_apply_planes(self.x.data, self.scale, self.shift, am, relu=self.relu, out=self.planes)
         else:
             fn.bn_stats(self.x.data, self.eps, None if self.gamma is None else self.gamma.data, self.beta.data,
                         self.mean, self.rstd, self.scale, self.shift)
@@ -745,6 +776,7 @@ class Conv(Node):
             if key not in g._am_x:
                 g._am_x[key] = g.new_scalar()
             self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(backward=True), g.new_scalar()
+        self.x_planes_bn = None      # the deferred BatchNorm that also leaves this node's input as piece planes (Graph._plan_input_planes)
         self.wp = self.wtp = None
         if g.device.type == "cuda":
             npc = fn.plane_pieces(g.math)
@@ -827,11 +859,18 @@ class Conv(Node):
                               x_absmax=xa, w_absmax=wa)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
-        fn.conv2d_forward(self.x_raw.data, self.wop(), None if self.b is None else self.b.data, self.stride,
+        xp = self._x_planes()
+        fn.conv2d_forward(self.x_raw.data if xp is None else xp, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
-                          residual=None if self.residual is None else self.residual.data, in_affine=self.in_affine,
+                          residual=None if self.residual is None else self.residual.data,
+                          in_affine=self.in_affine if xp is None else None,
                           out_stats=None if self.out_stats is None else self.out_stats[0], w_planes=self.wp,
-                          math=self.math, x_absmax=xa, w_absmax=wa, out_minmax=self.out_minmax)
+                          math=self.math, x_absmax=xa, w_absmax=wa, out_minmax=self.out_minmax, x_planes=xp is not None)
+
+    def _x_planes(self):
+        """the input as piece planes, when the BatchNorm in front wrote them this step (cut by this node's x magnitude)"""
+        bn = self.x_planes_bn
+        return bn.planes if (bn is not None and bn.planes_ready and self.am_x in self._g._am_done) else None
 
     def backward(self):
         if not self.out._gw:
@@ -862,11 +901,15 @@ class Conv(Node):
                 fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
                                 out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math, x_absmax=xa)
         elif self.slabs is not None:
-            fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
-                                  in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya, dy_planes=planes)
+            xp = self._x_planes()
+            fn.conv2d_wgrad_slabs(self.x_raw.data if xp is None else xp, dy, self.w.shape, self.slabs, self.stride, self.pad,
+                                  self.dil, in_affine=self.in_affine if xp is None else None, math=self.math, x_absmax=xa,
+                                  dy_absmax=dya, dy_planes=planes, x_planes=xp is not None)
         else:
-            fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
-                            in_affine=self.in_affine, math=self.math, x_absmax=xa, dy_absmax=dya, dy_planes=planes)
+            xp = self._x_planes()
+            fn.conv2d_wgrad(self.x_raw.data if xp is None else xp, dy, self.w.shape, self.stride, self.pad, self.dil,
+                            out=self.w.grad, in_affine=self.in_affine if xp is None else None, math=self.math, x_absmax=xa,
+                            dy_absmax=dya, dy_planes=planes, x_planes=xp is not None)
         self.slabs_fresh = self.slabs is not None
         if self.input_sum_grad is not None:
             fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,

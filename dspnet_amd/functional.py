@@ -57,6 +57,7 @@ _lib.register({
     "dspn_bn_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_bn_stats_f32": (_i, [_vp, _ll, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp]),
+    "dspn_bn_apply_planes_f32": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp]),
     "dspn_absmax_affine_bound_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "dspn_bn_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _sz,
                                   _vp]),
@@ -359,15 +360,17 @@ def weight_planes_batch(table, n, total):
 
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
                    in_affine=None, out_stats=None, w_planes=None, math=None, x_absmax=None, w_absmax=None,
-                   out_minmax=None):
+                   out_minmax=None, x_planes=False):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
     in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x.
     math: "fp32" / "bf16" / "bf16x3" / "f16x2" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split
-    math modes when Cin % 32 == 0 (made here, one extra launch, when the caller keeps none)."""
+    math modes when Cin % 32 == 0 (made here, one extra launch, when the caller keeps none).
+    x_planes: x holds the fp16 piece planes bn_apply_planes wrote (cut by x_absmax), "f16x2" only."""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
     math = _math_code(math)
+    assert not x_planes or (math == 3 and x.dtype == torch.float32 and x_absmax is not None and in_affine is None)
     assert out_minmax is None or (out_stats is not None and out_minmax.numel() == out_stats.numel())
     if math == 3 and x.dtype == torch.float32:     # "f16x2": operand magnitudes (made here when the caller keeps none)
         assert w_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
@@ -394,7 +397,8 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
                                          ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
-                                         ptr(out_minmax), math, ptr(x_absmax), ptr(w_absmax), ptr(ws), ws.numel(), stream()),
+                                         ptr(out_minmax), math | (MATH_X_PLANES if x_planes else 0), ptr(x_absmax),
+                                         ptr(w_absmax), ptr(ws), ws.numel(), stream()),
           "conv2d_forward")
     return out
 
@@ -452,6 +456,7 @@ def conv_dgrad_bn_tiles(x_shape, stride):
 
 
 MATH_DY_PLANES = 0x200       # include/dspn_nn.h DSPN_MATH_DY_PLANES
+MATH_X_PLANES = 0x400        # include/dspn_nn.h DSPN_MATH_X_PLANES
 
 
 def conv2d_dgrad(dy, wt, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, bn_bwd=None, wt_planes=None,
@@ -501,8 +506,9 @@ def _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax):
 
 
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, in_affine=None, math=None,
-                 x_absmax=None, dy_absmax=None, dy_planes=False):
-    """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward"""
+                 x_absmax=None, dy_absmax=None, dy_planes=False, x_planes=False):
+    """x (N,H,W,Cin), dy (N,Ho,Wo,ldy) -> dw (Cout,R,S,Cin); in_affine as in conv2d_forward; x_planes / dy_planes: the
+    operand is fp16 piece planes cut by its magnitude block ("f16x2")"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
     assert Cw == Cin
@@ -515,11 +521,12 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, dil=1, out=None, accumulate=Fa
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     assert x.dtype == dy.dtype and out.dtype == torch.float32
     math = _math_code(math)
+    assert not x_planes or (x_absmax is not None and in_affine is None)
     x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_bn", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(out), N, H, W, Cin, Cout, ldy,
                                        R, S, stride, ph, pw, dil, Ho, Wo, int(accumulate),
-                                       math | (MATH_DY_PLANES if dy_planes else 0), ptr(x_absmax),
-                                       ptr(dy_absmax), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
+                                       math | (MATH_DY_PLANES if dy_planes else 0) | (MATH_X_PLANES if x_planes else 0),
+                                       ptr(x_absmax), ptr(dy_absmax), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
     return out
 
 
@@ -550,7 +557,7 @@ def conv2d_wgrad_splits(x_shape, dy_shape, w_shape, stride):
 
 
 def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=None, math=None, x_absmax=None,
-                       dy_absmax=None, dy_planes=False):
+                       dy_absmax=None, dy_planes=False, x_planes=False):
     """the weight-gradient GEMM alone: split-K partial sums -> slabs (splits, Cout, R, S, Cin); see slab_reduce_batch"""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w_shape
@@ -559,11 +566,13 @@ def conv2d_wgrad_slabs(x, dy, w_shape, slabs, stride=1, pad=0, dil=1, in_affine=
     sc, sh, arelu = in_affine if in_affine is not None else (None, None, False)
     assert x.dtype == dy.dtype and slabs.dtype == torch.float32
     math = _math_code(math)
+    assert not x_planes or (x_absmax is not None and in_affine is None)
     x_absmax, dy_absmax = _wgrad_absmax(x, dy, in_affine, math, x_absmax, dy_absmax)
     check(_f("dspn_conv2d_wgrad_slabs", x)(ptr(x), ptr(sc), ptr(sh), int(arelu), ptr(dy), ptr(slabs), slabs.numel() * 4,
                                           N, H, W, Cin, Cout, dy.shape[3], R, S, stride, ph, pw, dil, dy.shape[1],
-                                          dy.shape[2], math | (MATH_DY_PLANES if dy_planes else 0), ptr(x_absmax),
-                                          ptr(dy_absmax), stream()), "conv2d_wgrad_slabs")
+                                          dy.shape[2],
+                                          math | (MATH_DY_PLANES if dy_planes else 0) | (MATH_X_PLANES if x_planes else 0),
+                                          ptr(x_absmax), ptr(dy_absmax), stream()), "conv2d_wgrad_slabs")
 
 
 def slab_reduce_table(entries, device):
@@ -623,6 +632,17 @@ def bn_apply(x, scale, shift, relu=False, out=None, out_absmax=None):
     assert out.dtype == x.dtype and (out_absmax is None or out_absmax.numel() == ABSMAX_SLOTS)
     check(_f("dspn_bn_apply", x)(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
                                 ptr(out_absmax if x.dtype == torch.float32 else None), stream()), "bn_apply")
+    return out
+
+
+def bn_apply_planes(x, scale, shift, y_absmax, relu=False, out=None):
+    """(relu)(x * scale + shift) as fp16 piece planes [pixel][C / 32][piece][32] in a buffer of x's shape and bytes, cut by
+    the magnitude block y_absmax (known beforehand: bn_stats_from_tiles out_absmax) -- the x operand of conv2d_forward /
+    conv2d_wgrad(x_planes=True)"""
+    out = torch.empty_like(x) if out is None else out
+    assert x.dtype == out.dtype == torch.float32 and x.shape[-1] % 32 == 0 and y_absmax.numel() == ABSMAX_SLOTS
+    check(L().dspn_bn_apply_planes_f32(ptr(x), ptr(scale), ptr(shift), ptr(out), _rows(x), x.shape[-1], int(relu),
+                                       ptr(y_absmax), stream()), "bn_apply_planes")
     return out
 
 

@@ -97,6 +97,10 @@ size_t dspn_conv2d_split_workspace_bytes(long long out_pixels, int Cout);
  * (dx_planes), cut with the scale of the block passed as dy_absmax.  Needs ldy % 32 == 0 (and ldy == Cout for the weight
  * gradient). */
 #define DSPN_MATH_DY_PLANES 0x200
+/* OR-ed into `math` of dspn_conv2d_forward_bn_f32 / dspn_conv2d_wgrad_bn_f32 / dspn_conv2d_wgrad_slabs_f32 (with
+ * DSPN_MATH_F32_F16X2; round 4): x is the piece planes dspn_bn_apply_planes_f32 wrote, cut with the scale of the block
+ * passed as x_absmax.  Needs Cin % 32 == 0 and no input affine (in_scale == NULL: the planes hold the affine's result). */
+#define DSPN_MATH_X_PLANES 0x400
 
 int dspn_conv2d_forward_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                             int N, int H, int W, int Cin, int Cout, int R, int S,
@@ -329,6 +333,13 @@ size_t dspn_bn_tiles_workspace_bytes(int tiles, int C);
  * convolutions that multiply it in DSPN_MATH_F32_F16X2).  The caller zeroes it, as for dspn_absmax_f32. */
 int dspn_bn_apply_f32(const float *x, const float *scale, const float *shift, float *y, long long rows,
                       int C, int relu, float *out_absmax, void *stream);
+/* (round 4) the same values written as fp16 PIECE PLANES for DSPN_MATH_F32_F16X2 -- [pixel][C / 32][piece][32] halves, the
+ * bytes and byte offsets of the float tensor (rows * C * 4 bytes) -- cut with the scale of the block y_absmax, which the
+ * caller has BEFORE this pass: dspn_bn_stats_from_tiles_f32 forms it from the producer's per-channel extremes (out_absmax).
+ * A multi-tap convolution behind the BatchNorm then reads the planes with DSPN_MATH_X_PLANES and copies them into LDS
+ * instead of applying the affine and cutting each element once per (tap, column tile).  C % 32 == 0; not in place. */
+int dspn_bn_apply_planes_f32(const float *x, const float *scale, const float *shift, void *y_planes, long long rows, int C,
+                             int relu, const float *y_absmax, void *stream);
 
 /* Backward of the fused op.  If relu != 0, dy is first masked with (x*scale + shift > 0), i.e. the
  * forward output's sign recomputed from x (the forward output itself is not read).

@@ -120,6 +120,20 @@ def test_convolution_argument_validation_without_gpu():
     assert b"piece planes" in lib.dspn_last_error()                                         # C % 32
     assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 1, p, p, p, 1, p, 1 << 20, None) == -1   # accumulate
     assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 0, p, None, p, 1, p, 1 << 20, None) == -1  # no dy_absmax
+    # ... and the INPUT as piece planes (written by dspn_bn_apply_planes_f32): two-piece math, Cin % 32, no affine, its block
+    assert fwd(Cin=64, math=0 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert fwd(Cin=48, math=3 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert fwd(Cin=64, math=3 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()      # no x_absmax
+    def wgrad(math, Cin=64, x_absmax=p, in_scale=None):
+        return lib.dspn_conv2d_wgrad_bn_f32(p, in_scale, in_scale, 0, p, p, 1, 8, 8, Cin, 64, 64, 3, 3, 1, 1, 1, 1, 8, 8, 0, math,
+                                            x_absmax, p, None, 0, None)
+    assert wgrad(2 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert wgrad(3 | 0x400, Cin=48) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert wgrad(3 | 0x400, x_absmax=None) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert wgrad(3 | 0x400, in_scale=p) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
+    assert lib.dspn_bn_apply_planes_f32(p, p, p, p, 64, 48, 1, p, None) == -1 and b"multiple of 32" in lib.dspn_last_error()
+    assert lib.dspn_bn_apply_planes_f32(p, p, p, p, 64, 64, 1, None, None) == -1      # the block the planes are cut by
+    assert lib.dspn_bn_apply_planes_f32(p, p, p, ctypes.c_void_p(256), 64, 64, 1, p, None) == -1 and b"in place" in lib.dspn_last_error()
     # batched weight transposes count 32 x 32 tiles of a tap
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout

@@ -849,6 +849,76 @@ def test_gradient_as_piece_planes_from_batchnorm_backward(gpu_device, case):
     assert float((dxa_p - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 96, 3, 1, 1), (3, 25, 23, 96, 64, 3, 2, 1), (2, 20, 20, 32, 160, 5, 1, 2),
+                                  (1, 17, 17, 128, 192, (1, 7), 1, (0, 3))])
+def test_input_as_piece_planes_from_batchnorm_apply(gpu_device, case):
+    """Round 4: relu(x * scale + shift) of a BatchNorm in front of a multi-tap convolution written ONCE as
+    fp16 piece planes (dspn_bn_apply_planes_f32), cut by the magnitude the statistics finalize formed from the producer's
+    extremes; the convolution's forward (with its own statistics epilogue) and weight gradient read them with
+    DSPN_MATH_X_PLANES.  The planes hold exactly the pieces the folded-affine loader cuts, so both paths give the same bits;
+    the weight gradient is also checked with dy as piece planes (both operands copied)."""
+    N, H, W, Cin, Cout, k, stride, pad = case
+    if fn.get_conv_math() != "f16x2":
+        pytest.skip("the two-piece math is not this process's default")
+    kh, kw = fn._hw(k); ph, pw = fn._hw(pad)
+    g = torch.Generator().manual_seed(N + H + Cin + Cout + 11)
+    x0 = torch.randn(N, H, W, 32, generator=g).cuda()
+    w0 = (torch.randn(Cin, 1, 1, 32, generator=g) / np.sqrt(32)).cuda()
+    gamma = (torch.rand(Cin, generator=g) * 1.5 + 0.25).cuda(); beta = (torch.randn(Cin, generator=g) * 0.3).cuda()
+    w = (torch.randn(Cout, kh, kw, Cin, generator=g) / np.sqrt(Cin * kh * kw)).cuda()
+    tiles, tile_rows = fn.conv_stats_layout(N * H * W, Cin)
+    st = torch.zeros(tiles, 2, Cin, device="cuda"); mm = torch.zeros(tiles, 2, Cin, device="cuda")
+    x = fn.conv2d_forward(x0, w0, None, 1, 0, 1, out_stats=st, out_minmax=mm)
+    mean, rstd, scale, shift = (torch.zeros(Cin, device="cuda") for _ in range(4))
+    am = torch.zeros(64, device="cuda")
+    fn.bn_stats_from_tiles(st, tiles, tile_rows, N * H * W, Cin, 2e-5, gamma, beta, mean, rstd, scale, shift,
+                           tile_minmax=mm, relu=True, out_absmax=am)
+    act = fn.bn_apply(x, scale, shift, relu=True)
+    assert float(am.max()) == float(act.abs().max()), "the finalize's magnitude is that of the activation"
+    pl = fn.bn_apply_planes(x, scale, shift, am, relu=True)
+    dec, s_x = _decode_planes(pl, tuple(x.shape), am)
+    assert float((dec - act.double()).abs().max()) <= 2.0 ** -21 * (2.0 ** 15 / s_x), "the planes are the cut of the activation"
+    # forward, with the statistics / extremes epilogue a following BatchNorm asks for
+    Ho, Wo = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+    t2, _ = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    outs = []
+    for planes in (False, True):
+        st2 = torch.zeros(t2, 2, Cout, device="cuda"); mm2 = torch.zeros(t2, 2, Cout, device="cuda")
+        y = fn.conv2d_forward(pl if planes else x, w, None, stride, pad, 1, in_affine=None if planes else (scale, shift, True),
+                              out_stats=st2, out_minmax=mm2, x_absmax=am, x_planes=planes)
+        y_plain = fn.conv2d_forward(pl if planes else x, w, None, stride, pad, 1, in_affine=None if planes else (scale, shift, True),
+                                    x_absmax=am, x_planes=planes)
+        # (without the statistics epilogue a small problem may take the split-K path: another summation order)
+        assert float((y - y_plain).abs().max()) <= 2e-6 * float(y.abs().max())
+        outs.append((y, st2, mm2, y_plain))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), "planes and folded affine cut the same pieces"
+    ref = fn.conv2d_forward(act, w, None, stride, pad, 1, math="fp32")
+    assert float((outs[1][0] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # weight gradient: x planes with a float dy, and with dy as planes too
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    am_dy = fn.absmax(dy)
+    dw_f = fn.conv2d_wgrad(x, dy, tuple(w.shape), stride, pad, 1, in_affine=(scale, shift, True), x_absmax=am, dy_absmax=am_dy)
+    dw_p = fn.conv2d_wgrad(pl, dy, tuple(w.shape), stride, pad, 1, x_absmax=am, dy_absmax=am_dy, x_planes=True)
+    assert torch.equal(dw_f, dw_p)
+    ref = fn.conv2d_wgrad(act, dy, tuple(w.shape), stride, pad, 1, math="fp32")
+    assert float((dw_p - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    if Cout % 32 == 0:
+        one, zero = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+        dyp = fn.bn_apply_planes(dy, one, zero, am_dy)            # (identity affine: dy cut into planes by its own block)
+        dw_pp = fn.conv2d_wgrad(pl, dyp, tuple(w.shape), stride, pad, 1, x_absmax=am, dy_absmax=am_dy, x_planes=True, dy_planes=True)
+        assert torch.equal(dw_pp, dw_p)
+        dw_fp = fn.conv2d_wgrad(x, dyp, tuple(w.shape), stride, pad, 1, in_affine=(scale, shift, True), x_absmax=am, dy_absmax=am_dy,
+                                dy_planes=True)
+        assert torch.equal(dw_fp, dw_p)
+    slabs_n = fn.conv2d_wgrad_splits(tuple(x.shape), tuple(dy.shape), tuple(w.shape), stride)
+    if slabs_n > 0:
+        sl_f = torch.zeros(slabs_n, w.numel(), device="cuda"); sl_p = torch.zeros_like(sl_f)
+        fn.conv2d_wgrad_slabs(x, dy, tuple(w.shape), sl_f, stride, pad, 1, in_affine=(scale, shift, True), x_absmax=am, dy_absmax=am_dy)
+        fn.conv2d_wgrad_slabs(pl, dy, tuple(w.shape), sl_p, stride, pad, 1, x_absmax=am, dy_absmax=am_dy, x_planes=True)
+        assert torch.equal(sl_f, sl_p)
+
+
 @pytest.mark.parametrize("rows,C,ld", [(1000, 64, 64), (70000, 30, 32), (5, 8, 8), (300000, 128, 128)])
 def test_relu_backward_colsum(gpu_device, rows, C, ld):
     g = torch.Generator().manual_seed(rows + C)
