@@ -690,6 +690,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         }
       };
       block(0);
+      // (Round 4, measured and not kept: with pure-copy operands, the k-step's four 1-KiB requests per wave issued BETWEEN
+      // this block's MFMAs -- sched_group_barrier MFMA / VMEM pairs -- instead of in a burst behind the barrier: 828.3 / 827.9
+      // against 830.0 / 827.5 images/s on one box, the data-gradient layers within 1 %: the order of issue is not the limit)
       // the rows requested before this k-step have had the first block's MFMAs to arrive: their pieces are formed on the
       // vector ALU between the second block's MFMAs
       __builtin_amdgcn_sched_barrier(0);

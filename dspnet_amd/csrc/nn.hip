@@ -195,6 +195,11 @@ __global__ __launch_bounds__(1024) void bn_stats_tiles_final_kernel(
 // single-workgroup-per-16-channels finalize kernels below read 32x fewer entries.
 //   MODE 0: (mean, M2) pairs  -> (mean_g, M2_g) by the one-sweep double formula;  MODE 1: plain sums
 constexpr int kTileGroup = 32;
+// tables at least this long are pre-reduced (DSPN_TILE_GROUP_MIN: timing experiments)
+static int tile_group_min() {
+  static const int v = [] { const char *e = getenv("DSPN_TILE_GROUP_MIN"); return e ? atoi(e) : 1024; }();
+  return v;
+}
 // mm / mm_out (MODE 0, optional): the per-tile (min, max) table of the same tiles, merged into one pair per group
 template <int MODE>
 __global__ __launch_bounds__(256) void tile_group_kernel(const float *__restrict__ ts, int tiles, int tile_rows,
@@ -291,15 +296,15 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const CA4Ptr x, const floa
 // pass (dspn_bn_stats_from_tiles_f32 out_absmax).  For a BatchNorm in front of a multi-tap convolution: that convolution's
 // forward and weight gradient copy the records (conv_nt_kernel EPIX & 4, conv_wgrad_kernel MATHX = 5 / 6) instead of
 // applying the affine and cutting every element once per (tap, column tile).
-__global__ __launch_bounds__(kT) void bn_apply_planes_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+// Streaming form of bn_bwd_apply_kernel below: a grid whose stride is a multiple of C4 (`fixed_c`) gives a thread ONE channel
+// group, and U elements are requested before the first is used.
+template <int U>
+__global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
                                 const float4 *__restrict__ shift, uint2 *__restrict__ planes,
-                                long long n4, int C4, int relu, const float *__restrict__ block) {
+                                long long n4, int C4, int relu, const float *__restrict__ block, int fixed_c) {
   const float s = dspn::pieces::operand_scale(block);
   const bool nf = dspn::pieces::operand_nonfinite(block);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const float4 v = x[i], a = scale[c4], b = shift[c4];
+  auto one = [&](const long long i, const int c4, const float4 v, const float4 a, const float4 b) __attribute__((always_inline)) {
     float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
     if (relu) {
       o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
@@ -311,6 +316,33 @@ __global__ __launch_bounds__(kT) void bn_apply_planes_kernel(const float4 *__res
     const long long u = (i - c4) * 2 + (c4 >> 3) * 16 + (c4 & 7);
     planes[u] = __builtin_bit_cast(uint2, p0);
     planes[u + 8] = __builtin_bit_cast(uint2, p1);
+  };
+  const long long cstride = (long long)gridDim.x * (U * 256);
+  long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
+  if (fixed_c) {
+    const int c4 = (int)(base % C4);
+    const float4 a = scale[c4], b = shift[c4];
+    for (; base + (U - 1) * 256 < n4; base += cstride) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = x[base + u * 256];
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(base + u * 256, c4, v[u], a, b);
+    }
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + u * 256;
+      if (i < n4) one(i, c4, x[i], a, b);
+    }
+  } else {
+    for (; base < n4; base += cstride) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = base + u * 256;
+        if (i >= n4) break;
+        const int c4 = (int)(i % C4);
+        one(i, c4, x[i], scale[c4], shift[c4]);
+      }
+    }
   }
 }
 
@@ -826,6 +858,28 @@ __global__ void copy_block_vec_kernel(const dspn::u32x4_t *__restrict__ src, dsp
   }
 }
 #ifndef DSPN_HALF
+// many block copies in ONE launch (the SSD head packing: six small maps per pass): rows sorted by `begin`, the first
+// element of the row's range in the launch's flat index space, found by binary search (as slab_reduce_batch_kernel)
+struct CopyDesc { const float *src; float *dst; long long rows_per_sample, sss, dss; int C, lds, soff, ldd, doff, accumulate; long long begin; };
+static_assert(sizeof(CopyDesc) == 72, "copy_block_batch table row (dspnet_amd/functional.py copy_block_table)");
+__global__ void copy_block_batch_kernel(const CopyDesc *__restrict__ d, int n, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const CopyDesc e = d[lo];
+    const long long j = i - e.begin;
+    const int c = (int)(j % e.C);
+    const long long r = j / e.C;
+    const long long sm = r / e.rows_per_sample, rr = r - sm * e.rows_per_sample;
+    const float v = e.src[sm * e.sss + rr * e.lds + e.soff + c];
+    const long long di = sm * e.dss + rr * e.ldd + e.doff + c;
+    e.dst[di] = e.accumulate ? e.dst[di] + v : v;
+  }
+}
 __global__ void transpose_bnc_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                      int N, int C, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -1545,7 +1599,7 @@ int dspn_bn_stats_from_tiles_f32(const float *tile_stats, int tiles, int tile_ro
                "bn_stats_from_tiles: bad argument");
   DSPN_REQUIRE((tile_minmax != nullptr) == (out_absmax != nullptr), "bn_stats_from_tiles: tile_minmax and out_absmax go together");
   int mm_tiles = tiles;
-  if (tiles >= 1024 && workspace && workspace_bytes >= bn_tiles_workspace_bytes(tiles, C)) {
+  if (tiles >= tile_group_min() && workspace && workspace_bytes >= bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = static_cast<float *>(workspace);
     float *grouped_mm = tile_minmax ? grouped + 2 * (size_t)groups * C : nullptr;
@@ -1641,9 +1695,11 @@ int dspn_bn_apply_planes_f32(const float *x, const float *scale, const float *sh
   DSPN_REQUIRE(rows > 0 && C > 0 && C % 32 == 0, "bn_apply_planes: C must be a positive multiple of 32");
   DSPN_REQUIRE(static_cast<const void *>(x) != y_planes, "bn_apply_planes: in place is not supported");
   const long long n4 = rows * (C / 4);
-  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(grid_for(n4)), dim3(kT), 0, S_(stream), reinterpret_cast<const float4 *>(x),
-                     reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
-                     static_cast<uint2 *>(y_planes), n4, C / 4, relu, y_absmax);
+  int fixed4 = 0, u4 = 0;
+  const int grid4 = grid_fixed_channel(n4, C / 4, &fixed4, &u4);
+  hipLaunchKernelGGL(u4 ? bn_apply_planes_kernel<4> : bn_apply_planes_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+                     reinterpret_cast<const float4 *>(shift), static_cast<uint2 *>(y_planes), n4, C / 4, relu, y_absmax, fixed4);
   return dspn::check_launch("bn_apply_planes");
 }
 #endif
@@ -1664,7 +1720,7 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_from_sums: workspace too small (3*C floats)");
   const int C4 = C / 4;
   float *coef = static_cast<float *>(workspace);
-  if (tiles >= 1024 && workspace_bytes >= sizeof(float) * 3 * (size_t)C + bn_tiles_workspace_bytes(tiles, C)) {
+  if (tiles >= tile_group_min() && workspace_bytes >= sizeof(float) * 3 * (size_t)C + bn_tiles_workspace_bytes(tiles, C)) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = coef + 3 * (size_t)C;
     hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
@@ -1808,6 +1864,14 @@ int DSPN_FN(dspn_copy_block)(const st_t *src, st_t *dst, int samples, long long 
                      total, accumulate);
   return dspn::check_launch("copy_block");
 }
+#ifndef DSPN_HALF
+int dspn_copy_block_batch_f32(const void *table, int n, long long total, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total > 0, "copy_block_batch: bad argument");
+  hipLaunchKernelGGL(copy_block_batch_kernel, dim3(grid_for(total)), dim3(kT), 0, S_(stream),
+                     static_cast<const CopyDesc *>(table), n, total);
+  return dspn::check_launch("copy_block_batch");
+}
+#endif
 #ifdef DSPN_HALF
 /* the same strided block copy between storage types: bf16 -> float (SSD head maps into the float loss inputs) and
  * float -> bf16 (their gradients back into the per-map gradient tensors) */

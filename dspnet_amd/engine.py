@@ -318,7 +318,7 @@ class Graph:
             n.am_dyin = self.new_scalar(backward=True)
 
     def _plan_input_planes(self):
-        """"f16x2" math, round 4: a deferred BatchNorm with a MULTI-TAP convolution among its readers also writes
+        """"f16x2" math, round 4: a deferred BatchNorm whose readers re-read it often (X_PLANES_MIN_READS) also writes
         (relu)(x * scale + shift) as fp16 piece planes (dspn_bn_apply_planes_f32), cut by the magnitude its statistics finalize
         has just formed; that convolution's forward and weight gradient then copy their x operand into LDS instead of applying
         the affine and cutting every element once per (tap, column tile) -- 9 x Cout / 128 times for a 3 x 3.  The 1 x 1 readers
@@ -332,9 +332,10 @@ class Graph:
             if (x.dtype != torch.float32 or x.shape[3] % 32 != 0 or x.data is None
                     or getattr(getattr(x, "producer", None), "out_minmax", None) is None):
                 continue
-            cons = [c for c in n.conv_consumers
-                    if c.w.shape[1] * c.w.shape[2] > 1 and c.math == "f16x2" and c.wp is not None and c.x_raw is x]
-            if not cons:
+            cons = [c for c in n.conv_consumers if c.math == "f16x2" and c.wp is not None and c.x_raw is x]
+            # how often the tile loaders would apply the affine to (and cut) one element: once per tap and 128-column tile
+            reads = sum(c.w.shape[1] * c.w.shape[2] * ((c.cout + 127) // 128) for c in cons)
+            if reads < X_PLANES_MIN_READS:
                 continue
             n.planes = fn.zeros(*x.shape, device=self.device)
             for c in cons:
@@ -586,6 +587,11 @@ class InputNCHW(Node):
 
     def forward(self):
         fn.nchw_to_nhwc(self.src.data, out=self.out.data)
+
+
+# Graph._plan_input_planes: a deferred BatchNorm output is ALSO written as piece planes when its readers would otherwise apply
+# the affine to each element at least this many times (taps x 128-column tiles, summed over the readers)
+X_PLANES_MIN_READS = int(_os.environ.get("DSPN_X_PLANES_MIN_READS", "6"))
 
 
 class BatchNorm(Node):

@@ -70,6 +70,7 @@ _lib.register({
     "dspn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dspn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dspn_copy_block_f32": (_i, [_vp, _vp, _i, _ll, _i, _ll, _i, _i, _ll, _i, _i, _i, _vp]),
+    "dspn_copy_block_batch_f32": (_i, [_vp, _i, _ll, _vp]),
     "dspn_transpose_bnc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dspn_avgpool2d_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool2d_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -754,6 +755,26 @@ def nhwc_to_nchw(src, C=None, out=None):
     out = empty(N, C, H, W, device=src.device) if out is None else out
     check(L().dspn_nhwc_to_nchw_f32(ptr(src), ptr(out), N, C, H, W, Cp, stream()), "nhwc_to_nchw")
     return out
+
+
+def copy_block_table(entries, device):
+    """entries: [(src, dst, samples, rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd, doff, accumulate)]
+    (the arguments of copy_block, float32 tensors) -> (device table, rows, total elements) for copy_block_batch"""
+    import numpy as np
+    rows = np.zeros(len(entries), dtype=[("src", "<u8"), ("dst", "<u8"), ("rps", "<i8"), ("sss", "<i8"), ("dss", "<i8"),
+                                         ("C", "<i4"), ("lds", "<i4"), ("soff", "<i4"), ("ldd", "<i4"), ("doff", "<i4"),
+                                         ("acc", "<i4"), ("begin", "<i8")])
+    assert rows.dtype.itemsize == 72
+    total = 0
+    for i, (src, dst, samples, rps, C, sss, lds, soff, dss, ldd, doff, acc) in enumerate(entries):
+        assert src.dtype == dst.dtype == torch.float32 and samples > 0 and rps > 0 and C > 0
+        rows[i] = (src.data_ptr(), dst.data_ptr(), rps, sss, dss, C, lds, soff, ldd, doff, int(bool(acc)), total)
+        total += samples * rps * C
+    return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(entries), total
+
+
+def copy_block_batch(table, n, total):
+    check(L().dspn_copy_block_batch_f32(ptr(table), n, total, stream()), "copy_block_batch")
 
 
 def copy_block(src, dst, samples, rows_per_sample, C, src_sample_stride, lds, soff, dst_sample_stride, ldd,

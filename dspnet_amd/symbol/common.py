@@ -46,22 +46,40 @@ class HeadPack(E.Node):
         self.total = self.offsets[-1]
         import torch
         self.out = g.tensor((B, self.total), name, dtype=torch.float32)     # loss / multibox-operator input: always float
+        self._tables = {}
+
+    def _batched(self, key, entries):
+        """float maps on the GPU: the copies of one pass as ONE launch (round 4; a table per distinct set of buffers)"""
+        import torch
+        if self.out.data.device.type != "cuda" or any(e[0].dtype != torch.float32 or e[1].dtype != torch.float32 for e in entries):
+            return False
+        key = (key,) + tuple((e[0].data_ptr(), e[1].data_ptr(), bool(e[-1])) for e in entries)
+        tab = self._tables.get(key)
+        if tab is None:
+            tab = self._tables[key] = fn.copy_block_table(entries, self.out.data.device)
+        fn.copy_block_batch(*tab)
+        return True
 
     def forward(self):
         B = self.out.shape[0]
-        for t, c, off in zip(self.maps, self.widths, self.offsets):
-            hw = t.shape[1] * t.shape[2]
-            fn.copy_block(t.data, self.out.data, B, hw, c, hw * t.shape[3], t.shape[3], 0, self.total, c, off)
+        entries = [(t.data, self.out.data, B, t.shape[1] * t.shape[2], c, t.shape[1] * t.shape[2] * t.shape[3], t.shape[3], 0,
+                    self.total, c, off, False) for t, c, off in zip(self.maps, self.widths, self.offsets)]
+        if not self._batched("f", entries):
+            for e in entries:
+                fn.copy_block(*e[:-1])
 
     def backward(self):
         if not self.out._gw:
             return
         B = self.out.shape[0]
+        entries = []
         for t, c, off in zip(self.maps, self.widths, self.offsets):
             hw = t.shape[1] * t.shape[2]
             dx, acc = t.grad_target()          # pad channels of dx stay zero (allocated zeroed)
-            fn.copy_block(self.out.grad, dx, B, hw, c, self.total, c, off, hw * t.shape[3], t.shape[3], 0,
-                          accumulate=acc)
+            entries.append((self.out.grad, dx, B, hw, c, self.total, c, off, hw * t.shape[3], t.shape[3], 0, acc))
+        if not self._batched("b", entries):
+            for e in entries:
+                fn.copy_block(*e[:-1], accumulate=e[-1])
 
 
 def multitask_layer(g, from_layers, num_classes, sizes, ratios, normalization=-1, clip=False, steps=()):

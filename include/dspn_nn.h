@@ -390,6 +390,11 @@ int dspn_nhwc_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int
 int dspn_copy_block_f32(const float *src, float *dst, int samples, long long rows_per_sample, int C,
                         long long src_sample_stride, int lds, int soff,
                         long long dst_sample_stride, int ldd, int doff, int accumulate, void *stream);
+/* (round 4) n block copies in one launch -- the SSD head packing moves six small maps per pass.  `table`: n rows of 72 bytes in
+ * device memory, { const float *src; float *dst; int64 rows_per_sample, src_sample_stride, dst_sample_stride;
+ * int32 C, lds, soff, ldd, doff, accumulate; int64 begin } with the meaning of dspn_copy_block_f32's arguments; begin = the
+ * number of elements (samples * rows_per_sample * C) of all earlier rows, total = that of all rows. */
+int dspn_copy_block_batch_f32(const void *table, int n, long long total, void *stream);
 /* (B, N, C) -> (B, C, N) */
 int dspn_transpose_bnc_f32(const float *src, float *dst, int B, int N, int C, void *stream);
 

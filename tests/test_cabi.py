@@ -134,6 +134,7 @@ def test_convolution_argument_validation_without_gpu():
     assert lib.dspn_bn_apply_planes_f32(p, p, p, p, 64, 48, 1, p, None) == -1 and b"multiple of 32" in lib.dspn_last_error()
     assert lib.dspn_bn_apply_planes_f32(p, p, p, p, 64, 64, 1, None, None) == -1      # the block the planes are cut by
     assert lib.dspn_bn_apply_planes_f32(p, p, p, ctypes.c_void_p(256), 64, 64, 1, p, None) == -1 and b"in place" in lib.dspn_last_error()
+    assert lib.dspn_copy_block_batch_f32(None, 6, 100, None) == -1 and lib.dspn_copy_block_batch_f32(p, 0, 100, None) == -1
     # batched weight transposes count 32 x 32 tiles of a tap
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout

@@ -1185,6 +1185,36 @@ def test_copy_block_in_16_byte_units_and_by_element(gpu_device, dtype, c, soff, 
 
 
 @pytest.mark.gpu
+def test_copy_block_batch_packs_head_maps_like_the_single_copies(gpu_device):
+    """dspn_copy_block_batch_f32 (round 4): the SSD head packing of one pass -- six maps of different sizes, channel padding
+    stripped, each at its offset of the (B, total) row -- as one launch, and its gradient (out of the row, into the padded
+    maps, with and without accumulation): bit for bit what the per-map dspn_copy_block_f32 calls give"""
+    g = torch.Generator().manual_seed(4)
+    B, maps = 3, [(16, 16, 20, 20), (8, 8, 30, 32), (4, 4, 30, 32), (2, 2, 30, 32), (1, 1, 20, 20), (5, 3, 54, 56)]   # H, W, c, ldc
+    srcs = [torch.randn(B, H, W, ld, generator=g).cuda() for (H, W, c, ld) in maps]
+    sizes = [H * W * c for (H, W, c, ld) in maps]
+    offs = np.cumsum([0] + sizes).tolist(); total = offs[-1]
+    out = torch.full((B, total), float("nan"), device="cuda"); ref = out.clone()
+    entries = [(t, out, B, H * W, c, H * W * ld, ld, 0, total, c, off, False) for t, (H, W, c, ld), off in zip(srcs, maps, offs)]
+    fn.copy_block_batch(*fn.copy_block_table(entries, out.device))
+    for e in entries:
+        fn.copy_block(e[0], ref, *e[2:-1])
+    assert torch.equal(out, ref) and bool(torch.isfinite(out).all())
+    for t, (H, W, c, ld), off in zip(srcs, maps, offs):
+        assert torch.equal(out[:, off:off + H * W * c].view(B, H, W, c), t[..., :c])
+    grad = torch.randn(B, total, generator=g).cuda()
+    dxs = [torch.randn(B, H, W, ld, generator=g).cuda() for (H, W, c, ld) in maps]
+    refs = [d.clone() for d in dxs]
+    accs = [False, True, False, True, True, False]
+    entries = [(grad, d, B, H * W, c, total, c, off, H * W * ld, ld, 0, a) for d, (H, W, c, ld), off, a in zip(dxs, maps, offs, accs)]
+    fn.copy_block_batch(*fn.copy_block_table(entries, grad.device))
+    for e, r in zip(entries, refs):
+        fn.copy_block(e[0], r, *e[2:-1], accumulate=e[-1])
+    for d, r in zip(dxs, refs):
+        assert torch.equal(d, r)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("half", [False, True])
 def test_batched_weight_transposes_match_permute(gpu_device, half):
     """dspn_conv2d_weight_transpose_batch_f32 / dspn_conv2d_weight_prepare_batch_bf16 (one 32 x 32 tile of a tap per
