@@ -2018,6 +2018,8 @@ int nt_config(long long M, int Cout) {
   // a Cout just past a multiple of 128 (171 = 19 classes x 9 taps) wastes up to half of the last
   // 128-wide column tile: 64-wide columns cut the padding to < 64
   if (cfg == 0 && (Cout + 63) / 64 * 64 < (Cout + 127) / 128 * 128) cfg = 1;
+  static const int cfg64 = [] { const char *e = getenv("DSPN_NT_CFG64"); return e ? atoi(e) : -1; }();   // experiments
+  if (cfg64 >= 0 && Cout > 32 && Cout <= 64 && tiles(kNtBm[cfg64], kNtBn[cfg64]) >= min_tiles) cfg = cfg64;
   if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
   return cfg;
 }

@@ -296,42 +296,60 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const CA4Ptr x, const floa
 // pass (dspn_bn_stats_from_tiles_f32 out_absmax).  For a BatchNorm in front of a multi-tap convolution: that convolution's
 // forward and weight gradient copy the records (conv_nt_kernel EPIX & 4, conv_wgrad_kernel MATHX = 5 / 6) instead of
 // applying the affine and cutting every element once per (tap, column tile).
-// Streaming form of bn_bwd_apply_kernel below: a grid whose stride is a multiple of C4 (`fixed_c`) gives a thread ONE channel
-// group, and U elements are requested before the first is used.
+// A thread OWNS one 16-byte chunk of the planes: index i = float4 index of the tensor = 16-byte chunk index of the planes;
+// chunk l = i & 7 of its 128-byte record holds piece l >> 2 of channels 8 (l & 3) .. + 7, so the thread reads the two float4
+// of those eight channels (each is read by two threads -- the second read is a cache hit), forms both pieces and stores
+// the one it owns: eight lanes write one whole 128-byte line per store instruction (the first form of this kernel wrote two
+// 8-byte halves per float4, 64-byte runs from two instructions per line: 3.7 TB/s).  Streaming form of bn_bwd_apply_kernel
+// below: a grid whose stride is a multiple of C4 (`fixed_c`) gives a thread ONE chunk position, and U chunks' inputs are
+// requested before the first is used.
+struct PlaneChunk { int ca; bool hi; };        // float4 index (within the pixel) of the chunk's first four channels; which piece
+__device__ __forceinline__ PlaneChunk plane_chunk(const int c) {   // c = i % C4
+  return PlaneChunk{(c & ~7) + 2 * (c & 3), (c & 4) != 0};
+}
+__device__ __forceinline__ uint4 plane_pack(const dspn::pieces::bf16x4 a, const dspn::pieces::bf16x4 b) {
+  const uint2 x = __builtin_bit_cast(uint2, a), y = __builtin_bit_cast(uint2, b);
+  return make_uint4(x.x, x.y, y.x, y.y);
+}
 template <int U>
 __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
-                                const float4 *__restrict__ shift, uint2 *__restrict__ planes,
+                                const float4 *__restrict__ shift, uint4 *__restrict__ planes,
                                 long long n4, int C4, int relu, const float *__restrict__ block, int fixed_c) {
   const float s = dspn::pieces::operand_scale(block);
   const bool nf = dspn::pieces::operand_nonfinite(block);
-  auto one = [&](const long long i, const int c4, const float4 v, const float4 a, const float4 b) __attribute__((always_inline)) {
+  auto affine = [&](const float4 v, const float4 a, const float4 b) __attribute__((always_inline)) {
     float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
     if (relu) {
       o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
       o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
-    dspn::pieces::bf16x4 p0, p1;
-    dspn::pieces::split2h(o, s, p0, p1);
-    if (__builtin_expect(nf, 0)) dspn::pieces::repair_inf(p0, p1);
-    const long long u = (i - c4) * 2 + (c4 >> 3) * 16 + (c4 & 7);
-    planes[u] = __builtin_bit_cast(uint2, p0);
-    planes[u + 8] = __builtin_bit_cast(uint2, p1);
+    return o;
+  };
+  auto one = [&](const long long i, const bool hi, const float4 v0, const float4 v1, const float4 a0, const float4 b0,
+                 const float4 a1, const float4 b1) __attribute__((always_inline)) {
+    dspn::pieces::bf16x4 p0, p1, q0, q1;
+    dspn::pieces::split2h(affine(v0, a0, b0), s, p0, p1);
+    dspn::pieces::split2h(affine(v1, a1, b1), s, q0, q1);
+    if (__builtin_expect(nf, 0)) { dspn::pieces::repair_inf(p0, p1); dspn::pieces::repair_inf(q0, q1); }
+    planes[i] = hi ? plane_pack(p1, q1) : plane_pack(p0, q0);
   };
   const long long cstride = (long long)gridDim.x * (U * 256);
   long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
   if (fixed_c) {
-    const int c4 = (int)(base % C4);
-    const float4 a = scale[c4], b = shift[c4];
+    const int c = (int)(base % C4);
+    const PlaneChunk pc = plane_chunk(c);
+    const float4 a0 = scale[pc.ca], b0 = shift[pc.ca], a1 = scale[pc.ca + 1], b1 = shift[pc.ca + 1];
+    const int d = pc.ca - c;
     for (; base + (U - 1) * 256 < n4; base += cstride) {
-      float4 v[U];
+      float4 v0[U], v1[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = x[base + u * 256];
+      for (int u = 0; u < U; ++u) { v0[u] = x[base + u * 256 + d]; v1[u] = x[base + u * 256 + d + 1]; }
 #pragma unroll
-      for (int u = 0; u < U; ++u) one(base + u * 256, c4, v[u], a, b);
+      for (int u = 0; u < U; ++u) one(base + u * 256, pc.hi, v0[u], v1[u], a0, b0, a1, b1);
     }
     for (int u = 0; u < U; ++u) {
       const long long i = base + u * 256;
-      if (i < n4) one(i, c4, x[i], a, b);
+      if (i < n4) one(i, pc.hi, x[i + d], x[i + d + 1], a0, b0, a1, b1);
     }
   } else {
     for (; base < n4; base += cstride) {
@@ -339,8 +357,10 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float4 *__re
       for (int u = 0; u < U; ++u) {
         const long long i = base + u * 256;
         if (i >= n4) break;
-        const int c4 = (int)(i % C4);
-        one(i, c4, x[i], scale[c4], shift[c4]);
+        const int c = (int)(i % C4);
+        const PlaneChunk pc = plane_chunk(c);
+        const long long xa = i - c + pc.ca;
+        one(i, pc.hi, x[xa], x[xa + 1], scale[pc.ca], shift[pc.ca], scale[pc.ca + 1], shift[pc.ca + 1]);
       }
     }
   }
@@ -370,13 +390,39 @@ __global__ __launch_bounds__(256) void absmax_affine_bound_kernel(const float *_
   }
 }
 
+// The output gradient of a BatchNorm whose (ReLU) output feeds a max pooling ALONE (the resnet stem), formed on the fly from
+// the pooled gradient and the argmax record instead of read from a dense tensor the pooling backward would first write
+// (round 4): the gather of maxpool_bwd_idx_kernel for 4 channels of one input pixel.  argmax == NULL: no pooling.
+struct PoolGrad { const uchar4 *argmax; const float4 *dy; int H, W, k, stride, pad, Ho, Wo; };
+__device__ __forceinline__ float4 pool_grad_at(const PoolGrad &p, long long row, int c4, int C4) {
+  const int w = (int)(row % p.W);
+  const long long t = row / p.W;
+  const int h = (int)(t % p.H);
+  const long long n = t / p.H;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ho_lo = (h + p.pad - p.k + p.stride) / p.stride; if (h + p.pad - p.k + 1 <= 0) ho_lo = 0;
+  int wo_lo = (w + p.pad - p.k + p.stride) / p.stride; if (w + p.pad - p.k + 1 <= 0) wo_lo = 0;
+  const int ho_hi = min(p.Ho - 1, (h + p.pad) / p.stride), wo_hi = min(p.Wo - 1, (w + p.pad) / p.stride);
+  for (int ho = ho_lo; ho <= ho_hi; ++ho)
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      const long long oi = ((n * p.Ho + ho) * p.Wo + wo) * C4 + c4;
+      const int pos = (h - (ho * p.stride - p.pad)) * p.k + (w - (wo * p.stride - p.pad));
+      const uchar4 a = p.argmax[oi];
+      const float4 d = p.dy[oi];
+      g.x += a.x == pos ? d.x : 0.f; g.y += a.y == pos ? d.y : 0.f;
+      g.z += a.z == pos ? d.z : 0.f; g.w += a.w == pos ? d.w : 0.f;
+    }
+  return g;
+}
+
 // partial[slab][0][c] = sum dy', partial[slab][1][c] = sum dy' * xhat ; dy' = relu ? dy*(y>0) : dy
 // The ReLU mask is recomputed as (x*scale + shift > 0) -- the very fma of the forward apply pass --
 // so the forward output is never re-read.
+template <bool POOL>
 __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
     const CA4Ptr x, const float4 *__restrict__ scale, const float4 *__restrict__ shift,
     const CA4Ptr dy, const float *__restrict__ mean, const float *__restrict__ rstd,
-    long long rows, int C4, int CL, int relu, float *__restrict__ partial, int kSlabRows) {
+    long long rows, int C4, int CL, int relu, float *__restrict__ partial, int kSlabRows, const PoolGrad pool) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -391,7 +437,9 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(
 #pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += RL) {
       const float4 xv = x[r * C4 + c4];
-      float4 g = dy[r * C4 + c4];
+      float4 g;
+      if constexpr (POOL) g = pool_grad_at(pool, r, c4, C4);
+      else g = dy[r * C4 + c4];
       if (relu) {
         g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
         g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
@@ -474,54 +522,98 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
 // the block the convolution in front of this BatchNorm reads as its dy magnitude.  That convolution's data gradient and
 // weight gradient then copy the records into LDS without any arithmetic (conv_nt_kernel EPIX & 4, conv_wgrad_kernel
 // MATHX = 4) instead of cutting every element once per (tap, column tile) that reads it.
+// (a thread owns one 16-byte chunk of the planes and forms it from the two float4 of its eight channels: bn_apply_planes_kernel)
 template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const CA4Ptr x, const float4 *__restrict__ scale,
                                     const float4 *__restrict__ shift, const CA4Ptr dy,
-                                    const float4 *__restrict__ coef, uint2 *__restrict__ planes,
+                                    const float4 *__restrict__ coef, uint4 *__restrict__ planes,
                                     long long n4, int C4, int relu, const float *__restrict__ bound, int fixed_c) {
   const float s = dspn::pieces::operand_scale(bound);
-  auto one = [&](const long long j, const int c4, const float4 xv, float4 g, const float4 sa, const float4 sb, const float4 a,
-                 const float4 c1, const float4 c0) __attribute__((always_inline)) {
-    if (relu) {
-      g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
-      g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
-    }
-    const float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
-                                 a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);     // (as bn_bwd_apply_kernel)
-    dspn::pieces::bf16x4 p0, p1;
-    dspn::pieces::split2h(o, s, p0, p1);
-    // float4 j = channels 4 c4 .. 4 c4 + 3 of pixel j / C4: 8-byte units -- pixel * (2 C4) + (c4 >> 3) * 16 + piece * 8 + (c4 & 7)
-    const long long u = (j - c4) * 2 + (c4 >> 3) * 16 + (c4 & 7);
-    planes[u] = __builtin_bit_cast(uint2, p0);
-    planes[u + 8] = __builtin_bit_cast(uint2, p1);
+  struct Co { float4 sa, sb, a, c1, c0; };
+  auto coefs = [&](const int c4) __attribute__((always_inline)) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    return Co{relu ? scale[c4] : zero, relu ? shift[c4] : zero, coef[c4], coef[C4 + c4], coef[2 * C4 + c4]};
   };
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto grad = [&](const float4 xv, float4 g, const Co &k) __attribute__((always_inline)) {
+    if (relu) {
+      g.x = fmaf(xv.x, k.sa.x, k.sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, k.sa.y, k.sb.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, k.sa.z, k.sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, k.sa.w, k.sb.w) > 0.f ? g.w : 0.f;
+    }
+    return make_float4(k.a.x * g.x + k.c1.x * xv.x + k.c0.x, k.a.y * g.y + k.c1.y * xv.y + k.c0.y,
+                       k.a.z * g.z + k.c1.z * xv.z + k.c0.z, k.a.w * g.w + k.c1.w * xv.w + k.c0.w);     // (as bn_bwd_apply_kernel)
+  };
+  auto one = [&](const long long i, const bool hi, const float4 x0, const float4 g0, const float4 x1, const float4 g1,
+                 const Co &k0, const Co &k1) __attribute__((always_inline)) {
+    dspn::pieces::bf16x4 p0, p1, q0, q1;
+    dspn::pieces::split2h(grad(x0, g0, k0), s, p0, p1);
+    dspn::pieces::split2h(grad(x1, g1, k1), s, q0, q1);
+    planes[i] = hi ? plane_pack(p1, q1) : plane_pack(p0, q0);
+  };
   const long long cstride = (long long)gridDim.x * (U * 256);
   long long base = blockIdx.x * (long long)(U * 256) + threadIdx.x;
   if (fixed_c) {
-    const int c4 = (int)(base % C4);
-    const float4 sa = relu ? scale[c4] : zero, sb = relu ? shift[c4] : zero;
-    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
+    const int c = (int)(base % C4);
+    const PlaneChunk pc = plane_chunk(c);
+    const Co k0 = coefs(pc.ca), k1 = coefs(pc.ca + 1);
+    const int d = pc.ca - c;
     for (; base + (U - 1) * 256 < n4; base += cstride) {
-      float4 xv[U], g[U];
+      float4 x0[U], g0[U], x1[U], g1[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { xv[u] = x[base + u * 256]; g[u] = dy[base + u * 256]; }
+      for (int u = 0; u < U; ++u) {
+        const long long a = base + u * 256 + d;
+        x0[u] = x[a]; g0[u] = dy[a]; x1[u] = x[a + 1]; g1[u] = dy[a + 1];
+      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) one(base + u * 256, c4, xv[u], g[u], sa, sb, a, c1, c0);
+      for (int u = 0; u < U; ++u) one(base + u * 256, pc.hi, x0[u], g0[u], x1[u], g1[u], k0, k1);
     }
     for (int u = 0; u < U; ++u) {
-      const long long j = base + u * 256;
-      if (j < n4) one(j, c4, x[j], dy[j], sa, sb, a, c1, c0);
+      const long long i = base + u * 256;
+      if (i < n4) one(i, pc.hi, x[i + d], dy[i + d], x[i + d + 1], dy[i + d + 1], k0, k1);
     }
   } else {
     for (; base < n4; base += cstride) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const long long j = base + u * 256;
-        if (j >= n4) break;
-        const int c4 = (int)(j % C4);
-        one(j, c4, x[j], dy[j], relu ? scale[c4] : zero, relu ? shift[c4] : zero, coef[c4], coef[C4 + c4], coef[2 * C4 + c4]);
+        const long long i = base + u * 256;
+        if (i >= n4) break;
+        const int c = (int)(i % C4);
+        const PlaneChunk pc = plane_chunk(c);
+        const long long a = i - c + pc.ca;
+        one(i, pc.hi, x[a], dy[a], x[a + 1], dy[a + 1], coefs(pc.ca), coefs(pc.ca + 1));
       }
+    }
+  }
+}
+
+// the apply pass with the pooled output gradient (pool_grad_at): dx = a dy' + c1 x + c0, float tensors, no accumulation
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+                                    const float4 *__restrict__ shift, const float4 *__restrict__ coef, float4 *__restrict__ dx,
+                                    long long n4, int C4, int relu, unsigned *__restrict__ absmax, const PoolGrad pool) {
+  float mx = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const float4 xv = x[i];
+    float4 g = pool_grad_at(pool, i / C4, c4, C4);
+    if (relu) {
+      const float4 sa = scale[c4], sb = shift[c4];
+      g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, sa.z, sb.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sa.w, sb.w) > 0.f ? g.w : 0.f;
+    }
+    const float4 a = coef[c4], c1 = coef[C4 + c4], c0 = coef[2 * C4 + c4];
+    const float4 o = make_float4(a.x * g.x + c1.x * xv.x + c0.x, a.y * g.y + c1.y * xv.y + c0.y,
+                                 a.z * g.z + c1.z * xv.z + c0.z, a.w * g.w + c1.w * xv.w + c0.w);     // (as bn_bwd_apply_kernel)
+    dx[i] = o;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  }
+  if (absmax) {          // (kernel-uniform)
+    __shared__ float sm[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) mx = fmaxf(mx, sm[w]);
+      if (mx > 0.f) atomicMax(absmax + (blockIdx.x & 63), __float_as_uint(mx));
     }
   }
 }
@@ -1657,10 +1749,10 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
   const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
   float *partial = static_cast<float *>(workspace);
   float *coef = partial + (size_t)ns * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(ns, (C4 + CL - 1) / CL), dim3(kT),
                      sizeof(float4) * 2 * kT, S_(stream), CA4Ptr(x),
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
-                     CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows));
+                     CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows), PoolGrad{});
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr);
   const long long n4 = rows * C4;
@@ -1686,6 +1778,36 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
   return dspn::check_launch("bn_backward");
 }
 
+#ifndef DSPN_HALF
+int dspn_bn_backward_maxpool_f32(const float *x, const float *scale, const float *shift, const float *dy_pool,
+                                 const unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho,
+                                 int Wo, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma,
+                                 float *dbeta, int relu, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(x && dy_pool && argmax && mean && rstd && dx && dbeta && workspace, "bn_backward_maxpool: null pointer");
+  DSPN_REQUIRE(!relu || (scale && shift), "bn_backward_maxpool: relu needs the forward scale/shift");
+  DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && Ho > 0 && Wo > 0,
+               "bn_backward_maxpool: bad geometry (C %% 4 == 0, k * k <= 255)");
+  const long long rows = (long long)N * H * W;
+  if (workspace_bytes < bn_workspace_bytes(rows, C))
+    return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_maxpool: workspace too small (dspn_bn_workspace_bytes)");
+  const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
+  float *partial = static_cast<float *>(workspace);
+  float *coef = partial + (size_t)ns * 2 * C;
+  const PoolGrad pool{reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<const float4 *>(dy_pool), H, W, k, stride, pad, Ho, Wo};
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(ns, (C4 + CL - 1) / CL), dim3(kT), sizeof(float4) * 2 * kT, S_(stream),
+                     CA4Ptr(x), reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
+                     CA4Ptr(x), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows), pool);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr);
+  const long long n4 = rows * C4;
+  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(grid_for(n4)), dim3(256), 0, S_(stream), reinterpret_cast<const float4 *>(x),
+                     reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
+                     reinterpret_cast<const float4 *>(coef), reinterpret_cast<float4 *>(dx), n4, C4, relu,
+                     reinterpret_cast<unsigned *>(dx_absmax), pool);
+  return dspn::check_launch("bn_backward_maxpool");
+}
+#endif
+
 // BatchNorm backward whose two reductions (sum dy', sum dy' xhat) were gathered per row tile by the data-gradient
 // kernel that produced dy (bn_sums of dspn_conv2d_dgrad_bn_f32): finalize + apply only
 #ifndef DSPN_HALF
@@ -1699,7 +1821,7 @@ int dspn_bn_apply_planes_f32(const float *x, const float *scale, const float *sh
   const int grid4 = grid_fixed_channel(n4, C / 4, &fixed4, &u4);
   hipLaunchKernelGGL(u4 ? bn_apply_planes_kernel<4> : bn_apply_planes_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
                      reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
-                     reinterpret_cast<const float4 *>(shift), static_cast<uint2 *>(y_planes), n4, C / 4, relu, y_absmax, fixed4);
+                     reinterpret_cast<const float4 *>(shift), static_cast<uint4 *>(y_planes), n4, C / 4, relu, y_absmax, fixed4);
   return dspn::check_launch("bn_apply_planes");
 }
 #endif
@@ -1737,7 +1859,7 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     const int grid4 = grid_fixed_channel(n4, C4, &fixed4, &u4);
     hipLaunchKernelGGL(u4 ? bn_bwd_apply_planes_kernel<4> : bn_bwd_apply_planes_kernel<1>, dim3(grid4), dim3(kT), 0, S_(stream),
                        CA4Ptr(x), reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), CA4Ptr(dy),
-                       reinterpret_cast<const float4 *>(coef), reinterpret_cast<uint2 *>(dx), n4, C4, relu, dx_absmax, fixed4);
+                       reinterpret_cast<const float4 *>(coef), reinterpret_cast<uint4 *>(dx), n4, C4, relu, dx_absmax, fixed4);
     return dspn::check_launch("bn_backward_from_sums");
   }
 #endif

@@ -591,6 +591,7 @@ class InputNCHW(Node):
 
 # Graph._plan_input_planes: a deferred BatchNorm output is ALSO written as piece planes when its readers would otherwise apply
 # the affine to each element at least this many times (taps x 128-column tiles, summed over the readers)
+FUSE_MAXPOOL_BACKWARD = _os.environ.get("DSPN_FUSE_POOL_BWD", "1") != "0"      # (A/B switch)
 X_PLANES_MIN_READS = int(_os.environ.get("DSPN_X_PLANES_MIN_READS", "6"))
 
 
@@ -642,6 +643,7 @@ class BatchNorm(Node):
         # round 4 (Graph._plan_input_planes): the output as fp16 piece planes for the multi-tap convolutions behind a DEFERRED
         # apply; planes_ready: written by this step's forward (the magnitude they are cut by came out of the finalize)
         self.planes, self.planes_ready = None, False
+        self.pool_grad = None        # (argmax, pooled gradient, k, stride, pad) left by a MaxPool that folds this node (one backward)
         self._g = g
         # True when this node's backward is the LAST writer of x's gradient (set by Graph.finalize): only then is the dx it
         # stores the complete gradient whose magnitude the producing convolution may use
@@ -697,7 +699,18 @@ class BatchNorm(Node):
                 am = g.scalar(prod.am_dy)
                 g._am_done.add(prod.am_dy)
         else:  # parameters still need their gradients; dx goes to scratch
-            dx, acc = self.out.grad, False
+            dx, acc = (self.out.grad if self.pool_grad is None else self.out.own_grad()), False
+        if self.pool_grad is not None:
+            argmax, dyp, k, s, p = self.pool_grad
+            self.pool_grad = None
+            if not acc:
+                fn.bn_backward_maxpool(self.x.data, self.scale, self.shift, dyp, argmax, k, s, p, self.mean, self.rstd,
+                                       None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
+                                       dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad, dx_absmax=am)
+                return
+            # (a second writer of x's gradient: materialise the pooling backward after all)
+            fn.maxpool_backward_argmax(argmax, dyp, self.out.shape, k, s, p, dx=self.out.own_grad())
+            self.out.grad = self.out.own_grad()
         if self.bwd_sums_ready and self.dx_planes and am is not None and not acc and self._x_ext_valid():
             # the gradient leaves as fp16 piece planes (same buffer): `am` receives the BOUND it is cut by
             self.bwd_sums_ready = False
@@ -1171,6 +1184,14 @@ class MaxPool(Node):
         if not self.out._gw or not self.x.requires_grad:
             return
         assert not self.x._gw, "maxpool input has a single consumer"
+        bn = getattr(self.x, "bn_node", None)
+        if (self.in_affine is not None and self.argmax is not None and bn is not None and FUSE_MAXPOOL_BACKWARD
+                and self.out.grad.dtype == torch.float32 and self.out.grad.device.type == "cuda"):
+            # round 4: the BatchNorm(+ReLU) folded into this pooling forms its output gradient from (pooled gradient, argmax)
+            # itself (dspn_bn_backward_maxpool_f32): the dense gradient of the pooling input is never written
+            bn.pool_grad = (self.argmax, self.out.grad, self.k, self.s, self.p)
+            self.x._gw = True
+            return
         dx, _ = self.x.grad_target()
         if self.argmax is not None:
             fn.maxpool_backward_argmax(self.argmax, self.out.grad, self.x.shape, self.k, self.s, self.p, dx=dx)

@@ -83,6 +83,8 @@ _lib.register({
     "dspn_maxpool_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_maxpool_forward_bn_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "dspn_maxpool_backward_argmax_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dspn_bn_backward_maxpool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _i, _vp, _vp, _sz, _vp]),
     "dspn_maxpool_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dspn_avgpool_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -670,6 +672,24 @@ def bn_backward(x, scale, shift, dy, mean, rstd, gamma, relu=False, dx=None, dga
     check(_f("dspn_bn_backward", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
                                    ptr(dgamma), ptr(dbeta), rows, C, int(relu), int(accumulate), ptr(dx_absmax), ptr(ws),
                                    ws.numel(), stream()), "bn_backward")
+    return dx, dgamma, dbeta
+
+
+def bn_backward_maxpool(x, scale, shift, dy_pool, argmax, k, stride, pad, mean, rstd, gamma, relu=False, dx=None, dgamma=None,
+                        dbeta=None, dx_absmax=None):
+    """bn_backward whose output gradient is the max-pooling backward of dy_pool (argmax record), formed on the fly: the
+    BatchNorm(+ReLU) -> max pooling pair of the resnet stem without the dense gradient tensor in between (float32)"""
+    N, H, W, C = x.shape
+    assert x.dtype == dy_pool.dtype == torch.float32 and argmax.dtype == torch.uint8 and argmax.shape == dy_pool.shape
+    dx = torch.empty_like(x) if dx is None else dx
+    dbeta = empty(C, device=x.device) if dbeta is None else dbeta
+    if gamma is not None and dgamma is None:
+        dgamma = empty(C, device=x.device)
+    ws = workspace(L().dspn_bn_workspace_bytes(N * H * W, C), x.device, "bn")
+    check(L().dspn_bn_backward_maxpool_f32(ptr(x), ptr(scale), ptr(shift), ptr(dy_pool), ptr(argmax), N, H, W, C, k, stride, pad,
+                                           dy_pool.shape[1], dy_pool.shape[2], ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), int(relu), ptr(dx_absmax), ptr(ws), ws.numel(), stream()),
+          "bn_backward_maxpool")
     return dx, dgamma, dbeta
 
 

@@ -422,6 +422,15 @@ int dspn_maxpool_forward_f32(const float *x, float *y, unsigned char *argmax, in
 int dspn_maxpool_forward_bn_f32(const float *x, const float *in_scale, const float *in_shift, int in_relu, float *y,
                                 unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
                                 float *out_absmax, void *stream);
+/* ... and its backward (round 4): the backward of that BatchNorm(+ReLU) with its output gradient formed ON THE FLY from the
+ * pooled gradient dy_pool (N, Ho, Wo, C) and the argmax record (the gather of dspn_maxpool_backward_argmax_f32) -- the dense
+ * (N, H, W, C) gradient of the pooling input is neither written nor read back twice.  x: the BatchNorm input (N, H, W, C);
+ * dx, dgamma (may be NULL), dbeta as dspn_bn_backward_f32; dx_absmax (optional): magnitude block of dx, zeroed by the caller;
+ * workspace: dspn_bn_workspace_bytes(N * H * W, C). */
+int dspn_bn_backward_maxpool_f32(const float *x, const float *scale, const float *shift, const float *dy_pool,
+                                 const unsigned char *argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho,
+                                 int Wo, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma,
+                                 float *dbeta, int relu, float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream);
 /* gradient goes to the first maximum of each window in (h, w) scan order; from the argmax record ... */
 int dspn_maxpool_backward_argmax_f32(const unsigned char *argmax, const float *dy, float *dx, int N, int H,
                                      int W, int C, int k, int stride, int pad, int Ho, int Wo, void *stream);

@@ -135,6 +135,9 @@ def test_convolution_argument_validation_without_gpu():
     assert lib.dspn_bn_apply_planes_f32(p, p, p, p, 64, 64, 1, None, None) == -1      # the block the planes are cut by
     assert lib.dspn_bn_apply_planes_f32(p, p, p, ctypes.c_void_p(256), 64, 64, 1, p, None) == -1 and b"in place" in lib.dspn_last_error()
     assert lib.dspn_copy_block_batch_f32(None, 6, 100, None) == -1 and lib.dspn_copy_block_batch_f32(p, 0, 100, None) == -1
+    assert lib.dspn_bn_backward_maxpool_f32(p, p, p, p, p, 1, 8, 8, 6, 3, 2, 1, 4, 4, p, p, None, p, None, p, 1, None, p, 1 << 20, None) == -1   # C % 4
+    assert lib.dspn_bn_backward_maxpool_f32(p, p, p, p, None, 1, 8, 8, 8, 3, 2, 1, 4, 4, p, p, None, p, None, p, 1, None, p, 1 << 20, None) == -1   # no argmax record
+    assert lib.dspn_bn_backward_maxpool_f32(p, p, p, p, p, 1, 8, 8, 8, 3, 2, 1, 4, 4, p, p, None, p, None, p, 1, None, p, 16, None) != 0 and b"workspace" in lib.dspn_last_error()
     # batched weight transposes count 32 x 32 tiles of a tap
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 64) == 2 * 9 * 2 and lib.dspn_conv2d_weight_transpose_tiles(19, 1, 128, 24) == 4
     assert lib.dspn_conv2d_weight_transpose_tiles(64, 9, 64, 32) == 0                # Cout_pad < Cout

@@ -1185,6 +1185,32 @@ def test_copy_block_in_16_byte_units_and_by_element(gpu_device, dtype, c, soff, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,k,stride,pad", [((2, 32, 32, 64), 3, 2, 1), ((3, 17, 23, 8), 3, 2, 1), ((2, 16, 16, 32), 2, 2, 0),
+                                                ((1, 12, 12, 16), 3, 1, 1)])
+def test_bn_backward_with_the_pooled_gradient_formed_on_the_fly(gpu_device, shape, k, stride, pad):
+    """dspn_bn_backward_maxpool_f32 (round 4; the resnet stem bn0 -> relu0 -> pooling0, symbol/resnet.py:96-98): the BatchNorm
+    backward that gathers its output gradient from (pooled gradient, argmax record) gives what the two separate operators
+    give (the reductions bit for bit, dx to a rounding) -- dspn_maxpool_backward_argmax_f32 into a dense tensor, then dspn_bn_backward_f32 on it"""
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape) + k)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda(); beta = (torch.randn(C, generator=g) * 0.2).cuda()
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(N, Ho, Wo, C, device="cuda"); argmax = torch.zeros(N, Ho, Wo, C, dtype=torch.uint8, device="cuda")
+    fn.maxpool_forward(x, k, stride, pad, out=y, argmax=argmax, in_affine=(scale, shift, True))
+    dyp = torch.randn(N, Ho, Wo, C, generator=g).cuda()
+    dense = fn.maxpool_backward_argmax(argmax, dyp, (N, H, W, C), k, stride, pad)
+    am_ref, am = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dx_ref, dg_ref, db_ref = fn.bn_backward(x, scale, shift, dense, mean, rstd, gamma, relu=True, dx_absmax=am_ref)
+    dx, dg, db = fn.bn_backward_maxpool(x, scale, shift, dyp, argmax, k, stride, pad, mean, rstd, gamma, relu=True, dx_absmax=am)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    # (dx = a dy' + c1 x + c0 in two kernels: the same three terms, possibly contracted into fused multiply-adds differently)
+    assert float((dx - dx_ref).abs().max()) <= 2.0 ** -22 * float(dx_ref.abs().max())
+    assert float(am.max()) == float(dx.abs().max()) and float(am_ref.max()) == float(dx_ref.abs().max())
+
+
+@pytest.mark.gpu
 def test_copy_block_batch_packs_head_maps_like_the_single_copies(gpu_device):
     """dspn_copy_block_batch_f32 (round 4): the SSD head packing of one pass -- six maps of different sizes, channel padding
     stripped, each at its offset of the (B, total) row -- as one launch, and its gradient (out of the row, into the padded
