@@ -881,6 +881,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         // 8 waves: the kernel has to fit in 128 VGPRs.  Rows in flight per thread and the unrolling of the chunk loop
         // are the settings that compile without scratch (hipcc 7.2): INTF + statistics 1 row / unrolled, the other
         // fused epilogues 2 rows / rolled, the plain epilogue 4 rows / unrolled
+        // (round 4, measured: four rows in flight / an unrolled chunk loop for the statistics epilogue without an input affine
+        // -- 118 - 120 registers, no scratch -- change nothing: 1.372 vs 1.367 ms over nine layers, 834 images/s either way)
         constexpr int RC8 = (EPI == 1 && INTF) ? 1 : (EPI != 0) ? 2 : 4;
         constexpr bool TIGHT = NTHR == 512 && TM * TN <= 2;     // the 128-register 8-wave kernels
         constexpr int RC = TIGHT ? (NP > RC8 ? RC8 : NP) : ((EPI == 2 && NP > 8) ? NP / 2 : NP);
@@ -1009,15 +1011,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         }
         if constexpr (EPI == 1) {
           // per-thread (mean, M2) of its rows -> LDS -> one thread per column merges the RPP row groups with
-          // Chan's update in a fixed order -> stats[m tile][mean | M2][column]
+          // Chan's update in a fixed order -> stats[m tile][mean | M2][column]; the extremes (g.minmax) travel with them in
+          // the same exchange (round 4: they had a second one, two more barriers per tile)
           __syncthreads();               // every staged row has been read
-          float *red = smem;             // [RPP][BN][2]
+          float *red = smem;             // [RPP][BN][2], then the extremes [RPP][BN][2]
+          float *red2 = smem + RPP * BN * 2;
+          bool mmx = false;
+          if constexpr (MINMAX) mmx = g.minmax != nullptr;        // (kernel-uniform)
           if (vec) {
             const float inv = scnt > 0 ? 1.f / (float)scnt : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               red[((er0 * BN) + c4 * 4 + e) * 2] = sK[e] + s1[e] * inv;
               red[((er0 * BN) + c4 * 4 + e) * 2 + 1] = s2[e] - s1[e] * s1[e] * inv;
+            }
+            if constexpr (MINMAX) {
+              if (mmx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  red2[((er0 * BN) + c4 * 4 + e) * 2] = vmn[e];
+                  red2[((er0 * BN) + c4 * 4 + e) * 2 + 1] = vmx[e];
+                }
+              }
             }
           }
           __syncthreads();
@@ -1041,25 +1056,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
             const long long mt_ = m0 / BM;
             g.stats[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mean;
             g.stats[(mt_ * 2 + 1) * g.Cout + n0 + tid] = m2;
-          }
-          if constexpr (MINMAX) {
-            if (g.minmax) {              // (kernel-uniform) the same two-stage reduction for the extremes
-              __syncthreads();           // the (mean, M2) table has been merged
-              if (vec) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  red[((er0 * BN) + c4 * 4 + e) * 2] = vmn[e];
-                  red[((er0 * BN) + c4 * 4 + e) * 2 + 1] = vmx[e];
-                }
-              }
-              __syncthreads();
-              if (tid < BN && n0 + tid < g.Cout) {
-                const int lim = min(M - m0, BM);
+            if constexpr (MINMAX) {
+              if (mmx) {
                 float mn = kInf, mx = -kInf;
                 for (int er = 0; er < RPP && er < lim; ++er) {      // row groups past the tile's last row hold nothing
-                  mn = fminf(mn, red[(er * BN + tid) * 2]); mx = fmaxf(mx, red[(er * BN + tid) * 2 + 1]);
+                  mn = fminf(mn, red2[(er * BN + tid) * 2]); mx = fmaxf(mx, red2[(er * BN + tid) * 2 + 1]);
                 }
-                const long long mt_ = m0 / BM;
                 g.minmax[(mt_ * 2 + 0) * g.Cout + n0 + tid] = mn;
                 g.minmax[(mt_ * 2 + 1) * g.Cout + n0 + tid] = mx;
               }

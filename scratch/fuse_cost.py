@@ -1,6 +1,6 @@
 """cost of the fused BatchNorm pieces per forward convolution: plain | +input affine | +output statistics | both"""
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dspnet_amd import functional as fn
 dev = torch.device("cuda", 0)
