@@ -626,10 +626,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   //   0 requests issued | 1 first MFMA block | 2 wait for the requested rows | 3 piece arithmetic | 4 second MFMA block |
   //   5 LDS stores | 6 barrier;   slot 7 counts the k-steps.  Written over the head of `out` by lane 0 of every wave.
   unsigned ph_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  unsigned ph_t = 0;
+  unsigned ph_t = (dbg & 32768) ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
   auto stamp = [&](const int slot) __attribute__((always_inline)) {
     if (dbg & 16384) {
       __builtin_amdgcn_sched_barrier(0);
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+      if (slot >= 0) ph_acc[slot] += now - ph_t;
+      ph_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // diagnostic build path (dspn_debug_set bit 32768; timing only): where the cycles of a tile's EPILOGUE go, per wave, in the
+  // slots of the k-step stamps: 0 accumulators -> LDS staging | 1 barrier | 2 row loop (LDS read, arithmetic, global store,
+  // statistics; INCLUDING the wait for its stores to be acknowledged) | 3 statistics / sums exchange and merge | 4 hand-over
+  // to the next tile (first k-step's LDS stores + barrier) | 5 the tile's k-loop;   slot 7 counts the tiles
+  auto estamp = [&](const int slot) __attribute__((always_inline)) {
+    if (dbg & 32768) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
       if (slot >= 0) ph_acc[slot] += now - ph_t;
       ph_t = now;
@@ -851,6 +865,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
     }
     if (__builtin_expect(last, 0)) {
       __syncthreads();   // every wave has read its last fragments: the LDS becomes the staging area
+      estamp(5);
       // ---- epilogue.  C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
       if (slab) {   // raw partial sums, dense [split][M][Cout]; bias / relu / accumulate happen in the reduce
         float *o = slab + (long long)blockIdx.y * M * g.Cout;
@@ -874,6 +889,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         // is read the same way, and ALL of a thread's rows are requested before the staging pass, so that
         // their HBM latency overlaps the LDS round trip instead of serialising with the stores (4 loads in
         // flight per thread held the residual convolutions to ~3 TB/s).
+        // (Round 4, measured and not kept -- scratch/two_pass_epilogue_experiment_r04.patch: hipcc waits `vmcnt(0)` in front of
+        // every chunk's operand rows, i.e. also for the previous chunk's STORES to be acknowledged (one counter for loads and
+        // stores, which complete out of order with each other), and in-kernel stamps (dspn_debug_set bit 32768) charge the row
+        // loop of the statistics epilogue with 40 - 65 thousand cycles per tile.  But a two-pass form -- operand rows,
+        // statistics and the finished values back into the staged tile first, a store-only pass after it -- ran SLOWER: 767
+        // against ~830 images/s, the nine-layer table 1.31 / 1.51 / 1.79 against 1.24 / 1.37 / 1.45 ms (plain / +statistics /
+        // both).  The acknowledgements are waited for in either form -- by the next tile's first k-step, whose prefetched
+        // rows sit behind the stores in the same counter -- and the other workgroup of the CU covers that wait in both.)
         constexpr int SLD = BN + 4;
         constexpr int C4 = BN / 4, RPP = NTHR / C4, NP = BM / RPP;   // float4 columns per row, rows per pass, passes
         // rows are handled RC at a time: all of them, or half of them when the BatchNorm-backward sums hold a second
@@ -930,7 +953,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
               st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] =
                   MATH == 3 ? acc[i][j][r] * inv_a * inv_b : acc[i][j][r];      // (two-piece mode: undo the operand scales, exact)
         rows_bn_x();   // requested once the accumulators are staged (their registers are free), ahead of the barrier
+        if (dbg & 32768) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned now = (unsigned)__builtin_amdgcn_s_memtime(); ph_acc[0] += now - ph_t; ph_t = now; }
         __syncthreads();
+        estamp(1);
         float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
         float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
         float gmx = 0.f;         // largest |dx| this thread stores (EPI == 2, two-piece math: g.bn_dy_absmax)
@@ -1009,6 +1034,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
             }
           }
         }
+        estamp(2);
         if constexpr (EPI == 1) {
           // per-thread (mean, M2) of its rows -> LDS -> one thread per column merges the RPP row groups with
           // Chan's update in a fixed order -> stats[m tile][mean | M2][column]; the extremes (g.minmax) travel with them in
@@ -1090,6 +1116,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
           if constexpr (MATH == 3) gmx_all = fmaxf(gmx_all, gmx);     // (published once, when the workgroup has run out of tiles)
         }
       }
+      estamp(3);
+      if (dbg & 32768) ph_acc[7] += 1u;
       if (!has_next) {
         if constexpr (EPI == 2 && MATH == 3) {
           // g.bn_dy_absmax: the largest |dx| this workgroup stored, over ALL its tiles -- one atomic per workgroup and launch
@@ -1107,7 +1135,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
             }
           }
         }
-        if ((dbg & 16384) && lane == 0 && blockIdx.y == 0) {
+        if ((dbg & (16384 | 32768)) && lane == 0 && blockIdx.y == 0) {
 #ifdef DSPN_ABLATE
           unsigned *po = g_phase_stamps + ((blockIdx.x * (NTHR / 64) + wave) & 8191) * 8;
 #pragma unroll
@@ -1142,6 +1170,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       if ((dbg & 16384) && !last) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(5); }
       if (!(dbg & 4)) __syncthreads();
       if ((dbg & 16384) && !last) { stamp(6); ph_acc[7] += 1u; }
+      if (last) estamp(4);
       buf ^= 1;
     }
     ++kt;
