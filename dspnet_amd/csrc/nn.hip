@@ -395,10 +395,13 @@ __global__ __launch_bounds__(256) void absmax_affine_bound_kernel(const float *_
 // (round 4): the gather of maxpool_bwd_idx_kernel for 4 channels of one input pixel.  argmax == NULL: no pooling.
 struct PoolGrad { const uchar4 *argmax; const float4 *dy; int H, W, k, stride, pad, Ho, Wo; };
 __device__ __forceinline__ float4 pool_grad_at(const PoolGrad &p, long long row, int c4, int C4) {
-  const int w = (int)(row % p.W);
-  const long long t = row / p.W;
-  const int h = (int)(t % p.H);
-  const long long n = t / p.H;
+  // (rows < 2^31 -- the entry point checks it: 32-bit divisions, a third of the instructions of the 64-bit ones)
+  const unsigned r = (unsigned)row;
+  const unsigned t = r / (unsigned)p.W;
+  const int w = (int)(r - t * (unsigned)p.W);
+  const unsigned nn = t / (unsigned)p.H;
+  const int h = (int)(t - nn * (unsigned)p.H);
+  const long long n = nn;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int ho_lo = (h + p.pad - p.k + p.stride) / p.stride; if (h + p.pad - p.k + 1 <= 0) ho_lo = 0;
   int wo_lo = (w + p.pad - p.k + p.stride) / p.stride; if (w + p.pad - p.k + 1 <= 0) wo_lo = 0;
@@ -591,9 +594,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float4 *__
                                     long long n4, int C4, int relu, unsigned *__restrict__ absmax, const PoolGrad pool) {
   float mx = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
+    const unsigned row = (unsigned)i / (unsigned)C4;          // (n4 < 2^31, checked by the entry point)
+    const int c4 = (int)((unsigned)i - row * (unsigned)C4);
     const float4 xv = x[i];
-    float4 g = pool_grad_at(pool, i / C4, c4, C4);
+    float4 g = pool_grad_at(pool, row, c4, C4);
     if (relu) {
       const float4 sa = scale[c4], sb = shift[c4];
       g.x = fmaf(xv.x, sa.x, sb.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sa.y, sb.y) > 0.f ? g.y : 0.f;
@@ -1788,6 +1792,7 @@ int dspn_bn_backward_maxpool_f32(const float *x, const float *scale, const float
   DSPN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && Ho > 0 && Wo > 0,
                "bn_backward_maxpool: bad geometry (C %% 4 == 0, k * k <= 255)");
   const long long rows = (long long)N * H * W;
+  DSPN_REQUIRE(rows * (C / 4) < (1ll << 31), "bn_backward_maxpool: N * H * W * C / 4 must stay below 2^31");
   if (workspace_bytes < bn_workspace_bytes(rows, C))
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_maxpool: workspace too small (dspn_bn_workspace_bytes)");
   const int C4 = C / 4, CL = std::min(C4, 64), ns = bn_slabs(rows);
