@@ -85,9 +85,10 @@ def MultiBoxPrior(data, sizes=(1.0,), ratios=(1.0,), clip=False, steps=(-1.0, -1
 def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=-1.0,
                    negative_mining_ratio=-1.0, negative_mining_thresh=0.5,
                    minimum_negative_samples=0, variances=(0.1, 0.1, 0.2, 0.2),
-                   check_errors=False, workspace=None):
+                   check_errors=False, workspace=None, out=None):
     """Training targets.  anchor (1,N,4), label (B,L,6), cls_pred (B,C+1,N) ->
     [loc_target (B,N*5), loc_mask (B,N*5), cls_target (B,N)].
+    out: optional (loc_target, loc_mask, cls_target) float32 device buffers of those shapes to write into.
     Shape rules and messages: multibox_target-inl.h:213-238.
     check_errors=True synchronises and raises on the data-dependent aborts of the
     reference (multibox_target.cc:98-101, :236).
@@ -119,9 +120,15 @@ def MultiBoxTarget(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label=
                                _dev_f32(cls_pred, "cls_pred"))
     B, N, Lr = int(label.shape[0]), int(anchor.shape[1]), int(label.shape[1])
     dev = anchor.device
-    loc_target = torch.empty((B, N * 5), dtype=torch.float32, device=dev)
-    loc_mask = torch.empty((B, N * 5), dtype=torch.float32, device=dev)
-    cls_target = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if out is not None:
+        loc_target, loc_mask, cls_target = out
+        for t, shp in ((loc_target, (B, N * 5)), (loc_mask, (B, N * 5)), (cls_target, (B, N))):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                raise DspnError(f"MultiBoxTarget: out buffers must be contiguous float32 {shp} tensors on {dev}")
+    else:
+        loc_target = torch.empty((B, N * 5), dtype=torch.float32, device=dev)
+        loc_mask = torch.empty((B, N * 5), dtype=torch.float32, device=dev)
+        cls_target = torch.empty((B, N), dtype=torch.float32, device=dev)
     L = _lib.lib()
     nbytes = L.dspn_multibox_target_workspace_bytes(B, N, Lr)
     if workspace is not None:

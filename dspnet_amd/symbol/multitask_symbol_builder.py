@@ -24,6 +24,8 @@ from . import vgg16_reduced as vgg_mod
 from . import inceptionv3 as inception_mod
 from .common import multi_layer_feature, multitask_layer
 
+import os as _os
+TARGET_SIDE_STREAM = _os.environ.get("DSPN_TARGET_SIDE", "1") != "0"      # (A/B switch)
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
 seg_classes = 19    # :7
 
@@ -36,23 +38,55 @@ class MultiBoxTargetNode(E.Node):
         self.anchors, self.label, self.cls_flat, self.C = anchors, label, cls_flat, num_cls
         B, N = cls_flat.shape[0], anchors.shape[1]
         self.cls_preds = g.tensor((B, num_cls, N), "multibox_cls_pred", requires_grad=False, dtype=torch.float32)
-        self.loc_target = self.loc_mask = self.cls_target = None
+        cuda = g.device.type == "cuda"
+        self.loc_target = torch.zeros(B, N * 5, device=g.device) if cuda else None
+        self.loc_mask = torch.zeros(B, N * 5, device=g.device) if cuda else None
+        self.cls_target = torch.zeros(B, N, device=g.device) if cuda else None
+        # Round 4: the matching kernels are one workgroup per sample (0.3 ms with 7/8 of the CUs idle) and only the two
+        # detection losses read their results, so they run on a second HIP stream beside whatever the graph builds between
+        # this node and the losses (the segmentation decoder's forward, _build); the losses join() first
+        self.side = torch.cuda.Stream(device=g.device) if (cuda and TARGET_SIDE_STREAM) else None
+        self.ready = torch.cuda.Event() if self.side is not None else None
+        self.done = torch.cuda.Event() if self.side is not None else None
+        self.pending = False
+        if self.side is not None:
+            g.pre_forward.append(self.join)
         # the operator's temp space, owned by this node: it also holds the per-sample abort codes of THIS node's last
         # forward (two graphs on one device -- a training and an evaluation net -- never read each other's)
         self.ws = (torch.empty(op.target_workspace_bytes(B, N, label.shape[1]), dtype=torch.uint8, device=g.device)
                    if g.device.type == "cuda" else None)
 
-    def forward(self):
+    def _run(self):
         B, C, N = self.cls_preds.shape
         fn.transpose_bnc(self.cls_flat.data.view(B, N, C), out=self.cls_preds.data)
+        out = None if self.loc_target is None else (self.loc_target, self.loc_mask, self.cls_target)
         self.loc_target, self.loc_mask, self.cls_target = op.MultiBoxTarget(
             self.anchors, self.label.data, self.cls_preds.data, overlap_threshold=.5, ignore_label=-1,
             negative_mining_ratio=3, minimum_negative_samples=0, negative_mining_thresh=.5,
-            variances=(0.1, 0.1, 0.2, 0.2), workspace=self.ws)
+            variances=(0.1, 0.1, 0.2, 0.2), workspace=self.ws, out=out)
+
+    def forward(self):
+        if self.side is None:
+            self._run()
+            return
+        main = torch.cuda.current_stream(self.cls_preds.data.device)
+        self.ready.record(main)
+        self.side.wait_event(self.ready)
+        with torch.cuda.stream(self.side):
+            self._run()
+            self.done.record(self.side)
+        self.pending = True
+
+    def join(self):
+        """order the current stream behind the matching kernels (the losses call it; idempotent)"""
+        if self.pending:
+            torch.cuda.current_stream(self.cls_preds.data.device).wait_event(self.done)
+            self.pending = False
 
     def raise_on_errors(self):
         """the reference's data-dependent CHECKs (multibox_target.cc:98-101, :236) for the last forward: synchronises;
         the kernel itself only records the codes so that the step never waits on the host"""
+        self.join()
         op.MultiBoxTarget_check(self.cls_preds.shape[0], self.cls_preds.data.device, workspace=self.ws)
 
 
@@ -71,6 +105,7 @@ class ClsSoftmaxOutput(E.Node):
 
     def forward(self):
         B, C, N = self.cls_prob.shape
+        self.tn.join()
         fn.count(self.tn.cls_target, "ne", -1.0, out=self.valid)
         fn.softmax_output(self.x.data.view(B * N, C), self.tn.cls_target, C, -1.0, 1.0, self.valid,
                           prob=self.prob_nc.view(B * N, C), grad=self.gbuf.view(B * N, C))
@@ -90,6 +125,7 @@ class LocLoss(E.Node):
         self.out = g.tensor(loc_preds.shape, "loc_loss", requires_grad=False, dtype=torch.float32)
 
     def forward(self):
+        self.tn.join()
         fn.smooth_l1_forward(self.x.data, self.tn.loc_target, self.tn.loc_mask, out=self.out.data)
         fn.count(self.out.data, "gt", 0.0, out=self.valid)
 
@@ -391,6 +427,15 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     else:
         seg_out = g.add(SegSoftmax(g, score4_conv, seg_classes))
 
+    if train and with_det and target is not None and target.side is not None:
+        # the detection losses (and MultiBoxDetection behind them) run AFTER the segmentation decoder's forward: the target
+        # matching kernels, issued on their own stream when the heads are done, have the decoder's ~1.5 ms to finish in.
+        # Backward order among the writers of a shared gradient is unchanged (decoder before heads, as before).
+        late = [cls_out, loc_loss, det]
+        for n in late:
+            g.nodes.remove(n)
+        at = g.nodes.index(seg_out)
+        g.nodes[at:at] = late
     g.finalize(seed)
     return MultiTaskNet(g, data, label, seg_label,
                         dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=seg_out,
