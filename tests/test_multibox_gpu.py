@@ -151,6 +151,31 @@ def test_target_run_to_run_deterministic(gpu_device):
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.gpu
+def test_target_into_caller_buffers_on_another_stream(gpu_device):
+    """op.MultiBoxTarget(out=...) (round 4: the graph node keeps its three outputs and runs the operator on a second HIP
+    stream beside the segmentation decoder): the same bits as the allocating call, from a side stream ordered by events;
+    buffers of the wrong shape are refused"""
+    anc = mc.r50_anchors(512, 512)
+    lab, pred = mc.target_inputs(anc, batch=4, seed=5)
+    a, l, p = dev(anc), dev(lab), dev(pred)
+    ref = host(op.MultiBoxTarget(a, l, p, negative_mining_ratio=3))
+    B, N = lab.shape[0], anc.shape[1]
+    out = (torch.full((B, N * 5), 7.0, device="cuda"), torch.full((B, N * 5), 7.0, device="cuda"), torch.full((B, N), 7.0, device="cuda"))
+    side, ready, done = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        got = op.MultiBoxTarget(a, l, p, negative_mining_ratio=3, out=out)
+        done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    assert all(g.data_ptr() == o.data_ptr() for g, o in zip(got, out))
+    for x, y in zip(host(got), ref):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(DspnError, match="out buffers"):
+        op.MultiBoxTarget(a, l, p, out=(out[0], out[1], torch.zeros(B, N + 1, device="cuda")))
+
+
 # ---------------------------------------------------------------- detection
 def run_detection(anc, prob, loc, **kw):
     got = op.MultiBoxDetection(dev(prob), dev(loc), dev(anc), **kw).cpu().numpy()
