@@ -120,6 +120,11 @@ class Graph:
         self.tensors = {}
         self.all_tensors = []
         self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
+        # round 4: nodes [first, last] whose FORWARD runs on a second stream beside the nodes behind them (the detection
+        # branch -- small SSD layers, heads, packing, target matching: tens of launches of 1 - 32 workgroups -- beside the
+        # segmentation decoder); the first reader of their results calls join_side().  (first, last, stream, ready, done)
+        self.side_segment = None
+        self.side_pending = False
         self.slab_tables = {}      # key -> (conv nodes, device table) of deferred split-K slab reductions
         self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
@@ -441,8 +446,35 @@ class Graph:
             fn.weight_planes_batch(*self.wp_table)     # "f16x2": cut relative to the magnitudes just taken)
         for f in self.pre_forward:
             f()
-        for n in self.nodes:
-            n.forward()
+        seg = self.side_segment
+        if seg is None:
+            for n in self.nodes:
+                n.forward()
+            return
+        first, last, side, ready, done = seg
+        self.join_side()
+        for i, n in enumerate(self.nodes):
+            if i < first or i > last:
+                n.forward()
+                continue
+            if i == first:       # the branch reads what the main stream has produced so far
+                ready.record(torch.cuda.current_stream(self.device))
+                side.wait_event(ready)
+            with torch.cuda.stream(side):
+                n.forward()
+                if i == last:
+                    done.record(side)
+                    self.side_pending = True
+
+    def set_side_segment(self, first, last):
+        assert 0 <= first <= last < len(self.nodes) and self.device.type == "cuda"
+        self.side_segment = (first, last, torch.cuda.Stream(device=self.device, priority=-1), torch.cuda.Event(), torch.cuda.Event())
+
+    def join_side(self):
+        """order the current stream behind the side segment's forward (idempotent; called by the first reader of its results)"""
+        if self.side_pending:
+            torch.cuda.current_stream(self.device).wait_event(self.side_segment[4])
+            self.side_pending = False
 
     def begin_backward(self):
         """reset the gradient bookkeeping; all data-gradient operands (transposed weights) in one launch"""

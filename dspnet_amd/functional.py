@@ -154,7 +154,9 @@ _ws = {}
 
 
 def workspace(nbytes, device, tag="nn"):
-    key = (tag, device)
+    # one buffer per (purpose, device, STREAM): two streams of one graph (the detection branch beside the segmentation
+    # decoder, round 4) must not share scratch
+    key = (tag, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -26,6 +26,7 @@ from .common import multi_layer_feature, multitask_layer
 
 import os as _os
 TARGET_SIDE_STREAM = _os.environ.get("DSPN_TARGET_SIDE", "1") != "0"      # (A/B switch)
+DET_SIDE_BRANCH = _os.environ.get("DSPN_DET_SIDE", "1") != "0"            # (A/B switch)
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
 seg_classes = 19    # :7
 
@@ -45,6 +46,7 @@ class MultiBoxTargetNode(E.Node):
         # Round 4: the matching kernels are one workgroup per sample (0.3 ms with 7/8 of the CUs idle) and only the two
         # detection losses read their results, so they run on a second HIP stream beside whatever the graph builds between
         # this node and the losses (the segmentation decoder's forward, _build); the losses join() first
+        self._g = g
         self.side = torch.cuda.Stream(device=g.device) if (cuda and TARGET_SIDE_STREAM) else None
         self.ready = torch.cuda.Event() if self.side is not None else None
         self.done = torch.cuda.Event() if self.side is not None else None
@@ -66,7 +68,7 @@ class MultiBoxTargetNode(E.Node):
             variances=(0.1, 0.1, 0.2, 0.2), workspace=self.ws, out=out)
 
     def forward(self):
-        if self.side is None:
+        if self.side is None or self._g.side_segment is not None:     # (the whole detection branch is on a side stream already)
             self._run()
             return
         main = torch.cuda.current_stream(self.cls_preds.data.device)
@@ -79,6 +81,7 @@ class MultiBoxTargetNode(E.Node):
 
     def join(self):
         """order the current stream behind the matching kernels (the losses call it; idempotent)"""
+        self._g.join_side()
         if self.pending:
             torch.cuda.current_stream(self.cls_preds.data.device).wait_event(self.done)
             self.pending = False
@@ -375,6 +378,7 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     res3 = internals[from_layers[0] + "_output"]
     res4 = internals[from_layers[1] + "_output"]
 
+    det_first = len(g.nodes) if with_det else None       # the first node of the detection branch
     if with_det:
         (conv_feat, target, cls_out, loc_loss, det, anchor_boxes, loc_preds, cls_flat) = _detection_branch(
             g, train, internals, label, num_classes, from_layers, num_filters, strides, pads, sizes, ratios,
@@ -436,6 +440,11 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
             g.nodes.remove(n)
         at = g.nodes.index(seg_out)
         g.nodes[at:at] = late
+        if DET_SIDE_BRANCH and det_first is not None:
+            # ... and the whole detection branch in front of them -- extra layers, heads, packing, matching -- runs its FORWARD
+            # on that stream, from the first node the branch added (backward stays on the main stream: it accumulates into
+            # gradients the decoder also writes)
+            g.set_side_segment(det_first, g.nodes.index(target))
     g.finalize(seed)
     return MultiTaskNet(g, data, label, seg_label,
                         dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=seg_out,
