@@ -125,6 +125,9 @@ class Graph:
         # segmentation decoder); the first reader of their results calls join_side().  (first, last, stream, ready, done)
         self.side_segment = None
         self.side_pending = False
+        # ... and the BACKWARD of some of those nodes beside the decoder's (set_side_backward): only nodes whose gradients
+        # stay inside the branch; every main-stream node of the branch waits for what the side stream has been given so far
+        self.side_bwd = None
         self.slab_tables = {}      # key -> (conv nodes, device table) of deferred split-K slab reductions
         self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
@@ -470,6 +473,48 @@ class Graph:
         assert 0 <= first <= last < len(self.nodes) and self.device.type == "cuda"
         self.side_segment = (first, last, torch.cuda.Stream(device=self.device, priority=-1), torch.cuda.Event(), torch.cuda.Event())
 
+    def set_side_backward(self, side_nodes, lo, hi, fork_after):
+        """side_nodes: indices (within [lo, hi]) whose backward runs on the side stream; it starts behind the backward of
+        node `fork_after` (the last producer of the branch's incoming gradients), not behind whatever the main stream was
+        given after it"""
+        assert self.side_segment is not None and all(lo <= i <= hi for i in side_nodes) and fork_after > hi
+        self.side_bwd = dict(side=frozenset(side_nodes), lo=lo, hi=hi, fork_after=fork_after, fork_ev=torch.cuda.Event(),
+                             prog_ev=torch.cuda.Event(), forked=False, dirty=False, active=True)
+
+    def backward_node(self, idx):
+        """backward of node idx on the stream it belongs to (the main stream unless set_side_backward says otherwise)"""
+        sb, n = self.side_bwd, self.nodes[idx]
+        if sb is None or not sb["active"]:
+            n.backward()
+            return
+        if idx in sb["side"]:
+            side = self.side_segment[2]
+            if not sb["forked"]:
+                side.wait_event(sb["fork_ev"])
+                sb["forked"] = True
+            with torch.cuda.stream(side):
+                n.backward()
+                sb["prog_ev"].record(side)
+            sb["dirty"] = True
+            return
+        if sb["dirty"] and idx <= sb["hi"]:      # a main-stream node of (or below) the branch: behind everything given to the side stream
+            torch.cuda.current_stream(self.device).wait_event(sb["prog_ev"])
+            sb["dirty"] = False
+        n.backward()
+        if idx == sb["fork_after"]:
+            sb["fork_ev"].record(torch.cuda.current_stream(self.device))
+
+    def join_side_backward(self):
+        sb = self.side_bwd
+        if sb is not None and sb["dirty"]:
+            torch.cuda.current_stream(self.device).wait_event(sb["prog_ev"])
+            sb["dirty"] = False
+
+    def side_backward_busy(self, idx):
+        """True while gradients of the branch may still be in flight on the side stream (the solver holds its slab reductions)"""
+        sb = self.side_bwd
+        return sb is not None and sb["active"] and sb["dirty"] and idx >= sb["lo"]
+
     def join_side(self):
         """order the current stream behind the side segment's forward (idempotent; called by the first reader of its results)"""
         if self.side_pending:
@@ -482,6 +527,9 @@ class Graph:
             t._gw = False
             t.grad = None
             t.grad_planes = False
+        if self.side_bwd is not None:
+            assert not self.side_bwd["dirty"], "the previous backward pass left side-stream work unjoined"
+            self.side_bwd["forked"] = False
         if self.scalars is not None:
             if self._am_bwd_ran:       # a second backward pass on the same forward pass: new gradients, new magnitudes
                 for slot in self._am_bwd_slots & self._am_done:
@@ -496,8 +544,9 @@ class Graph:
 
     def backward(self):
         self.begin_backward()
-        for n in reversed(self.nodes):
-            n.backward()
+        for idx in range(len(self.nodes) - 1, -1, -1):
+            self.backward_node(idx)
+        self.join_side_backward()
         self.flush_slabs()
 
     def num_params(self):

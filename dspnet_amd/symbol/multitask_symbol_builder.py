@@ -27,6 +27,7 @@ from .common import multi_layer_feature, multitask_layer
 import os as _os
 TARGET_SIDE_STREAM = _os.environ.get("DSPN_TARGET_SIDE", "1") != "0"      # (A/B switch)
 DET_SIDE_BRANCH = _os.environ.get("DSPN_DET_SIDE", "1") != "0"            # (A/B switch)
+DET_SIDE_BACKWARD = _os.environ.get("DSPN_DET_SIDE_BWD", "1") != "0"      # (A/B switch)
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
 seg_classes = 19    # :7
 
@@ -445,6 +446,16 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
             # on that stream, from the first node the branch added (backward stays on the main stream: it accumulates into
             # gradients the decoder also writes)
             g.set_side_segment(det_first, g.nodes.index(target))
+            if DET_SIDE_BACKWARD:
+                # ... and, in backward, the part of the branch whose gradients stay inside it -- head packing, the heads on the
+                # extra maps, the extra layers behind the first -- beside the decoder's backward; the heads on backbone maps
+                # and the first extra layer write gradients the decoder also writes and stay on the main stream
+                from .common import HeadPack
+                hi = g.nodes.index(target)
+                side = [i for i in range(det_first + 1, hi + 1)
+                        if isinstance(g.nodes[i], HeadPack)
+                        or (isinstance(g.nodes[i], E.Conv) and g.nodes[i].w.name.startswith("multi_feat_"))]
+                g.set_side_backward(side, det_first, hi, g.nodes.index(cls_out))
     g.finalize(seed)
     return MultiTaskNet(g, data, label, seg_label,
                         dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=seg_out,

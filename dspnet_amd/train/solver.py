@@ -160,14 +160,17 @@ class MultiTaskSolver:
         g.begin_backward()
         if self.reducer is not None:
             self.reducer.begin()
+        if g.side_bwd is not None:       # (a reducer releases buckets node by node on the main stream: everything stays there)
+            g.side_bwd["active"] = self.reducer is None
         pending = list(range(len(self.bucket_convs)))      # buckets in release order
         for idx in range(len(g.nodes) - 1, -1, -1):
-            g.nodes[idx].backward()
-            while pending and self.bucket_convs[pending[0]][0] >= idx:
+            g.backward_node(idx)
+            while pending and self.bucket_convs[pending[0]][0] >= idx and not g.side_backward_busy(idx):
                 b = pending.pop(0)
                 g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
             if self.reducer is not None:
                 self.reducer.node_done(idx)
+        g.join_side_backward()
         for b in pending:
             g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
         if self.reducer is not None:
