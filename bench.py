@@ -668,6 +668,8 @@ def main():
                 other[key] = f()
             except Exception as e:          # a side measurement must never cost the headline line
                 other[key] = {"error": str(e)[:200]}
+            import gc
+            gc.collect()                    # (graphs hold reference cycles: without this the previous one's ~25 GB stay cached)
             torch.cuda.empty_cache()
 
     if rank == 0:

@@ -37,6 +37,23 @@ import os as _os
 MATERIALISE_MULTITAP_INPUT_BF16 = _os.environ.get("DSPN_MAT3X3", "1") != "0"
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(device, kind, priority=0):
+    """ONE stream per (device, purpose) for the whole process -- the step stream of the solvers, the side streams of the
+    detection branch / MultiBoxTarget / MultiBoxDetection.  Round 4, measured: with a fresh set of streams per graph, the
+    SECOND graph of a process ran its convolutions 25 % slower (fp32 MFMA mode: 57.5 -> 79.0 ms per step, conv kernel time 52.9
+    -> 65.9 ms): HIP multiplexes streams onto a few hardware queues, and a main stream that lands on the queue of a side
+    stream waits behind its long one-workgroup-per-sample kernels.  Graphs of one process run one at a time; sharing the
+    streams keeps the mapping of the first graph."""
+    key = (str(device), kind)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return st
+
+
 class Tensor:
     """An activation: NHWC (or any) device buffer + its gradient slot.  dtype: the graph's activation storage type
     (functional.ACT_DTYPE: float32, or bfloat16 for the `*_bf16` kernels) unless given -- graph inputs, loss inputs
@@ -463,7 +480,7 @@ class Graph:
             if i == first:       # the branch reads what the main stream has produced so far
                 ready.record(torch.cuda.current_stream(self.device))
                 side.wait_event(ready)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), fn.workspace_lane(1):
                 n.forward()
                 if i == last:
                     done.record(side)
@@ -471,7 +488,7 @@ class Graph:
 
     def set_side_segment(self, first, last):
         assert 0 <= first <= last < len(self.nodes) and self.device.type == "cuda"
-        self.side_segment = (first, last, torch.cuda.Stream(device=self.device, priority=-1), torch.cuda.Event(), torch.cuda.Event())
+        self.side_segment = (first, last, shared_stream(self.device, "branch", -1), torch.cuda.Event(), torch.cuda.Event())
 
     def set_side_backward(self, side_nodes, lo, hi, fork_after):
         """side_nodes: indices (within [lo, hi]) whose backward runs on the side stream; it starts behind the backward of
@@ -492,7 +509,7 @@ class Graph:
             if not sb["forked"]:
                 side.wait_event(sb["fork_ev"])
                 sb["forked"] = True
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), fn.workspace_lane(1):
                 n.backward()
                 sb["prog_ev"].record(side)
             sb["dirty"] = True

@@ -153,10 +153,28 @@ def ptr(t):
 _ws = {}
 
 
+_WS_LANE = 0      # 0: the graph's main stream, 1: its side stream (engine.Graph sets it around the nodes it runs there)
+
+
+class workspace_lane:
+    """`with workspace_lane(1):` -- scratch buffers of the calls inside come from another set: two streams of one graph (the
+    detection branch beside the segmentation decoder, round 4) must not share scratch.  (Not keyed by the stream itself:
+    every solver and every graph makes its own streams, and the buffers of dead ones would pile up.)"""
+
+    def __init__(self, lane):
+        self.lane = lane
+
+    def __enter__(self):
+        global _WS_LANE
+        self.prev, _WS_LANE = _WS_LANE, self.lane
+
+    def __exit__(self, *a):
+        global _WS_LANE
+        _WS_LANE = self.prev
+
+
 def workspace(nbytes, device, tag="nn"):
-    # one buffer per (purpose, device, STREAM): two streams of one graph (the detection branch beside the segmentation
-    # decoder, round 4) must not share scratch
-    key = (tag, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (tag, device, _WS_LANE)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

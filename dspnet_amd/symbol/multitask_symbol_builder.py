@@ -48,7 +48,7 @@ class MultiBoxTargetNode(E.Node):
         # detection losses read their results, so they run on a second HIP stream beside whatever the graph builds between
         # this node and the losses (the segmentation decoder's forward, _build); the losses join() first
         self._g = g
-        self.side = torch.cuda.Stream(device=g.device) if (cuda and TARGET_SIDE_STREAM) else None
+        self.side = E.shared_stream(g.device, "target") if (cuda and TARGET_SIDE_STREAM) else None
         self.ready = torch.cuda.Event() if self.side is not None else None
         self.done = torch.cuda.Event() if self.side is not None else None
         self.pending = False
@@ -156,7 +156,7 @@ class Detection(E.Node):
         # so its one-workgroup-per-sample sort + NMS kernels run on a second HIP stream beside the decoder and the
         # backward pass instead of leaving 7/8 of the CUs idle for ~1.3 ms.  join() (called at the top of the next
         # forward, before cls_prob / loc_preds are overwritten, and by outputs()) orders the main stream behind it.
-        self.side = torch.cuda.Stream(device=g.device) if g.device.type == "cuda" else None
+        self.side = E.shared_stream(g.device, "detection") if g.device.type == "cuda" else None
         self.ready = torch.cuda.Event() if self.side is not None else None
         self.done = torch.cuda.Event() if self.side is not None else None
         self.pending = False

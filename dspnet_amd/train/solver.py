@@ -120,7 +120,8 @@ class MultiTaskSolver:
         self.stream = None
         if high_priority and net.g.device.type == "cuda":
             import torch
-            self.stream = torch.cuda.Stream(device=net.g.device, priority=-1)
+            from ..engine import shared_stream
+            self.stream = shared_stream(net.g.device, "step", -1)
         self.lr, self.momentum, self.wd = learning_rate, momentum, wd
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
