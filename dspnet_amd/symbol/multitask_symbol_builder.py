@@ -25,9 +25,10 @@ from . import inceptionv3 as inception_mod
 from .common import multi_layer_feature, multitask_layer
 
 import os as _os
-TARGET_SIDE_STREAM = _os.environ.get("DSPN_TARGET_SIDE", "1") != "0"      # (A/B switch)
-DET_SIDE_BRANCH = _os.environ.get("DSPN_DET_SIDE", "1") != "0"            # (A/B switch)
-DET_SIDE_BACKWARD = _os.environ.get("DSPN_DET_SIDE_BWD", "1") != "0"      # (A/B switch)
+def _switch(name):
+    """A/B switches of the side-stream schedule, read when a graph is BUILT: DSPN_TARGET_SIDE, DSPN_DET_SIDE, DSPN_DET_SIDE_BWD
+    (all on by default; "0" puts that part back on the main stream -- results are bit-identical either way)"""
+    return _os.environ.get(name, "1") != "0"
 eps = 2e-5          # symbol/multitask_symbol_builder.py:5
 seg_classes = 19    # :7
 
@@ -48,7 +49,7 @@ class MultiBoxTargetNode(E.Node):
         # detection losses read their results, so they run on a second HIP stream beside whatever the graph builds between
         # this node and the losses (the segmentation decoder's forward, _build); the losses join() first
         self._g = g
-        self.side = E.shared_stream(g.device, "target") if (cuda and TARGET_SIDE_STREAM) else None
+        self.side = E.shared_stream(g.device, "target") if (cuda and _switch("DSPN_TARGET_SIDE")) else None
         self.ready = torch.cuda.Event() if self.side is not None else None
         self.done = torch.cuda.Event() if self.side is not None else None
         self.pending = False
@@ -441,12 +442,12 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
             g.nodes.remove(n)
         at = g.nodes.index(seg_out)
         g.nodes[at:at] = late
-        if DET_SIDE_BRANCH and det_first is not None:
+        if _switch("DSPN_DET_SIDE") and det_first is not None:
             # ... and the whole detection branch in front of them -- extra layers, heads, packing, matching -- runs its FORWARD
             # on that stream, from the first node the branch added (backward stays on the main stream: it accumulates into
             # gradients the decoder also writes)
             g.set_side_segment(det_first, g.nodes.index(target))
-            if DET_SIDE_BACKWARD:
+            if _switch("DSPN_DET_SIDE_BWD"):
                 # ... and, in backward, the part of the branch whose gradients stay inside it -- head packing, the heads on the
                 # extra maps, the extra layers behind the first -- beside the decoder's backward; the heads on backbone maps
                 # and the first extra layer write gradients the decoder also writes and stay on the main stream

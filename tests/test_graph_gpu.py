@@ -1111,3 +1111,48 @@ def test_detector_batch_64_det_out_is_the_oracles(gpu_device):
     out2, _ = det.forward()
     assert torch.equal(out2, out)
     assert tuple(seg.shape[:3]) == (B, 128, 128) and torch.isfinite(seg).all()
+
+
+@pytest.mark.gpu
+def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule(gpu_device):
+    """Round 4: the detection branch (SSD extra layers, heads, packing, MultiBoxTarget) runs its forward, and the part of its
+    backward whose gradients stay inside it, on a second stream beside the segmentation decoder (Graph.set_side_segment /
+    set_side_backward).  Only the STREAMS change -- every accumulation keeps its order -- so parameters and gradients after
+    each of several SGD steps must equal, bit for bit, those of the same graph built with the whole schedule on the main stream
+    (DSPN_TARGET_SIDE = DSPN_DET_SIDE = 0), and a second run of the side-stream schedule must reproduce the first."""
+    import os
+    from dspnet_amd import synthetic
+    from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
+    from dspnet_amd.train.solver import MultiTaskSolver
+    B, S, steps = 4, 256, 4
+
+    def run(side):
+        saved = {k: os.environ.get(k) for k in ("DSPN_TARGET_SIDE", "DSPN_DET_SIDE", "DSPN_DET_SIDE_BWD")}
+        for k in saved:
+            os.environ[k] = "1" if side else "0"
+        try:
+            net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=torch.device("cuda", 0), seed=0)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert (net.g.side_segment is not None) == side and (net.g.side_bwd is not None) == side
+        g = synthetic.rng(3)
+        solver = MultiTaskSolver(net)
+        solver.set_batch(torch.from_numpy(synthetic.images(B, S, S, g)).cuda(),
+                         torch.from_numpy(synthetic.det_labels(B, gen=g, height=S, width=S, first_empty=False)).cuda(),
+                         torch.from_numpy(synthetic.seg_labels(B, S, S, gen=g)).cuda())
+        out = []
+        for _ in range(steps):
+            solver.step()
+            torch.cuda.synchronize()
+            out.append((net.g.arena.clone(), net.g.grad_arena.clone()))
+        return out
+
+    on1, off, on2 = run(True), run(False), run(True)
+    for k in range(steps):
+        for a, b, c in zip(on1[k], off[k], on2[k]):
+            assert torch.equal(a, b), "step %d: side-stream schedule differs from the main-stream schedule" % k
+            assert torch.equal(a, c), "step %d: the side-stream schedule is not reproducible" % k
