@@ -725,6 +725,15 @@ def main():
             # seen by a BatchNorm finalize, how many of them span more than 2^16, and the widest span in bits
             line["config"]["f16x2_range_monitor"] = {"tensors": range_rep[0], "wider_than_2^16": range_rep[1],
                                                      "widest_span_bits": round(range_rep[2], 1)}
+        # round 4: which part of the step runs beside the main stream (engine.Graph.set_side_segment / set_side_backward).  While
+        # it does, the convolution family's kernels share the chip with it, so `roofline.achieved` -- work / the HIP-event
+        # brackets of those kernels -- is lower than with everything on one stream (DSPN_DET_SIDE=0), though the step is shorter
+        gsched = net.g
+        line["config"]["side_stream_schedule"] = {
+            "detection_branch_forward": gsched.side_segment is not None,
+            "detection_branch_backward_part": bool(gsched.side_bwd is not None and gsched.side_bwd.get("active", False)),
+            "nodes_on_side_stream": (0 if gsched.side_segment is None else gsched.side_segment[1] - gsched.side_segment[0] + 1,
+                                     0 if gsched.side_bwd is None else len(gsched.side_bwd["side"]))}
         if other is not None:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
