@@ -161,6 +161,7 @@ class Detection(E.Node):
         self.ready = torch.cuda.Event() if self.side is not None else None
         self.done = torch.cuda.Event() if self.side is not None else None
         self.pending = False
+        self._g = g
         g.pre_forward.append(self.join)
 
     def forward(self):
@@ -176,6 +177,7 @@ class Detection(E.Node):
         self.pending = True
 
     def join(self):
+        self._g.join_side()        # (test graphs: the whole detection branch, this node included, runs on the branch stream)
         if self.pending:
             torch.cuda.current_stream(self.out.data.device).wait_event(self.done)
             self.pending = False
@@ -457,6 +459,10 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
                         if isinstance(g.nodes[i], HeadPack)
                         or (isinstance(g.nodes[i], E.Conv) and g.nodes[i].w.name.startswith("multi_feat_"))]
                 g.set_side_backward(side, det_first, hi, g.nodes.index(cls_out))
+    if (not train) and with_det and det is not None and g.device.type == "cuda" and _switch("DSPN_DET_SIDE"):
+        # test graph: the detection branch up to and including MultiBoxDetection beside the segmentation decoder; its only
+        # reader is the caller, through det.join()
+        g.set_side_segment(det_first, g.nodes.index(det))
     g.finalize(seed)
     return MultiTaskNet(g, data, label, seg_label,
                         dict(target=target, cls_out=cls_out, loc_loss=loc_loss, det=det, seg_out=seg_out,
