@@ -567,7 +567,8 @@ def main():
 
     lib = _lib.lib()
     reserved = max(args.reserve_cus, 0)
-    lib.dspn_conv_set_reserved_cus(reserved)
+    if lib.dspn_conv_set_reserved_cus(reserved) != 0:
+        sys.exit("bench.py: --reserve-cus %d rejected by the library (0 .. 128)" % reserved)
     if solver.reducer is not None:
         solver.reducer.measure_exposed = True          # event records around the collective waits (and per bucket)
     for _ in range(args.warmup):
@@ -583,7 +584,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if float(t.item()) > 1.0:
             reserved = 16
-            lib.dspn_conv_set_reserved_cus(reserved)
+            if lib.dspn_conv_set_reserved_cus(reserved) != 0:
+                sys.exit("bench.py: dspn_conv_set_reserved_cus(16) failed")
             for _ in range(2):
                 solver.step()
             sync()

@@ -48,10 +48,11 @@ def shared_stream(device, kind, priority=0):
     stream waits behind its long one-workgroup-per-sample kernels.  Graphs of one process run one at a time; sharing the
     streams keeps the mapping of the first graph."""
     key = (str(device), kind)
-    st = _SHARED_STREAMS.get(key)
-    if st is None:
-        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
-    return st
+    ent = _SHARED_STREAMS.get(key)
+    if ent is None:
+        ent = _SHARED_STREAMS[key] = (torch.cuda.Stream(device=device, priority=priority), priority)
+    assert ent[1] == priority, "shared stream %r of %s was created with priority %d, asked for %d" % (kind, device, ent[1], priority)
+    return ent[0]
 
 
 class Tensor:
@@ -145,6 +146,8 @@ class Graph:
         # ... and the BACKWARD of some of those nodes beside the decoder's (set_side_backward): only nodes whose gradients
         # stay inside the branch; every main-stream node of the branch waits for what the side stream has been given so far
         self.side_bwd = None
+        self.side_fwd_events, self.side_fwd_waits = {}, {}   # _plan_side_sync
+        self.side_plan = None      # what the builder asked for (any device) and what _plan_side_sync made of it
         self.slab_tables = {}      # key -> (conv nodes, device table) of deferred split-K slab reductions
         self.wt_table = None       # descriptor table of every Conv's (weight, transposed weight) pair
         self.wt_batched = False    # True while backward() runs after one batched transpose launch
@@ -369,6 +372,7 @@ class Graph:
     def finalize(self, seed=0):
         """allocate the flat parameter / gradient / momentum arenas and initialise"""
         self._resolve_auto_deferred()
+        self._plan_side_sync()
         if _os.environ.get("DSPN_X_PLANES", "1") != "0":       # (A/B switch)
             self._plan_input_planes()
         self._plan_bn_backward_fusion()
@@ -448,6 +452,97 @@ class Graph:
         for k, v in values.items():
             self.params[k].data.copy_(torch.from_numpy(np.ascontiguousarray(v, np.float32)).view(self.params[k].shape))
 
+
+    # -- stream ordering of the side segment (round 5) ---------------------------------------------
+    def _node_tensors(self, n):
+        """every engine Tensor a node holds (attributes, lists / tuples of them), each with the tensors whose buffers it reads
+        through: the raw input of a deferred BatchNorm (affine_src) and the source of a BlockGrad alias"""
+        seen, out = set(), []
+
+        def take(t):
+            while t is not None and id(t) not in seen:
+                seen.add(id(t))
+                out.append(t)
+                if t.affine_src is not None:
+                    take(t.affine_src[0])
+                t = t.alias_of
+
+        for v in vars(n).values():
+            for t in (v if isinstance(v, (list, tuple)) else [v]):
+                if isinstance(t, Tensor):
+                    take(t)
+        return out
+
+    @staticmethod
+    def _node_outputs(n):
+        outs = []
+        for k, v in vars(n).items():
+            if k == "out" or k.startswith("out_") or k in ("outs", "cls_prob", "cls_preds", "prob"):
+                outs += [t for t in (v if isinstance(v, (list, tuple)) else [v]) if isinstance(t, Tensor)]
+        return outs
+
+    def _plan_side_sync(self):
+        """Called by finalize().  The builder only says WHICH nodes run beside the main stream; what orders the two streams
+        is derived here from the tensors the nodes hold, so that a preset whose wiring differs (vgg16_reduced, inceptionv3,
+        resnet-101: the decoder reads an SSD extra layer's output, symbol/multitask_symbol_builder.py `conv_feat`) cannot
+        silently become a race:
+        * forward: a main-stream node behind the segment that holds a tensor written inside it waits for an event recorded
+          behind the LAST in-segment node that writes (or, failing that, first holds) that tensor -- not for the whole branch;
+        * backward: a node leaves the side set if it shares a tensor with a main-stream node that runs between the fork and
+          itself (the decoder writes that tensor's gradient on the main stream while the side stream, which only waits for
+          the fork event, would read or accumulate into it), repeated until nothing changes."""
+        plan = self.side_plan
+        self.side_fwd_events, self.side_fwd_waits = {}, {}
+        if plan is None:
+            return
+        first, last = plan["first"], plan["last"]
+        cuda = self.side_segment is not None
+        refs = [self._node_tensors(n) for n in self.nodes]
+        holders = {}
+        for i, ts in enumerate(refs):
+            for t in ts:
+                holders.setdefault(id(t), []).append(i)
+        before = set()
+        for i in range(first):
+            before.update(id(t) for t in refs[i])
+        for tid, idxs in holders.items():
+            inside = [i for i in idxs if first <= i <= last]
+            outside = [i for i in idxs if i > last]
+            if not inside or not outside or tid in before:
+                continue
+            writers = [i for i in inside if any(id(t) == tid for t in self._node_outputs(self.nodes[i]))]
+            src = max(writers) if writers else min(inside)
+            if src not in self.side_fwd_events:
+                self.side_fwd_events[src] = torch.cuda.Event() if cuda else None
+            for r in outside:
+                w = self.side_fwd_waits.setdefault(r, [])
+                if src not in w:
+                    w.append(src)
+        plan["fwd_waits"] = {r: list(w) for r, w in self.side_fwd_waits.items()}
+        sb = plan["bwd"]
+        if sb is None:
+            return
+        side, fork_after = set(sb["side"]), sb["fork_after"]
+        has_bwd = [type(n).backward is not Node.backward for n in self.nodes]
+        changed = True
+        while changed:
+            changed = False
+            for i in sorted(side):
+                mine = {id(t) for t in refs[i]}
+                for x in range(i + 1, fork_after):
+                    if x in side or not has_bwd[x]:
+                        continue
+                    if mine & {id(t) for t in refs[x]}:
+                        side.discard(i)
+                        changed = True
+                        break
+        sb["removed"] = frozenset(sb["side"]) - side
+        sb["side"] = frozenset(side)
+        if self.side_bwd is not None:
+            self.side_bwd["side"] = frozenset(side)
+            if not side:
+                self.side_bwd = None
+
     # -- execution ------------------------------------------------------------
     def forward(self):
         self.wt_batched = False        # the weights may have changed since the last batched transpose
@@ -475,6 +570,8 @@ class Graph:
         self.join_side()
         for i, n in enumerate(self.nodes):
             if i < first or i > last:
+                for src in self.side_fwd_waits.get(i, ()):     # (a tensor written inside the segment: _plan_side_sync)
+                    torch.cuda.current_stream(self.device).wait_event(self.side_fwd_events[src])
                 n.forward()
                 continue
             if i == first:       # the branch reads what the main stream has produced so far
@@ -482,21 +579,29 @@ class Graph:
                 side.wait_event(ready)
             with torch.cuda.stream(side), fn.workspace_lane(1):
                 n.forward()
+                if i in self.side_fwd_events:
+                    self.side_fwd_events[i].record(side)
                 if i == last:
                     done.record(side)
                     self.side_pending = True
 
     def set_side_segment(self, first, last):
-        assert 0 <= first <= last < len(self.nodes) and self.device.type == "cuda"
-        self.side_segment = (first, last, shared_stream(self.device, "branch", -1), torch.cuda.Event(), torch.cuda.Event())
+        """nodes [first, last] run their forward on the branch stream.  On a CPU graph only the plan is kept (side_plan):
+        tests/test_side_plan.py checks what _plan_side_sync derives from it for every preset without a GPU."""
+        assert 0 <= first <= last < len(self.nodes)
+        self.side_plan = dict(first=first, last=last, bwd=None)
+        if self.device.type == "cuda":
+            self.side_segment = (first, last, shared_stream(self.device, "branch", -1), torch.cuda.Event(), torch.cuda.Event())
 
     def set_side_backward(self, side_nodes, lo, hi, fork_after):
         """side_nodes: indices (within [lo, hi]) whose backward runs on the side stream; it starts behind the backward of
         node `fork_after` (the last producer of the branch's incoming gradients), not behind whatever the main stream was
         given after it"""
-        assert self.side_segment is not None and all(lo <= i <= hi for i in side_nodes) and fork_after > hi
-        self.side_bwd = dict(side=frozenset(side_nodes), lo=lo, hi=hi, fork_after=fork_after, fork_ev=torch.cuda.Event(),
-                             prog_ev=torch.cuda.Event(), forked=False, dirty=False, active=True)
+        assert self.side_plan is not None and all(lo <= i <= hi for i in side_nodes) and fork_after > hi
+        self.side_plan["bwd"] = dict(side=frozenset(side_nodes), lo=lo, hi=hi, fork_after=fork_after)
+        if self.side_segment is not None:
+            self.side_bwd = dict(side=frozenset(side_nodes), lo=lo, hi=hi, fork_after=fork_after, fork_ev=torch.cuda.Event(),
+                                 prog_ev=torch.cuda.Event(), forked=False, dirty=False, active=True)
 
     def backward_node(self, idx):
         """backward of node idx on the stream it belongs to (the main stream unless set_side_backward says otherwise)"""

@@ -435,7 +435,7 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
     else:
         seg_out = g.add(SegSoftmax(g, score4_conv, seg_classes))
 
-    if train and with_det and target is not None and target.side is not None:
+    if train and with_det and target is not None and _switch("DSPN_TARGET_SIDE"):
         # the detection losses (and MultiBoxDetection behind them) run AFTER the segmentation decoder's forward: the target
         # matching kernels, issued on their own stream when the heads are done, have the decoder's ~1.5 ms to finish in.
         # Backward order among the writers of a shared gradient is unchanged (decoder before heads, as before).
@@ -459,7 +459,7 @@ def _build(train, with_seg, network, num_classes, from_layers, num_filters, stri
                         if isinstance(g.nodes[i], HeadPack)
                         or (isinstance(g.nodes[i], E.Conv) and g.nodes[i].w.name.startswith("multi_feat_"))]
                 g.set_side_backward(side, det_first, hi, g.nodes.index(cls_out))
-    if (not train) and with_det and det is not None and g.device.type == "cuda" and _switch("DSPN_DET_SIDE"):
+    if (not train) and with_det and det is not None and _switch("DSPN_DET_SIDE"):
         # test graph: the detection branch up to and including MultiBoxDetection beside the segmentation decoder; its only
         # reader is the caller, through det.join()
         g.set_side_segment(det_first, g.nodes.index(det))

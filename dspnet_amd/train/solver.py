@@ -36,6 +36,12 @@ def plan_buckets(params, owner_index, total, bucket_elems):
     return buckets
 
 
+def side_buckets(buckets, params, owner_index, side_nodes):
+    """per bucket (release order): does it hold a parameter whose gradient a node of `side_nodes` writes?"""
+    side_nodes = set(side_nodes)
+    return [any(o < hi and o + s > lo and owner_index[n] in side_nodes for n, o, s in params) for lo, hi, _ in buckets]
+
+
 class GradBucketReducer:
     """Sum-all-reduce of the gradient arena in buckets, each launched (async) as soon as backward has
     passed the first node that writes into it, so RCCL traffic overlaps the remaining kernels.
@@ -58,9 +64,15 @@ class GradBucketReducer:
         self.works, self.launched = [], []
         self._issue_ev = []
 
-    def node_done(self, idx):
+    def node_done(self, idx, before_release=None):
+        """release every bucket whose last gradient the backward of node idx has produced.  before_release(bucket index in
+        release order), if given, runs first: the solver sums the bucket's split-K slabs there and, when part of the bucket
+        was written on the side stream, orders the current stream behind it -- the collective starts behind the CURRENT
+        stream's work, whichever stream wrote the bucket's last gradient"""
         import torch.distributed as dist
         while self.pending and self.pending[0][2] >= idx:
+            if before_release is not None:
+                before_release(len(self.buckets) - len(self.pending))
             lo, hi, _ = self.pending.pop(0)
             self.launched.append((lo, hi))
             if self.measure_exposed and self.arena.is_cuda:
@@ -143,6 +155,10 @@ class MultiTaskSolver:
         for lo, hi, first in self.buckets:
             self.bucket_convs.append((first, [n for n in g.nodes if getattr(n, "slabs", None) is not None
                                               and lo <= n.w.offset < hi]))
+        # buckets that hold a gradient written by the side-stream part of backward (Graph.set_side_backward): their release
+        # waits for the side stream's progress event; the others are released as before, beside it
+        self.bucket_side = side_buckets(self.buckets, params, owner,
+                                        g.side_bwd["side"] if g.side_bwd is not None else ())
 
     def set_batch(self, data, label_det, label_seg):
         """device tensors in the reference's layouts: (B,3,H,W), (B,200,6), (B,H/4,W/4); a label the graph has
@@ -161,21 +177,31 @@ class MultiTaskSolver:
         g.begin_backward()
         if self.reducer is not None:
             self.reducer.begin()
-        if g.side_bwd is not None:       # (a reducer releases buckets node by node on the main stream: everything stays there)
-            g.side_bwd["active"] = self.reducer is None
-        pending = list(range(len(self.bucket_convs)))      # buckets in release order
+        if self.reducer is None:
+            pending = list(range(len(self.bucket_convs)))      # buckets in release order
+            for idx in range(len(g.nodes) - 1, -1, -1):
+                g.backward_node(idx)
+                while pending and self.bucket_convs[pending[0]][0] >= idx and not g.side_backward_busy(idx):
+                    b = pending.pop(0)
+                    g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
+            g.join_side_backward()
+            for b in pending:
+                g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
+            return
+        # N > 1 (round 5): the SAME schedule as N = 1 -- the side-stream part of backward stays on its stream.  A bucket is
+        # released when backward has passed its first owner, as before; one that holds side-stream gradients first makes the
+        # main stream wait for the side stream's progress event (every side node of the bucket has been issued by then)
+
+        def before_release(b):
+            if self.bucket_side[b]:
+                g.join_side_backward()
+            g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
+
         for idx in range(len(g.nodes) - 1, -1, -1):
             g.backward_node(idx)
-            while pending and self.bucket_convs[pending[0]][0] >= idx and not g.side_backward_busy(idx):
-                b = pending.pop(0)
-                g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
-            if self.reducer is not None:
-                self.reducer.node_done(idx)
+            self.reducer.node_done(idx, before_release)
         g.join_side_backward()
-        for b in pending:
-            g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
-        if self.reducer is not None:
-            self.reducer.finish()
+        self.reducer.finish()
 
     def update(self):
         g = self.g

@@ -126,3 +126,40 @@ def test_bucketed_allreduce_world2_gloo_on_the_real_graph_layout():
         assert p.exitcode == 0
     for rank, ok, order_ok, n in res:
         assert ok and order_ok and n == 8, (rank, ok, order_ok, n)
+
+
+def test_side_stream_buckets_on_the_real_graph_layout():
+    """Round 5 (N > 1 runs the N = 1 schedule): which buckets of the REAL graph must wait for the side stream before their
+    release -- exactly those holding a parameter of a node whose backward runs there (the SSD extra layers behind the first
+    and the heads on the extra maps) -- and that the reducer calls the solver's hook once per bucket, in release order,
+    BEFORE the bucket's collective is issued."""
+    from dspnet_amd.train.solver import side_buckets
+    params, owner, total, doc = real_layout()
+    buckets = plan_buckets(params, owner, total, int(4.0 * (1 << 20) / 4))
+    side_nodes = {owner[n] for n, _, _ in params
+                  if n.startswith("multi_feat_") and not n.startswith("multi_feat_2_conv_1x1")}
+    flags = side_buckets(buckets, params, owner, side_nodes)
+    assert any(flags) and not all(flags)
+    for (lo, hi, _), f in zip(buckets, flags):
+        names = [n for n, o, s in params if o < hi and o + s > lo]
+        assert f == any(owner[n] in side_nodes for n in names)
+    assert side_buckets(buckets, params, owner, ()) == [False] * len(buckets)
+
+    class FakeWork:
+        def wait(self):
+            pass
+    log = []
+    red = GradBucketReducer(torch.zeros(total), buckets)
+    import torch.distributed as dist_mod
+    real = dist_mod.all_reduce
+    dist_mod.all_reduce = lambda t, group=None, async_op=False: (log.append(("reduce", t.numel())), FakeWork())[1]
+    try:
+        red.begin()
+        for idx in range(doc["nodes"] - 1, -1, -1):
+            red.node_done(idx, lambda b: log.append(("hook", b)))
+        red.finish()
+    finally:
+        dist_mod.all_reduce = real
+    assert [e for e in log if e[0] == "hook"] == [("hook", b) for b in range(len(buckets))]
+    for k in range(len(buckets)):          # hook b directly precedes collective b
+        assert log[2 * k] == ("hook", k) and log[2 * k + 1] == ("reduce", buckets[k][1] - buckets[k][0])

@@ -434,6 +434,10 @@ def test_gradient_reducer_path_is_bit_identical_at_world_1(gpu_device):
             nets.append((net, solver))
         (na, sa), (nb, sb) = nets
         assert sa.reducer is None and sb.reducer is not None
+        # round 5: the reducer path runs the N = 1 schedule -- the side-stream part of backward stays active, and the buckets
+        # that hold its gradients (the SSD extra layers and their heads) wait for the side stream before their release
+        assert nb.g.side_bwd is not None and nb.g.side_bwd["active"] and len(nb.g.side_bwd["side"]) == 17
+        assert any(sb.bucket_side) and not all(sb.bucket_side)
         assert torch.equal(na.g.arena, nb.g.arena) and torch.equal(na.g.grad_arena, nb.g.grad_arena)
         launched = sb.reducer.launched
         assert len(launched) == len(sb.buckets) > 4
@@ -1114,12 +1118,17 @@ def test_detector_batch_64_det_out_is_the_oracles(gpu_device):
 
 
 @pytest.mark.gpu
-def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule(gpu_device):
+@pytest.mark.parametrize("network", ["resnet-50", "vgg16_reduced", "inceptionv3"])
+def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule(gpu_device, network):
     """Round 4: the detection branch (SSD extra layers, heads, packing, MultiBoxTarget) runs its forward, and the part of its
     backward whose gradients stay inside it, on a second stream beside the segmentation decoder (Graph.set_side_segment /
     set_side_backward).  Only the STREAMS change -- every accumulation keeps its order -- so parameters and gradients after
     each of several SGD steps must equal, bit for bit, those of the same graph built with the whole schedule on the main stream
-    (DSPN_TARGET_SIDE = DSPN_DET_SIDE = 0), and a second run of the side-stream schedule must reproduce the first."""
+    (DSPN_TARGET_SIDE = DSPN_DET_SIDE = 0), and a second run of the side-stream schedule must reproduce the first.
+    Round 5: all three presets -- for vgg16_reduced / inceptionv3 the decoder reads a tensor written INSIDE the branch (conv_feat
+    is the first SSD extra layer), which the stream ordering derived in Graph._plan_side_sync has to cover (structure:
+    tests/test_side_plan.py) -- and the steps are issued back to back, so that the host runs ahead of the device as it
+    does in training."""
     import os
     from dspnet_amd import synthetic
     from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
@@ -1131,7 +1140,7 @@ def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule
         for k in saved:
             os.environ[k] = "1" if side else "0"
         try:
-            net = get_multi_symbol_train("resnet-50", S, num_classes=8, batch_size=B, device=torch.device("cuda", 0), seed=0)
+            net = get_multi_symbol_train(network, S, num_classes=8, batch_size=B, device=torch.device("cuda", 0), seed=0)
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -1146,9 +1155,9 @@ def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule
                          torch.from_numpy(synthetic.seg_labels(B, S, S, gen=g)).cuda())
         out = []
         for _ in range(steps):
-            solver.step()
-            torch.cuda.synchronize()
+            solver.step()       # (no synchronize: the clones are ordered behind the step on the current stream)
             out.append((net.g.arena.clone(), net.g.grad_arena.clone()))
+        torch.cuda.synchronize()
         return out
 
     on1, off, on2 = run(True), run(False), run(True)
