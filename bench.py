@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="CUs the persistent convolution grids leave free for RCCL (dspn_conv_set_reserved_cus).  -1 (default): "
                          "0 at N = 1; at N > 1 switched to 16 after warm-up iff the exposed all-reduce time exceeds 1 ms")
+    ap.add_argument("--wide-tiles", type=int, default=0,
+                    help="dspn_conv_set_wide_tiles: 0 automatic (default), 1 never (the round-4 128x128 kernels), 2 / 3 / 4 force a shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -569,6 +571,8 @@ def main():
     reserved = max(args.reserve_cus, 0)
     if lib.dspn_conv_set_reserved_cus(reserved) != 0:
         sys.exit("bench.py: --reserve-cus %d rejected by the library (0 .. 128)" % reserved)
+    if lib.dspn_conv_set_wide_tiles(args.wide_tiles) != 0:
+        sys.exit("bench.py: --wide-tiles %d rejected by the library (0 .. 4)" % args.wide_tiles)
     if solver.reducer is not None:
         solver.reducer.measure_exposed = True          # event records around the collective waits (and per bucket)
     for _ in range(args.warmup):
@@ -701,6 +705,9 @@ def main():
                                    "N=%d anchors, forward+backward+SGD%s" % (args.network, S, Wd, net.anchors.shape[1],
                                                                             ", bf16 tensors in HBM" if args.store == "bf16" else ""),
                        "conv_math": MATH_LABEL[args.math],
+                       "conv_tiles": {0: "automatic (plane-fed two-piece layers on the wide family: 64x64 outputs per wave, "
+                                         "operands global -> LDS directly)", 1: "128x128 conv_nt_kernel only (the round-4 schedule)",
+                                      2: "forced 256x128", 3: "forced 128x256", 4: "forced 128x128 on four waves"}[args.wide_tiles],
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
                        "train_gflop_per_image_3x_convention": round(flops_3x / B / 1e9, 2),
                        "train_gflop_per_image_executed": round(flops_step / B / 1e9, 2)},

@@ -48,6 +48,8 @@ void prof_end(hipStream_t s) { if (t_prof_end) (void)hipEventRecord(t_prof_end, 
 // which otherwise only finds room between two convolution launches.
 static std::atomic<int> g_reserved_cus{0};
 int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
+static std::atomic<int> g_wide_tiles{0};
+int wide_tiles_mode() { return g_wide_tiles.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
 extern "C" {
@@ -71,6 +73,11 @@ int dspn_profile_collect(int family, double *total_ms, long long *launches) {
 int dspn_conv_set_reserved_cus(int cus) {
   if (cus < 0 || cus > 128) return dspn::fail(DSPN_ERR_ARG_, "conv_set_reserved_cus: 0 .. 128 CUs, got %d", cus);
   dspn::g_reserved_cus.store(cus);
+  return 0;
+}
+int dspn_conv_set_wide_tiles(int mode) {
+  if (mode < 0 || mode > 4) return dspn::fail(DSPN_ERR_ARG_, "conv_set_wide_tiles: 0 automatic, 1 never, 2 256x128, 3 128x256, 4 128x128, got %d", mode);
+  dspn::g_wide_tiles.store(mode);
   return 0;
 }
 const char *dspn_last_error(void) { return dspn::last_error_buf(); }

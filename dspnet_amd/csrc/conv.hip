@@ -26,6 +26,7 @@
 #include "dspn_common.h"
 #include "dspn_store.h"
 #include "dspn_pieces.h"
+#include "conv_geom.h"
 #include <cstdlib>
 #include "../../include/dspn_nn.h"
 
@@ -41,8 +42,8 @@ using dspn::u32x4_t;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using dspn::conv::f32x16;
+using dspn::conv::bf16x8;
 using dspn::pieces::bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -90,10 +91,7 @@ using namespace dspn::pieces;
 constexpr int kEPC = 16 / (int)sizeof(st_t);   // elements per 16-byte chunk: 4 floats or 8 bf16
 constexpr int kBK = 8 * kEPC;                  // K elements per k-step of the NT kernel (8 chunks per tile row): 32 or 64
 constexpr int kBKF = 32;                       // ... of its fp32-MFMA path
-#ifndef DSPN_WG_PK
-#define DSPN_WG_PK 32
-#endif
-constexpr int kPK = DSPN_WG_PK;                // pixels per k-step of the weight-gradient kernel
+constexpr int kPK = 32;                              // pixels per k-step of the weight-gradient kernel
 __device__ __forceinline__ float4 ld4(const st_t *p) { return dspn::CA1Ptr(p).vec4()[0]; }
 __device__ __forceinline__ void st4(st_t *p, const float4 v) { dspn::A1Ptr(p).vec4()[0] = v; }
 // 8 bf16 of one 16-byte chunk <-> 8 floats
@@ -108,59 +106,8 @@ __device__ __forceinline__ u32x4_t narrow8(const float (&f)[8]) {
 }
 constexpr int kLdsRow = 36;    // padded LDS row (floats)
 
-struct ConvGeom {
-  int N, Hin, Win, Cin;            // gathered tensor (Cin % kEPC == 0)
-  int Hg, Wg;                      // grid of output points per image
-  int ish, isw, ioh, iow, idh, idw;  // ih = i*ish + ioh + tr*idh
-  int TR, TS;                      // taps enumerated
-  int WTAPS, WS, wr0, wrs, ws0, wss;  // weight tap = (wr0+tr*wrs)*WS + ws0+ts*wss
-  int Cout;
-  long long obs;                   // output batch stride (floats)
-  int OW, osh, osw, ooh, oow, ldc; // out pixel = ((i*osh+ooh)*OW + j*osw+oow)*ldc
-  int flags;                       // 1 bias, 2 relu, 4 accumulate, 8 add residual (same layout as out), 16 float4 rows legal, 32 ReLU after the input affine
-  int dense;                       // output address = m*ldc (no decomposition needed)
-  int dbg;                         // timing-only ablation bits (DSPN_ABLATE builds), 0 in production
-  int bf16;                        // host side only: the call's math mode (DSPN_MATH_*): 0 fp32 MFMA, 1 bf16 MFMA, 2 three-piece bf16
-  unsigned in_bytes, w_bytes;      // sizes of the gathered tensor / weight tensor (buffer bounds)
-  // optional per-input-channel affine (+ReLU when flags & 32) applied to the gathered tensor on its way into
-  // LDS: the BatchNorm(+ReLU) in front of a convolution (symbol/resnet.py:30-45) without materialising its output
-  const float *in_scale, *in_shift;
-  // optional BatchNorm statistics of the OUTPUT, per row tile: stats[(mt*2 + 0)*Cout + c] = mean over the tile's
-  // rows, stats[(mt*2 + 1)*Cout + c] = sum of squared deviations from that mean (merged by dspn_bn_stats_from_tiles_f32)
-  float *stats;
-  // optional (two-piece math, with stats): minmax[(mt*2 + 0)*Cout + c] = smallest, [(mt*2 + 1)*Cout + c] = largest stored value
-  // of the tile's rows in column c.  A BatchNorm(+ReLU) of the output is monotone per channel, so the magnitude of what the
-  // NEXT convolution's loader forms from this tensor is the largest |f_c(extreme)| over this small table
-  // (dspn_absmax_f32 on it, with the affine) -- instead of a pass over the whole tensor
-  float *minmax;
-  // optional BatchNorm-backward sums of the OUTPUT (a data gradient dy of a BatchNorm(+ReLU) output whose input was
-  // bn_x, same layout as out): per row tile t, bn_sums[((tile_base + t)*2 + 0)*Cout + c] = sum of dy' and
-  // [... + 1 ...] = sum of dy' * xhat, with dy' = dy where (bn_x*bn_scale + bn_shift > 0 or no ReLU) else 0 and
-  // xhat = (bn_x - bn_mean) * bn_rstd: the layout dspn_bn_backward_from_sums_f32 reads
-  const st_t *bn_x;
-  const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
-  float *bn_sums;
-  int bn_relu, bn_tile_base;
-  // optional, with bn_sums (round 4): 64 partial maxima of |dx| as stored -- the largest output gradient the following
-  // BatchNorm backward meets, from which it bounds the dx IT stores before it writes it as fp16 piece planes (dspn_nn.h)
-  unsigned *bn_dy_absmax;
-  // DSPN_MATH_F32_F16X2: device scalars holding the largest magnitude of the A operand (the gathered tensor AFTER its input
-  // affine) and of the B operand (the weights); the kernel derives the power-of-two scales that put them just below 2^15
-  // (operand_scale) and undoes both in the epilogue.  NULL = scale 1 (the caller vouches for |operand| < 65504).
-  const float *a_absmax, *b_absmax;
-  int a_planes;                    // host side only: the gathered tensor is fp16 piece planes (conv_nt_kernel, EPIX & 4)
-  // host side only: the weight operand as three bf16 piece planes [Cout][WTAPS][Cin / 32][3][32] (split mode, Cin % 32 == 0:
-  // dspn_conv2d_weight_planes_f32); the kernel then receives this pointer in place of the float weights
-  const void *w_planes;
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD a
-  // contiguous run of logical tiles so neighbouring tiles share its L2.
-  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-  const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return start + (bid >> 3);
-}
+using ConvGeom = dspn::conv::ConvGeomT<st_t>;
+using dspn::conv::xcd_remap;
 
 // Split modes, round 3 -- PRE (every split-mode kernel whose k-steps never straddle a tap, Cin % 32 == 0): the weight operand
 // arrives as piece planes, [row][tap][Cin / 32][piece][32] with three bf16 or two fp16 pieces (dspn_conv2d_weight_planes_*: cut
@@ -202,28 +149,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   constexpr int PB = NPC * 32;                          // 16-bit elements of one (row, tap, 32-channel block) of the planes
   // 16-B loads per thread per k-step
   constexpr int A_LD = BM / RSTEP;
-  // Two-piece math with weight planes (round 4): the B tile is a PURE COPY of 128-byte (row, tap, 32-channel block) records,
-  // so it goes global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction: no VGPRs, no ds_write, no vector
-  // instruction besides one address add).  The LDS destination of such a load is lane-linear, so the image cannot be padded
-  // against bank conflicts; it is XOR-swizzled instead, on the SOURCE address here and on the fragment reads in mma_step:
-  // rows are 128 B, two per 256-B bank line, and the 16-byte slot s = (row & 1) * 8 + chunk of line L = row >> 1 holds what
-  // an unswizzled image would keep in slot s ^ (L & 7).  A 16-lane group of ds_read_b128 (rows {0-3, 12-15, 20-27} or
-  // {4-11, 16-19, 28-31} of a 32-row fragment, one chunk index) then covers all 16 slots of the bank line once.
-    // MEASURED (round 4, same box, twice each): 782 images/s with it, 785 - 787 with the register path it replaces (forward
-  // layers 1.5 % slower: at a tile's end the next tile's B piece can only be requested AFTER the epilogue has released the
-  // LDS, where the register path requests it before; data gradients 0.4 % faster).  In-kernel stamps say why neither
-  // matters much: a k-step spends ~600 of ~3100 cycles getting its four 1-KiB requests ACCEPTED by the texture path
-  // (64 B/clk per CU, 16 waves asking at once behind the barrier), whichever instruction carries them.  Kept as a build
-  // option (make DMA_B=1 -> -DDSPN_DMA_B), parity-green; the default build stages B through registers.
-#ifdef DSPN_DMA_B
-  constexpr bool DMA_B = PRE && MATH == 3;
-#else
-  constexpr bool DMA_B = false;
-#endif
-  constexpr int NWV = NTHR / 64;
-  constexpr int B_NI = DMA_B ? BN / (8 * NWV) : 1;      // 1-KiB pieces (8 rows of the B tile) per wave and k-step
-  static_assert(!DMA_B || (BN % (8 * NWV) == 0 && B_NI >= 1), "the B tile is a whole number of 1-KiB pieces per wave");
-  constexpr int B_LD = DMA_B ? 1 : PRE ? NPC * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
+  // (Round 4 had the weight planes go global -> LDS directly inside this kernel as a build option -- 782 against 785 - 787
+  // images/s with the register path below; round 5 made that, for BOTH operands, the wide family of conv_wide.h.)
+  constexpr int B_LD = PRE ? NPC * ((4 * BN + NTHR - 1) / NTHR) : BN / RSTEP;
   constexpr bool B_EXACT = (4 * BN) % NTHR == 0;
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   float *sA = smem;                          // [2][BM][kLdsRow]
@@ -231,15 +159,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   constexpr int ROWH = SPLIT ? NPC * 32 + 8 : kLdsRowH;   // LDS row (16-bit elements) of the 16-bit images: 208 / 144 / 80 B
   // the three-piece image is single-buffered (two barriers per k-step: two stages of 208-B rows do not leave two workgroups
   // per CU); the two-piece image (144-B rows) fits twice: one barrier per k-step, as in the unsplit modes
-#ifdef DSPN_F16X2_ONE_STAGE
-  constexpr int STAGES = SPLIT ? 1 : 2;
-#else
   constexpr int STAGES = MATH == 2 ? 1 : 2;
-#endif
-  static_assert(!DMA_B || STAGES == 2, "the direct-to-LDS B tile is double buffered");
-  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH] (DMA_B: [STAGES][BN][64], swizzled)
+  __bf16 *hA = reinterpret_cast<__bf16 *>(smem);   // bf16 mode: [STAGES][BM][ROWH], then [STAGES][BN][ROWH] 
   __bf16 *hB = hA + STAGES * BM * ROWH;
-  static_assert(!DMA_B || (STAGES * BM * ROWH * 2) % 256 == 0, "the B image starts on a bank line");
 
 #ifdef DSPN_ABLATE
   const int dbg = g.dbg;   // timing-only ablation build (make ABLATE=1): results are WRONG when non-zero
@@ -306,7 +228,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   // PRE: thread (row = tid >> 2, part = tid & 3) moves chunks 3 * part .. 3 * part + 2 of the 12 chunks (192 B) of tile
   // row `row` (+ NTHR / 4 per pass): one address register per pass, the three chunks at immediate offsets
   constexpr int B_PASS = PRE ? (4 * BN + NTHR - 1) / NTHR : 1;
-  static_assert(!PRE || DMA_B || B_LD == NPC * B_PASS, "chunk count of the piece-plane loader");
+  static_assert(!PRE || B_LD == NPC * B_PASS, "chunk count of the piece-plane loader");
   const int CB = g.Cin >> 5;                 // PRE: 32-channel blocks per tap
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
@@ -324,19 +246,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       a_iw0[i] = mv ? iw0 : 0;
       a_eoff[i] = mv ? ((n * g.Hin + ih0) * g.Win + iw0) * g.Cin : 0;
     }
-    if constexpr (DMA_B) {
-      // piece q = wave * B_NI + i of the B image (1 KiB = bank lines 4q .. 4q+3 = tile rows 8q .. 8q+7): lane l fills slot
-      // l & 15 of line 4q + (l >> 4), i.e. fetches chunk c of row r with (r & 1) * 8 + c = (l & 15) ^ (line & 7).  Rows past
-      // Cout read the last row instead (finite values; their output columns are never stored): no reliance on what an
-      // out-of-range LDS-DMA load leaves in LDS
-#pragma unroll
-      for (int i = 0; i < B_NI; ++i) {
-        const int line = 4 * (wave * B_NI + i) + (lane >> 4);
-        const int sl = (lane & 15) ^ (line & 7);
-        const int k = min(ld_n0 + 2 * line + (sl >> 3), g.Cout - 1);
-        b_eoff[i] = k * (g.WTAPS * CB * PB * 2) + (sl & 7) * 16;      // BYTES
-      }
-    } else if constexpr (PRE) {
+    if constexpr (PRE) {
 #pragma unroll
       for (int ps = 0; ps < B_PASS; ++ps) {
         const int br = (tid >> 2) + ps * (NTHR / 4), k = ld_n0 + br;
@@ -359,8 +269,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
 
   float4 ra[A_LD], rb[B_LD];
   u32x4_t ha[A_LD], hb[B_LD];    // the same chunks as loaded, bf16 tensors (8 channels each)
-  int b_soff = 0;                // DMA_B: what load_tiles() worked out for issue_b()
-  bool b_qv = false;
   // timing-only ablation (bits 4096 / 8192, split modes): the A side of a k-step -- loads, affine, pieces, LDS stores -- only
   // every 3rd / 9th k-step: the upper bound of what an A tile kept in LDS across a kernel row's / all nine taps could save
   int abl_phase = 0;
@@ -425,11 +333,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
                                __uint_as_float(t[3]));
     }
     const int wtap = (g.wr0 + tr * g.wrs) * g.WS + g.ws0 + ts * g.wss;
-    if constexpr (DMA_B) {
-      // (wave-uniform) byte offset of this k-step's (tap, 32-channel block) inside a row of the planes; issue_b() sends it
-      b_soff = (wtap * CB + (cq0 >> 3)) * (PB * 2);
-      b_qv = qv;
-    } else if constexpr (PRE) {
+    if constexpr (PRE) {
       // piece planes: the 192 bytes of (row, tap, block of 32 channels) are contiguous; 12 chunks per row
       const int boff = (wtap * CB + (cq0 >> 3)) * PB;
 #pragma unroll
@@ -450,20 +354,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       else rb[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
                                __uint_as_float(t[3]));
     }
-    }
-  };
-  // DMA_B: the B tile of the k-step load_tiles() addressed last goes straight into stage `dst` of the LDS image.  Not part of
-  // load_tiles(): at a tile's last k-step the A rows of the next tile are requested BEFORE the epilogue (they wait in
-  // registers), the B tile only after it -- the epilogue's staging area covers both stages
-  auto issue_b = [&](const int dst, const int soff, const bool qv) __attribute__((always_inline)) {
-    if constexpr (DMA_B) {
-      if (qv) {
-        char *base = reinterpret_cast<char *>(hB) + dst * (BN * 128) + (wave * B_NI) * 1024;
-#pragma unroll
-        for (int i = 0; i < B_NI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(base + i * 1024), 16,
-                                                   b_eoff[i], soff, 0, 0);
-      }
     }
   };
   // float tensors: the input affine of this thread's A rows, in registers
@@ -556,8 +446,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
         for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<bf16x4 *>(d + 32 * pc) = pa[i][pc];
       }
       }
-      if constexpr (DMA_B) {   // (already on its way: issue_b)
-      } else if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
+      if constexpr (PRE) {   // three 16-byte chunks per 32 channels, as loaded
 #pragma unroll
         for (int ps = 0; ps < B_PASS; ++ps) {
           const int br = (tid >> 2) + ps * (NTHR / 4);
@@ -668,10 +557,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       // first.  Lane (row r = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of the block, as in the bf16 mode.
       const __bf16 *a = hA + buf * BM * ROWH + (wm + frow) * ROWH + (lane >> 5) * 8;
       const __bf16 *b = hB + buf * BN * ROWH + (wn + frow) * ROWH + (lane >> 5) * 8;
-      // DMA_B: row r = wn + 32 j + frow sits in bank line r >> 1; chunk c = 4 p + 2 kk + (lane >> 5) of it in slot
-      // ((r & 1) * 8 + c) ^ ((r >> 1) & 7) (see DMA_B above; wn + 32 j adds whole groups of 16 lines, so the row bits are frow's)
-      const char *bsw = reinterpret_cast<const char *>(hB) + buf * (BN * 128) + wn * 128 + (frow >> 1) * 256;
-      const int bslot = ((((frow & 1) << 3) | (lane >> 5)) ^ ((frow >> 1) & 7)) << 4;
       auto block = [&](const int kk) __attribute__((always_inline)) {
         bf16x8 fa[NPC][TM], fb[NPC][TN];
 #pragma unroll
@@ -680,10 +565,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
           for (int i = 0; i < TM; ++i)
             fa[p][i] = *reinterpret_cast<const bf16x8 *>(a + i * 32 * ROWH + p * 32 + kk * 16);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (DMA_B) fb[p][j] = *reinterpret_cast<const bf16x8 *>(bsw + j * 4096 + (bslot ^ ((4 * p + 2 * kk) << 4)));
-            else fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
-          }
+          for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * ROWH + p * 32 + kk * 16);
         }
         // piece pairs, smallest terms first: three-piece bf16 (p + q <= 2), two-piece fp16 (p + q <= 1)
         constexpr int NPROD = MATH == 3 ? 3 : 6;
@@ -823,17 +705,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
   };
   setup_tile(t);
   load_tiles();
-  issue_b(0, b_soff, b_qv);
-  if constexpr (DMA_B) {
-    // a K range without taps (parity class of a strided data gradient) runs its one k-step on zero operands: nothing is ever
-    // loaded into the B image then, so clear it (both stages) -- stale LDS bits could be NaNs
-    if (nk == 0)
-      for (int i = tid; i < STAGES * BN * 8; i += NTHR) reinterpret_cast<u32x4_t *>(hB)[i] = u32x4_t{0u, 0u, 0u, 0u};
-  }
   split_tiles();
   half_affine();
   store_tiles(0);
-  if constexpr (DMA_B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B tile has landed (the barrier below publishes it)
   __syncthreads();
   zero_acc();
   int m0 = ld_m0, n0 = ld_n0;
@@ -848,7 +722,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
     if (__builtin_expect(last && has_next, 0)) setup_tile(tn);
     stamp(-1);
     load_tiles();   // k-step kt+1 of this tile | k-step 0 of the next | past K without a next tile: out of range, zero-cost
-    if (!last) issue_b(buf ^ 1, b_soff, b_qv);   // (DMA_B; at a tile's last k-step the epilogue's staging area is in the way: issued after it)
     stamp(0);
     // nk == 0 (a parity class of a strided data gradient without taps): the loads return zeros, so the k-step may run
     // (accumulators stay 0) or be skipped.  The 8-wave build must NOT branch here: with the branch hipcc keeps the
@@ -1160,7 +1033,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       m0 = ld_m0; n0 = ld_n0;
       kt = -1;
       __syncthreads();   // every staged row has been read before the next tile's first k-step overwrites the LDS
-      issue_b(buf ^ 1, b_soff, b_qv);
     }
     if constexpr (STAGES == 1) {
       if (!last && !(dbg & 4)) __syncthreads();   // every wave has read the fragments of this k-step (the epilogue's barriers cover `last`)
@@ -1168,7 +1040,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8 && 
       if (!(dbg & 4)) __syncthreads();
     } else {
       if (!(dbg & 2)) store_tiles(buf ^ 1);
-      if constexpr (DMA_B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the B tile have landed
       if ((dbg & 16384) && !last) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(5); }
       if (!(dbg & 4)) __syncthreads();
       if ((dbg & 16384) && !last) { stamp(6); ph_acc[7] += 1u; }
@@ -1231,12 +1102,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   // is, the tiles of one split -- which all stream the SAME pixel range of dy and x -- land on all eight L2s and every L2
   // fetches that range for its four or five tiles.  xcd_remap gives each XCD a contiguous run of (split, tile) pairs
   // instead: a pixel range is then read through ONE L2 and shared there by all the tiles of its split
-#ifdef DSPN_WG_NO_XCD
-  const int tile = blockIdx.x, split = blockIdx.y;
-#else
   const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int split = lin / (int)gridDim.x, tile = lin - split * (int)gridDim.x;
-#endif
   const int kt_i = tile / j_tiles, jt_i = tile - kt_i * j_tiles;
   const int k0 = kt_i * BM, j0 = jt_i * BN;
   const int P = g.N * g.Ho * g.Wo;
@@ -1332,14 +1199,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   };
   constexpr int RAB = wg_row_bytes(BM), RBB = wg_row_bytes(BN);   // bf16 image row strides (bytes)
   // split mode: three piece planes per operand, single-buffered: [3][kPK][RAB] then [3][kPK][RBB]
-  // LDS stages: the three-piece image is single-buffered (two barriers per k-step); the two-piece image of the 8-wave
-  // 128 x 128 tile fits TWICE in half a CU's LDS exactly (2 stages x 2 pieces x 32 pixels x (320 + 320) B = 80 KiB), which
-  // takes one of the two barriers out of every k-step (round 4, DSPN_WG_STAGES2: measured below before it became default)
-#ifdef DSPN_WG_STAGES2
-  constexpr int STAGES = (MATH == 2 || (MATH == 3 && WAVES_M * WAVES_N != 8)) ? 1 : 2, PLANES = SPLIT ? NPC : 1;
-#else
+  // LDS stages: the split-mode images are single-buffered (two barriers per k-step).  (Round 4, measured neutral and not kept:
+  // two stages for the two-piece image of the 8-wave 128 x 128 tile -- 80 KiB, one barrier per k-step: 8.78 - 8.82 against 8.84 ms
+  // of weight gradients per step.)
   constexpr int STAGES = SPLIT ? 1 : 2, PLANES = SPLIT ? NPC : 1;
-#endif
   const float sc_a = MATH == 3 ? operand_scale(g.dy_absmax) : 1.f, sc_b = MATH == 3 ? operand_scale(g.x_absmax) : 1.f;
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
   const bool nf_a = MATH == 3 && operand_nonfinite(g.dy_absmax), nf_b = MATH == 3 && operand_nonfinite(g.x_absmax);
@@ -1929,6 +1792,7 @@ __global__ void nt_split_reduce_kernel(const float *__restrict__ slab, const flo
 struct SplitWs { float *ptr; size_t bytes; };
 
 
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool UNIFORM_TAP, int MATH, bool INTF, int EPI>
 int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
@@ -1937,12 +1801,7 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   if (M <= 0) return 0;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // mainloop buffers | staged output tile of the epilogue
-#ifdef DSPN_F16X2_ONE_STAGE
-  constexpr int kStages3 = 1;
-#else
-  constexpr int kStages3 = 2;
-#endif
-  const size_t lds = std::max<size_t>(MATH == 3   ? sizeof(__bf16) * kStages3 * (BM + BN) * (2 * 32 + 8)
+  const size_t lds = std::max<size_t>(MATH == 3   ? sizeof(__bf16) * 2 * (BM + BN) * (2 * 32 + 8)
                                       : MATH == 2 ? sizeof(__bf16) * (BM + BN) * kLdsRowS
                                       : MATH == 1 ? sizeof(__bf16) * 2 * (BM + BN) * kLdsRowH
                                                   : sizeof(float) * 2 * (BM + BN) * kLdsRow,
@@ -1960,7 +1819,6 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
     slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
-    if (const char *e = getenv("DSPN_NT_SLOTS_DIV")) slots = std::max(8, slots / std::max(1, atoi(e)) / 8 * 8);   // experiments
     if (getenv("DSPN_DEBUG_PRINT"))
       fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
               WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
@@ -1991,10 +1849,6 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
 #define DSPN_NT_(U, B, T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, U, B, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
 #ifdef DSPN_HALF
 #define DSPN_NT_UB_(T, E) (uni ? DSPN_NT_(true, 1, T, E) : DSPN_NT_(false, 1, T, E))
-#elif defined(DSPN_DEV_X3ONLY)   /* development builds: only the split-mode kernels are instantiated (compile time) */
-#define DSPN_NT_UB_(T, E) (g.bf16 == 3   ? (uni ? DSPN_NT_(true, 3, T, E) : DSPN_NT_(false, 3, T, E)) \
-                           : g.bf16 == 2 ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
-                                         : dspn::fail(DSPN_ERR_ARG_, "development build: split math modes only"))
 #else
 #define DSPN_NT_UB_(T, E) (g.bf16 == 3   ? (uni ? DSPN_NT_(true, 3, T, E) : DSPN_NT_(false, 3, T, E)) \
                            : g.bf16 == 2 ? (uni ? DSPN_NT_(true, 2, T, E) : DSPN_NT_(false, 2, T, E)) \
@@ -2012,22 +1866,6 @@ int launch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const
   return g.stats ? DSPN_NT_UB_(false, 1) : DSPN_NT_UB_(false, 0);
 #undef DSPN_NT_UB_
 #undef DSPN_NT_
-}
-
-// the two-piece kernels alone (uniform taps), for tile shapes that exist only in that math
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_nt_f16x2(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g,
-                    hipStream_t s, int splits, int ksteps_per_split, float *slab, const st_t *residual) {
-#ifdef DSPN_HALF
-  return dspn::fail(DSPN_ERR_ARG_, "conv: no two-piece kernels for bf16 tensors");
-#else
-#define DSPN_NT3_(T, E) launch_nt_impl<WAVES_M, WAVES_N, TM, TN, true, 3, T, E>(in, w, bias, out, g, s, splits, ksteps_per_split, slab, residual)
-  if (g.a_planes) return g.bn_sums ? DSPN_NT3_(false, 6) : (g.stats ? DSPN_NT3_(false, 5) : DSPN_NT3_(false, 4));
-  if (g.bn_sums) return DSPN_NT3_(false, 2);
-  if (g.in_scale) return g.stats ? DSPN_NT3_(true, 1) : DSPN_NT3_(true, 0);
-  return g.stats ? DSPN_NT3_(false, 1) : DSPN_NT3_(false, 0);
-#undef DSPN_NT3_
-#endif
 }
 
 // Tile choice: the largest tile that still yields >= one workgroup per CU; if even the smallest
@@ -2115,16 +1953,15 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 >= 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
-  // experiment (DSPN_NT_WIDE=<min tiles>): 128 x 256 tiles on 8 waves of 64 x 64 (one workgroup per CU, 256 registers) for
-  // the two-piece layers with >= 256 output columns: half the A-side loads / piece arithmetic / LDS stores per multiply-add
-  static const int wide_min = [] { const char *e = getenv("DSPN_NT_WIDE"); return e ? atoi(e) : 0; }();
-#ifndef DSPN_DEV_FAST
-  if (wide_min > 0 && pre && g.bf16 == 3 && splits == 1 && cfg == 0 && g.Cout % 256 == 0 && tiles(128, 256) >= wide_min)
-    return launch_nt_f16x2<2, 4, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
+#ifndef DSPN_HALF
+  // The wide family (conv_wide.h): both operands pure copies, 64 x 64 outputs per wave.  Legal when the A operand is piece
+  // planes (=> two-piece math, whole 32-channel blocks, no input affine), the vector epilogue applies, there is at least one
+  // tap, no split-K, and the BatchNorm tables are per 128 rows (cfg 0) -- the layout the wide epilogue writes.
+  if (g.a_planes && pre && g.bf16 == 3 && splits == 1 && cfg == 0 && (g.flags & 16) && g.Cout % 4 == 0 && g.TR * g.TS > 0) {
+    const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk);
+    if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
+  }
 #endif
-#ifdef DSPN_DEV_FAST   /* development: compile ONLY the 8-wave two-piece kernels (register / ISA inspection in under a minute) */
-  return launch_nt_f16x2<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
-#else
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
@@ -2132,7 +1969,6 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
     case 2: return launch_nt<2, 2, 1, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
     default: return launch_nt<4, 1, 2, 1>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   }
-#endif
 }
 
 struct WgradPlan { int bm; int bn; int splits; int pps; };
@@ -2611,14 +2447,9 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
   // mainloop buffers | staged output tile
   // (the float build sizes for its largest mode: float images 2 * kPK * (BM + BN) * 4 B; the three-piece bf16 image of the
   // split mode, single-buffered, 3 * kPK * row bytes, is smaller than the staged output tile for every tile shape but 32 x 128)
-#ifdef DSPN_WG_STAGES2
-  constexpr bool wg_two_stages = true;
-#else
-  constexpr bool wg_two_stages = false;
-#endif
   const size_t lds = kHalf ? std::max<size_t>(2 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)), sizeof(float) * BM * (BN + 4))
                            : std::max<size_t>(sizeof(float) * std::max(2 * kPK * (BM + BN), BM * (BN + 4)),
-                                              (wg_two_stages && g.bf16 == 3 && BM == 128 && BN == 128 ? 4 : 3) * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)));
+                                              3 * (size_t)kPK * (wg_row_bytes(BM) + wg_row_bytes(BN)));
   dspn::ProfScope prof(1, s);
 #ifdef DSPN_HALF
 #define DSPN_WGRAD_LAUNCH(WM, WN, TM_, TN_)                                                              \
@@ -2658,12 +2489,6 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     }                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
-#ifdef DSPN_DEV_FAST
-  if (g.bf16 == 3 && g.x_planes) { if (g.dy_planes) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 6, false) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 5, false) }
-  else if (g.bf16 == 3 && g.dy_planes) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 4, false) }
-  else if (g.bf16 == 3) { if (g.in_scale) DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, true) else DSPN_WGRAD_LAUNCH_(4, 2, 1, 2, 3, false) }
-  else
-#endif
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64

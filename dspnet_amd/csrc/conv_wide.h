@@ -1,0 +1,493 @@
+// The WIDE tile family of the two-piece convolution math (round 5).  Included by conv.hip (float build), inside its anonymous
+// namespace, behind conv_nt_kernel: same ConvGeom, same K order, same epilogues, same results to the last bit of the
+// accumulation order per output -- what changes is how a workgroup is fed.
+//
+// conv_nt_kernel's 128 x 128 tile on 8 waves of 32 x 64 (128 registers, two workgroups per CU) asks the texture path for
+// 32 KiB per k-step and issues 12 LDS fragment reads for 12 MFMAs per wave; its stamps showed a
+// k-step of ~3100 cycles of which ~980 are MFMA, the rest queueing for shared units.  Here:
+//   * both operands are PURE COPIES (A: fp16 piece planes of the gathered tensor, B: piece planes of the weights), so both go
+//     global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction): no staging registers, no ds_write, no vector
+//     arithmetic in the k-loop besides a handful of address instructions.  A tap outside the image (or a row past M) is an
+//     out-of-range buffer offset: the hardware writes ZEROS into the LDS image for those lanes (measured on gfx950:
+//     profiles/r05_lds_dma_out_of_range_probe.txt), so padding needs no branch and no second instruction;
+//   * a wave owns 64 x 64 outputs (2 x 2 accumulators of 32 x 32): 16 fragment reads feed 24 MFMAs per k-step, and a
+//     256 x 128 (128 x 256) workgroup asks for 48 KiB per k-step for TWICE the multiply-adds of the 128 x 128 tile;
+//   * the LDS images are a ring of STAGES k-steps filled STAGES - 1 ahead behind a COUNTED s_waitcnt vmcnt(N) and a raw
+//     s_barrier (a __syncthreads() would drain the ring: cdna_hip_programming.md section 5, "Pipelining across barriers"): one
+//     barrier per k-step, the loads of the next k-steps stay in flight across it;
+//   * the images are unpadded 128-byte rows (a DMA destination is lane-linear), XOR-swizzled on the SOURCE address and on
+//     the fragment reads exactly as conv_nt_kernel's DMA_B image: 16-byte slot s = (row & 1) * 8 + chunk of bank line
+//     L = row >> 1 holds what an unswizzled image keeps in slot s ^ (L & 7): conflict-free ds_read_b128.
+// One workgroup per CU at 256 registers (8 waves), or two at 256 registers (4 waves, 128 x 128).
+//
+// BatchNorm tables keep their 128-row layout whatever the tile: a 256-row tile writes two rows of g.stats / g.minmax /
+// g.bn_sums, so dspn_conv2d_stats_layout / dspn_conv2d_dgrad_bn_tiles and every consumer are untouched by the routing.
+
+// The tile epilogue of the wide family, from the staged fp32 tile in LDS (st[row * (BN + 4) + col], written by the caller, which
+// has NOT yet met the barrier that publishes it) to the stored outputs and BatchNorm tables; ends with the barrier after which
+// the LDS may be overwritten.  conv_nt_kernel's epilogue per 128-row half: same arithmetic, same tables.
+template <int BM, int BN, int NTHR, int EPI>
+__device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, const int m0, const int n0, const int M, const int tid,
+                                              const float *__restrict__ bias, float *__restrict__ out,
+                                              const float *__restrict__ residual, float &gmx_all) {
+  constexpr int HALVES = BM / 128;
+  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
+  constexpr int SLD = BN + 4;
+  constexpr int C4 = BN / 4, RPP = NTHR / C4, NPH = 128 / RPP;   // float4 columns per row, rows per pass, passes per half
+  constexpr int RC = NPH > 8 ? 8 : NPH;                          // rows in flight per thread
+  float *st = reinterpret_cast<float *>(wsm);
+  const int c4 = tid % C4, er0 = tid / C4;
+  const int co = n0 + c4 * 4;
+  const bool cvalid = co < g.Cout;                               // (Cout % 4 == 0 and aligned rows: the host routes nothing else)
+  const float *addsrc = has_res ? residual : (accum ? out : nullptr);
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == 2 && cvalid) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bmu[e] = g.bn_mean[co + e]; brs[e] = g.bn_rstd[co + e];
+      if (g.bn_relu) { bsc[e] = g.bn_scale[co + e]; bsh[e] = g.bn_shift[co + e]; }
+    }
+  }
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_bias && cvalid) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = bias[co + e];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr float kInf = __builtin_huge_valf();
+  float sK[HALVES][4], s1[HALVES][4], s2[HALVES][4], vmn[HALVES][4], vmx[HALVES][4], gs[HALVES][4], gss[HALVES][4];
+  int scnt[HALVES];
+  float gmx = 0.f;
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    scnt[h] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sK[h][e] = 0.f; s1[h][e] = 0.f; s2[h][e] = 0.f; vmn[h][e] = kInf; vmx[h][e] = -kInf; gs[h][e] = 0.f; gss[h][e] = 0.f; }
+  }
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+#pragma unroll 1
+    for (int ch = 0; ch < NPH / RC; ++ch) {
+      int offs[RC];
+      float4 rq[RC], xq[EPI == 2 ? RC : 1];
+#pragma unroll
+      for (int p = 0; p < RC; ++p) {
+        const int m = m0 + h * 128 + er0 + (ch * RC + p) * RPP;
+        if (g.dense) {
+          offs[p] = m * g.ldc + co;
+        } else {
+          const int hw = g.Hg * g.Wg;
+          const int n = m / hw, rem = m - n * hw;
+          const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+          offs[p] = n * (int)g.obs + ((oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
+        }
+        if (m >= M || !cvalid) offs[p] = -1;
+        rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (addsrc && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
+        if constexpr (EPI == 2) {
+          xq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (offs[p] >= 0) xq[p] = *reinterpret_cast<const float4 *>(g.bn_x + offs[p]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < RC; ++p) {
+        const int off = offs[p];
+        if (off < 0) continue;
+        const float4 tv = *reinterpret_cast<const float4 *>(st + (h * 128 + er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
+        float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
+        v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
+        if (has_res && accum) {
+          const float4 q = *reinterpret_cast<const float4 *>(out + off);
+          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (EPI == 2) {
+          const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gd = (!g.bn_relu || fmaf(xv[e], bsc[e], bsh[e]) > 0.f) ? v[e] : 0.f;
+            gs[h][e] += gd;
+            gss[h][e] += gd * ((xv[e] - bmu[e]) * brs[e]);
+          }
+          gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+        if constexpr (EPI == 1) {
+          if (scnt[h] == 0) { sK[h][0] = v[0]; sK[h][1] = v[1]; sK[h][2] = v[2]; sK[h][3] = v[3]; }
+          ++scnt[h];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - sK[h][e];
+            s1[h][e] += d; s2[h][e] += d * d;
+            vmn[h][e] = fminf(vmn[h][e], v[e]); vmx[h][e] = fmaxf(vmx[h][e], v[e]);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (EPI == 1) {
+    // per-thread (mean, M2) of its rows of each half -> LDS -> one thread per (half, column) merges the RPP row groups with
+    // Chan's update in a fixed order -> stats[128-row tile][mean | M2][column]; the extremes (g.minmax) travel with them
+    __builtin_amdgcn_s_barrier();      // every staged row has been read
+    float *red = reinterpret_cast<float *>(wsm);             // [HALVES][RPP][BN][2], then the extremes, same shape
+    float *red2 = red + HALVES * RPP * BN * 2;
+    const bool mmx = g.minmax != nullptr;                    // (kernel-uniform)
+    if (cvalid) {
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        const float inv = scnt[h] > 0 ? 1.f / (float)scnt[h] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[((h * RPP + er0) * BN + c4 * 4 + e) * 2] = sK[h][e] + s1[h][e] * inv;
+          red[((h * RPP + er0) * BN + c4 * 4 + e) * 2 + 1] = s2[h][e] - s1[h][e] * s1[h][e] * inv;
+          if (mmx) {
+            red2[((h * RPP + er0) * BN + c4 * 4 + e) * 2] = vmn[h][e];
+            red2[((h * RPP + er0) * BN + c4 * 4 + e) * 2 + 1] = vmx[h][e];
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int hc = tid; hc < HALVES * BN; hc += NTHR) {
+      const int h = hc / BN, col = hc - h * BN;
+      const int lim = min(M - (m0 + h * 128), 128);
+      if (n0 + col >= g.Cout || lim <= 0) continue;
+      // merge of the RPP row groups about the first group's mean (no division inside the loop):
+      //   mean = m_0 + sum n_e d_e / n,  M2 = sum (M2_e + n_e d_e^2) - n (mean - m_0)^2,  d_e = mean_e - m_0
+      const float *rh = red + (size_t)h * RPP * BN * 2, *rh2 = red2 + (size_t)h * RPP * BN * 2;
+      const float mref = rh[col * 2];                        // row group 0 is never empty
+      float n = 0.f, sd = 0.f, sq = 0.f;
+#pragma unroll 4
+      for (int er = 0; er < RPP; ++er) {
+        const int ne_i = lim > er ? (lim - er + RPP - 1) / RPP : 0;
+        const float ne = (float)ne_i;
+        const float d = ne_i > 0 ? rh[(er * BN + col) * 2] - mref : 0.f;
+        const float m2e = ne_i > 0 ? rh[(er * BN + col) * 2 + 1] : 0.f;
+        n += ne; sd += ne * d; sq += m2e + ne * d * d;
+      }
+      const float dm = sd / n;
+      const long long mt_ = m0 / 128 + h;
+      g.stats[(mt_ * 2 + 0) * g.Cout + n0 + col] = mref + dm;
+      g.stats[(mt_ * 2 + 1) * g.Cout + n0 + col] = fmaxf(sq - n * dm * dm, 0.f);
+      if (mmx) {
+        float mn = kInf, mx = -kInf;
+        for (int er = 0; er < RPP && er < lim; ++er) { mn = fminf(mn, rh2[(er * BN + col) * 2]); mx = fmaxf(mx, rh2[(er * BN + col) * 2 + 1]); }
+        g.minmax[(mt_ * 2 + 0) * g.Cout + n0 + col] = mn;
+        g.minmax[(mt_ * 2 + 1) * g.Cout + n0 + col] = mx;
+      }
+    }
+  }
+  if constexpr (EPI == 2) {
+    __builtin_amdgcn_s_barrier();      // every staged row has been read
+    float *red = reinterpret_cast<float *>(wsm);             // [HALVES][RPP][BN][2]
+    if (cvalid) {
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[((h * RPP + er0) * BN + c4 * 4 + e) * 2] = gs[h][e];
+          red[((h * RPP + er0) * BN + c4 * 4 + e) * 2 + 1] = gss[h][e];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int hc = tid; hc < HALVES * BN; hc += NTHR) {
+      const int h = hc / BN, col = hc - h * BN;
+      if (n0 + col >= g.Cout || m0 + h * 128 >= M) continue;
+      const float *rh = red + (size_t)h * RPP * BN * 2;
+      float a = 0.f, b = 0.f;
+      for (int er = 0; er < RPP; ++er) { a += rh[(er * BN + col) * 2]; b += rh[(er * BN + col) * 2 + 1]; }
+      const long long mt_ = g.bn_tile_base + m0 / 128 + h;
+      g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + col] = a;
+      g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + col] = b;
+    }
+    gmx_all = fmaxf(gmx_all, gmx);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();        // the staging area / the exchange has been read: the next tile's images may land
+}
+
+// g.bn_dy_absmax: the largest |dx| this workgroup stored, over ALL its tiles -- one atomic per workgroup and launch
+template <int NWV>
+__device__ __forceinline__ void wide_publish_absmax(const ConvGeom &g, char *wsm, float gmx_all, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+    if (g.bn_dy_absmax) {       // (kernel-uniform)
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) gmx_all = fmaxf(gmx_all, __shfl_xor(gmx_all, o, 64));
+      float *sm = reinterpret_cast<float *>(wsm);
+      if (lane == 0) sm[wave] = gmx_all;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) {
+        float m = sm[0];
+        for (int q = 1; q < NWV; ++q) m = fmaxf(m, sm[q]);
+        if (m > 0.f) atomicMax(g.bn_dy_absmax + (blockIdx.x & 63u), __float_as_uint(m));
+      }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
+    const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
+    const float *__restrict__ residual) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  constexpr int NWV = WAVES_M * WAVES_N, NTHR = NWV * 64;
+  constexpr int A_NI = BM / (8 * NWV), B_NI = BN / (8 * NWV), NI = A_NI + B_NI;   // 1-KiB pieces per wave and k-step
+  static_assert(BM % (8 * NWV) == 0 && BN % (8 * NWV) == 0, "whole pieces per wave");
+  constexpr int STG = (BM + BN) * 128;                   // bytes of one k-step's images: A rows, then B rows
+  constexpr int D = STAGES - 1;                          // k-steps in flight ahead of the one being multiplied
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  static_assert(BM % 128 == 0, "BatchNorm tables are per 128 rows");
+  extern __shared__ __attribute__((aligned(1024))) char wsm[];
+
+#ifdef DSPN_ABLATE
+  // timing-only ablation build (results WRONG when non-zero): 1 no requests inside the k-loop, 2 no MFMAs, 4 no fragment reads,
+  // 8 no barrier, 16 no epilogue
+  const int dbg = g.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = m_tiles * n_tiles;
+  const int M = g.N * g.Hg * g.Wg;
+  const int CB = g.Cin >> 5;                             // 32-channel blocks per tap
+  const int ntaps = g.TR * g.TS;
+  const int nk = ntaps * CB;                             // (the host routes nk >= 1 only)
+  const float sc_a = operand_scale(g.a_absmax), sc_b = operand_scale(g.b_absmax);
+  const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;    // exact: powers of two
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- loader: lane l of piece q (bank lines 4q .. 4q+3 = tile rows 8q .. 8q+7) fills slot l & 15 of line 4q + (l >> 4), i.e.
+  // fetches chunk c of row r with (r & 1) * 8 + c = (l & 15) ^ (line & 7)
+  int a_row[A_NI], b_row[B_NI], a_cb[A_NI], b_cb[B_NI];
+#pragma unroll
+  for (int i = 0; i < A_NI; ++i) {
+    const int line = 4 * (wave * A_NI + i) + (lane >> 4), sl = (lane & 15) ^ (line & 7);
+    a_row[i] = 2 * line + (sl >> 3); a_cb[i] = (sl & 7) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_NI; ++i) {
+    const int line = 4 * (wave * B_NI + i) + (lane >> 4), sl = (lane & 15) ^ (line & 7);
+    b_row[i] = 2 * line + (sl >> 3); b_cb[i] = (sl & 7) * 16;
+  }
+  int a_ih0[A_NI], a_iw0[A_NI], a_boff[A_NI], b_boff[B_NI];   // state of ONE output tile
+  int ld_m0 = 0, ld_n0 = 0;
+  int l_tr = 0, l_ts = 0, l_cb = 0;                           // (tap, channel block) of the next k-step to request
+  auto setup_tile = [&](const int t) __attribute__((always_inline)) {
+    const int tile = xcd_remap(t, ntiles);
+    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;  // n fastest: the A rows are shared through L2
+    ld_m0 = mt * BM; ld_n0 = nt * BN;
+    const int hw = g.Hg * g.Wg;
+#pragma unroll
+    for (int i = 0; i < A_NI; ++i) {
+      const int m = ld_m0 + a_row[i];
+      const int n = m / hw, rem = m - n * hw;
+      const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+      const int ih0 = oi * g.ish + g.ioh, iw0 = oj * g.isw + g.iow;
+      const bool mv = m < M;                                  // rows past M: every tap fails the bounds test
+      a_ih0[i] = mv ? ih0 : -0x40000000;
+      a_iw0[i] = mv ? iw0 : 0;
+      a_boff[i] = mv ? (((n * g.Hin + ih0) * g.Win + iw0) * g.Cin) * 4 + a_cb[i] : 0;   // BYTES of tap (0, 0) (may be negative)
+    }
+#pragma unroll
+    for (int i = 0; i < B_NI; ++i) {
+      // rows past Cout read the last row (finite values; their output columns are never stored)
+      const int k = min(ld_n0 + b_row[i], g.Cout - 1);
+      b_boff[i] = k * (g.WTAPS * CB * 128) + b_cb[i];
+    }
+    l_tr = 0; l_ts = 0; l_cb = 0;
+  };
+  // Requests of ONE k-step, one 1-KiB piece at a time so that mma_step can place them between its MFMAs.  K order as
+  // conv_nt_kernel: channel blocks outer, taps inner.  Past the last k-step of the tile the pieces are still requested, with
+  // every lane out of range (zeros into a ring slot nobody reads again, no memory traffic): the k-loop then has ONE instruction
+  // stream and ONE counted wait, no tail cases.
+  int q_dh = 0, q_dw = 0, q_atap = 0, q_bsoff = 0;            // (wave-uniform) constants of the k-step being requested
+  unsigned q_oob = 0u;
+  char *q_base = wsm;
+  auto issue_begin = [&](const int slot, const bool live) __attribute__((always_inline)) {
+    q_dh = l_tr * g.idh; q_dw = l_ts * g.idw;
+    q_atap = ((q_dh * g.Win + q_dw) * g.Cin + l_cb * 32) * 4;
+    const int wtap = (g.wr0 + l_tr * g.wrs) * g.WS + g.ws0 + l_ts * g.wss;
+    q_bsoff = (wtap * CB + l_cb) * 128;
+    q_oob = live ? 0u : kOOB;
+    q_base = wsm + slot * STG;
+    ++l_ts;                                   // wave-uniform advance: taps inner, channel blocks outer
+    const bool wrap = l_ts == g.TS;
+    l_ts = wrap ? 0 : l_ts;
+    l_tr += wrap ? 1 : 0;
+    const bool wrap2 = l_tr == g.TR;
+    l_tr = wrap2 ? 0 : l_tr;
+    l_cb += wrap2 ? 1 : 0;
+  };
+  auto issue_piece = [&](const int i) __attribute__((always_inline)) {     // i: compile-time constant, 0 .. NI - 1 (A pieces first)
+    if (dbg & 1) return;
+    if (i < A_NI) {
+      const int ih = a_ih0[i < A_NI ? i : 0] + q_dh, iw = a_iw0[i < A_NI ? i : 0] + q_dw;
+      const bool v = (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+      const unsigned off = (unsigned)(a_boff[i < A_NI ? i : 0] + q_atap) | (v ? q_oob : kOOB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void *)(q_base + (wave * A_NI + i) * 1024),
+                                               16, (int)off, 0, 0, 0);
+    } else {
+      const int j = i - A_NI;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(q_base + BM * 128 + (wave * B_NI + j) * 1024),
+                                               16, (int)((unsigned)b_boff[j < B_NI ? (j < 0 ? 0 : j) : 0] | q_oob), q_bsoff, 0, 0);
+    }
+  };
+  auto issue = [&](const int slot, const bool live) __attribute__((always_inline)) {
+    issue_begin(slot, live);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_piece(i);
+  };
+
+  // ---- fragments: row r = w? + 32 i + frow of an image sits in bank line r >> 1, chunk c = 4 p + 2 kk + (lane >> 5) of it in slot
+  // ((r & 1) * 8 + c) ^ ((r >> 1) & 7); the wave's row offset is a whole number of 16 lines, so the row bits are frow's
+  const int wm = (wave / WAVES_N) * (TM * 32), wn = (wave % WAVES_N) * (TN * 32);
+  const int frow = lane & 31;
+  const int fslot = ((((frow & 1) << 3) | (lane >> 5)) ^ ((frow >> 1) & 7)) << 4;
+  const int foff = (frow >> 1) * 256 + fslot;
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // One k-step: ALL sixteen fragment reads first (64 registers: this kernel has them), in the order the MFMAs want them, then
+  // the 24 MFMAs in groups between which the NI requests of the k-step D ahead are placed -- the matrix pipe works through a
+  // group while the vector / scalar units form the next request's addresses.  x w = h0 g0 + h0 g1 + h1 g0, smallest terms
+  // first (conv_nt_kernel's order per accumulator).
+  auto mma_step = [&](const int slot) __attribute__((always_inline)) {
+    const char *sa = wsm + slot * STG + wm * 128, *sb = wsm + slot * STG + BM * 128 + wn * 128;
+    bf16x8 fa[2][2][TM], fb[2][2][TN];                    // [kk][piece][...]
+    if (dbg & 4) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) { fa[kk][p][i] = bf16x8{}; asm volatile("" : "+v"(fa[kk][p][i])); }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) { fb[kk][p][j] = bf16x8{}; asm volatile("" : "+v"(fb[kk][p][j])); }
+        }
+    } else
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[kk][1][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((4 + 2 * kk) << 4)));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kk][0][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((2 * kk) << 4)));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[kk][0][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((2 * kk) << 4)));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kk][1][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((4 + 2 * kk) << 4)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    constexpr int NMMA = 2 * 3 * TM * TN, GRP = NMMA / NI;           // MFMAs per k-step; MFMAs between two requests
+    static_assert(NMMA % NI == 0, "requests spread evenly over the MFMAs");
+#pragma unroll
+    for (int m = 0; m < NMMA; ++m) {
+      const int kk = m / (3 * TM * TN), t3 = (m / (TM * TN)) % 3, i = (m / TN) % TM, j = m % TN;
+      if (dbg & 2) { asm volatile("" :: "v"(fa[kk][PA[t3]][i]), "v"(fb[kk][PB[t3]][j])); }
+      else
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kk][PA[t3]][i]),
+                                                         __builtin_bit_cast(f16x8, fb[kk][PB[t3]][j]), acc[i][j], 0, 0, 0);
+      if (m % GRP == GRP - 1) {
+        issue_piece(m / GRP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  float gmx_all = 0.f;       // EPI == 2: largest |dx| stored by this thread over all its tiles (g.bn_dy_absmax)
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    setup_tile(t);
+    const int m0 = ld_m0, n0 = ld_n0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(j, j < nk);
+    zero_acc();
+    int slot = 0, islot = D % STAGES;
+    for (int kt = 0; kt < nk; ++kt) {
+      // the images of k-step kt have landed (this wave's pieces: the counted wait -- D - 1 k-steps stay in flight; the other
+      // waves': the barrier), and every wave has read the fragments of k-step kt - 1, whose ring slot is requested into next
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
+      if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+      issue_begin(islot, kt + D < nk);
+      mma_step(slot);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      islot = islot + 1 == STAGES ? 0 : islot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the out-of-range requests past K: nothing may land in the staging area)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // every wave has read its last fragments (nothing is in flight): the LDS becomes the staging area
+    if (dbg & 16) { if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5]; continue; }
+
+    // ---- epilogue.  C/D layout: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    {
+      constexpr int SLD = BN + 4;
+      float *st = reinterpret_cast<float *>(wsm);
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r)
+            st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
+    }
+    wide_epilogue<BM, BN, NTHR, EPI>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
+  }
+  if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+}
+
+// host side: one launch of the wide family.  Persistent grid as conv_nt_kernel's (occupancy x CUs, a multiple of 8).
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI>
+int launch_ntw_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
+                    const float *residual) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  const long long M = (long long)g.N * g.Hg * g.Wg;
+  const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
+  const size_t lds = std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI>;
+  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
+  if (!slots) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, dev = 0, cus = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
+    slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
+    if (getenv("DSPN_DEBUG_PRINT"))
+      fprintf(stderr, "[dspn] conv_ntw<%d,%d,stages=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+              STAGES, EPI, lds, per_cu, cus, slots);
+  }
+  const int reserved = dspn::reserved_cus();
+  const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
+  const int grid_x = (int)std::min<long long>((long long)mt * nt, avail);
+  {
+    dspn::ProfScope prof(0, s);
+    hipLaunchKernelGGL(kern, dim3(grid_x), dim3(WAVES_M * WAVES_N * 64), lds, s, in, w, bias, out, g, mt, nt, residual);
+  }
+  return dspn::check_launch("conv_ntw");
+}
+
+template <int WAVES_M, int WAVES_N, int STAGES>
+int launch_ntw(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s, const float *residual) {
+  if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2>(in, w, bias, out, g, s, residual);
+  if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1>(in, w, bias, out, g, s, residual);
+  return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0>(in, w, bias, out, g, s, residual);
+}
+

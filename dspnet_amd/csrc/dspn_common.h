@@ -39,6 +39,8 @@ struct ProfScope {
 
 // CUs the persistent convolution grids leave free (dspn_conv_set_reserved_cus; a launch setting, results do not depend on it)
 int reserved_cus();
+// tile family of the plane-fed two-piece convolutions (dspn_conv_set_wide_tiles; a launch setting as well)
+int wide_tiles_mode();
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

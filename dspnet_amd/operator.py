@@ -155,6 +155,10 @@ def target_workspace_bytes(batch, num_anchors, num_labels):
     return int(_lib.lib().dspn_multibox_target_workspace_bytes(int(batch), int(num_anchors), int(num_labels)))
 
 
+def detection_workspace_bytes(batch, num_anchors):
+    return int(_lib.lib().dspn_multibox_detection_workspace_bytes(int(batch), int(num_anchors)))
+
+
 def MultiBoxTarget_check(batch, device, workspace=None):
     """Deferred form of check_errors=True: reads the per-sample abort codes a MultiBoxTarget call of `batch` samples left
     in its workspace (synchronises) and raises DspnError with the reference's message if a label row after the
@@ -172,11 +176,14 @@ def MultiBoxTarget_check(batch, device, workspace=None):
 
 def MultiBoxDetection(cls_prob, loc_pred, anchor, clip=True, threshold=0.01, background_id=0,
                       nms_threshold=0.5, force_suppress=False, variances=(0.1, 0.1, 0.2, 0.2),
-                      nms_topk=-1, out=None):
+                      nms_topk=-1, out=None, workspace=None):
     """Decode + NMS.  cls_prob (B,C+1,N), loc_pred (B,N*5), anchor (1,N,4) ->
     (B,N,7) rows [id, score, xmin, ymin, xmax, ymax, dist], id=-1 for empty rows.
     Shape rules: multibox_detection-inl.h:149-171.  background_id is accepted and,
-    as in the reference kernels, class 0 is always the background."""
+    as in the reference kernels, class 0 is always the background.
+    workspace: a caller-owned uint8 buffer of detection_workspace_bytes(B, N) (the operator's kTempSpace,
+    multibox_detection-inl.h:183-186).  A graph node keeps its own, so two graphs -- or one graph's side stream and an
+    eager caller -- never share scratch; default: one buffer per device, for callers on ONE stream."""
     variances = _tuple(variances)
     if cls_prob.dim() != 3:
         raise DspnError(f"Provided: {tuple(cls_prob.shape)}")
@@ -202,7 +209,12 @@ def MultiBoxDetection(cls_prob, loc_pred, anchor, clip=True, threshold=0.01, bac
         out = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
     L = _lib.lib()
     nbytes = L.dspn_multibox_detection_workspace_bytes(B, N)
-    ws = _workspace(nbytes, dev, "detection")
+    if workspace is not None:
+        if workspace.numel() < nbytes or not workspace.is_cuda or workspace.dtype != torch.uint8:
+            raise DspnError(f"MultiBoxDetection: workspace needs {nbytes} bytes of uint8 device memory")
+        ws = workspace
+    else:
+        ws = _workspace(nbytes, dev, "detection")
     check(L.dspn_multibox_detection_f32(
         cls_prob.data_ptr(), loc_pred.data_ptr(), anchor.data_ptr(), B, N,
         int(cls_prob.shape[1]), float(threshold), int(bool(clip)), _lib.floats(variances),

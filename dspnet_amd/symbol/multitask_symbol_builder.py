@@ -163,6 +163,10 @@ class Detection(E.Node):
         self.pending = False
         self._g = g
         g.pre_forward.append(self.join)
+        # the operator's temp space, owned by this node (as MultiBoxTargetNode's): its kernels run on a side stream, beside
+        # whatever another graph or an eager caller on this device does with the shared buffer
+        if g.device.type == "cuda":
+            self.kw["workspace"] = torch.empty(op.detection_workspace_bytes(B, N), dtype=torch.uint8, device=g.device)
 
     def forward(self):
         if self.side is None:

@@ -53,6 +53,11 @@ int dspn_profile_collect(int family, double *total_ms, long long *launches);
  * workgroup slots free (0 .. 128; 0 = default).  bench.py --gpus N switches it on after warm-up only if the measured
  * exposed all-reduce time says the collectives are not being hidden. */
 int dspn_conv_set_reserved_cus(int cus);
+/* Launch setting (round 5; not compute state): which tile family the two-piece convolutions whose operands are both piece
+ * planes run on.  0 = automatic (by layer shape), 1 = never the wide family (conv_nt_kernel's 128 x 128 tiles, the round-4
+ * schedule), 2 / 3 / 4 = always 256 x 128 / 128 x 256 / 128 x 128-on-four-waves where legal (tests and experiments).  The K
+ * order and the per-output accumulation order are the same on every tile. */
+int dspn_conv_set_wide_tiles(int mode);
 
 /* Replaces MultiBoxPriorOp::Forward (operator/multibox_prior-inl.h:97-129) +
  * MultiBoxPriorForward (operator/multibox_prior.cc:30-71; GPU twin

@@ -27,6 +27,21 @@ def lib():
     return _lib
 
 
+_lib_expd = None
+
+
+def lib_exp_double():
+    """the oracle built with -DDSPN_ORACLE_EXP_DOUBLE (the other reading of multibox_detection.cc:113)"""
+    global _lib_expd
+    if _lib_expd is None:
+        so = os.path.join(_HERE, "_build", "libdspn_oracle_expd.so")
+        src = os.path.join(_HERE, "multibox_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _lib_expd = ctypes.CDLL(so)
+    return _lib_expd
+
+
 def _p(a):
     return a.ctypes.data_as(_f32p)
 
@@ -76,12 +91,12 @@ def multibox_target(anchor, label, cls_pred, overlap_threshold=0.5, ignore_label
 
 def multibox_detection(cls_prob, loc_pred, anchor, clip=True, threshold=0.01, background_id=0,
                        nms_threshold=0.5, force_suppress=False, variances=(0.1, 0.1, 0.2, 0.2),
-                       nms_topk=-1):
+                       nms_topk=-1, exp_double=False):
     cls_prob, loc_pred, anchor = _f32(cls_prob), _f32(loc_pred), _f32(anchor)
     B, C, A = cls_prob.shape
     var = _f32(variances)
     out = np.empty((B, A, 7), np.float32)
-    rc = lib().dspn_oracle_multibox_detection(
+    rc = (lib_exp_double() if exp_double else lib()).dspn_oracle_multibox_detection(
         _p(cls_prob), _p(loc_pred), _p(anchor), B, A, C, ctypes.c_float(threshold),
         int(bool(clip)), _p(var), ctypes.c_float(nms_threshold), int(bool(force_suppress)),
         int(nms_topk), _p(out))

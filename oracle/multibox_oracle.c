@@ -141,6 +141,10 @@ int dspn_oracle_multibox_target(const float *anchors /* (A,4) */,
                                 float *cls_target /* (B,A)   */) {
   (void)minimum_negative_samples;
   if (B <= 0 || A <= 0 || L <= 0 || label_w < 6 || Cp1 <= 0) return -1;
+  /* .cc:185 CHECK_GT(negative_mining_thresh, 0), inside `if (negative_mining_ratio > 0)`: the reference aborts there for the
+   * first sample that has a valid ground truth.  Rejected as an argument here -- as the HIP entry does (multibox.hip) -- so
+   * the checker is never laxer than the product; a batch WITHOUT any ground truth is the one input the reference lets pass. */
+  if (negative_mining_ratio > 0 && !(negative_mining_thresh > 0)) return -1;
   int rc = 0;
   /* -inl.h:121-123 */
   memset(loc_target, 0, sizeof(float) * (size_t)B * A * 5);
@@ -331,8 +335,16 @@ int dspn_oracle_multibox_detection(const float *cls_prob /* (B,Cp1,A) */,
         float ax = (al + ar) / 2.f, ay = (at + ab) / 2.f;
         float ox = p[0] * vx * aw + ax;
         float oy = p[1] * vy * ah + ay;
+#ifdef DSPN_ORACLE_EXP_DOUBLE
+        /* the other reading of `exp(pw * vw) * aw / 2` (.cc:113): ::exp(double), the product and the division in double,
+         * rounded once on assignment -- built as libdspn_oracle_expd.so; tests/test_oracle_multibox.py shows that ids, row
+         * order and suppression are the same under both readings and the coordinates agree to 1 ulp */
+        float ow = (float)(exp((double)(p[2] * vw)) * (double)aw / 2);
+        float oh = (float)(exp((double)(p[3] * vh)) * (double)ah / 2);
+#else
         float ow = expf(p[2] * vw) * aw / 2;
         float oh = expf(p[3] * vh) * ah / 2;
+#endif
         float oz = (float)((double)p[4] * 0.1);
         row[2] = clip ? clip01(ox - ow) : ox - ow;
         row[3] = clip ? clip01(oy - oh) : oy - oh;

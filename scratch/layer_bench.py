@@ -21,9 +21,16 @@ def timeit(f, reps=3):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
+# round 5: operands as the GRAPH hands them over -- dy as fp16 piece planes where the BatchNorm behind the convolution writes its
+# dx that way (BatchNorm.dx_planes), x as planes where Graph._plan_input_planes materialised them -- and, per layer, the
+# algorithmic HBM bytes of each pass (x or dy read once, y or dx written once, weights) with the bandwidth they imply
+planes_dy = {id(b.x): True for b in net.g.nodes if isinstance(b, E.BatchNorm) and getattr(b, "dx_planes", False)}
+def as_planes(t):
+    am = fn.absmax(t)
+    return fn.bn_apply_planes(t, torch.ones(t.shape[-1], device=dev), torch.zeros(t.shape[-1], device=dev), am), am
 tot = [0, 0, 0]; totf = [0, 0, 0]
 seen = set(); cnt = {}; rows = {}
-print("%-34s %9s %5s %6s | %8s %6s | %8s %6s | %8s %6s" % ("layer", "M", "N", "K", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF"))
+print("%-36s %9s %5s %6s | %8s %6s %4s %4s | %8s %6s %4s %4s | %8s %6s %4s %4s" % ("layer", "M", "N", "K", "fwd ms", "TF", "frac", "TB/s", "dgrad ms", "TF", "frac", "TB/s", "wgrad ms", "TF", "frac", "TB/s"))
 for n in net.g.nodes:
     if not isinstance(n, E.Conv): continue
     N_, H, W, Cin = n.x.shape
@@ -37,19 +44,29 @@ for n in net.g.nodes:
     f16 = n.math == "f16x2"
     xa, wa = (n._magnitudes("x"), n._magnitudes("w")) if f16 else (None, None)
     dya = fn.absmax(dy) if f16 else None
-    tw = timeit(lambda: fn.conv2d_wgrad(n.x_raw.data, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad, in_affine=n.in_affine, math=n.math, x_absmax=xa, dy_absmax=dya))
+    dyp = False
+    if f16 and planes_dy.get(id(n.out)) and dy.dtype == torch.float32 and dy.shape[-1] % 32 == 0:
+        dy.normal_(); dy, dya = as_planes(dy); dyp = True
+    xp = n._x_planes() if (f16 and hasattr(n, "_x_planes")) else None
+    if xp is not None:
+        tw = timeit(lambda: fn.conv2d_wgrad(xp, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad, math=n.math, x_absmax=xa, dy_absmax=dya, dy_planes=dyp, x_planes=True))
+    else:
+        tw = timeit(lambda: fn.conv2d_wgrad(n.x_raw.data, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad, in_affine=n.in_affine, math=n.math, x_absmax=xa, dy_absmax=dya, dy_planes=dyp))
     td = None
     if n.x.requires_grad:
         dx = n.x.own_grad()
-        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa, wt_shape=n.wt_shape))
+        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa, wt_shape=n.wt_shape, dy_planes=dyp))
     tot[0] += tf; tot[2] += tw; totf[0] += fl; totf[2] += fl
     if td: tot[1] += td; totf[1] += fl
     cnt[key] = cnt.get(key, 0) + 1
-    rows.setdefault(key, (n.w.name[:-7], M, Cout, R * S * Cin, tf, fl, td, tw))
-for key, (name, M, Cout, K, tf, fl, td, tw) in rows.items():
-    print("%-30s x%-2d %8d %5d %6d | %7.3f %6.1f %4.2f | %7s %6s %4s | %7.3f %6.1f %4.2f" % (
-        name, cnt[key], M, Cout, K, tf, fl / tf / 1e9, fl / tf / 1e9 / PEAK,
+    xin = N_ * H * W * Cin * 4 // (n.stride * n.stride if R * S == 1 else 1)          # (a strided 1x1 reads every stride-th pixel)
+    byt = xin + M * Cout * 4 + Cout * R * S * Cin * 4
+    rows.setdefault(key, (n.w.name[:-7] + ("*" if dyp else "") + ("+" if xp is not None else ""), M, Cout, R * S * Cin, tf, fl, td, tw, byt))
+print("(* dy as piece planes in dgrad / wgrad, + x as piece planes in forward / wgrad; TB/s = algorithmic bytes of the pass / time, of 8)")
+for key, (name, M, Cout, K, tf, fl, td, tw, byt) in rows.items():
+    print("%-32s x%-2d %8d %5d %6d | %7.3f %6.1f %4.2f %4.1f | %7s %6s %4s %4s | %7.3f %6.1f %4.2f %4.1f" % (
+        name, cnt[key], M, Cout, K, tf, fl / tf / 1e9, fl / tf / 1e9 / PEAK, byt / tf / 1e9,
         ("%.3f" % td) if td else "-", ("%.1f" % (fl / td / 1e9)) if td else "-", ("%.2f" % (fl / td / 1e9 / PEAK)) if td else "-",
-        tw, fl / tw / 1e9, fl / tw / 1e9 / PEAK))
+        ("%.1f" % (byt / td / 1e9)) if td else "-", tw, fl / tw / 1e9, fl / tw / 1e9 / PEAK, byt / tw / 1e9))
 print("TOTAL fwd %.2f ms (%.1f TF)  dgrad %.2f ms (%.1f TF)  wgrad %.2f ms (%.1f TF)" % (
     tot[0], totf[0] / tot[0] / 1e9, tot[1], totf[1] / tot[1] / 1e9, tot[2], totf[2] / tot[2] / 1e9))

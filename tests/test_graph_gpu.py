@@ -1133,7 +1133,7 @@ def test_side_stream_detection_branch_gives_the_bits_of_the_main_stream_schedule
     from dspnet_amd import synthetic
     from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
     from dspnet_amd.train.solver import MultiTaskSolver
-    B, S, steps = 4, 256, 4
+    B, S, steps = (4, 256, 4) if network == "resnet-50" else (2, 512, 3)     # (the vgg16_reduced preset's seventh map needs 512)
 
     def run(side):
         saved = {k: os.environ.get(k) for k in ("DSPN_TARGET_SIDE", "DSPN_DET_SIDE", "DSPN_DET_SIDE_BWD")}

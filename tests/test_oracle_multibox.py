@@ -169,3 +169,51 @@ def test_self_generated_regression_fixtures_reproduce():
         np.testing.assert_array_equal(v, g[k])
     det = om.multibox_detection(g["cls_prob"], g["loc_pred"], anc, nms_threshold=.45, nms_topk=20)
     np.testing.assert_array_equal(det, g["det"])
+
+
+# ---- round 5: oracle hygiene ("What's weak" 1a / 1b) ----------------------------------
+def test_target_rejects_non_positive_mining_threshold():
+    """multibox_target.cc:185 CHECK_GT(negative_mining_thresh, 0) under `negative_mining_ratio > 0`: the oracle reports it as
+    the HIP entry does (an argument error); without hard-negative mining the threshold is not looked at"""
+    anc = mc.small_anchors()
+    lab, pred = mc.target_inputs(anc, batch=2, num_labels=6, num_classes=3, max_gt=3, seed=3)
+    for thr in (0.0, -0.5):
+        _, rc = om.multibox_target(anc, lab, pred, negative_mining_ratio=3, negative_mining_thresh=thr, return_code=True)
+        assert rc == -1
+        _, rc = om.multibox_target(anc, lab, pred, negative_mining_ratio=-1, negative_mining_thresh=thr, return_code=True)
+        assert rc == 0
+
+
+@pytest.mark.parametrize("case", ["golden", "small-1", "small-2", "r50-512", "r50-512-topk", "r50-cs-force"])
+def test_detection_indices_do_not_depend_on_the_reading_of_exp(case):
+    """multibox_detection.cc:113 `exp(pw * vw) * aw / 2` with DType = float: expf() and float arithmetic (this oracle's reading)
+    or ::exp(double) with the product in double, rounded once (-DDSPN_ORACLE_EXP_DOUBLE).  The one ambiguity the missing MXNet
+    build leaves cannot be pinned, so it is bounded: on every committed fixture and on the R50 shapes the class ids, the row
+    order, which rows NMS suppresses and the scores are IDENTICAL under both readings, and every corner agrees to one ulp of
+    the box's half extent (a suppression decision would need an IoU within an ulp of the threshold)."""
+    kw = dict(nms_threshold=.45, nms_topk=-1)
+    if case == "golden":
+        g = np.load(os.path.join(GOLDEN, "multibox_small.npz"))
+        anc, prob, loc = g["anchors"], g["cls_prob"], g["loc_pred"]
+        kw["nms_topk"] = 20
+    elif case.startswith("small"):
+        anc = mc.small_anchors(6, 7)
+        prob, loc = mc.detection_inputs(anc, batch=2, num_classes=4, seed=int(case[-1]), peaky=False)
+    elif case.startswith("r50-512"):
+        anc = mc.r50_anchors(512, 512)
+        prob, loc = mc.detection_inputs(anc, batch=2, num_classes=8, seed=7)
+        if case.endswith("topk"):
+            kw["nms_topk"] = 400
+    else:
+        anc = mc.r50_anchors(512, 1024)
+        prob, loc = mc.detection_inputs(anc, batch=1, num_classes=10, seed=11)
+        kw["force_suppress"] = True
+    a = om.multibox_detection(prob, loc, anc, **kw)
+    b = om.multibox_detection(prob, loc, anc, exp_double=True, **kw)
+    np.testing.assert_array_equal(a[..., 0], b[..., 0])        # ids incl. the -1 of suppressed / absent rows, in row order
+    np.testing.assert_array_equal(a[..., 1], b[..., 1])        # scores
+    np.testing.assert_array_equal(a[..., 6], b[..., 6])        # distance (no exp)
+    assert int((a[..., 0] >= 0).sum()) > 0
+    # corners = centre -+ half extent: one ulp of the half extent (<= 2^-24 of a box in [0, 1]; more for the unclipped case)
+    ca, cb = a[..., 2:6].astype(np.float64), b[..., 2:6].astype(np.float64)
+    assert float(np.abs(ca - cb).max()) <= 2.0 ** -23 * max(1.0, float(np.abs(ca).max()))

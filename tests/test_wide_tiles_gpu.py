@@ -1,0 +1,135 @@
+"""Round 5: the wide tile family of the two-piece convolution math (csrc/conv_wide.h) -- both operands as fp16 piece planes,
+global -> LDS directly, 64 x 64 outputs per wave.  It must give the BITS of conv_nt_kernel (same K order, same accumulation
+order per output, same epilogue arithmetic) on every tile shape, forward and data gradient, with every epilogue: plain,
+bias / residual / ReLU / accumulate, BatchNorm statistics + extremes, BatchNorm-backward sums + largest stored gradient;
+and both must agree with the fp32-MFMA convolution of the decoded operands to fp32 accuracy."""
+import numpy as np
+import pytest
+import torch
+
+from dspnet_amd import _lib
+from dspnet_amd import functional as fn
+
+pytestmark = pytest.mark.gpu
+MODES = {1: "conv_nt_kernel", 2: "256x128", 3: "128x256", 4: "128x128 on four waves"}
+
+
+@pytest.fixture()
+def tiles(gpu_device):
+    if fn.get_conv_math() != "f16x2":
+        pytest.skip("the two-piece math is not this process's default")
+    L = _lib.lib()
+    yield lambda mode: _lib.check(L.dspn_conv_set_wide_tiles(mode), "set_wide_tiles")
+    L.dspn_conv_set_wide_tiles(0)
+
+
+def planes_of(t):
+    am = fn.absmax(t)
+    one, zero = torch.ones(t.shape[-1], device="cuda"), torch.zeros(t.shape[-1], device="cuda")
+    return fn.bn_apply_planes(t, one, zero, am), am
+
+
+def test_setter_rejects_unknown_modes(gpu_device):
+    L = _lib.lib()
+    assert L.dspn_conv_set_wide_tiles(5) != 0 and b"conv_set_wide_tiles" in L.dspn_last_error()
+    assert L.dspn_conv_set_wide_tiles(-1) != 0
+    assert L.dspn_conv_set_wide_tiles(0) == 0
+
+
+# (N, H, W, Cin, Cout, k, stride): tile counts around one / many per CU, M and Cout not multiples of the tiles, one k-step
+FWD = [(2, 24, 24, 64, 128, 3, 1), (3, 25, 23, 96, 256, 3, 2), (1, 17, 19, 128, 256, 1, 1), (2, 9, 9, 256, 512, 3, 1),
+       (1, 40, 40, 32, 384, 3, 1), (2, 31, 33, 64, 192, 3, 1), (4, 64, 64, 32, 96, 1, 1), (8, 32, 32, 128, 320, 3, 1)]
+
+
+@pytest.mark.parametrize("case", FWD)
+def test_forward_on_every_tile_is_bit_identical(tiles, case):
+    N, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(H + Cin + Cout + k)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda().abs_()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    base = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    xp, xa = planes_of(x)
+    wa = fn.absmax(w); wp = fn.weight_planes(w, math="f16x2", w_absmax=wa)
+    t2, rows = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    out = {}
+    for mode in MODES:
+        tiles(mode)
+        kw = dict(w_planes=wp, x_absmax=xa, w_absmax=wa, x_planes=True)
+        y_plain = fn.conv2d_forward(xp, w, None, stride, pad, 1, **kw)
+        got = [y_plain, fn.conv2d_forward(xp, w, bias, stride, pad, 1, residual=res, relu=True, **kw)]
+        acc = base.clone()
+        fn.conv2d_forward(xp, w, None, stride, pad, 1, out=acc, accumulate=True, **kw)
+        got.append(acc)
+        if t2 > 0:
+            st = torch.zeros(t2, 2, Cout, device="cuda"); mm = torch.zeros(t2, 2, Cout, device="cuda")
+            got += [fn.conv2d_forward(xp, w, None, stride, pad, 1, out_stats=st, out_minmax=mm, **kw), mm, st]
+        out[mode] = got
+    ref32 = fn.conv2d_forward(x, w, None, stride, pad, 1, math="fp32")
+    assert float((out[1][0] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    for mode in (2, 3, 4):
+        for i, (a, b) in enumerate(zip(out[mode], out[1])):
+            if i == 5:      # per-tile (mean, M2): the row groups of a thread differ between tile shapes -- fp32 rounding only
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (MODES[mode], "statistics")
+            else:
+                assert torch.equal(a, b), (MODES[mode], i)
+
+
+# data gradient of a (Cin -> Cout, k x k, stride) convolution at input size H x W; Cin plays the role of the output columns
+BWD = [(2, 24, 24, 128, 64, 3, 1), (3, 25, 23, 256, 96, 3, 2), (1, 17, 19, 256, 128, 1, 1), (2, 9, 9, 512, 256, 3, 1),
+       (2, 16, 16, 128, 64, 1, 2), (2, 30, 34, 192, 64, 3, 1), (8, 32, 32, 320, 128, 3, 2)]
+
+
+@pytest.mark.parametrize("case", BWD)
+def test_data_gradient_on_every_tile_is_bit_identical(tiles, case):
+    N, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(H + Cin + Cout + k + 7)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    dyp, dya = planes_of(dy)
+    wa = fn.absmax(w); wt = fn.weight_transpose(w)
+    wtp = fn.weight_planes(w, transposed=True, cols=Cout, math="f16x2", w_absmax=wa)
+    gamma = torch.rand(Cin, device="cuda") + 0.5; beta = torch.randn(Cin, device="cuda")
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    ntile = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    out = {}
+    for mode in MODES:
+        tiles(mode)
+        kw = dict(wt_planes=wtp, dy_absmax=dya, w_absmax=wa, dy_planes=True)
+        sums = torch.zeros(ntile, 2, Cin, device="cuda"); bam = torch.zeros(64, device="cuda")
+        dx = torch.empty_like(x); dx2 = torch.empty_like(x); dx3 = x.clone()
+        fn.conv2d_dgrad(dyp, wt, tuple(x.shape), stride, pad, 1, out=dx, bn_bwd=(x, scale, shift, mean, rstd, True, sums),
+                        bn_dy_absmax=bam, **kw)
+        fn.conv2d_dgrad(dyp, wt, tuple(x.shape), stride, pad, 1, out=dx2, **kw)
+        fn.conv2d_dgrad(dyp, wt, tuple(x.shape), stride, pad, 1, out=dx3, accumulate=True, **kw)
+        out[mode] = [dx, dx2, dx3, bam.max().reshape(1).clone(), sums]
+    ref32 = fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, math="fp32")
+    assert float((out[1][1] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    assert float(out[1][3]) == float(out[1][0].abs().max()), "bn_dy_absmax is the largest stored gradient"
+    for mode in (2, 3, 4):
+        for i, (a, b) in enumerate(zip(out[mode], out[1])):
+            if i == 4:
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (MODES[mode], "BatchNorm-backward sums")
+            else:
+                assert torch.equal(a, b), (MODES[mode], i)
+
+
+def test_automatic_choice_is_one_of_the_tested_paths(tiles):
+    """mode 0 (what the graph runs): same bits as mode 1 on a layer the automatic policy routes to the wide family"""
+    N, H, W, Cin, Cout, k = 8, 32, 32, 256, 256, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda().abs_()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    xp, xa = planes_of(x)
+    wa = fn.absmax(w); wp = fn.weight_planes(w, math="f16x2", w_absmax=wa)
+    ys = []
+    for mode in (1, 0):
+        tiles(mode)
+        ys.append(fn.conv2d_forward(xp, w, None, 1, 1, 1, w_planes=wp, x_absmax=xa, w_absmax=wa, x_planes=True))
+    assert torch.equal(ys[0], ys[1])
