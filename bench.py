@@ -734,6 +734,13 @@ def main():
             # seen by a BatchNorm finalize, how many of them span more than 2^16, and the widest span in bits
             line["config"]["f16x2_range_monitor"] = {"tensors": range_rep[0], "wider_than_2^16": range_rep[1],
                                                      "widest_span_bits": round(range_rep[2], 1)}
+            # round 5: the guard that acts on it (engine.Graph._update_guard): convolutions whose operand spans exceeded 2^16 in
+            # the previous pass run in the three-piece bf16 math; 0 calls expected on synthetic data
+            gconv, gcalls, gslots = net.g.guard_report()
+            line["config"]["f16x2_fallback_calls"] = gcalls
+            line["config"]["f16x2_range_guard"] = {"enabled": bool(net.g.guard["enabled"]), "convolutions_on_fallback": gconv,
+                                                   "slots_wider_than_2^16_last_pass": gslots,
+                                                   "fallback_calls_since_start": net.g.guard["calls_total"]}
         # round 4: which part of the step runs beside the main stream (engine.Graph.set_side_segment / set_side_backward).  While
         # it does, the convolution family's kernels share the chip with it, so `roofline.achieved` -- work / the HIP-event
         # brackets of those kernels -- is lower than with everything on one stream (DSPN_DET_SIDE=0), though the step is shorter

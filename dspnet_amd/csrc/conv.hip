@@ -2083,6 +2083,15 @@ static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine
   g.w_planes = w_planes;
   g.a_absmax = scales.a; g.b_absmax = scales.b;
   g.a_planes = scales.a_planes;
+#ifndef DSPN_HALF
+  // the ResNet stem (7x7 / 2 on 4 physical channels -> 64, with BatchNorm statistics) has a kernel of its own (conv_stem.h)
+  if (math == DSPN_MATH_F32_F16X2 && R == 7 && S == 7 && stride == 2 && pad_h == 3 && pad_w == 3 && dil == 1 && Cin == 4 &&
+      Cout == 64 && !bias && !relu && !accumulate && !residual && !tf.scale && g.dense && g.ldc == Cout && scales.a && scales.b &&
+      !scales.a_planes && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int rc = dspn::conv::launch_stem(x, w, y, N, H, W, Cin, Cout, Ho, Wo, scales.a, scales.b, stats, g.minmax, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
+#endif
   return dispatch_nt(x, w, bias, y, g, (hipStream_t)stream,
                      SplitWs{static_cast<float *>(workspace), workspace ? workspace_bytes : 0}, residual);
 }

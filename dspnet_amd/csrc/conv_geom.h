@@ -73,5 +73,10 @@ int wide_tile_choice(long long M, int Cout, int nk);
 int launch_wide(int shape, const float *in, const float *w_planes, const float *bias, float *out, const ConvGeomT<float> &g,
                 hipStream_t s, const float *residual);
 
+// conv_wide.hip (conv_stem.h): the 7x7 / 2, pad 3, 4 -> 64 channel stem convolution in the two-piece math with BatchNorm
+// statistics (64-row tiles) and extremes: 0 = launched, 1 = not this shape (the generic kernel runs), < 0 = launch error
+int launch_stem(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int Ho, int Wo,
+                const float *x_absmax, const float *w_absmax, float *stats, float *minmax, hipStream_t s);
+
 }  // namespace conv
 }  // namespace dspn

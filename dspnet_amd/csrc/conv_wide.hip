@@ -3,6 +3,7 @@
 #include "dspn_common.h"
 #include "dspn_pieces.h"
 #include "conv_geom.h"
+#include "../../include/dspn_nn.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -13,7 +14,68 @@ using dspn::conv::bf16x8;
 using dspn::conv::xcd_remap;
 using ConvGeom = dspn::conv::ConvGeomT<float>;
 #include "conv_wide.h"
+#include "conv_stem.h"
 }  // namespace
+
+// ---- range guard of the two-piece math (round 5): two small bookkeeping kernels (include/dspn_nn.h)
+namespace {
+struct AbsminRowsDesc { const float *w; unsigned *out; int rows, row_len; long long begin; };
+__global__ __launch_bounds__(256) void absmin_rows_batch_kernel(const AbsminRowsDesc *__restrict__ d, int n) {
+  __shared__ float sm[4];
+  const long long row = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].begin <= row) lo = mid; else hi = mid - 1;
+  }
+  const AbsminRowsDesc e = d[lo];
+  const float *p = e.w + (row - e.begin) * (long long)e.row_len;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < e.row_len; i += 256) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (m > 0.f && m < __builtin_huge_valf()) atomicMin(e.out, __float_as_uint(m));     // positive floats order like their bits
+  }
+}
+__global__ __launch_bounds__(256) void tile_minmax_kernel(const float4 *__restrict__ x, long long rows, int C4, int tile_rows,
+                                                          float4 *__restrict__ minmax) {
+  const long long t = blockIdx.x;
+  const long long r0 = t * tile_rows, r1 = r0 + tile_rows < rows ? r0 + tile_rows : rows;
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < C4; c += gridDim.y * 256) {
+    constexpr float kInf = __builtin_huge_valf();
+    float4 mn = make_float4(kInf, kInf, kInf, kInf), mx = make_float4(-kInf, -kInf, -kInf, -kInf);
+    for (long long r = r0; r < r1; ++r) {
+      const float4 v = x[r * C4 + c];
+      mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+      mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+    }
+    minmax[(t * 2 + 0) * C4 + c] = mn;
+    minmax[(t * 2 + 1) * C4 + c] = mx;
+  }
+}
+}  // namespace
+
+extern "C" {
+int dspn_absmin_rows_batch_f32(const void *table, int n, long long total_rows, void *stream) {
+  DSPN_REQUIRE(table && n > 0 && total_rows > 0 && total_rows < (1ll << 31), "absmin_rows_batch: bad argument");
+  static_assert(sizeof(AbsminRowsDesc) == 32, "table row layout: 2 pointers, 2 ints, 1 int64");
+  hipLaunchKernelGGL(absmin_rows_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const AbsminRowsDesc *>(table), n);
+  return dspn::check_launch("absmin_rows_batch");
+}
+int dspn_tile_minmax_f32(const float *x, long long rows, int C, int tile_rows, float *minmax, void *stream) {
+  DSPN_REQUIRE(x && minmax && rows > 0 && C > 0 && C % 4 == 0 && tile_rows > 0, "tile_minmax: bad argument (C must be a multiple of 4)");
+  const long long tiles = (rows + tile_rows - 1) / tile_rows;
+  DSPN_REQUIRE(tiles < (1ll << 31), "tile_minmax: too many tiles");
+  hipLaunchKernelGGL(tile_minmax_kernel, dim3((unsigned)tiles, (C / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(x), rows, C / 4, tile_rows, reinterpret_cast<float4 *>(minmax));
+  return dspn::check_launch("tile_minmax");
+}
+}  // extern "C"
 
 namespace dspn {
 namespace conv {
@@ -29,6 +91,10 @@ int wide_tile_choice(long long M, int Cout, int nk) {
   if (mode >= 2) return mode - 1;
   if (nk < 4) return 0;
   return 3;
+}
+int launch_stem(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int Ho, int Wo,
+                const float *x_absmax, const float *w_absmax, float *stats, float *minmax, hipStream_t s) {
+  return launch_conv_stem(x, w, y, N, H, W, Cin, Cout, Ho, Wo, x_absmax, w_absmax, stats, minmax, s);
 }
 int launch_wide(int shape, const float *in, const float *w_planes, const float *bias, float *out, const ConvGeomT<float> &g,
                 hipStream_t s, const float *residual) {

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
     const float *__restrict__ partial, int nslabs, int C, double inv_rows,
     const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
     float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    const float *__restrict__ dy_absmax, const float *__restrict__ x_minmax, unsigned *__restrict__ dx_bound) {
+    const float *__restrict__ dy_absmax, const float *__restrict__ x_minmax, unsigned *__restrict__ dx_bound,
+    unsigned *__restrict__ dx_bound_min) {
   __shared__ double s_S[16][64];
   __shared__ double s_SS[16][64];
   __shared__ float s_D;
@@ -521,6 +522,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
       float bf = (float)b;
       if (!(bf == bf)) bf = INFINITY;
       if (bf > 0.f) atomicMax(dx_bound + (c & 63), __float_as_uint(bf));
+      // round 5 (range guard): the SMALLEST non-zero per-channel bound -- the ratio to the block above is the span of channel
+      // magnitudes the planes are cut over (one word, the caller presets it to +inf; min of positive floats = min of their bits)
+      if (dx_bound_min && bf > 0.f && bf < INFINITY) atomicMin(dx_bound_min, __float_as_uint(bf));
     }
   }
 }
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const CA4Ptr x
                                     const float4 *__restrict__ coef, uint4 *__restrict__ planes,
                                     long long n4, int C4, int relu, const float *__restrict__ bound, int fixed_c) {
   const float s = dspn::pieces::operand_scale(bound);
+  const bool nf = dspn::pieces::operand_nonfinite(bound);       // (round 5: an infinite gradient leaves as (+-65504, +-inf), as bn_apply_planes_kernel's)
   struct Co { float4 sa, sb, a, c1, c0; };
   auto coefs = [&](const int c4) __attribute__((always_inline)) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -556,6 +561,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const CA4Ptr x
     dspn::pieces::bf16x4 p0, p1, q0, q1;
     dspn::pieces::split2h(grad(x0, g0, k0), s, p0, p1);
     dspn::pieces::split2h(grad(x1, g1, k1), s, q0, q1);
+    if (__builtin_expect(nf, 0)) { dspn::pieces::repair_inf(p0, p1); dspn::pieces::repair_inf(q0, q1); }
     planes[i] = hi ? plane_pack(p1, q1) : plane_pack(p0, q0);
   };
   const long long cstride = (long long)gridDim.x * (U * 256);
@@ -1764,7 +1770,8 @@ int DSPN_FN(dspn_bn_backward)(const st_t *x, const float *scale, const float *sh
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
                      CA4Ptr(dy), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows), PoolGrad{});
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
-                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr);
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr,
+                     static_cast<unsigned *>(nullptr));
   const long long n4 = rows * C4;
 #ifdef DSPN_HALF
   if (C % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
@@ -1809,7 +1816,8 @@ int dspn_bn_backward_maxpool_f32(const float *x, const float *scale, const float
                      CA4Ptr(x), reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
                      CA4Ptr(x), mean, rstd, rows, C4, CL, relu, partial, slab_rows_for(rows), pool);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), partial, ns, C,
-                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr);
+                     1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, nullptr, nullptr, nullptr,
+                     static_cast<unsigned *>(nullptr));
   const long long n4 = rows * C4;
   hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(grid_for(n4)), dim3(256), 0, S_(stream), reinterpret_cast<const float4 *>(x),
                      reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
@@ -1840,7 +1848,7 @@ int dspn_bn_apply_planes_f32(const float *x, const float *scale, const float *sh
 int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const float *shift, const st_t *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax, const float *dy_absmax, const float *x_chan_minmax,
+                                   int accumulate, float *dx_absmax, float *dx_absmin, const float *dy_absmax, const float *x_chan_minmax,
                                    int dx_planes, void *workspace, size_t workspace_bytes, void *stream) {
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
   DSPN_REQUIRE(!dx_planes || (!dspn::kHalf && !accumulate && C % 32 == 0 && dx_absmax && dy_absmax && x_chan_minmax &&
@@ -1862,7 +1870,8 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
   }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, S_(stream), tile_sums, tiles, C,
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, dx_planes ? dy_absmax : nullptr,
-                     dx_planes ? x_chan_minmax : nullptr, dx_planes ? reinterpret_cast<unsigned *>(dx_absmax) : nullptr);
+                     dx_planes ? x_chan_minmax : nullptr, dx_planes ? reinterpret_cast<unsigned *>(dx_absmax) : nullptr,
+                     dx_planes ? reinterpret_cast<unsigned *>(dx_absmin) : nullptr);
   const long long n4 = rows * C4;
 #ifndef DSPN_HALF
   if (dx_planes) {

@@ -169,6 +169,14 @@ class Graph:
         # range monitor of the "f16x2" math: per convolution-input slot the smallest non-zero per-channel magnitude, where a
         # BatchNorm finalize sees the channels (range_report)
         self.scalars_min = None
+        # round 5: the range GUARD of the "f16x2" math.  Per magnitude slot the smallest non-zero per-channel magnitude travels
+        # beside the largest (scalars_min: inputs from the BatchNorm finalize, weights from one batched launch per step, output
+        # gradients from the BatchNorm backward's per-channel bounds); a convolution one of whose operands spanned more than
+        # 2^GUARD_BITS in the PREVIOUS pass runs all three of its calls in the three-piece bf16 math this step (guard_fb on the
+        # node; the span of a trained net's channels moves over many steps, not within one).  DSPN_RANGE_GUARD=0 switches it off.
+        self.guard = dict(enabled=_os.environ.get("DSPN_RANGE_GUARD", "1") != "0", have_stats=False, risk=frozenset(),
+                          calls=0, calls_total=0, at_risk_slots=0)
+        self.wmin_table = None     # descriptor table of the per-output-channel weight minima (one launch per step)
 
     # -- construction ---------------------------------------------------------
     def tensor(self, shape, name, requires_grad=True, data=None, virtual=False, dtype=None):
@@ -228,6 +236,76 @@ class Graph:
             return (0, 0, 0.0)
         span = np.log2(mx[ok] / mn[ok])
         return (int(ok.sum()), int((span > 16).sum()), float(span.max()))
+
+    GUARD_BITS = 16
+    GUARD_PERIOD = 4
+
+    def _spans_device(self):
+        """(2, slots) device tensor: the largest (FINITE partial maxima, as the kernels read them) and the smallest non-zero
+        per-channel magnitude per slot of the pass that has just been issued"""
+        mx = self.scalars.view(-1, fn.ABSMAX_SLOTS)
+        mx = torch.where(mx < 3.0e38, mx, torch.zeros_like(mx)).max(dim=1).values
+        return torch.stack([mx, self.scalars_min])
+
+    def slot_spans(self):
+        """the same as numpy arrays (synchronises); nan / inf where a slot has no per-channel information"""
+        both = self._spans_device().cpu().numpy()
+        return both[0], both[1]
+
+    def _update_guard(self, blocking=False):
+        """Called at the top of forward(), before the magnitude arena is zeroed: which convolutions run their calls of THIS
+        pass in the three-piece math.  The spans of the pass issued last are copied to pinned host memory behind it (no
+        synchronisation); the decisions are taken from the copy made one pass EARLIER, which has long arrived -- the host
+        runs ahead of the device and must not wait for it, and taking a fixed lag (not "whatever has arrived") keeps a run
+        reproducible.  blocking=True (MultiTaskSolver's calibration pass, tests): decide from the pass issued last."""
+        gd = self.guard
+        gd["calls"] = 0
+        gd["count"] = gd.get("count", 0) + 1
+        # the weights' per-channel minima cost a launch over every weight: taken in the pass BEFORE one whose spans are read
+        gd["wmin_now"] = blocking or gd["count"] % self.GUARD_PERIOD == self.GUARD_PERIOD - 1 or not gd["have_stats"]
+        if not gd["enabled"] or self.scalars is None or not gd["have_stats"]:
+            return
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return                     # (a recorded step cannot look at the device: it keeps the decisions it was recorded with)
+        if not blocking and gd["count"] % self.GUARD_PERIOD != 0:
+            return                     # spans move over many steps: looked at every GUARD_PERIOD-th pass (0.7 % of the step -> 0.2 %)
+        if blocking:
+            gd["queue"] = []
+            both = self._spans_device().cpu().numpy()
+        else:
+            pool = gd.setdefault("pinned", [torch.empty((2, self.scalars_min.numel()), dtype=torch.float32, pin_memory=True)
+                                            for _ in range(3)])       # (at most two copies are in flight)
+            host = pool[gd.get("pin_i", 0) % 3]
+            gd["pin_i"] = gd.get("pin_i", 0) + 1
+            host.copy_(self._spans_device(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            gd.setdefault("queue", []).append((host, ev))
+            if len(gd["queue"]) < 2:
+                return
+            host, ev = gd["queue"].pop(0)
+            ev.synchronize()
+            both = host.numpy()
+        mx, mn = both[0], both[1]
+        ok = np.isfinite(mn) & (mn > 0) & (mx > 0)
+        wide = np.zeros(mx.shape, bool)
+        wide[ok] = np.log2(mx[ok] / mn[ok]) > self.GUARD_BITS
+        gd["at_risk_slots"] = int(wide.sum())
+        risk = set()
+        if wide.any():
+            for n in self.nodes:
+                if isinstance(n, Conv) and n.am_x is not None and not n.tap_expand:
+                    if wide[n.am_x] or wide[n.am_w] or wide[n.am_dy]:
+                        risk.add(id(n))
+        if risk != gd["risk"]:
+            gd["risk"] = frozenset(risk)
+            for n in self.nodes:
+                if isinstance(n, Conv):
+                    n.guard_fb = id(n) in risk
+
+    def guard_report(self):
+        """(convolutions on the fallback this pass, fallback kernel calls this pass, slots whose span exceeded 2^GUARD_BITS last pass)"""
+        return len(self.guard["risk"]), self.guard["calls"], self.guard["at_risk_slots"]
 
     def _resolve_auto_deferred(self):
         """BatchNorm(defer_apply="auto"): keep the output virtual only if every reader is a plain convolution input;
@@ -417,6 +495,9 @@ class Graph:
                 self._am_table_slots = {n.am_w for n in wnodes}
                 if pairs:
                     self.am_table = fn.absmax_table(pairs, self.device)
+                    if self.guard["enabled"]:
+                        self.wmin_table = fn.absmin_rows_table(
+                            [(n.w.data.view(n.w.shape[0], -1), self.scalars_min[n.am_w:n.am_w + 1]) for n in wnodes], self.device)
             planes = [(n.w.data, n.wp, n.wtp) + ((self.scalar(n.am_w),) if self.math == "f16x2" else ())
                       for n in self.nodes if isinstance(n, Conv) and (n.wp is not None or n.wtp is not None)]
             if planes:
@@ -550,8 +631,11 @@ class Graph:
             fn.weight_transpose_batch(*self.wt_table)
             self.wt_batched = True
         if self.scalars is not None:   # "f16x2" math: every operand magnitude of the step starts from zero; the weights' now
+            self._update_guard(blocking=self.guard.pop("decide_now", False))
             self.scalars.zero_()
             self.scalars_min.fill_(float("inf"))
+            if self.wmin_table is not None and self.guard.get("wmin_now", True):
+                fn.absmin_rows_batch(*self.wmin_table)
             self._am_done = set()
             self._am_bwd_ran = False
             if self.am_table is not None:
@@ -652,6 +736,7 @@ class Graph:
         if self.side_bwd is not None:
             assert not self.side_bwd["dirty"], "the previous backward pass left side-stream work unjoined"
             self.side_bwd["forked"] = False
+        self.guard["have_stats"] = True      # (the spans of a whole pass -- inputs, weights, gradients -- exist once this one has run)
         if self.scalars is not None:
             if self._am_bwd_ran:       # a second backward pass on the same forward pass: new gradients, new magnitudes
                 for slot in self._am_bwd_slots & self._am_done:
@@ -914,14 +999,16 @@ class BatchNorm(Node):
             # (a second writer of x's gradient: materialise the pooling backward after all)
             fn.maxpool_backward_argmax(argmax, dyp, self.out.shape, k, s, p, dx=self.out.own_grad())
             self.out.grad = self.out.own_grad()
-        if self.bwd_sums_ready and self.dx_planes and am is not None and not acc and self._x_ext_valid():
+        if (self.bwd_sums_ready and self.dx_planes and am is not None and not acc and self._x_ext_valid()
+                and not getattr(prod, "guard_fb", False)):      # (a convolution on the guard's fallback reads a FLOAT gradient)
             # the gradient leaves as fp16 piece planes (same buffer): `am` receives the BOUND it is cut by
             self.bwd_sums_ready = False
             fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                                      None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
                                      relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
                                      dbeta=self.beta.grad, accumulate=False, dx_absmax=am,
-                                     dy_absmax=self._g.scalar(self.am_dyin), x_chan_minmax=self.x_ext, dx_planes=True)
+                                     dy_absmax=self._g.scalar(self.am_dyin), x_chan_minmax=self.x_ext, dx_planes=True,
+                                     dx_absmin=g.scalars_min[prod.am_dy:prod.am_dy + 1] if g.guard["enabled"] else None)
             self.x.grad_planes = True
             return
         if self.bwd_sums_ready:      # the two reductions came out of the data-gradient kernel's epilogue
@@ -999,6 +1086,7 @@ class Conv(Node):
                 g._am_x[key] = g.new_scalar()
             self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(backward=True), g.new_scalar()
         self.x_planes_bn = None      # the deferred BatchNorm that also leaves this node's input as piece planes (Graph._plan_input_planes)
+        self.guard_fb = False        # range guard (Graph._update_guard): this pass's calls run in the three-piece bf16 math
         self.wp = self.wtp = None
         if g.device.type == "cuda":
             npc = fn.plane_pieces(g.math)
@@ -1081,6 +1169,8 @@ class Conv(Node):
                               x_absmax=xa, w_absmax=wa)
             fn.tap_sum(self.z, None if self.b is None else self.b.data, cout, kh, kw, self.pad, out=self.out.data)
             return
+        if self.guard_fb:
+            return self._forward_fallback()
         xp = self._x_planes()
         fn.conv2d_forward(self.x_raw.data if xp is None else xp, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
@@ -1092,7 +1182,29 @@ class Conv(Node):
     def _x_planes(self):
         """the input as piece planes, when the BatchNorm in front wrote them this step (cut by this node's x magnitude)"""
         bn = self.x_planes_bn
+        if self.guard_fb:
+            return None
         return bn.planes if (bn is not None and bn.planes_ready and self.am_x in self._g._am_done) else None
+
+    def _w3(self, transposed):
+        """the weight operand of a fallback call: three bf16 piece planes cut on the spot (None where the three-piece kernels
+        read the float weights: contractions that are not whole 32-channel blocks)"""
+        cols = self.wt_shape[3] if transposed else self.w.shape[3]
+        if cols % 32 != 0:
+            return None
+        return fn.weight_planes(self.w.data, transposed=transposed, cols=cols, math="bf16x3")
+
+    def _forward_fallback(self):
+        """range guard: the same convolution in the three-piece bf16 math, on the float input (affine in the loader); the
+        per-tile extremes the two-piece consumers take their magnitudes from are filled by a pass of their own"""
+        fn.conv2d_forward(self.x_raw.data, self.wop(), None if self.b is None else self.b.data, self.stride, self.pad, self.dil,
+                          relu=self.relu, out=self.out.data, residual=None if self.residual is None else self.residual.data,
+                          in_affine=self.in_affine, out_stats=None if self.out_stats is None else self.out_stats[0],
+                          w_planes=self._w3(False), math="bf16x3")
+        if self.out_minmax is not None:
+            fn.tile_minmax(self.out.data, self.out_stats[2], self.out_minmax)
+        self._g.guard["calls"] += 1
+        self._g.guard["calls_total"] += 1
 
     def backward(self):
         if not self.out._gw:
@@ -1122,6 +1234,16 @@ class Conv(Node):
             else:
                 fn.conv2d_wgrad(self.x.data, self.z, (cout * kh * kw, 1, 1, cin), 1, 0, 1,
                                 out=self.w.grad.view(cout * kh * kw, 1, 1, cin), math=self.math, x_absmax=xa)
+        elif self.guard_fb:
+            assert not planes, "a convolution on the guard's fallback got its gradient as piece planes"
+            if self.slabs is not None:
+                fn.conv2d_wgrad_slabs(self.x_raw.data, dy, self.w.shape, self.slabs, self.stride, self.pad, self.dil,
+                                      in_affine=self.in_affine, math="bf16x3")
+            else:
+                fn.conv2d_wgrad(self.x_raw.data, dy, self.w.shape, self.stride, self.pad, self.dil, out=self.w.grad,
+                                in_affine=self.in_affine, math="bf16x3")
+            self._g.guard["calls"] += 1
+            self._g.guard["calls_total"] += 1
         elif self.slabs is not None:
             xp = self._x_planes()
             fn.conv2d_wgrad_slabs(self.x_raw.data if xp is None else xp, dy, self.w.shape, self.slabs, self.stride, self.pad,
@@ -1150,6 +1272,15 @@ class Conv(Node):
                 bn.bwd_sums_ready = True
                 if bn.dx_planes:         # that BatchNorm's backward bounds its dx from the largest gradient stored here
                     bn_dya = self._g.scalar(bn.am_dyin)
+            if self.guard_fb:
+                w3 = self._w3(True)
+                fn.conv2d_dgrad(dy, self.wt if w3 is None else None, self.x.shape, self.stride, self.pad, self.dil, out=dx,
+                                accumulate=acc, bn_bwd=bn_bwd, wt_planes=w3, math="bf16x3", wt_shape=self.wt_shape)
+                if bn_dya is not None:       # (the two-piece data gradient leaves this by-product in its epilogue)
+                    fn.absmax(dx, out=bn_dya)
+                self._g.guard["calls"] += 1
+                self._g.guard["calls_total"] += 1
+                return
             fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
                             bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa,
                             bn_dy_absmax=bn_dya, dy_planes=planes, wt_shape=self.wt_shape)

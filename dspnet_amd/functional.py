@@ -47,7 +47,9 @@ _lib.register({
     "dspn_conv2d_dgrad_bn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                       _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_bn_backward_from_sums_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i,
-                                            _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+                                            _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "dspn_absmin_rows_batch_f32": (_i, [_vp, _i, _ll, _vp]),
+    "dspn_tile_minmax_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "dspn_conv2d_input_sum_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dspn_conv2d_input_sum_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                             _vp, _sz, _vp]),
@@ -308,6 +310,31 @@ def absmax_table(pairs, device):
         total += (t.numel() // 4 + 1023) // 1024
     assert rows.dtype.itemsize == 32
     return torch.from_numpy(rows.view(np.uint8).copy()).to(device), len(pairs), total
+
+
+def absmin_rows_table(pairs, device):
+    """pairs: [(float32 weight [rows, ...], 1-element float32 output)] -> (device table, rows, total rows) for absmin_rows_batch"""
+    import numpy as np
+    rows = np.zeros(len(pairs), dtype=[("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("row_len", "<i4"), ("begin", "<i8")])
+    begin = 0
+    for i, (w, out) in enumerate(pairs):
+        assert w.dtype == torch.float32 and w.is_contiguous() and out.numel() == 1
+        rows[i] = (w.data_ptr(), out.data_ptr(), w.shape[0], w.numel() // w.shape[0], begin)
+        begin += w.shape[0]
+    table = torch.from_numpy(rows.view(np.uint8).copy()).to(device)
+    return table, len(pairs), begin
+
+
+def absmin_rows_batch(table, n, total):
+    """the smallest non-zero per-output-channel magnitude of every weight of the table (outputs preset to +inf by the caller)"""
+    check(L().dspn_absmin_rows_batch_f32(ptr(table), n, total, stream()), "absmin_rows_batch")
+
+
+def tile_minmax(x, tile_rows, out):
+    """out (tiles, 2, C): smallest / largest value of each channel over each tile of `tile_rows` rows of x (..., C)"""
+    C = x.shape[-1]
+    check(L().dspn_tile_minmax_f32(ptr(x), _rows(x), C, int(tile_rows), ptr(out), stream()), "tile_minmax")
+    return out
 
 
 def absmax_batch(table, n, total):
@@ -714,7 +741,8 @@ def bn_backward_maxpool(x, scale, shift, dy_pool, argmax, k, stride, pad, mean, 
 
 
 def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=False, dx=None, dgamma=None,
-                          dbeta=None, accumulate=False, dx_absmax=None, dy_absmax=None, x_chan_minmax=None, dx_planes=False):
+                          dbeta=None, accumulate=False, dx_absmax=None, dy_absmax=None, x_chan_minmax=None, dx_planes=False,
+                          dx_absmin=None):
     """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...)).
     dx_planes ("f16x2" math): dx is written as fp16 piece planes (same bytes, same buffer shape) cut by the power of two of a
     BOUND of |dx| that is formed from dy_absmax (the magnitude block of dy, conv2d_dgrad's bn_dy_absmax) and x_chan_minmax
@@ -729,7 +757,7 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     assert dy.dtype == x.dtype == dx.dtype
     check(_f("dspn_bn_backward_from_sums", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
-                                             int(accumulate), ptr(dx_absmax), ptr(dy_absmax), ptr(x_chan_minmax),
+                                             int(accumulate), ptr(dx_absmax), ptr(dx_absmin), ptr(dy_absmax), ptr(x_chan_minmax),
                                              int(bool(dx_planes)), ptr(ws), ws.numel(), stream()),
           "bn_backward_from_sums")
     return dx, dgamma, dbeta

@@ -220,7 +220,20 @@ class MultiTaskSolver:
             self._step()
         cur.wait_stream(self.stream)
 
+    def _calibrate_guard(self):
+        """range guard of the "f16x2" math (engine.Graph._update_guard): the decisions of a pass come from the spans the previous
+        pass measured, so the very first step is preceded by ONE forward / backward whose only product is those spans (no
+        update, no reduction: parameters, momenta and the batch are untouched; a net loaded from a checkpoint whose channels
+        span more than 2^16 is then guarded from its first update on)"""
+        g = self.g
+        if g.scalars is None or not g.guard["enabled"] or g.guard["have_stats"]:
+            return
+        g.forward()
+        g.backward()
+        g.guard["decide_now"] = True      # the next forward() decides from this pass (one synchronisation, once)
+
     def _step(self):
+        self._calibrate_guard()
         if self._graph is not None:
             # the recorded SGD launch carries lr / momentum / wd BY VALUE: a schedule that moved them since the recording
             # (the reference's optimizer takes an lr_scheduler, multi_solver.py:221) drops the graph and records a new one

@@ -237,6 +237,15 @@ int dspn_conv2d_slab_reduce_batch_f32(const void *table, int n, long long total4
 #define DSPN_ABSMAX_SLOTS 64
 int dspn_absmax_f32(const float *x, long long rows, int C, const float *scale, const float *shift, int relu,
                     float *out_dev, void *stream);
+/* Range guard of DSPN_MATH_F32_F16X2 (round 5).  dspn_absmin_rows_batch_f32: for every row of the table -- { const float *w;
+ * float *out_min; int32 rows, row_len; int64 begin (= sum of `rows` over the preceding table rows) }, 32 bytes, DEVICE memory
+ * -- the smallest non-zero per-output-channel magnitude of w [rows][row_len] into *out_min (preset to +inf by the caller):
+ * beside the weight's magnitude block this is the span of its channels.  One launch for every weight of a graph.
+ * dspn_tile_minmax_f32: minmax[(t*2 + 0)*C + c] / [(t*2 + 1)*C + c] = smallest / largest x[r][c] over the rows of tile t
+ * (tile_rows rows each) -- the table a dspn_conv2d_forward_bn_f32 call writes as out_minmax, for an output that was produced
+ * by a call in another math (the guard's fallback), so that the consumers' magnitudes still come from the table. */
+int dspn_absmin_rows_batch_f32(const void *table, int n, long long total_rows, void *stream);
+int dspn_tile_minmax_f32(const float *x, long long rows, int C, int tile_rows, float *minmax, void *stream);
 int dspn_absmax_batch_f32(const void *table, int n, long long total_chunks, void *stream);
 /* a BOUND instead of the magnitude (round 4): out_dev (+max)= max over c of |scale[c]| * M + |shift[c]|, M = the magnitude
  * in x_absmax_dev -- an upper bound of |(relu)(x * scale[c] + shift[c])| for a convolution that folds a BatchNorm into its
@@ -355,8 +364,11 @@ int dspn_bn_backward_f32(const float *x, const float *scale, const float *shift,
 int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const float *shift, const float *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax, const float *dy_absmax, const float *x_chan_minmax,
+                                   int accumulate, float *dx_absmax, float *dx_absmin, const float *dy_absmax, const float *x_chan_minmax,
                                    int dx_planes, void *workspace, size_t workspace_bytes, void *stream);
+/* dx_absmin (optional, with dx_planes; round 5): ONE float, preset to +inf by the caller, that receives the smallest non-zero
+ * per-channel bound of |dx| -- with dx_absmax, the span of channel magnitudes the planes are cut over (the range guard of
+ * DSPN_MATH_F32_F16X2 reads it; elements more than 2^17 below the tensor's largest magnitude lose relative accuracy). */
 /* dx_planes != 0 (round 4; float tensors, C % 32 == 0, accumulate == 0): dx is written as fp16 PIECE PLANES for
  * DSPN_MATH_F32_F16X2 instead of floats -- [row][C / 32][piece][32] 16-bit elements, the same 4 bytes per element and the
  * same byte offset for every group of four channels as the float tensor, (p0, p1) = (f16(s dx), f16(s dx - p0)) -- so that
@@ -572,7 +584,7 @@ int dspn_bn_backward_bf16(const dspn_bf16 *x, const float *scale, const float *s
 int dspn_bn_backward_from_sums_bf16(const dspn_bf16 *x, const float *scale, const float *shift, const dspn_bf16 *dy,
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, dspn_bf16 *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
-                                   int accumulate, float *dx_absmax_unused, const float *dy_absmax_unused,
+                                   int accumulate, float *dx_absmax_unused, float *dx_absmin_unused, const float *dy_absmax_unused,
                                    const float *x_chan_minmax_unused, int dx_planes /* must be 0 */, void *workspace,
                                    size_t workspace_bytes, void *stream);
 int dspn_add_bf16(const dspn_bf16 *a, const dspn_bf16 *b, dspn_bf16 *out, long long n, void *stream);

@@ -1,0 +1,9 @@
+#!/bin/bash
+OUT=gpurun_out/r05_stem; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_wide_tiles_gpu.py -x -q -m gpu > $OUT/wide.log 2>&1; echo "wide rc $?"; tail -4 $OUT/wide.log
+timeout 900 python -m pytest tests/test_graph_gpu.py -x -q -m gpu -k "forward_backward_matches or channel_spread or training_reduces" > $OUT/graph.log 2>&1; echo "graph rc $?"; tail -3 $OUT/graph.log
+python scratch/layer_bench.py 32 > $OUT/layer_table.txt 2>&1; head -8 $OUT/layer_table.txt | cut -c1-200; tail -1 $OUT/layer_table.txt
+for i in 1 2; do
+timeout 600 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('auto  ', d['value'], d['ms_per_step'], d['roofline'].get('conv_ms_per_step'), d['config'].get('f16x2_fallback_calls'))"
+timeout 600 python bench.py --no-cpu-baseline --no-other-configs --wide-tiles 1 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('narrow', d['value'], d['ms_per_step'], d['roofline'].get('conv_ms_per_step'))"
+done

@@ -116,10 +116,10 @@ def test_convolution_argument_validation_without_gpu():
     assert dgrad(0 | 0x200) == -1 and b"DSPN_MATH_DY_PLANES" in lib.dspn_last_error()       # not the two-piece math
     assert dgrad(3 | 0x200, ldy=48) == -1 and b"DSPN_MATH_DY_PLANES" in lib.dspn_last_error()
     assert dgrad(3 | 0x200, dy_absmax=None) == -1
-    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 48, 1, 0, p, p, p, 1, p, 1 << 20, None) == -1
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 48, 1, 0, p, None, p, p, 1, p, 1 << 20, None) == -1
     assert b"piece planes" in lib.dspn_last_error()                                         # C % 32
-    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 1, p, p, p, 1, p, 1 << 20, None) == -1   # accumulate
-    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 0, p, None, p, 1, p, 1 << 20, None) == -1  # no dy_absmax
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 1, p, None, p, p, 1, p, 1 << 20, None) == -1   # accumulate
+    assert lib.dspn_bn_backward_from_sums_f32(p, p, p, p, p, p, None, p, 4, p, None, p, 512, 64, 1, 0, p, None, None, p, 1, p, 1 << 20, None) == -1  # no dy_absmax
     # ... and the INPUT as piece planes (written by dspn_bn_apply_planes_f32): two-piece math, Cin % 32, no affine, its block
     assert fwd(Cin=64, math=0 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()
     assert fwd(Cin=48, math=3 | 0x400) == -1 and b"DSPN_MATH_X_PLANES" in lib.dspn_last_error()

@@ -133,3 +133,82 @@ def test_automatic_choice_is_one_of_the_tested_paths(tiles):
         tiles(mode)
         ys.append(fn.conv2d_forward(xp, w, None, 1, 1, 1, w_planes=wp, x_absmax=xa, w_absmax=wa, x_planes=True))
     assert torch.equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("mode", [1, 4])
+def test_infinite_activation_through_the_planes_gives_fp32s_infinities(tiles, mode):
+    """VERDICT r04 item 4 (second half): an infinite ACTIVATION.  The plane writers repair an infinite element to the pieces
+    (+-65504, +-inf) (dspn_bn_apply_planes_f32 since round 4, the BatchNorm backward's planes since round 5), so every plane-fed
+    call -- conv_nt_kernel's EPIX & 4 path and the wide family alike -- gives x w = h0 g0 + h0 g1 + h1 g0 = +-inf with fp32's
+    sign, NaN where the weight is 0 (inf * 0), and leaves every output the element does not touch as accurate as before."""
+    N, H, W, Cin, Cout = 2, 12, 12, 64, 128
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) / 24
+    inf = float("inf")
+    x[0, 3, 3, 1] = inf; x[0, 8, 2, 5] = -inf; x[1, 5, 5, 2] = float("nan"); x[1, 9, 9, 7] = inf
+    w[5, 1, 1, 1] = 0.0                      # inf * 0 -> NaN at (0, 3, 3) of output channel 5
+    x, w = x.cuda(), w.cuda()
+    ref = fn.conv2d_forward(x, w, None, 1, 1, 1, math="fp32")
+    xp, xa = planes_of(x)
+    wa = fn.absmax(w); wp = fn.weight_planes(w, math="f16x2", w_absmax=wa)
+    tiles(mode)
+    got = fn.conv2d_forward(xp, w, None, 1, 1, 1, w_planes=wp, x_absmax=xa, w_absmax=wa, x_planes=True)
+    fin = torch.isfinite(ref)
+    assert 0 < int((~fin).sum()) < ref.numel() // 2
+    assert torch.equal(torch.isfinite(got), fin)
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)])        # the same signed infinities
+    assert float((got[fin] - ref[fin]).abs().max()) <= 1e-5 * float(ref[fin].abs().max())
+    # ... and an infinite OUTPUT GRADIENT through the data gradient (dy as planes)
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    dy[0, 6, 6, 3] = inf; dy[1, 2, 9, 11] = -inf
+    dy = dy.cuda()
+    w2 = (torch.randn(Cout, 3, 3, Cin, generator=g) / 24).cuda()
+    wt = fn.weight_transpose(w2)
+    ref = fn.conv2d_dgrad(dy, wt, tuple(x.shape), 1, 1, 1, math="fp32")
+    dyp, dya = planes_of(dy)
+    w2a = fn.absmax(w2); wtp = fn.weight_planes(w2, transposed=True, cols=Cout, math="f16x2", w_absmax=w2a)
+    got = fn.conv2d_dgrad(dyp, wt, tuple(x.shape), 1, 1, 1, wt_planes=wtp, dy_absmax=dya, w_absmax=w2a, dy_planes=True)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(got), fin) and torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)])
+    assert float((got[fin] - ref[fin]).abs().max()) <= 1e-5 * float(ref[fin].abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512), (1, 256, 1024), (3, 70, 512)])
+def test_stem_convolution_kernel_matches_the_generic_one(tiles, shape):
+    """Round 5: the 7x7 / 2 stem convolution (4 physical input channels -> 64, BatchNorm statistics + extremes) on its own
+    kernel (csrc/conv_stem.h: a kernel row is one contiguous 32-deep k-step of the image row) against conv_nt_kernel's
+    non-uniform-tap path (mode 1 switches the stem kernel off with the wide family) and the fp32 MFMA: outputs to fp32
+    accuracy (the two kernels group the 49 taps differently: another summation order), tile statistics / extremes within
+    rounding, odd heights and strips that end inside the image."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, H, W, 4, generator=g).cuda()
+    x[..., 3] = 0                                           # the pad channel of the RGB image
+    w = (torch.randn(64, 7, 7, 4, generator=g) / 12).cuda()
+    w[..., 3] = 0
+    xa, wa = fn.absmax(x), fn.absmax(w)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    t, rows = fn.conv_stats_layout(N * Ho * Wo, 64)
+    assert rows == 64
+    out = {}
+    for mode in (1, 0):
+        tiles(mode)
+        st = torch.zeros(t, 2, 64, device="cuda"); mm = torch.zeros(t, 2, 64, device="cuda")
+        y = fn.conv2d_forward(x, w, None, 2, 3, 1, out_stats=st, out_minmax=mm, x_absmax=xa, w_absmax=wa)
+        out[mode] = (y, st, mm)
+    ref = fn.conv2d_forward(x, w, None, 2, 3, 1, math="fp32")
+    scale = float(ref.abs().max())
+    for mode in (1, 0):
+        assert float((out[mode][0] - ref).abs().max()) <= 1e-5 * scale, mode
+    y, st, mm = out[0]
+    # the tables describe the STORED values: recompute them from y
+    yt = y.view(-1, 64)[: t * 64].view(t, 64, 64).double() if (N * Ho * Wo) % 64 == 0 else None
+    assert yt is not None
+    mean = yt.mean(dim=1); m2 = ((yt - mean[:, None, :]) ** 2).sum(dim=1)
+    assert float((st[:, 0].double() - mean).abs().max()) <= 1e-5 * scale
+    assert float((st[:, 1].double() - m2).abs().max()) <= 1e-4 * float(m2.max())
+    assert torch.equal(mm[:, 0], y.view(t, 64, 64).min(dim=1).values) and torch.equal(mm[:, 1], y.view(t, 64, 64).max(dim=1).values)
+    assert float((st - out[1][1]).abs().max()) <= 1e-4 * float(out[1][1].abs().max())
