@@ -1956,9 +1956,11 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
 #ifndef DSPN_HALF
   // The wide family (conv_wide.h): both operands pure copies, 64 x 64 outputs per wave.  Legal when the A operand is piece
   // planes (=> two-piece math, whole 32-channel blocks, no input affine), the vector epilogue applies, there is at least one
-  // tap, no split-K, and the BatchNorm tables are per 128 rows (cfg 0) -- the layout the wide epilogue writes.
-  if (g.a_planes && pre && g.bf16 == 3 && splits == 1 && cfg == 0 && (g.flags & 16) && g.Cout % 4 == 0 && g.TR * g.TS > 0) {
-    const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk);
+  // tap, no split-K, and the BatchNorm tables are per 128 rows (cfg 0), or per 64 rows with at most 64 output columns (cfg 2) --
+  // the layouts the wide epilogue writes.
+  if (g.a_planes && pre && g.bf16 == 3 && splits == 1 && (cfg == 0 || (cfg == 2 && g.Cout > 32 && g.Cout <= 64)) && (g.flags & 16) &&
+      g.Cout % 4 == 0 && g.TR * g.TS > 0) {
+    const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk, (g.stats || g.bn_sums) ? 1 : 0);
     if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
   }
 #endif

@@ -66,8 +66,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 
 // conv_wide.hip: which wide tile a plane-fed layer runs on: 0 none (conv_nt_kernel), 1 256 x 128, 2 128 x 256 (8 waves, one
-// workgroup per CU), 3 128 x 128 on four waves (two workgroups per CU); M output points, nk k-steps of 32 channels
-int wide_tile_choice(long long M, int Cout, int nk);
+// workgroup per CU), 3 128 x 128 on four waves (two workgroups per CU), 4 256 x 64 on four waves (Cout <= 64, 64-row
+// BatchNorm tables); M output points, nk k-steps of 32 channels
+int wide_tile_choice(long long M, int Cout, int nk, int fused_epilogue);
 // conv_wide.hip: one launch of the wide family (shape 1: 256 x 128, 2: 128 x 256, 3: 128 x 128 on four waves) -- both operands
 // piece planes, vector epilogue, at least one tap (dispatch_nt checks)
 int launch_wide(int shape, const float *in, const float *w_planes, const float *bias, float *out, const ConvGeomT<float> &g,

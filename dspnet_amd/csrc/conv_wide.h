@@ -20,20 +20,22 @@
 //     L = row >> 1 holds what an unswizzled image keeps in slot s ^ (L & 7): conflict-free ds_read_b128.
 // One workgroup per CU at 256 registers (8 waves), or two at 256 registers (4 waves, 128 x 128).
 //
-// BatchNorm tables keep their 128-row layout whatever the tile: a 256-row tile writes two rows of g.stats / g.minmax /
-// g.bn_sums, so dspn_conv2d_stats_layout / dspn_conv2d_dgrad_bn_tiles and every consumer are untouched by the routing.
+// BatchNorm tables keep their layout whatever the tile -- 128 rows per entry, 64 for the layers with at most 64 output columns
+// (template parameter SR): a 256-row tile writes two (four) rows of g.stats / g.minmax / g.bn_sums, so
+// dspn_conv2d_stats_layout / dspn_conv2d_dgrad_bn_tiles and every consumer are untouched by the routing.
 
 // The tile epilogue of the wide family, from the staged fp32 tile in LDS (st[row * (BN + 4) + col], written by the caller, which
 // has NOT yet met the barrier that publishes it) to the stored outputs and BatchNorm tables; ends with the barrier after which
 // the LDS may be overwritten.  conv_nt_kernel's epilogue per 128-row half: same arithmetic, same tables.
-template <int BM, int BN, int NTHR, int EPI>
+template <int BM, int BN, int NTHR, int EPI, int SR>
 __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, const int m0, const int n0, const int M, const int tid,
                                               const float *__restrict__ bias, float *__restrict__ out,
                                               const float *__restrict__ residual, float &gmx_all) {
-  constexpr int HALVES = BM / 128;
+  constexpr int HALVES = BM / SR;          // statistics tiles (SR rows: 128, or 64 for the Cout <= 64 layers) per output tile
+  static_assert(BM % SR == 0, "whole statistics tiles");
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
   constexpr int SLD = BN + 4;
-  constexpr int C4 = BN / 4, RPP = NTHR / C4, NPH = 128 / RPP;   // float4 columns per row, rows per pass, passes per half
+  constexpr int C4 = BN / 4, RPP = NTHR / C4, NPH = SR / RPP;   // float4 columns per row, rows per pass, passes per half
   constexpr int RC = NPH > 8 ? 8 : NPH;                          // rows in flight per thread
   float *st = reinterpret_cast<float *>(wsm);
   const int c4 = tid % C4, er0 = tid / C4;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
       float4 rq[RC], xq[EPI == 2 ? RC : 1];
 #pragma unroll
       for (int p = 0; p < RC; ++p) {
-        const int m = m0 + h * 128 + er0 + (ch * RC + p) * RPP;
+        const int m = m0 + h * SR + er0 + (ch * RC + p) * RPP;
         if (g.dense) {
           offs[p] = m * g.ldc + co;
         } else {
@@ -94,7 +96,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
       for (int p = 0; p < RC; ++p) {
         const int off = offs[p];
         if (off < 0) continue;
-        const float4 tv = *reinterpret_cast<const float4 *>(st + (h * 128 + er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
+        const float4 tv = *reinterpret_cast<const float4 *>(st + (h * SR + er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
         float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
         v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
         if (has_res && accum) {
@@ -155,7 +157,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
     __builtin_amdgcn_s_barrier();
     for (int hc = tid; hc < HALVES * BN; hc += NTHR) {
       const int h = hc / BN, col = hc - h * BN;
-      const int lim = min(M - (m0 + h * 128), 128);
+      const int lim = min(M - (m0 + h * SR), SR);
       if (n0 + col >= g.Cout || lim <= 0) continue;
       // merge of the RPP row groups about the first group's mean (no division inside the loop):
       //   mean = m_0 + sum n_e d_e / n,  M2 = sum (M2_e + n_e d_e^2) - n (mean - m_0)^2,  d_e = mean_e - m_0
@@ -171,7 +173,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
         n += ne; sd += ne * d; sq += m2e + ne * d * d;
       }
       const float dm = sd / n;
-      const long long mt_ = m0 / 128 + h;
+      const long long mt_ = m0 / SR + h;
       g.stats[(mt_ * 2 + 0) * g.Cout + n0 + col] = mref + dm;
       g.stats[(mt_ * 2 + 1) * g.Cout + n0 + col] = fmaxf(sq - n * dm * dm, 0.f);
       if (mmx) {
@@ -198,11 +200,11 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
     __builtin_amdgcn_s_barrier();
     for (int hc = tid; hc < HALVES * BN; hc += NTHR) {
       const int h = hc / BN, col = hc - h * BN;
-      if (n0 + col >= g.Cout || m0 + h * 128 >= M) continue;
+      if (n0 + col >= g.Cout || m0 + h * SR >= M) continue;
       const float *rh = red + (size_t)h * RPP * BN * 2;
       float a = 0.f, b = 0.f;
       for (int er = 0; er < RPP; ++er) { a += rh[(er * BN + col) * 2]; b += rh[(er * BN + col) * 2 + 1]; }
-      const long long mt_ = g.bn_tile_base + m0 / 128 + h;
+      const long long mt_ = g.bn_tile_base + m0 / SR + h;
       g.bn_sums[(mt_ * 2 + 0) * g.Cout + n0 + col] = a;
       g.bn_sums[(mt_ * 2 + 1) * g.Cout + n0 + col] = b;
     }
@@ -231,7 +233,7 @@ __device__ __forceinline__ void wide_publish_absmax(const ConvGeom &g, char *wsm
     }
 }
 
-template <int WAVES_M, int WAVES_N, int STAGES, int EPI>
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR = 128>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   constexpr int STG = (BM + BN) * 128;                   // bytes of one k-step's images: A rows, then B rows
   constexpr int D = STAGES - 1;                          // k-steps in flight ahead of the one being multiplied
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-  static_assert(BM % 128 == 0, "BatchNorm tables are per 128 rows");
+  static_assert(BM % SR == 0, "BatchNorm tables are per SR rows");
   extern __shared__ __attribute__((aligned(1024))) char wsm[];
 
 #ifdef DSPN_ABLATE
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-    constexpr int NMMA = 2 * 3 * TM * TN, GRP = NMMA / NI;           // MFMAs per k-step; MFMAs between two requests
-    static_assert(NMMA % NI == 0, "requests spread evenly over the MFMAs");
+    constexpr int NMMA = 2 * 3 * TM * TN;                            // MFMAs per k-step; request i goes behind MFMA (i + 1) NMMA / NI - 1
+    static_assert(NI <= NMMA, "at most one request per MFMA");
 #pragma unroll
     for (int m = 0; m < NMMA; ++m) {
       const int kk = m / (3 * TM * TN), t3 = (m / (TM * TN)) % 3, i = (m / TN) % TM, j = m % TN;
@@ -404,10 +406,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
       else
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kk][PA[t3]][i]),
                                                          __builtin_bit_cast(f16x8, fb[kk][PB[t3]][j]), acc[i][j], 0, 0, 0);
-      if (m % GRP == GRP - 1) {
-        issue_piece(m / GRP);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (((i + 1) * NMMA) / NI - 1 == m) {
+          issue_piece(i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
     }
   };
 
@@ -447,20 +451,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
           for (int r = 0; r < 16; ++r)
             st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
     }
-    wide_epilogue<BM, BN, NTHR, EPI>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
+    wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
   }
   if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
 // host side: one launch of the wide family.  Persistent grid as conv_nt_kernel's (occupancy x CUs, a multiple of 8).
-template <int WAVES_M, int WAVES_N, int STAGES, int EPI>
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR>
 int launch_ntw_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
                     const float *residual) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   const size_t lds = std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
-  auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI>;
+  auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR>;
   static int slots = 0, slots_per_cu = 0, slots_cus = 0;
   if (!slots) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -484,10 +488,10 @@ int launch_ntw_impl(const float *in, const float *w, const float *bias, float *o
   return dspn::check_launch("conv_ntw");
 }
 
-template <int WAVES_M, int WAVES_N, int STAGES>
+template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
 int launch_ntw(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s, const float *residual) {
-  if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2>(in, w, bias, out, g, s, residual);
-  if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1>(in, w, bias, out, g, s, residual);
-  return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0>(in, w, bias, out, g, s, residual);
+  if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR>(in, w, bias, out, g, s, residual);
+  if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR>(in, w, bias, out, g, s, residual);
+  return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR>(in, w, bias, out, g, s, residual);
 }
 

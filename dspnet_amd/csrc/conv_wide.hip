@@ -85,11 +85,18 @@ namespace conv {
 // the stage-3 3x3 layer: conv_nt_kernel 125 / 148 us, 256 x 128 119 / 118, 128 x 256 110 / 110, 128 x 128 on four waves 111 / 112):
 // the four-wave tile wins or ties on every layer of the headline graph -- two workgroups per CU cover each other's epilogue,
 // which the one-workgroup-per-CU tiles expose -- and is the only one that also pays on the short-K 1x1 layers.
-int wide_tile_choice(long long M, int Cout, int nk) {
+int wide_tile_choice(long long M, int Cout, int nk, int fused_epilogue) {
   const int mode = dspn::wide_tiles_mode();
   if (mode == 1) return 0;
-  if (mode >= 2) return mode - 1;
-  if (nk < 4) return 0;
+  if (mode >= 2) return Cout <= 64 ? 4 : mode - 1;
+  // one or two k-steps (K = 32 / 64): the kernels are all epilogue -- the wide family's costs less with BatchNorm statistics
+  // or BatchNorm-backward sums in it (K = 64: 250 -> 229 us forward, 323 -> 259 us data gradient at 128 x 128 x 32 images),
+  // the plain one is a tie
+  if (Cout <= 64) return nk >= 4 ? 4 : 0;      // 64 output columns (stage 1): 256 x 64 on four waves
+  if (nk < 4 && !(fused_epilogue && nk >= 2)) return 0;
+  // 128 x 256 where it divides the columns, fills the chip and the k-loop is long enough to matter (K >= 256, N = 512: 155 / 172
+  // against 179 / 190 us on four waves, plain / fused); the four-wave tile everywhere else
+  if (Cout % 256 == 0 && nk >= 8 && ((M + 127) / 128) * (Cout / 256) >= 256) return 2;
   return 3;
 }
 int launch_stem(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int Ho, int Wo,
@@ -101,6 +108,7 @@ int launch_wide(int shape, const float *in, const float *w_planes, const float *
   if (shape == 1) return launch_ntw<4, 2, 3>(in, w_planes, bias, out, g, s, residual);
   if (shape == 2) return launch_ntw<2, 4, 3>(in, w_planes, bias, out, g, s, residual);
   if (shape == 3) return launch_ntw<2, 2, 2>(in, w_planes, bias, out, g, s, residual);
+  if (shape == 4) return launch_ntw<4, 1, 2, 64>(in, w_planes, bias, out, g, s, residual);      // 256 x 64, 64-row BatchNorm tables
   return dspn::fail(DSPN_ERR_ARG_, "conv: no wide tile shape %d", shape);
 }
 }  // namespace conv

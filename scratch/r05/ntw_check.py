@@ -99,6 +99,14 @@ def dgrad_case(N, H, W, Cin, Cout, k, stride, quick):
         if tt: line += " %.0f/%.0f us %.0f TF" % (tt[0], tt[1], flop / tt[0] * 1e-6)
     print(line, flush=True)
 
+if len(sys.argv) > 1 and sys.argv[1] == "shortk":
+    B = 32
+    for c in [(B, 128, 128, 64, 256, 1, 1), (B, 128, 128, 64, 128, 1, 1), (B, 64, 64, 128, 512, 1, 1), (B, 64, 64, 256, 512, 1, 1), (B, 32, 32, 256, 1024, 1, 1)]:
+        forward_case(*c, False)
+    for c in [(B, 128, 128, 256, 64, 1, 1), (B, 128, 128, 128, 64, 1, 1), (B, 64, 64, 512, 128, 1, 1), (B, 64, 64, 256, 128, 1, 1)]:
+        dgrad_case(*c, False)
+    L.dspn_conv_set_wide_tiles(0)
+    sys.exit(0)
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 small = [(2, 24, 24, 64, 128, 3, 1), (3, 25, 23, 96, 256, 3, 2), (1, 17, 19, 128, 256, 1, 1), (2, 9, 9, 256, 512, 3, 1), (1, 40, 40, 32, 384, 3, 1)]
 for c in small:

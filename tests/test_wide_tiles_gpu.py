@@ -38,7 +38,9 @@ def test_setter_rejects_unknown_modes(gpu_device):
 
 # (N, H, W, Cin, Cout, k, stride): tile counts around one / many per CU, M and Cout not multiples of the tiles, one k-step
 FWD = [(2, 24, 24, 64, 128, 3, 1), (3, 25, 23, 96, 256, 3, 2), (1, 17, 19, 128, 256, 1, 1), (2, 9, 9, 256, 512, 3, 1),
-       (1, 40, 40, 32, 384, 3, 1), (2, 31, 33, 64, 192, 3, 1), (4, 64, 64, 32, 96, 1, 1), (8, 32, 32, 128, 320, 3, 1)]
+       (1, 40, 40, 32, 384, 3, 1), (2, 31, 33, 64, 192, 3, 1), (4, 64, 64, 32, 96, 1, 1), (8, 32, 32, 128, 320, 3, 1),
+       # at most 64 output columns: the 256 x 64 tile with 64-row BatchNorm tables (stage 1 of the ResNets)
+       (4, 64, 64, 64, 64, 3, 1), (3, 33, 31, 128, 48, 3, 1), (2, 64, 64, 128, 64, 1, 1)]
 
 
 @pytest.mark.parametrize("case", FWD)
@@ -80,7 +82,8 @@ def test_forward_on_every_tile_is_bit_identical(tiles, case):
 
 # data gradient of a (Cin -> Cout, k x k, stride) convolution at input size H x W; Cin plays the role of the output columns
 BWD = [(2, 24, 24, 128, 64, 3, 1), (3, 25, 23, 256, 96, 3, 2), (1, 17, 19, 256, 128, 1, 1), (2, 9, 9, 512, 256, 3, 1),
-       (2, 16, 16, 128, 64, 1, 2), (2, 30, 34, 192, 64, 3, 1), (8, 32, 32, 320, 128, 3, 2)]
+       (2, 16, 16, 128, 64, 1, 2), (2, 30, 34, 192, 64, 3, 1), (8, 32, 32, 320, 128, 3, 2),
+       (4, 64, 64, 64, 64, 3, 1), (3, 33, 31, 48, 128, 3, 1), (2, 64, 64, 64, 256, 1, 1), (2, 64, 64, 64, 128, 3, 2)]
 
 
 @pytest.mark.parametrize("case", BWD)
