@@ -1953,17 +1953,24 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
   // the split mode's kernels all fit the 128-register budget of the 8-wave form without scratch, fused epilogues included
   const bool eight = eight_mode == 0 ? false : eight_mode == 1 ? true : (kHalf || g.bf16 >= 2) ? true
                      : ((!g.stats && !g.bn_sums) || (eight_mode == 2 && one_tap && g.bn_sums) || (eight_mode == 3 && one_tap));
-#ifndef DSPN_HALF
-  // The wide family (conv_wide.h): both operands pure copies, 64 x 64 outputs per wave.  Legal when the A operand is piece
-  // planes (=> two-piece math, whole 32-channel blocks, no input affine), the vector epilogue applies, there is at least one
-  // tap, no split-K, and the BatchNorm tables are per 128 rows (cfg 0), or per 64 rows with at most 64 output columns (cfg 2) --
-  // the layouts the wide epilogue writes.
-  if (g.a_planes && pre && g.bf16 == 3 && splits == 1 && (cfg == 0 || (cfg == 2 && g.Cout > 32 && g.Cout <= 64)) && (g.flags & 16) &&
-      g.Cout % 4 == 0 && g.TR * g.TS > 0) {
-    const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk, (g.stats || g.bn_sums) ? 1 : 0);
-    if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
+  // The wide family (conv_wide.h): both operands pure copies, 64 x 64 outputs per wave.  Legal when the vector epilogue applies,
+  // there is at least one tap, no split-K, and the BatchNorm tables are per 128 rows (cfg 0), or per 64 rows with at most 64 output
+  // columns (cfg 2) -- the layouts the wide epilogue writes -- and the A operand is a pure copy: fp16 piece planes in the float
+  // build (=> two-piece math, whole 32-channel blocks, no input affine), the bf16 tensor itself in the bf16 build (whole
+  // 64-channel blocks, no input affine).
+  {
+    bool wide_ok = splits == 1 && (cfg == 0 || (cfg == 2 && g.Cout > 32 && g.Cout <= 64)) && (g.flags & 16) && g.Cout % 4 == 0 &&
+                   g.TR * g.TS > 0;
+    // bf16 tensors: legal, bit-identical (tests/test_wide_tiles_gpu.py) and NOT faster -- the training step measured 1340 - 1343
+    // images/s with the family against 1345 - 1347 without, every forced shape lower still (profiles/r05_bf16_wide_ab.txt): those
+    // kernels are bound by the bytes they ask the L2 for, which a 128 x 128 tile does not change.  Only a forced mode routes them.
+    if (kHalf) wide_ok = wide_ok && !g.in_scale && g.Cin % 64 == 0 && dspn::wide_tiles_mode() >= 2;
+    else wide_ok = wide_ok && g.a_planes && pre && g.bf16 == 3;
+    if (wide_ok) {
+      const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk, (g.stats || g.bn_sums) ? 1 : 0);
+      if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
+    }
   }
-#endif
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
   switch (cfg) {
     case 0: return launch_nt<2, 2, 2, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);

@@ -73,6 +73,10 @@ int wide_tile_choice(long long M, int Cout, int nk, int fused_epilogue);
 // piece planes, vector epilogue, at least one tap (dispatch_nt checks)
 int launch_wide(int shape, const float *in, const float *w_planes, const float *bias, float *out, const ConvGeomT<float> &g,
                 hipStream_t s, const float *residual);
+// ... and on bfloat16 tensors (conv_wide_h.hip): the activations / weight copies themselves are the operands; whole 64-channel
+// blocks, no input affine
+int launch_wide(int shape, const __bf16 *in, const __bf16 *w, const float *bias, __bf16 *out, const ConvGeomT<__bf16> &g,
+                hipStream_t s, const __bf16 *residual);
 
 // conv_wide.hip (conv_stem.h): the 7x7 / 2, pad 3, 4 -> 64 channel stem convolution in the two-piece math with BatchNorm
 // statistics (64-row tiles) and extremes: 0 = launched, 1 = not this shape (the generic kernel runs), < 0 = launch error

@@ -29,8 +29,8 @@
 // the LDS may be overwritten.  conv_nt_kernel's epilogue per 128-row half: same arithmetic, same tables.
 template <int BM, int BN, int NTHR, int EPI, int SR>
 __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, const int m0, const int n0, const int M, const int tid,
-                                              const float *__restrict__ bias, float *__restrict__ out,
-                                              const float *__restrict__ residual, float &gmx_all) {
+                                              const float *__restrict__ bias, st_t *__restrict__ out,
+                                              const st_t *__restrict__ residual, float &gmx_all) {
   constexpr int HALVES = BM / SR;          // statistics tiles (SR rows: 128, or 64 for the Cout <= 64 layers) per output tile
   static_assert(BM % SR == 0, "whole statistics tiles");
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
@@ -41,7 +41,8 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
   const int c4 = tid % C4, er0 = tid / C4;
   const int co = n0 + c4 * 4;
   const bool cvalid = co < g.Cout;                               // (Cout % 4 == 0 and aligned rows: the host routes nothing else)
-  const float *addsrc = has_res ? residual : (accum ? out : nullptr);
+  const st_t *addsrc = has_res ? residual : (accum ? out : nullptr);
+  auto ld4 = [](const st_t *q) __attribute__((always_inline)) { return dspn::CA1Ptr(q).vec4()[0]; };
   float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
   if (EPI == 2 && cvalid) {
 #pragma unroll
@@ -86,10 +87,10 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
         }
         if (m >= M || !cvalid) offs[p] = -1;
         rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (addsrc && offs[p] >= 0) rq[p] = *reinterpret_cast<const float4 *>(addsrc + offs[p]);
+        if (addsrc && offs[p] >= 0) rq[p] = ld4(addsrc + offs[p]);
         if constexpr (EPI == 2) {
           xq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (offs[p] >= 0) xq[p] = *reinterpret_cast<const float4 *>(g.bn_x + offs[p]);
+          if (offs[p] >= 0) xq[p] = ld4(g.bn_x + offs[p]);
         }
       }
 #pragma unroll
@@ -100,14 +101,18 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
         float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
         v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
         if (has_res && accum) {
-          const float4 q = *reinterpret_cast<const float4 *>(out + off);
+          const float4 q = ld4(out + off);
           v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        *reinterpret_cast<float4 *>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (kHalf) {   // what is stored (and what the statistics / sums below describe) is the bf16 value
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dspn::round_bf16(v[e]);
+        }
+        dspn::A1Ptr(out + off).vec4()[0] = make_float4(v[0], v[1], v[2], v[3]);
         if constexpr (EPI == 2) {
           const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
 #pragma unroll
@@ -137,7 +142,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
     __builtin_amdgcn_s_barrier();      // every staged row has been read
     float *red = reinterpret_cast<float *>(wsm);             // [HALVES][RPP][BN][2], then the extremes, same shape
     float *red2 = red + HALVES * RPP * BN * 2;
-    const bool mmx = g.minmax != nullptr;                    // (kernel-uniform)
+    const bool mmx = !kHalf && g.minmax != nullptr;           // (kernel-uniform)
     if (cvalid) {
 #pragma unroll
       for (int h = 0; h < HALVES; ++h) {
@@ -235,10 +240,14 @@ __device__ __forceinline__ void wide_publish_absmax(const ConvGeom &g, char *wsm
 
 template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR = 128>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
-    const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
-    const float *__restrict__ residual) {
+    const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
+    st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
+    const st_t *__restrict__ residual) {
   constexpr int TM = 2, TN = 2;
+  // a 128-byte row record of an image: float build -- two fp16 pieces of 32 channels (the planes); bf16 build -- 64 channels of
+  // the tensor itself (its activations and weight copies ARE the operands: a k-step is four 16-deep MFMA blocks, one product)
+  constexpr int KB = 128 / (int)sizeof(st_t);            // channels per record
+  constexpr int NKK = kHalf ? 4 : 2, NPROD = kHalf ? 1 : 3;
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int NWV = WAVES_M * WAVES_N, NTHR = NWV * 64;
   constexpr int A_NI = BM / (8 * NWV), B_NI = BN / (8 * NWV), NI = A_NI + B_NI;   // 1-KiB pieces per wave and k-step
@@ -260,13 +269,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = m_tiles * n_tiles;
   const int M = g.N * g.Hg * g.Wg;
-  const int CB = g.Cin >> 5;                             // 32-channel blocks per tap
+  const int CB = g.Cin / KB;                             // channel blocks (records) per tap
   const int ntaps = g.TR * g.TS;
   const int nk = ntaps * CB;                             // (the host routes nk >= 1 only)
-  const float sc_a = operand_scale(g.a_absmax), sc_b = operand_scale(g.b_absmax);
+  const float sc_a = kHalf ? 1.f : operand_scale(g.a_absmax), sc_b = kHalf ? 1.f : operand_scale(g.b_absmax);
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;    // exact: powers of two
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(in), 0, g.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<st_t *>(wgt), 0, g.w_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
   // ---- loader: lane l of piece q (bank lines 4q .. 4q+3 = tile rows 8q .. 8q+7) fills slot l & 15 of line 4q + (l >> 4), i.e.
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
       const bool mv = m < M;                                  // rows past M: every tap fails the bounds test
       a_ih0[i] = mv ? ih0 : -0x40000000;
       a_iw0[i] = mv ? iw0 : 0;
-      a_boff[i] = mv ? (((n * g.Hin + ih0) * g.Win + iw0) * g.Cin) * 4 + a_cb[i] : 0;   // BYTES of tap (0, 0) (may be negative)
+      a_boff[i] = mv ? (((n * g.Hin + ih0) * g.Win + iw0) * g.Cin) * (int)sizeof(st_t) + a_cb[i] : 0;   // BYTES of tap (0, 0) (may be negative)
     }
 #pragma unroll
     for (int i = 0; i < B_NI; ++i) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   char *q_base = wsm;
   auto issue_begin = [&](const int slot, const bool live) __attribute__((always_inline)) {
     q_dh = l_tr * g.idh; q_dw = l_ts * g.idw;
-    q_atap = ((q_dh * g.Win + q_dw) * g.Cin + l_cb * 32) * 4;
+    q_atap = ((q_dh * g.Win + q_dw) * g.Cin + l_cb * KB) * (int)sizeof(st_t);
     const int wtap = (g.wr0 + l_tr * g.wrs) * g.WS + g.ws0 + l_ts * g.wss;
     q_bsoff = (wtap * CB + l_cb) * 128;
     q_oob = live ? 0u : kOOB;
@@ -372,44 +381,50 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   // first (conv_nt_kernel's order per accumulator).
   auto mma_step = [&](const int slot) __attribute__((always_inline)) {
     const char *sa = wsm + slot * STG + wm * 128, *sb = wsm + slot * STG + BM * 128 + wn * 128;
-    bf16x8 fa[2][2][TM], fb[2][2][TN];                    // [kk][piece][...]
+    // fragment f of a row: chunk 2 f + (lane >> 5) of its record.  Float build: f = 2 piece + kk (pieces of 32 channels); bf16
+    // build: f = kk (64 channels).  Read in the order the MFMAs want them.
+    bf16x8 fa[4][TM], fb[4][TN];
+    constexpr int ORD[4] = {kHalf ? 0 : 2, 0, kHalf ? 1 : 3, kHalf ? 2 : 1};     // float: (p1,kk0) (p0,kk0) (p1,kk1) (p0,kk1); bf16: kk 0 1 2 3
+    constexpr int ORDH[4] = {0, 1, 2, 3};
     if (dbg & 4) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int f = 0; f < 4; ++f) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int i = 0; i < TM; ++i) { fa[f][i] = bf16x8{}; asm volatile("" : "+v"(fa[f][i])); }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) { fa[kk][p][i] = bf16x8{}; asm volatile("" : "+v"(fa[kk][p][i])); }
+        for (int j = 0; j < TN; ++j) { fb[f][j] = bf16x8{}; asm volatile("" : "+v"(fb[f][j])); }
+      }
+    } else {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) { fb[kk][p][j] = bf16x8{}; asm volatile("" : "+v"(fb[kk][p][j])); }
-        }
-    } else
+      for (int q = 0; q < 4; ++q) {
+        const int f = kHalf ? ORDH[q] : ORD[q];
+        // float build: the first product of a block needs A piece 1 and B piece 0 (f and f ^ 2): read both sides of each
+        const int fbq = kHalf ? f : (f ^ 2);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+        for (int i = 0; i < TM; ++i) fa[f][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((2 * f) << 4)));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[kk][1][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((4 + 2 * kk) << 4)));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[kk][0][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((2 * kk) << 4)));
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[kk][0][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((2 * kk) << 4)));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[kk][1][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((4 + 2 * kk) << 4)));
+        for (int j = 0; j < TN; ++j) fb[fbq][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((2 * fbq) << 4)));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-    constexpr int NMMA = 2 * 3 * TM * TN;                            // MFMAs per k-step; request i goes behind MFMA (i + 1) NMMA / NI - 1
+    constexpr int NMMA = NKK * NPROD * TM * TN;                      // MFMAs per k-step; request i goes behind MFMA (i + 1) NMMA / NI - 1
     static_assert(NI <= NMMA, "at most one request per MFMA");
+    // float build: x w = h0 g0 + h0 g1 + h1 g0, smallest terms first (conv_nt_kernel's order per accumulator); fragment = 2 piece + kk
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
     for (int m = 0; m < NMMA; ++m) {
-      const int kk = m / (3 * TM * TN), t3 = (m / (TM * TN)) % 3, i = (m / TN) % TM, j = m % TN;
-      if (dbg & 2) { asm volatile("" :: "v"(fa[kk][PA[t3]][i]), "v"(fb[kk][PB[t3]][j])); }
+      const int kk = m / (NPROD * TM * TN), t3 = (m / (TM * TN)) % NPROD, i = (m / TN) % TM, j = m % TN;
+      const int ia = kHalf ? kk : 2 * PA[t3] + kk, ib = kHalf ? kk : 2 * PB[t3] + kk;
+      if (dbg & 2) { asm volatile("" :: "v"(fa[ia][i]), "v"(fb[ib][j])); }
+      else if constexpr (kHalf)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ia][i], fb[ib][j], acc[i][j], 0, 0, 0);
       else
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kk][PA[t3]][i]),
-                                                         __builtin_bit_cast(f16x8, fb[kk][PB[t3]][j]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ia][i]),
+                                                           __builtin_bit_cast(f16x8, fb[ib][j]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        if (((i + 1) * NMMA) / NI - 1 == m) {
-          issue_piece(i);
+      for (int q = 0; q < NI; ++q)
+        if (((q + 1) * NMMA) / NI - 1 == m) {
+          issue_piece(q);
           __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the out-of-range requests past K: nothing may land in the staging area)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // every wave has read its last fragments (nothing is in flight): the LDS becomes the staging area
-    if (dbg & 16) { if (acc[0][0][0] == 1.2345e33f) out[0] = acc[TM - 1][TN - 1][5]; continue; }
+    if (dbg & 16) { if (acc[0][0][0] == 1.2345e33f) out[0] = (st_t)acc[TM - 1][TN - 1][5]; continue; }
 
     // ---- epilogue.  C/D layout: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     {
@@ -458,8 +473,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
 
 // host side: one launch of the wide family.  Persistent grid as conv_nt_kernel's (occupancy x CUs, a multiple of 8).
 template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR>
-int launch_ntw_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
-                    const float *residual) {
+int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s,
+                    const st_t *residual) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
@@ -489,7 +504,7 @@ int launch_ntw_impl(const float *in, const float *w, const float *bias, float *o
 }
 
 template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
-int launch_ntw(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s, const float *residual) {
+int launch_ntw(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s, const st_t *residual) {
   if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR>(in, w, bias, out, g, s, residual);
   if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR>(in, w, bias, out, g, s, residual);
   return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR>(in, w, bias, out, g, s, residual);

@@ -1,6 +1,9 @@
 // The wide tile family of the two-piece convolution math as a translation unit of its own (conv_wide.h holds the kernel):
 // compiled in under a minute, where conv.hip with its four math modes and two storage types takes five.
+// Compiled twice, like conv.hip (dspn_store.h): as is -- float tensors whose operands are fp16 piece planes -- and through
+// conv_wide_h.hip with DSPN_HALF -- bfloat16 tensors, whose activations and weight copies are the operands as they stand.
 #include "dspn_common.h"
+#include "dspn_store.h"
 #include "dspn_pieces.h"
 #include "conv_geom.h"
 #include "../../include/dspn_nn.h"
@@ -9,14 +12,19 @@
 
 namespace {
 using namespace dspn::pieces;
+using dspn::st_t;
+using dspn::kHalf;
 using dspn::conv::f32x16;
 using dspn::conv::bf16x8;
 using dspn::conv::xcd_remap;
-using ConvGeom = dspn::conv::ConvGeomT<float>;
+using ConvGeom = dspn::conv::ConvGeomT<st_t>;
 #include "conv_wide.h"
+#ifndef DSPN_HALF
 #include "conv_stem.h"
+#endif
 }  // namespace
 
+#ifndef DSPN_HALF
 // ---- range guard of the two-piece math (round 5): two small bookkeeping kernels (include/dspn_nn.h)
 namespace {
 struct AbsminRowsDesc { const float *w; unsigned *out; int rows, row_len; long long begin; };
@@ -77,8 +85,11 @@ int dspn_tile_minmax_f32(const float *x, long long rows, int C, int tile_rows, f
 }
 }  // extern "C"
 
+#endif   // !DSPN_HALF
+
 namespace dspn {
 namespace conv {
+#ifndef DSPN_HALF
 // dspn_conv_set_wide_tiles(mode): 0 automatic, 1 never, 2 / 3 / 4 always that shape where it is legal (tests, experiments) -- a
 // launch setting: the K order and the accumulation order per output are the same on every tile.
 // Automatic choice, measured on MI355X (scratch/r05/ntw_check.py, profiles/r05_ntw_check_*.txt; plain / fused-epilogue time of
@@ -103,8 +114,9 @@ int launch_stem(const float *x, const float *w, float *y, int N, int H, int W, i
                 const float *x_absmax, const float *w_absmax, float *stats, float *minmax, hipStream_t s) {
   return launch_conv_stem(x, w, y, N, H, W, Cin, Cout, Ho, Wo, x_absmax, w_absmax, stats, minmax, s);
 }
-int launch_wide(int shape, const float *in, const float *w_planes, const float *bias, float *out, const ConvGeomT<float> &g,
-                hipStream_t s, const float *residual) {
+#endif   // !DSPN_HALF
+int launch_wide(int shape, const st_t *in, const st_t *w_planes, const float *bias, st_t *out, const ConvGeomT<st_t> &g,
+                hipStream_t s, const st_t *residual) {
   if (shape == 1) return launch_ntw<4, 2, 3>(in, w_planes, bias, out, g, s, residual);
   if (shape == 2) return launch_ntw<2, 4, 3>(in, w_planes, bias, out, g, s, residual);
   if (shape == 3) return launch_ntw<2, 2, 2>(in, w_planes, bias, out, g, s, residual);

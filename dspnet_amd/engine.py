@@ -649,6 +649,7 @@ class Graph:
         if seg is None:
             for n in self.nodes:
                 n.forward()
+            self.guard["have_stats"] = True
             return
         first, last, side, ready, done = seg
         self.join_side()
@@ -668,6 +669,7 @@ class Graph:
                 if i == last:
                     done.record(side)
                     self.side_pending = True
+        self.guard["have_stats"] = True       # (forward-only use -- the Detector -- is guarded by the spans of inputs and weights)
 
     def set_side_segment(self, first, last):
         """nodes [first, last] run their forward on the branch stream.  On a CPU graph only the plan is kept (side_plan):

@@ -215,3 +215,53 @@ def test_stem_convolution_kernel_matches_the_generic_one(tiles, shape):
     assert float((st[:, 1].double() - m2).abs().max()) <= 1e-4 * float(m2.max())
     assert torch.equal(mm[:, 0], y.view(t, 64, 64).min(dim=1).values) and torch.equal(mm[:, 1], y.view(t, 64, 64).max(dim=1).values)
     assert float((st - out[1][1]).abs().max()) <= 1e-4 * float(out[1][1].abs().max())
+
+
+BF_CASES = [(4, 32, 32, 64, 128, 3, 1), (8, 32, 32, 128, 256, 3, 1), (4, 33, 31, 64, 192, 3, 2), (8, 64, 64, 64, 256, 1, 1),
+            (8, 64, 64, 128, 64, 3, 1), (16, 32, 32, 256, 128, 1, 1)]
+
+
+@pytest.mark.parametrize("case", BF_CASES)
+def test_bf16_tensors_on_every_tile_are_bit_identical(gpu_device, case):
+    """Round 5: the same family on bfloat16 TENSORS (conv_wide_h.hip): the activations / weight copies are the operands as they
+    stand (128-byte records of 64 channels, one MFMA product per block).  Forward with statistics / residual + ReLU, data
+    gradient plain / accumulating / with BatchNorm-backward sums: the bits of conv_nt_kernel's bf16 build on every tile."""
+    N, H, W, Cin, Cout, k, stride = case
+    L = _lib.lib()
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).to(BF).cuda()
+    w32 = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).to(BF).float().cuda()
+    wh = w32.to(BF)
+    wt = fn.weight_transpose(w32, dtype=BF)
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).to(BF).cuda()
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(BF).cuda()
+    mean = x.float().view(-1, Cin).mean(0)
+    rstd = 1.0 / torch.sqrt(x.float().view(-1, Cin).var(0, unbiased=False) + 2e-5)
+    scale, shift = rstd.clone(), (-mean * rstd)
+    t2, _ = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    ntile = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    out = {}
+    try:
+        for mode in MODES:
+            _lib.check(L.dspn_conv_set_wide_tiles(mode), "set_wide_tiles")
+            st = torch.zeros(max(t2, 1), 2, Cout, device="cuda")
+            got = [fn.conv2d_forward(x, wh, None, stride, pad, 1), fn.conv2d_forward(x, wh, None, stride, pad, 1, residual=res, relu=True)]
+            if t2 > 0:
+                got += [fn.conv2d_forward(x, wh, None, stride, pad, 1, out_stats=st), st]
+            sums = torch.zeros(ntile, 2, Cin, device="cuda")
+            dx = fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, bn_bwd=(x, scale, shift, mean, rstd, True, sums))
+            acc = x.clone()
+            fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=acc, accumulate=True)
+            got += [dx, fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1), acc, sums]
+            out[mode] = got
+    finally:
+        L.dspn_conv_set_wide_tiles(0)
+    for mode in (2, 3, 4):
+        for i, (a, b) in enumerate(zip(out[mode], out[1])):
+            if a.dtype == torch.float32:      # statistics / sums: other row groups per thread, fp32 rounding only
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, (MODES[mode], i)
+            else:
+                assert torch.equal(a, b), (MODES[mode], i)
