@@ -1965,9 +1965,12 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
     // images/s with the family against 1345 - 1347 without, every forced shape lower still (profiles/r05_bf16_wide_ab.txt): those
     // kernels are bound by the bytes they ask the L2 for, which a 128 x 128 tile does not change.  Only a forced mode routes them.
     if (kHalf) wide_ok = wide_ok && !g.in_scale && g.Cin % 64 == 0 && dspn::wide_tiles_mode() >= 2;
-    else wide_ok = wide_ok && g.a_planes && pre && g.bf16 == 3;
+    else wide_ok = wide_ok && pre && g.bf16 == 3;       // (pre: whole 32-channel blocks, the weights as piece planes)
     if (wide_ok) {
-      const int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk, (g.stats || g.bn_sums) ? 1 : 0);
+      int shape = dspn::conv::wide_tile_choice(M, g.Cout, nk, (g.stats || g.bn_sums) ? 1 : 0);
+      // a float A operand (with or without the folded BatchNorm affine) goes through the family's register-staged member:
+      // shapes 12 / 13 / 14 = 128 x 256, 128 x 128 on four waves, 256 x 64 (conv_wide.h, conv_ntv_kernel)
+      if (shape && !kHalf && !g.a_planes) shape = 10 + (shape == 1 ? 3 : shape);
       if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
     }
   }

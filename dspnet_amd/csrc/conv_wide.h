@@ -471,6 +471,285 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
+#ifndef DSPN_HALF
+// ---- the same tiles for an A operand that is NOT a pure copy (round 5, second family member): a float tensor, optionally with
+// the BatchNorm affine (+ ReLU) of the layer in front folded into the loader (conv_nt_kernel's INTF), cut into its two fp16
+// pieces on the way into the SAME swizzled LDS image.  The A rows go global -> registers -> (affine, cut) -> LDS as in
+// conv_nt_kernel; what the family changes for these layers is the rest: the weight planes still go global -> LDS directly, a
+// wave owns 64 x 64 outputs (16 fragment reads per 24 MFMAs instead of 12 per 12), and the BatchNorm epilogues are the wide
+// family's (statistics at no measurable cost where conv_nt_kernel's 128-register epilogue pays 15 - 30 %).
+// A thread moves `A_U` units of (row, 8 channels): two 16-byte loads, two 16-byte LDS stores (one per piece).  Two LDS stages:
+// the requests of k-step kt + 1 are issued before the MFMAs of k-step kt, the pieces are formed between its two MFMA halves.
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
+    const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+    float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
+    const float *__restrict__ residual) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  constexpr int NWV = WAVES_M * WAVES_N, NTHR = NWV * 64;
+  constexpr int A_U = BM * 4 / NTHR;                     // (row, 8-channel) units per thread and k-step
+  constexpr int B_NI = BN / (8 * NWV);                   // 1-KiB pieces of the weight image per wave and k-step
+  static_assert((BM * 4) % NTHR == 0 && BN % (8 * NWV) == 0, "whole units / pieces per thread / wave");
+  constexpr int STG = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(1024))) char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = m_tiles * n_tiles;
+  const int M = g.N * g.Hg * g.Wg;
+  const int CB = g.Cin >> 5;
+  const int nk = g.TR * g.TS * CB;
+  const float sc_a = operand_scale(g.a_absmax), sc_b = operand_scale(g.b_absmax);
+  const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.in_scale), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.in_shift), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  const bool in_relu = g.flags & 32;
+
+  // ---- A units of this thread: unit u = tid + j NTHR -> row u >> 2, channel group q = tid & 3 (the same for all its units)
+  const int aq = tid & 3;
+  int a_lds[A_U];                                        // byte offset of the unit's piece-0 chunk inside the A image
+#pragma unroll
+  for (int j = 0; j < A_U; ++j) {
+    const int r = (tid + j * NTHR) >> 2, line = r >> 1;
+    a_lds[j] = line * 256 + (((((r & 1) << 3) | aq) ^ (line & 7)) << 4);      // piece 1: chunk aq + 4 -> this ^ 64
+  }
+  int b_row[B_NI], b_cb[B_NI];
+#pragma unroll
+  for (int i = 0; i < B_NI; ++i) {
+    const int line = 4 * (wave * B_NI + i) + (lane >> 4), sl = (lane & 15) ^ (line & 7);
+    b_row[i] = 2 * line + (sl >> 3); b_cb[i] = (sl & 7) * 16;
+  }
+  int a_ih0[A_U], a_iw0[A_U], a_boff[A_U], b_boff[B_NI];
+  int l_tr = 0, l_ts = 0, l_cb = 0;
+  float4 ra[A_U][2];                                     // the rows requested last
+  float4 tsc[2], tsh[2];                                 // affine of this thread's 8 channels (INTF)
+  unsigned a_mask = 0;                                   // bit j: unit j of the k-step requested last lies inside the image
+  u32x4_t pa[A_U][2];                                    // its pieces, kept until the image being read has been released
+
+  const int wm = (wave / WAVES_N) * (TM * 32), wn = (wave % WAVES_N) * (TN * 32);
+  const int frow = lane & 31;
+  const int fslot = ((((frow & 1) << 3) | (lane >> 5)) ^ ((frow >> 1) & 7)) << 4;
+  const int foff = (frow >> 1) * 256 + fslot;
+  f32x16 acc[TM][TN];
+  float gmx_all = 0.f;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tile = xcd_remap(t, ntiles);
+    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    {
+      const int hw = g.Hg * g.Wg;
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) {
+        const int m = m0 + ((tid + j * NTHR) >> 2);
+        const int n = m / hw, rem = m - n * hw;
+        const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+        const int ih0 = oi * g.ish + g.ioh, iw0 = oj * g.isw + g.iow;
+        const bool mv = m < M;
+        a_ih0[j] = mv ? ih0 : -0x40000000;
+        a_iw0[j] = mv ? iw0 : 0;
+        a_boff[j] = mv ? (((n * g.Hin + ih0) * g.Win + iw0) * g.Cin + aq * 8) * 4 : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < B_NI; ++i) {
+        const int k = min(n0 + b_row[i], g.Cout - 1);
+        b_boff[i] = k * (g.WTAPS * CB * 128) + b_cb[i];
+      }
+      l_tr = 0; l_ts = 0; l_cb = 0;
+    }
+    // requests of the next k-step: the A rows into registers, the weight pieces into ring slot `slot`; past the last k-step every
+    // lane is out of range (zeros, no traffic)
+    auto request = [&](const int slot, const bool live) __attribute__((always_inline)) {
+      const int dh = l_tr * g.idh, dw = l_ts * g.idw;
+      const int a_tap = ((dh * g.Win + dw) * g.Cin + l_cb * 32) * 4;
+      const int wtap = (g.wr0 + l_tr * g.wrs) * g.WS + g.ws0 + l_ts * g.wss;
+      const int b_soff = (wtap * CB + l_cb) * 128;
+      const unsigned oob = live ? 0u : kOOB;
+      if constexpr (INTF) {
+        const unsigned coff = (unsigned)(l_cb * 32 + aq * 8) * 4u | oob;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const auto s4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)(coff + 16u * h), 0, 0);
+          const auto h4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)(coff + 16u * h), 0, 0);
+          tsc[h] = make_float4(__uint_as_float(s4[0]), __uint_as_float(s4[1]), __uint_as_float(s4[2]), __uint_as_float(s4[3]));
+          tsh[h] = make_float4(__uint_as_float(h4[0]), __uint_as_float(h4[1]), __uint_as_float(h4[2]), __uint_as_float(h4[3]));
+        }
+      }
+      a_mask = 0;
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) {
+        const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+        const bool v = live && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+        a_mask |= v ? (1u << j) : 0u;
+        const unsigned off = (unsigned)(a_boff[j] + a_tap) | (v ? 0u : kOOB);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const auto q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * h), 0, 0);
+          ra[j][h] = make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
+        }
+      }
+      char *base = wsm + slot * STG + BM * 128;
+#pragma unroll
+      for (int i = 0; i < B_NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(base + (wave * B_NI + i) * 1024),
+                                                 16, (int)((unsigned)b_boff[i] | oob), b_soff, 0, 0);
+      ++l_ts;
+      const bool wrap = l_ts == g.TS;
+      l_ts = wrap ? 0 : l_ts;
+      l_tr += wrap ? 1 : 0;
+      const bool wrap2 = l_tr == g.TR;
+      l_tr = wrap2 ? 0 : l_tr;
+      l_cb += wrap2 ? 1 : 0;
+    };
+    // affine (+ ReLU, zero outside the image: the padding is applied AFTER the affine, as in the forward of the layer in front) and
+    // the cut of the rows requested last
+    auto cut = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) {
+        bf16x4 p0[2], p1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4 u = ra[j][h];
+          if constexpr (INTF) {
+            // fmaf, like every other place that evaluates this affine: the ReLU mask must come out identical in forward and backward
+            u = make_float4(fmaf(u.x, tsc[h].x, tsh[h].x), fmaf(u.y, tsc[h].y, tsh[h].y), fmaf(u.z, tsc[h].z, tsh[h].z), fmaf(u.w, tsc[h].w, tsh[h].w));
+            if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+            const bool v = (a_mask >> j) & 1u;
+            u = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
+          }
+          split2h(u, sc_a, p0[h], p1[h]);
+        }
+        const dspn::u32x2_t a0 = __builtin_bit_cast(dspn::u32x2_t, p0[0]), a1 = __builtin_bit_cast(dspn::u32x2_t, p0[1]);
+        const dspn::u32x2_t c0 = __builtin_bit_cast(dspn::u32x2_t, p1[0]), c1 = __builtin_bit_cast(dspn::u32x2_t, p1[1]);
+        pa[j][0] = u32x4_t{a0[0], a0[1], a1[0], a1[1]};
+        pa[j][1] = u32x4_t{c0[0], c0[1], c1[0], c1[1]};
+      }
+    };
+    auto store_a = [&](const int slot) __attribute__((always_inline)) {
+      char *base = wsm + slot * STG;
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) {
+        *reinterpret_cast<u32x4_t *>(base + a_lds[j]) = pa[j][0];
+        *reinterpret_cast<u32x4_t *>(base + (a_lds[j] ^ 64)) = pa[j][1];
+      }
+    };
+    request(0, true);
+    cut();
+    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      request(cur ^ 1, kt + 1 < nk);        // (every wave has read ring slot cur ^ 1 before the barrier it has just passed)
+      __builtin_amdgcn_sched_barrier(0);
+      const char *sa = wsm + cur * STG + wm * 128, *sb = wsm + cur * STG + BM * 128 + wn * 128;
+      bf16x8 fa[4][TM], fb[4][TN];          // fragment f = 2 piece + kk: chunk 2 f + (lane >> 5) of the row's record
+      constexpr int ORD[4] = {2, 0, 3, 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = ORD[q], fbq = f ^ 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[f][i] = *reinterpret_cast<const bf16x8 *>(sa + i * 4096 + (foff ^ ((2 * f) << 4)));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[fbq][j] = *reinterpret_cast<const bf16x8 *>(sb + j * 4096 + (foff ^ ((2 * fbq) << 4)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk == 1) {                      // the rows requested above have had the first half's MFMAs to arrive
+          __builtin_amdgcn_sched_barrier(0);
+          cut();
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[2 * PA[t3] + kk][i]),
+                                                                 __builtin_bit_cast(f16x8, fb[2 * PB[t3] + kk][j]), acc[i][j], 0, 0, 0);
+      }
+      // pin the pieces here: their only readers (the LDS stores) sit behind the MFMAs, and hipcc otherwise sinks the whole piece
+      // arithmetic down there, next to them; then spread it over the second half's MFMAs
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) { asm volatile("" : "+v"(pa[j][0])); asm volatile("" : "+v"(pa[j][1])); }
+#pragma unroll
+      for (int m = 0; m < 3 * TM * TN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (INTF ? 14 : 8) * A_U / 2 + 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      store_a(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    {
+      constexpr int SLD = BN + 4;
+      float *st = reinterpret_cast<float *>(wsm);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
+    }
+    wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
+  }
+  if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+}
+
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR>
+int launch_ntv_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
+                    const float *residual) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  const long long M = (long long)g.N * g.Hg * g.Wg;
+  const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
+  const size_t lds = std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  auto kern = conv_ntv_kernel<WAVES_M, WAVES_N, INTF, EPI, SR>;
+  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
+  if (!slots) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, dev = 0, cus = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
+    slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
+    if (getenv("DSPN_DEBUG_PRINT"))
+      fprintf(stderr, "[dspn] conv_ntv<%d,%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+              (int)INTF, EPI, lds, per_cu, cus, slots);
+  }
+  const int reserved = dspn::reserved_cus();
+  const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
+  const int grid_x = (int)std::min<long long>((long long)mt * nt, avail);
+  {
+    dspn::ProfScope prof(0, s);
+    hipLaunchKernelGGL(kern, dim3(grid_x), dim3(WAVES_M * WAVES_N * 64), lds, s, in, w, bias, out, g, mt, nt, residual);
+  }
+  return dspn::check_launch("conv_ntv");
+}
+template <int WAVES_M, int WAVES_N, int SR = 128>
+int launch_ntv(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s, const float *residual) {
+#define DSPN_NTV_(T) \
+  (g.bn_sums ? launch_ntv_impl<WAVES_M, WAVES_N, T, 2, SR>(in, w, bias, out, g, s, residual) \
+   : g.stats ? launch_ntv_impl<WAVES_M, WAVES_N, T, 1, SR>(in, w, bias, out, g, s, residual) \
+             : launch_ntv_impl<WAVES_M, WAVES_N, T, 0, SR>(in, w, bias, out, g, s, residual))
+  return g.in_scale ? DSPN_NTV_(true) : DSPN_NTV_(false);
+#undef DSPN_NTV_
+}
+#endif   // !DSPN_HALF
+
 // host side: one launch of the wide family.  Persistent grid as conv_nt_kernel's (occupancy x CUs, a multiple of 8).
 template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR>
 int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s,

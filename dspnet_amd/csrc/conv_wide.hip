@@ -14,6 +14,7 @@ namespace {
 using namespace dspn::pieces;
 using dspn::st_t;
 using dspn::kHalf;
+using dspn::u32x4_t;
 using dspn::conv::f32x16;
 using dspn::conv::bf16x8;
 using dspn::conv::xcd_remap;
@@ -121,6 +122,12 @@ int launch_wide(int shape, const st_t *in, const st_t *w_planes, const float *bi
   if (shape == 2) return launch_ntw<2, 4, 3>(in, w_planes, bias, out, g, s, residual);
   if (shape == 3) return launch_ntw<2, 2, 2>(in, w_planes, bias, out, g, s, residual);
   if (shape == 4) return launch_ntw<4, 1, 2, 64>(in, w_planes, bias, out, g, s, residual);      // 256 x 64, 64-row BatchNorm tables
+#ifndef DSPN_HALF
+  // 10 + shape: the A operand is a float tensor (cut, and optionally affine-transformed, in the loader): conv_ntv_kernel
+  if (shape == 12) return launch_ntv<2, 4>(in, w_planes, bias, out, g, s, residual);
+  if (shape == 13) return launch_ntv<2, 2>(in, w_planes, bias, out, g, s, residual);
+  if (shape == 14) return launch_ntv<4, 1, 64>(in, w_planes, bias, out, g, s, residual);
+#endif
   return dspn::fail(DSPN_ERR_ARG_, "conv: no wide tile shape %d", shape);
 }
 }  // namespace conv

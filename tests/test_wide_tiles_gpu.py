@@ -265,3 +265,83 @@ def test_bf16_tensors_on_every_tile_are_bit_identical(gpu_device, case):
                 assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, (MODES[mode], i)
             else:
                 assert torch.equal(a, b), (MODES[mode], i)
+
+
+FLOAT_A = [(2, 24, 24, 64, 128, 3, 1), (3, 25, 23, 96, 256, 3, 2), (1, 17, 19, 128, 256, 1, 1), (4, 64, 64, 64, 64, 3, 1),
+           (2, 64, 64, 256, 64, 1, 1), (8, 32, 32, 128, 320, 1, 1), (2, 33, 35, 32, 192, 3, 1)]
+
+
+@pytest.mark.parametrize("case", FLOAT_A)
+@pytest.mark.parametrize("affine", [None, "relu", "linear"])
+def test_float_operand_forward_on_every_tile_is_bit_identical(tiles, case, affine):
+    """The register-staged member of the family (conv_ntv_kernel): the A operand is a FLOAT tensor, cut into its two pieces in
+    the loader, optionally behind the folded BatchNorm affine (+ ReLU; zero padding AFTER the affine).  Same pieces, same K
+    order, same epilogue as conv_nt_kernel's INTF / float paths: identical bits on every tile, with every epilogue."""
+    N, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(H + Cin + Cout + k + 3)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    aff = None
+    if affine is not None:
+        aff = ((torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda(), affine == "relu")
+    xa = fn.absmax(x, aff)
+    wa = fn.absmax(w); wp = fn.weight_planes(w, math="f16x2", w_absmax=wa)
+    t2, _ = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    out = {}
+    for mode in MODES:
+        tiles(mode)
+        kw = dict(w_planes=wp, x_absmax=xa, w_absmax=wa, in_affine=aff)
+        got = [fn.conv2d_forward(x, w, None, stride, pad, 1, **kw), fn.conv2d_forward(x, w, None, stride, pad, 1, residual=res, relu=True, **kw)]
+        if t2 > 0:
+            st = torch.zeros(t2, 2, Cout, device="cuda"); mm = torch.zeros(t2, 2, Cout, device="cuda")
+            got += [fn.conv2d_forward(x, w, None, stride, pad, 1, out_stats=st, out_minmax=mm, **kw), mm, st]
+        out[mode] = got
+    act = x if aff is None else fn.bn_apply(x, aff[0], aff[1], relu=aff[2])
+    ref32 = fn.conv2d_forward(act, w, None, stride, pad, 1, math="fp32")
+    assert float((out[1][0] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    for mode in (2, 3, 4):
+        for i, (a, b) in enumerate(zip(out[mode], out[1])):
+            if i == 4:
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (MODES[mode], "statistics")
+            else:
+                assert torch.equal(a, b), (MODES[mode], i)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 128, 64, 3, 1), (3, 25, 23, 256, 96, 3, 2), (1, 17, 19, 256, 128, 1, 1),
+                                  (4, 64, 64, 64, 256, 1, 1), (2, 16, 16, 128, 64, 1, 2), (8, 32, 32, 320, 128, 1, 1)])
+def test_float_gradient_data_gradient_on_every_tile_is_bit_identical(tiles, case):
+    """... and the data gradient whose output gradient is a float tensor (the residual stream's: no BatchNorm writes it as
+    planes), plain / accumulating / with the BatchNorm-backward sums"""
+    N, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(H + Cin + Cout + k + 9)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    dya = fn.absmax(dy)
+    wa = fn.absmax(w); wt = fn.weight_transpose(w)
+    wtp = fn.weight_planes(w, transposed=True, cols=Cout, math="f16x2", w_absmax=wa)
+    gamma = torch.rand(Cin, device="cuda") + 0.5; beta = torch.randn(Cin, device="cuda")
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    ntile = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    out = {}
+    for mode in MODES:
+        tiles(mode)
+        kw = dict(wt_planes=wtp, dy_absmax=dya, w_absmax=wa)
+        sums = torch.zeros(ntile, 2, Cin, device="cuda"); bam = torch.zeros(64, device="cuda")
+        dx = torch.empty_like(x); dx2 = torch.empty_like(x); dx3 = x.clone()
+        fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=dx, bn_bwd=(x, scale, shift, mean, rstd, True, sums),
+                        bn_dy_absmax=bam, **kw)
+        fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=dx2, **kw)
+        fn.conv2d_dgrad(dy, wt, tuple(x.shape), stride, pad, 1, out=dx3, accumulate=True, **kw)
+        out[mode] = [dx, dx2, dx3, bam.max().reshape(1).clone(), sums]
+    for mode in (2, 3, 4):
+        for i, (a, b) in enumerate(zip(out[mode], out[1])):
+            if i == 4:
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (MODES[mode], "BatchNorm-backward sums")
+            else:
+                assert torch.equal(a, b), (MODES[mode], i)
