@@ -48,9 +48,9 @@ MATH_LABEL = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (operands rounded to bf16)
               "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)",
               "f16x2": "fp32 on the fp16 MFMA (2-piece split after a per-tensor power-of-two scale, 3 products)"}
 # committed rocprofv3 --pmc passes of the headline workload per math mode, newest first (roofline.traffic is read from these)
-TRAFFIC_PROFILES = {"f16x2": ["r04_f16x2_pmc_conv_family.json", "r03_f16x2_pmc_conv_family.json"],
-                    "bf16x3": ["r04_x3_pmc_conv_family.json", "r03_x3_pmc_conv_family.json", "r02_x3_pmc_conv_family.json"],
-                    "fp32": ["r04_fp32_pmc_conv_family.json", "r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json",
+TRAFFIC_PROFILES = {"f16x2": ["r05_f16x2_pmc_conv_family.json", "r04_f16x2_pmc_conv_family.json", "r03_f16x2_pmc_conv_family.json"],
+                    "bf16x3": ["r05_x3_pmc_conv_family.json", "r04_x3_pmc_conv_family.json", "r03_x3_pmc_conv_family.json", "r02_x3_pmc_conv_family.json"],
+                    "fp32": ["r05_fp32_pmc_conv_family.json", "r04_fp32_pmc_conv_family.json", "r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json",
                              "r01_j_pmc_conv_family.json"]}
 PROF_STEPS = 2   # steps of the timed region whose convolution launches are bracketed by HIP events (roofline.achieved)
 
@@ -354,7 +354,7 @@ def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, tr
     out = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
            "frac_end_to_end_3x": round(flops_3x_step / step_s / 1e12 / peak, 4),
-           "kernel": "conv_nt_kernel (fwd+dgrad) + conv_wgrad_kernel: implicit-GEMM family, %s" % MATH_LABEL[math],
+           "kernel": "conv_nt / conv_ntw / conv_ntv / conv_stem kernels (fwd+dgrad) + conv_wgrad_kernel: implicit-GEMM family, %s" % MATH_LABEL[math],
            "launches_per_step": (nt_n + wg_n) // steps,
            "avg_launch_us": round((nt_ms + wg_ms) * 1e3 / max(1, nt_n + wg_n), 2),
            "conv_ms_per_step": round(conv_s * 1e3, 3),

@@ -16,6 +16,7 @@
 #include "dspn_common.h"
 #include "../../include/dspn_multibox.h"
 #include <cstdint>
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -132,6 +133,8 @@ struct TargetWs {
   int *row_gt;         // [B*A] arg of it (later: matched GT of positives)
   unsigned *bgkey;     // [B*A] float bits of softmax P(background)
   signed char *flag;   // [B*A] -1 ignore, 0 negative, 1 positive
+  unsigned long long *cpart;   // [B*nblk*L] per (256-anchor block, GT): best anchor of the block, packed (IoU bits, ~anchor); 0 = none
+  int nblk;            // anchor blocks per sample
 };
 
 // number of valid GT rows = index of the first row whose class is -1
@@ -144,11 +147,28 @@ __device__ int count_valid_gt(const float *lab, int L, int lw, int *s_G) {
   return *s_G;
 }
 
-// K1: per anchor, best GT by IoU and softmax background probability.
+// largest value of the wave, in every lane (row reductions by DPP, then across the four rows)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  auto step = [](unsigned x, unsigned y) { return x > y ? x : y; };
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));   // row_mirror: every lane holds its row's max
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return step(step(a, b), step(c, d));
+}
+
+// K1: per anchor, best GT by IoU and softmax background probability; per GT, the best anchor of this 256-anchor block.
+// Round 5: the column maxima (best anchor of every GT: G x A IoUs per sample) were the matching kernel's largest phase, on ONE
+// compute unit per sample; every one of those IoUs is formed here anyway, on the whole chip.  A block's candidate for GT k is
+// packed as (IoU bits << 32 | ~anchor): unsigned order = larger IoU first, then the lower anchor, the reference's scan order
+// (multibox_target.cc:113-149); only IoU > 0 can ever be matched (the cut is 1e-6), so 0 stands for "none".
 __global__ __launch_bounds__(256) void target_rows_kernel(
     const float4 *__restrict__ anchors, const float *__restrict__ labels,
     const float *__restrict__ cls_preds, int A, int L, int lw, int C, TargetWs ws) {
   __shared__ float s_gt[kMaxLabels * 4];
+  __shared__ unsigned long long s_cmax[kMaxLabels];
   __shared__ int s_G;
   const int b = blockIdx.y;
   const float *lab = labels + (size_t)b * L * lw;
@@ -157,31 +177,44 @@ __global__ __launch_bounds__(256) void target_rows_kernel(
     const int k = i >> 2, q = i & 3;
     s_gt[i] = lab[k * lw + 1 + q];
   }
+  for (int k = threadIdx.x; k < G; k += blockDim.x) s_cmax[k] = 0ull;
   __syncthreads();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= A) return;
   const size_t o = (size_t)b * A + j;
   if (G == 0) {  // nothing downstream reads the workspace of an empty sample
-    ws.row_iou[o] = -1.f; ws.row_gt[o] = -1; ws.bgkey[o] = 0u;
+    if (j < A) { ws.row_iou[o] = -1.f; ws.row_gt[o] = -1; ws.bgkey[o] = 0u; }
     return;
   }
-  const float4 a = anchors[j];
-  float best = -1.0f; int bk = -1;
-  for (int k = 0; k < G; ++k) {
-    const float iou = target_iou(a, s_gt[4 * k], s_gt[4 * k + 1], s_gt[4 * k + 2], s_gt[4 * k + 3]);
-    if (iou > best) { best = iou; bk = k; }
+  if (j < A) {
+    const float4 a = anchors[j];
+    float best = -1.0f; int bk = -1;
+    for (int k = 0; k < G; ++k) {
+      const float iou = target_iou(a, s_gt[4 * k], s_gt[4 * k + 1], s_gt[4 * k + 2], s_gt[4 * k + 3]);
+      if (iou > best) { best = iou; bk = k; }
+      // the wave's best for GT k: largest IoU bits (positive floats order as unsigned), lowest lane = lowest anchor among equals
+      const unsigned bits = iou > 0.f ? __float_as_uint(iou) : 0u;
+      const unsigned top = wave_max_u32(bits);
+      if (top != 0u) {
+        const int first = __ffsll((long long)__ballot(bits == top)) - 1;
+        if ((threadIdx.x & 63) == first)
+          atomicMax(&s_cmax[k], ((unsigned long long)top << 32) | (0xffffffffu - (unsigned)j));
+      }
+    }
+    ws.row_iou[o] = best;
+    ws.row_gt[o] = bk;
+    // softmax P(background), float, sequential sum (multibox_target.cc:218-232)
+    const float *p = cls_preds + (size_t)b * C * A + j;
+    const float p0 = p[0];
+    float mx = p0;
+    for (int k = 1; k < C; ++k) { const float t = p[(size_t)k * A]; if (t > mx) mx = t; }
+    float sum = 0.f;
+    for (int k = 0; k < C; ++k) sum += expf_cr(p[(size_t)k * A] - mx);
+    const float prob = expf_cr(p0 - mx) / sum;
+    ws.bgkey[o] = __float_as_uint(prob);
   }
-  ws.row_iou[o] = best;
-  ws.row_gt[o] = bk;
-  // softmax P(background), float, sequential sum (multibox_target.cc:218-232)
-  const float *p = cls_preds + (size_t)b * C * A + j;
-  const float p0 = p[0];
-  float mx = p0;
-  for (int k = 1; k < C; ++k) { const float t = p[(size_t)k * A]; if (t > mx) mx = t; }
-  float sum = 0.f;
-  for (int k = 0; k < C; ++k) sum += expf_cr(p[(size_t)k * A] - mx);
-  const float prob = expf_cr(p0 - mx) / sum;
-  ws.bgkey[o] = __float_as_uint(prob);
+  __syncthreads();
+  unsigned long long *cp = ws.cpart + ((size_t)b * ws.nblk + blockIdx.x) * L;
+  for (int k = threadIdx.x; k < G; k += blockDim.x) cp[k] = s_cmax[k];
 }
 
 struct Best { float iou; int a; int k; };
@@ -413,6 +446,229 @@ __global__ __launch_bounds__(kTB) void target_match_kernel(
   }
 }
 
+// K2, A <= kPer x 1024 anchors (round 5): the same stages with every per-anchor quantity where one compute unit can reach it
+// without a trip to L2 -- best IoU and background key of a thread's kPer anchors in registers, the flags in LDS -- and the
+// column maxima merged from target_rows_kernel's per-block partials instead of G x A IoUs formed here.  The generic kernel
+// above made some ten sweeps over global arrays, six dependent load rounds each (0.17 ms at 32 x 6132, of which the column
+// maxima were about half).  Decisions and their order are those of the generic kernel.
+template <int kPer>
+__global__ __launch_bounds__(kTB) void target_match_reg_kernel(
+    const float4 *__restrict__ anchors, const float *__restrict__ labels, int A, int L, int lw,
+    float overlap_threshold, float neg_ratio, float neg_thresh, TargetWs ws) {
+  __shared__ float s_gt[kMaxLabels * 4];
+  __shared__ float s_ciou[kMaxLabels];
+  __shared__ int s_ca[kMaxLabels];
+  __shared__ int s_gflag[kMaxLabels];
+  __shared__ Best s_wb[kTB / 64];
+  __shared__ Best s_best;
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_w[kTB / 64];
+  __shared__ int s_G, s_cnt, s_bin, s_kk, s_ties;
+  __shared__ signed char s_flag[kPer * kTB];
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *lab = labels + (size_t)b * L * lw;
+  const int G = count_valid_gt(lab, L, lw, &s_G);
+  if (tid == 0) {
+    int err = 0;
+    if (G < L) {  // CHECK_EQ x4 on the terminating row (multibox_target.cc:98-101)
+      const float *row = lab + G * lw;
+      if (row[1] != -1.0f || row[2] != -1.0f || row[3] != -1.0f || row[4] != -1.0f) err = 2;
+    }
+    ws.err[b] = err;
+    ws.ngt[b] = G;
+  }
+  if (G == 0) return;
+  int *row_gt = ws.row_gt + (size_t)b * A;
+  signed char *flag = ws.flag + (size_t)b * A;
+
+  float riou[kPer];
+  unsigned key[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int j = u * kTB + tid;
+    riou[u] = j < A ? ws.row_iou[(size_t)b * A + j] : 0.f;
+    key[u] = j < A ? ws.bgkey[(size_t)b * A + j] : 0u;
+    s_flag[j] = -1;
+  }
+  auto flush = [&]() {      // a thread's own anchors: nobody else writes them after the matching stage
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) { const int j = u * kTB + tid; if (j < A) flag[j] = s_flag[j]; }
+  };
+  for (int i = tid; i < G * 4; i += kTB) s_gt[i] = lab[(i >> 2) * lw + 1 + (i & 3)];
+  for (int k = tid; k < G; k += kTB) {
+    const unsigned long long *cp = ws.cpart + (size_t)b * ws.nblk * L + k;
+    unsigned long long m = 0ull;
+    for (int q = 0; q < ws.nblk; ++q) { const unsigned long long c = cp[(size_t)q * L]; m = c > m ? c : m; }
+    s_ciou[k] = m ? __uint_as_float((unsigned)(m >> 32)) : -1.0f;
+    s_ca[k] = m ? (int)(0xffffffffu - (unsigned)m) : 0x7fffffff;
+    s_gflag[k] = 0;
+  }
+  __syncthreads();
+
+  // greedy bipartite matching (multibox_target.cc:113-149), as in the generic kernel: wave 0 runs consecutive picks, the
+  // workgroup meets only when a pick consumed an anchor that is still some unmatched GT's column maximum
+  int npos = 0;
+  for (;;) {
+    if (wave == 0) {
+      int consumed = -1;
+      for (;;) {
+        Best v{-2.0f, 0x7fffffff, -1};
+        for (int k = lane; k < G; k += 64) {
+          if (s_gflag[k]) continue;
+          Best c{s_ciou[k], s_ca[k], k};
+          if (better(c, v)) v = c;
+        }
+        v = wave_best(v);
+        if (v.k < 0 || !(v.iou > 1e-6f)) break;
+        if (lane == 0) { s_flag[v.a] = 1; row_gt[v.a] = v.k; s_gflag[v.k] = 1; }
+        ++npos;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        bool hit = false;
+        for (int k = lane; k < G; k += 64) hit |= (k != v.k && !s_gflag[k] && s_ca[k] == v.a);
+        if (__ballot(hit) != 0ull) { consumed = v.a; break; }
+      }
+      if (lane == 0) { s_best.a = consumed; s_best.k = npos; }
+    }
+    __syncthreads();
+    const int consumed = s_best.a;
+    npos = s_best.k;
+    if (consumed < 0) break;
+    for (int k = 0; k < G; ++k) {
+      if (s_gflag[k] || s_ca[k] != consumed) continue;   // block-uniform
+      const float gl = s_gt[4 * k], gt = s_gt[4 * k + 1], gr = s_gt[4 * k + 2], gb = s_gt[4 * k + 3];
+      Best v{-1.0f, 0x7fffffff, k};
+      for (int j = tid; j < A; j += kTB) {
+        if (s_flag[j] == 1) continue;
+        const float iou = target_iou(anchors[j], gl, gt, gr, gb);
+        if (iou > v.iou) { v.iou = iou; v.a = j; }
+      }
+      v = wave_best(v);
+      if (lane == 0) s_wb[wave] = v;
+      __syncthreads();
+      if (wave == 0) {
+        Best u = lane < kTB / 64 ? s_wb[lane] : Best{-1.0f, 0x7fffffff, k};
+        u = wave_best(u);
+        if (lane == 0) { s_ciou[k] = u.iou; s_ca[k] = u.a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+
+  // threshold stage (multibox_target.cc:151-180)
+  {
+    int add = 0;
+    if (overlap_threshold > 0) {
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int j = u * kTB + tid;
+        if (j < A && s_flag[j] != 1 && riou[u] > overlap_threshold) { s_flag[j] = 1; ++add; }
+      }
+    }
+    for (int m = 32; m >= 1; m >>= 1) add += __shfl_xor(add, m, 64);
+    if (lane == 0 && add) atomicAdd(&s_cnt, add);
+  }
+  __syncthreads();
+  npos += s_cnt;
+  __syncthreads();
+
+  if (!(neg_ratio > 0)) {  // use all negatives (multibox_target.cc:242-249)
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) { const int j = u * kTB + tid; if (s_flag[j] != 1) s_flag[j] = 0; }
+    flush();
+    return;
+  }
+  int num_negative = (int)((float)npos * neg_ratio);
+  if (num_negative > A - npos) num_negative = A - npos;
+  if (num_negative <= 0) { flush(); return; }
+
+  // candidates: not positive and best IoU below the mining threshold
+  unsigned cand = 0;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  {
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int j = u * kTB + tid;
+      if (j < A && s_flag[j] != 1 && riou[u] < neg_thresh) { cand |= 1u << u; ++c; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if (lane == 0 && c) atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  const int ncand = s_cnt;
+  if (ncand < num_negative) {  // CHECK_GE(temp.size(), num_negative), multibox_target.cc:236
+    if (tid == 0) ws.err[b] = 3;
+    num_negative = ncand;
+  }
+  if (num_negative == ncand) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) if ((cand >> u) & 1u) s_flag[u * kTB + tid] = 0;
+    flush();
+    return;
+  }
+
+  // radix-select the num_negative-th smallest P(background); ties go to the lower anchor index
+  // ( == std::stable_sort on -prob, multibox_target.cc:58-70,237 )
+  unsigned prefix = 0;
+  int kk = num_negative;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += kTB) s_hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      if (!((cand >> u) & 1u)) continue;
+      const bool match = (shift == 24) ? true : ((key[u] >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&s_hist[(key[u] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {      // first bin whose running count reaches kk: four bins per lane, a shuffle scan over the lanes
+      unsigned h[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = s_hist[4 * lane + q];
+      const int mine = (int)(h[0] + h[1] + h[2] + h[3]);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+      const unsigned long long reach = __ballot(incl >= kk);
+      const int first = __ffsll((long long)reach) - 1;     // (ncand >= kk candidates match the prefix: some lane reaches it)
+      if (lane == first) {
+        int cum = incl - mine, bin = 4 * lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (cum + (int)h[q] >= kk) { bin = 4 * lane + q; break; }
+          cum += (int)h[q];
+        }
+        s_bin = bin; s_kk = kk - cum; s_ties = (int)s_hist[bin];
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)s_bin << shift;
+    kk = s_kk;
+  }
+  const unsigned T = prefix;
+  if (kk == s_ties) {       // every anchor at the cut is taken: no order among them is needed (the usual case)
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) if (((cand >> u) & 1u) && key[u] <= T) s_flag[u * kTB + tid] = 0;
+    flush();
+    return;
+  }
+  int taken_ties = 0;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const bool c = (cand >> u) & 1u;
+    const bool tie = c && key[u] == T;
+    int total;
+    const int off = block_scan_pred(tie, s_w, total);
+    if (c && (key[u] < T || (tie && taken_ties + off < kk))) s_flag[u * kTB + tid] = 0;
+    taken_ties += total;
+  }
+  flush();
+}
+
 // K3: expand flags into the three outputs (multibox_target.cc:251-281; init
 // values of multibox_target-inl.h:121-123 for untouched anchors).
 __global__ __launch_bounds__(256) void target_write_kernel(
@@ -461,6 +717,7 @@ struct DetWs {
   unsigned long long *mask;    // [B*A*nwords] suppression bit matrix, over GROUPED positions (see det_decode_sort_kernel)
   int *perm;                   // [B*A] grouped position -> output row: the valid rows ordered by (class id, row)
   int *gcls;                   // [B*A] class id of each grouped position (ascending)
+  float4 *gbox;                // [B*A*2] per grouped position: (x1, y1, x2, y2), (area, class id, 0, 0) -- what nms_mask_kernel reads
 };
 
 __device__ __forceinline__ unsigned ordered_bits(float s) {
@@ -501,6 +758,18 @@ __device__ __forceinline__ void bitonic_sort_keys(unsigned long long *keys, int 
   constexpr int kWaves = kTB / 64;
   const int S = (kLds && n2 >= 128 * kWaves) ? n2 / kWaves : 0;      // segment per wave (>= 128 keys), 0: every pass by the workgroup
   const int wave = tid >> 6, lane = tid & 63;
+  if (kLds && n2 <= 1024) {     // round 5: a short list (the nms_topk rows) is sorted by ONE wave, no workgroup barrier per pass
+    if (wave == 0) {
+      for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          pass(lane, n2 >> 1, 64, j, k);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    return;
+  }
   for (int k = 2; k <= n2; k <<= 1) {
     int j = k >> 1;
     for (; j > 0 && j >= S; j >>= 1) {
@@ -519,14 +788,19 @@ __device__ __forceinline__ void bitonic_sort_keys(unsigned long long *keys, int 
   }
 }
 
+constexpr int kCountCls = 256;   // classes the counting sort of the grouping step holds in LDS
 template <bool kLdsKeys>
 __global__ __launch_bounds__(kTB) void det_decode_sort_kernel(
     const float *__restrict__ cls_prob, const float *__restrict__ loc_pred,
     const float4 *__restrict__ anchors, int A, int C, float threshold, int clip,
-    float vx, float vy, float vw, float vh, int nms_enabled, int nms_topk, int force, int n2cap,
+    float vx, float vy, float vw, float vh, int nms_enabled, int nms_topk, int force, int n2cap, int selcap,
     DetWs ws, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_w[kTB / 64];
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_sel[4];                       // radix select: bin, remaining rank, ties in the bin, slot counter
+  __shared__ int s_ccnt[kTB / 64][kCountCls];    // grouping: rows of a class in a wave's range, then its running offset
+  __shared__ int s_ctot[kCountCls];
   const int b = blockIdx.x, tid = threadIdx.x;
   unsigned long long *keys = kLdsKeys ? reinterpret_cast<unsigned long long *>(smem)
                                       : ws.keys + (size_t)b * n2cap;
@@ -578,43 +852,188 @@ __global__ __launch_bounds__(kTB) void det_decode_sort_kernel(
   if (tid == 0) ws.nms_count[b] = do_nms ? V : 0;
   if (!do_nms) return;
 
-  // stable sort by score, descending: keys are unique (score, position) pairs
-  int n2 = 1;
-  while (n2 < V) n2 <<= 1;
-  for (int i = V + tid; i < n2; i += kTB) keys[i] = ~0ull;
-  __syncthreads();
-  bitonic_sort_keys<kLdsKeys>(keys, n2, tid);
+  // (a) order by score, descending; keys are unique (score, position) pairs, so the order is that of a stable sort.
+  // Only the first nkeep = min(V, nms_topk) sorted rows are ever written back (multibox_detection.cc:143-151).  Round 5: when
+  // nms_topk cuts the list, those rows are SELECTED first -- a radix select of the nkeep-th smallest score key over four 8-bit
+  // digits, ties at the cut taken in position order -- and only they are sorted (512 keys by one wave instead of 8192 by the
+  // workgroup: 91 passes over 64 KiB of LDS were 0.05 ms of this kernel).
   int nkeep = V;
   if (nms_topk > 0 && nms_topk < nkeep) nkeep = nms_topk;
+  int n2 = 1;
+  while (n2 < V) n2 <<= 1;
+  int n2k = 1;
+  while (n2k < nkeep) n2k <<= 1;
+  const bool select = kLdsKeys && nkeep < V && n2k <= selcap;        // (block-uniform)
+  unsigned long long *sorted = keys;
+  __syncthreads();
+  if (select) {
+    unsigned long long *sel = keys + n2cap;
+    unsigned prefix = 0;
+    int kk = nkeep;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int i = tid; i < 256; i += kTB) s_hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += kTB) {
+        const unsigned hi = (unsigned)(keys[i] >> 32);
+        const bool match = (shift == 24) ? true : ((hi >> (shift + 8)) == (prefix >> (shift + 8)));
+        if (match) atomicAdd(&s_hist[(hi >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {      // first bin whose running count reaches kk: four bins per lane, a shuffle scan over the lanes
+        unsigned h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = s_hist[4 * tid + q];
+        const int mine = (int)(h[0] + h[1] + h[2] + h[3]);
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
+        const unsigned long long reach = __ballot(incl >= kk);
+        const int first = __ffsll((long long)reach) - 1;
+        if (tid == first) {
+          int cum = incl - mine, bin = 4 * tid;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (cum + (int)h[q] >= kk) { bin = 4 * tid + q; break; }
+            cum += (int)h[q];
+          }
+          s_sel[0] = bin; s_sel[1] = kk - cum; s_sel[2] = (int)s_hist[bin];
+        }
+      }
+      __syncthreads();
+      prefix |= (unsigned)s_sel[0] << shift;
+      kk = s_sel[1];
+    }
+    const unsigned T = prefix;
+    const int nless = nkeep - kk, ties = s_sel[2];
+    if (tid == 0) s_sel[3] = 0;
+    __syncthreads();
+    if (kk == ties) {          // every row at the cut is kept: any slot will do, the sort below orders them
+      for (int i = tid; i < V; i += kTB) {
+        const unsigned long long k = keys[i];
+        if ((unsigned)(k >> 32) <= T) sel[atomicAdd(&s_sel[3], 1)] = k;
+      }
+    } else {                   // equal scores across the cut: the first kk of them in position order
+      int taken = 0;
+      for (int base = 0; base < V; base += kTB) {
+        const int i = base + tid;
+        const unsigned long long k = i < V ? keys[i] : ~0ull;
+        const unsigned hi = (unsigned)(k >> 32);
+        const bool tie = i < V && hi == T;
+        int total;
+        const int off = block_scan_pred(tie, s_w, total);
+        if (i < V && hi < T) sel[atomicAdd(&s_sel[3], 1)] = k;
+        if (tie && taken + off < kk) sel[nless + taken + off] = k;
+        taken += total;
+      }
+    }
+    for (int i = nkeep + tid; i < n2k; i += kTB) sel[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort_keys<true>(sel, n2k, tid);
+    sorted = sel;
+  } else {
+    for (int i = V + tid; i < n2; i += kTB) keys[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort_keys<kLdsKeys>(keys, n2, tid);
+  }
   for (int e = tid; e < nkeep * 7; e += kTB) {
     const int i = e / 7, q = e - i * 7;
-    const unsigned src = (unsigned)(keys[i] & 0xffffffffull);
+    const unsigned src = (unsigned)(sorted[i] & 0xffffffffull);
     po[e] = pt[(size_t)src * 7 + q];
   }
-  // Suppression only ever relates rows of ONE class (multibox_detection.cc:159; every pair under force_suppress), and a row's
-  // fate depends only on the earlier rows of its class: the greedy pass over all rows is C - 1 independent greedy passes.
-  // perm = the valid rows ordered by (class id, row) -- a second sort of (class, row) keys: the suppression matrix and the
-  // scan work on these GROUPED positions, where a class is a contiguous segment (A^2 / 2 -> sum_c n_c^2 / 2 box pairs, and
-  // a chain of n_c / 64 dependent blocks per scan instead of A / 64).
+  // (b) Suppression only ever relates rows of ONE class (multibox_detection.cc:159; every pair under force_suppress), and a
+  // row's fate depends only on the earlier rows of its class: the greedy pass over all rows is C - 1 independent greedy
+  // passes.  perm = the valid rows ordered by (class id, row): the suppression matrix and the scan work on these GROUPED
+  // positions, where a class is a contiguous segment (A^2 / 2 -> sum_c n_c^2 / 2 box pairs, and a chain of n_c / 64 dependent
+  // blocks per scan instead of A / 64).  gbox = the boxes in that order with their areas, so that the mask kernel reads
+  // contiguous 32-byte records instead of gathering through perm.
   int *perm = ws.perm + (size_t)b * A, *gcls = ws.gcls + (size_t)b * A;
+  float4 *gbox = ws.gbox + (size_t)b * A * 2;
+  auto put_box = [&](int pos, const float *r, int c) {
+    const float x1 = r[2], y1 = r[3], x2 = r[4], y2 = r[5];
+    gbox[2 * pos] = make_float4(x1, y1, x2, y2);
+    gbox[2 * pos + 1] = make_float4((x2 - x1) * (y2 - y1), (float)c, 0.f, 0.f);
+  };
+  // the source row of output row i (rows past nms_topk keep their pre-sort contents)
+  auto source = [&](int i) { return i < nkeep ? (unsigned)(sorted[i] & 0xffffffffull) : (unsigned)i; };
   if (force) {
-    for (int i = tid; i < V; i += kTB) { perm[i] = i; gcls[i] = 0; }
+    for (int i = tid; i < V; i += kTB) { perm[i] = i; gcls[i] = 0; put_box(i, pt + (size_t)source(i) * 7, 0); }
     return;
   }
+  const int ncls = C - 1;
+  if (ncls <= kCountCls) {
+    // Round 5: a stable counting sort by class instead of a second 8192-key bitonic sort.  Wave w owns the contiguous rows
+    // [w R, (w+1) R); inside a 64-row step the rows of one class are found with a ballot per class present.
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < (kTB / 64) * kCountCls; i += kTB) (&s_ccnt[0][0])[i] = 0;
+    __syncthreads();
+    const int R = ((V + kTB - 1) / kTB) * 64;
+    const int r0 = wave * R, r1 = min(V, r0 + R);
+    for (int base = r0; base < r1; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < r1;
+      const int c = valid ? (int)pt[(size_t)source(i) * 7] : -1;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cc = __shfl(c, leader, 64);
+        const unsigned long long m = __ballot(valid && c == cc);
+        if (lane == leader) atomicAdd(&s_ccnt[wave][cc], (int)__popcll(m));
+        todo &= ~m;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < ncls; c += kTB) {       // exclusive prefix over the waves, per class
+      int run = 0;
+      for (int w = 0; w < kTB / 64; ++w) { const int t = s_ccnt[w][c]; s_ccnt[w][c] = run; run += t; }
+      s_ctot[c] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {                               // exclusive prefix of the class totals
+      int t[4], mine = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int idx = 4 * tid + q; t[q] = idx < ncls ? s_ctot[idx] : 0; mine += t[q]; }
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (tid >= d) incl += v; }
+      int excl = incl - mine;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int idx = 4 * tid + q; if (idx < ncls) s_ctot[idx] = excl; excl += t[q]; }
+    }
+    __syncthreads();
+    for (int base = r0; base < r1; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < r1;
+      const unsigned src = valid ? source(i) : 0u;
+      const int c = valid ? (int)pt[(size_t)src * 7] : -1;
+      unsigned long long todo = __ballot(valid);
+      int pos = 0;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cc = __shfl(c, leader, 64);
+        const unsigned long long m = __ballot(valid && c == cc);
+        int start = 0;
+        if (lane == leader) start = s_ctot[cc] + atomicAdd(&s_ccnt[wave][cc], (int)__popcll(m));
+        start = __shfl(start, leader, 64);
+        if (valid && c == cc) pos = start + (int)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+      if (valid) { perm[pos] = i; gcls[pos] = c; put_box(pos, pt + (size_t)src * 7, c); }
+    }
+    return;
+  }
+  // more classes than the counting table holds: a second sort, of (class, row) keys
   for (int i = tid; i < n2; i += kTB) {     // (entry i is read and rewritten by the same thread)
     unsigned long long k2 = ~0ull;
-    if (i < V) {
-      // the class of output row i: that of its source row (rows past nms_topk keep their pre-sort contents)
-      const unsigned src = i < nkeep ? (unsigned)(keys[i] & 0xffffffffull) : (unsigned)i;
-      k2 = ((unsigned long long)(unsigned)(int)pt[(size_t)src * 7] << 32) | (unsigned)i;
-    }
+    if (i < V) k2 = ((unsigned long long)(unsigned)(int)pt[(size_t)source(i) * 7] << 32) | (unsigned)i;
     keys[i] = k2;
   }
   __syncthreads();
   bitonic_sort_keys<kLdsKeys>(keys, n2, tid);
   for (int i = tid; i < V; i += kTB) {
-    perm[i] = (int)(unsigned)(keys[i] & 0xffffffffull);
-    gcls[i] = (int)(keys[i] >> 32);
+    const int r = (int)(unsigned)(keys[i] & 0xffffffffull), c = (int)(keys[i] >> 32);
+    perm[i] = r;
+    gcls[i] = c;
+    put_box(i, po + (size_t)r * 7, c);      // (output rows: written above by this workgroup, several barriers ago)
   }
 }
 
@@ -628,57 +1047,100 @@ __device__ __forceinline__ float nms_iou(const float *a, const float *b) {
 
 // 64x64 tiles of the upper-triangular suppression matrix over the GROUPED positions (ws.perm: rows ordered by class, then
 // row): bit (i,j), j>i: grouped row i would suppress grouped row j (multibox_detection.cc:153-167).
-// One single-wave workgroup per (64-row tile, sample, chunk of kMaskChunk column tiles).  A row tile only meets the column
-// tiles up to the end of its last row's class segment; the others are never read by the scan.
+// One four-wave workgroup per (64-row tile, sample); wave q takes the column tiles rt + q, rt + q + 4, ...  A row tile only
+// meets the column tiles up to the end of its last row's class segment; the others are never read by the scan.
 // The kernel runs on MultiBoxDetection's side stream beside the training step, and the dispatcher hands out the workgroups
 // of ONE queue's kernel at a time: with 295 000 tiny workgroups (96 x 96 tiles x 32 samples, the first version) every
 // main-stream kernel that became ready meanwhile waited for the whole dispatch (a 7-us BatchNorm table merge took 0.46 ms,
 // rocprofv3 kernel trace of the step); a few thousand longer-lived ones are handed out in microseconds.
-constexpr int kMaskChunk = 16;
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ out, int A,
-                                                      int nwords, float nms_threshold,
-                                                      int force, DetWs ws) {
+// Round 5 (0.24 -> see DESIGN.md): a lane owns a COLUMN; the 64 rows of the tile pass by as wave-uniform values (v_readlane of
+// the 32-byte grouped records det_decode_sort_kernel left: box, area, class) -- no LDS, no barrier, no gather through perm --
+// and row t's 64-bit word is the ballot of its comparison, written into lane t's registers.  The division of IoU >= threshold is only executed when
+// some lane's products are within 2^-20 of the cut: i >= t_hi u (t_hi = threshold (1 + 2^-20)) implies the rounded quotient
+// reaches the threshold, i <= t_lo u implies it does not (rounding is monotone and the threshold is a float), and boxes that
+// do not overlap at all (i = 0), nearly all of them, are in the second class.  A tile holding a non-finite (or absurdly large)
+// coordinate takes the literal expression (the reference's min / max are not IEEE minNum / maxNum on NaN).
+constexpr int kMaskWaves = 4;
+__global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4 *__restrict__ gbox_all, const int *__restrict__ gcls_all,
+                                                      const int *__restrict__ nms_count,
+                                                      unsigned long long *__restrict__ mask_all, int A,
+                                                      int nwords, float nms_threshold, int force) {
   const int rt = blockIdx.x, b = blockIdx.y;
-  const int V = ws.nms_count[b];
+  const int V = nms_count[b];
   const int ntile = (V + 63) >> 6;
-  const int ct0 = rt + blockIdx.z * kMaskChunk;
+  const int ct0 = rt + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (the wave index, as a scalar)
   if (rt * 64 >= V || ct0 >= ntile) return;
-  __shared__ float s_box[64][5];
-  const float *po = out + (size_t)b * A * 7;
-  const int *perm = ws.perm + (size_t)b * A;
-  const int lane = threadIdx.x;
-  const int i = rt * 64 + lane;
-  float bi[4] = {0.f, 0.f, 0.f, 0.f}, idi = -1.f;
-  if (i < V) {
-    const float *ri = po + (size_t)perm[i] * 7;
-    bi[0] = ri[2]; bi[1] = ri[3]; bi[2] = ri[4]; bi[3] = ri[5];
-    idi = ri[0];
-  }
-  // class of this tile's last row: grouped positions ascend in class, so a column tile that starts above it has no pair
-  const int *gcls = ws.gcls + (size_t)b * A;
-  const int c_hi = gcls[min(V, rt * 64 + 64) - 1];
-  const int ct1 = min(ntile, ct0 + kMaskChunk);
-  for (int ct = ct0; ct < ct1; ++ct) {
+  const float4 *gbox = gbox_all + (size_t)b * A * 2;
+  const int *gcls = gcls_all + (size_t)b * A;
+  const int lane = threadIdx.x & 63;
+  const int nrow = min(64, V - rt * 64);
+  // this lane's row of the tile; row t reaches the wave as scalars through v_readlane (no memory latency inside the loop)
+  float4 rb = make_float4(0.f, 0.f, 0.f, 0.f), re = make_float4(0.f, -1.f, 0.f, 0.f);
+  if (lane < nrow) { rb = gbox[2 * (rt * 64 + lane)]; re = gbox[2 * (rt * 64 + lane) + 1]; }
+  // "tame": every coordinate is a number below 1e15 in magnitude -- no product below can overflow or be NaN
+  auto tame4 = [](const float4 v) { return fabsf(v.x) <= 1e15f && fabsf(v.y) <= 1e15f && fabsf(v.z) <= 1e15f && fabsf(v.w) <= 1e15f; };
+  const bool rows_tame = __ballot(!tame4(rb)) == 0ull;
+  const float t_hi = nms_threshold * (1.0f + 0x1p-20f), t_lo = nms_threshold * (1.0f - 0x1p-20f);
+  // class of this tile's first and last row: grouped positions ascend in class, so a column tile that starts above the last
+  // row's class has no pair, and one that ends in the first row's class holds that class only
+  const int c_lo = gcls[rt * 64], c_hi = gcls[rt * 64 + nrow - 1];
+  unsigned long long *mrow = mask_all + ((size_t)b * A + rt * 64 + lane) * nwords;
+  // lane t of (lo, hi) := a wave-uniform 64-bit word.  (On gfx9 the lane select of v_writelane beside a scalar source has to
+  // be M0; nothing else in this kernel uses M0 -- the compiler reserves it and warns about the clobber.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  auto put_word = [](int &lo, int &hi, unsigned long long word, int t) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                 : "+v"(lo), "+v"(hi) : "s"((int)(unsigned)word), "s"((int)(unsigned)(word >> 32)), "s"(t) : "m0");
+  };
+#pragma clang diagnostic pop
+  auto vmin_sv = [](float sv, float vv) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(sv), "v"(vv)); return r; };
+  auto vmax_sv = [](float sv, float vv) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(sv), "v"(vv)); return r; };
+  auto rl = [](float v, int t) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t)); };
+  for (int ct = ct0; ct < ntile; ct += kMaskWaves) {
     if (gcls[ct * 64] > c_hi) break;      // (wave-uniform) this and every later column tile hold other classes only
-    __syncthreads();                      // the previous column tile has been read by every lane
     const int jc = ct * 64 + lane;
-    if (jc < V) {
-      const float *r = po + (size_t)perm[jc] * 7;
-      s_box[lane][0] = r[2]; s_box[lane][1] = r[3]; s_box[lane][2] = r[4]; s_box[lane][3] = r[5];
-      s_box[lane][4] = r[0];
-    }
-    __syncthreads();
-    if (i >= V) continue;
-    unsigned long long bits = 0;
-    const int jmax = min(64, V - ct * 64);
-    for (int t = 0; t < jmax; ++t) {
-      const int j = ct * 64 + t;
-      if (j <= i) continue;
-      if (force || idi == s_box[t][4]) {
-        if (nms_iou(bi, s_box[t]) >= nms_threshold) bits |= 1ull << t;
+    const bool colv = jc < V;
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), ce = make_float4(0.f, -2.f, 0.f, 0.f);
+    if (colv) { cb = gbox[2 * jc]; ce = gbox[2 * jc + 1]; }
+    const bool diag = ct == rt;
+    // every pair of the two tiles is of one class (or classes do not matter), and no pair is below the diagonal
+    const bool plain = !diag && (force || (c_lo == c_hi && gcls[min(V, ct * 64 + 64) - 1] == c_lo));
+    int bits_lo = 0, bits_hi = 0;
+    const unsigned long long colv_m = __ballot(colv);
+    if (rows_tame && __ballot(!tame4(cb)) == 0ull) {
+      for (int t = 0; t < nrow; ++t) {
+        const float rx = rl(rb.x, t), ry = rl(rb.y, t), rz = rl(rb.z, t), rw = rl(rb.w, t), ra = rl(re.x, t);
+        // (tame numbers: the bare v_min / v_max instructions, without the quieting copies fminf / fmaxf come with)
+        const float w = fmaxf(0.f, vmin_sv(rz, cb.z) - vmax_sv(rx, cb.x));
+        const float h = fmaxf(0.f, vmin_sv(rw, cb.w) - vmax_sv(ry, cb.y));
+        const float i = w * h;
+        const float u = ra + ce.x - i;
+        unsigned long long elig = colv_m;
+        if (!plain) {
+          if (diag) elig &= (~0ull << t) << 1;               // (columns right of the diagonal: lanes > t)
+          if (!force) elig &= __ballot(rl(re.y, t) == ce.y);
+        }
+        // certain without dividing: yes if i >= t_hi u, no if i <= t_lo u (u in the normal range), no if u <= 0
+        const unsigned long long normal = __ballot(u >= 1e-30f), ge_hi = __ballot(i >= t_hi * u);
+        const unsigned long long le_lo = __ballot(i <= t_lo * u), pos = __ballot(u > 0.f);
+        unsigned long long yes = normal & ge_hi;
+        const unsigned long long sure = (normal & (ge_hi | le_lo)) | ~pos;
+        if (elig & ~sure) yes = __ballot(u > 0.f && i / u >= nms_threshold);
+        put_word(bits_lo, bits_hi, elig & yes, t);
+      }
+    } else {
+      for (int t = 0; t < nrow; ++t) {
+        float a[4], c[4];
+        a[0] = rl(rb.x, t); a[1] = rl(rb.y, t); a[2] = rl(rb.z, t); a[3] = rl(rb.w, t);
+        c[0] = cb.x; c[1] = cb.y; c[2] = cb.z; c[3] = cb.w;
+        const bool elig = colv && (force || rl(re.y, t) == ce.y) && (!diag || lane > t);
+        const unsigned long long word = __ballot(elig && nms_iou(a, c) >= nms_threshold);
+        put_word(bits_lo, bits_hi, word, t);
       }
     }
-    ws.mask[((size_t)b * A + i) * nwords + ct] = bits;
+    const unsigned long long bits = ((unsigned long long)(unsigned)bits_hi << 32) | (unsigned)bits_lo;
+    if (lane < nrow) mrow[ct] = bits;
   }
 }
 
@@ -775,8 +1237,8 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restric
     if ((removed[i >> 6] >> (i & 63)) & 1ull) po[(size_t)perm[i] * 7] = -1.f;
 }
 
-struct TargetLayout { size_t err, ngt, row_iou, row_gt, bgkey, flag, total; };
-TargetLayout target_layout(int B, int A) {
+struct TargetLayout { size_t err, ngt, row_iou, row_gt, bgkey, flag, cpart, total; int nblk; };
+TargetLayout target_layout(int B, int A, int L) {
   TargetLayout l;
   size_t o = 0;
   l.err = o; o = dspn::align_up(o + sizeof(int) * B, 256);
@@ -785,13 +1247,15 @@ TargetLayout target_layout(int B, int A) {
   l.row_gt = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
   l.bgkey = o; o = dspn::align_up(o + sizeof(unsigned) * (size_t)B * A, 256);
   l.flag = o; o = dspn::align_up(o + (size_t)B * A, 256);
+  l.nblk = (A + 255) / 256;
+  l.cpart = o; o = dspn::align_up(o + 8 * (size_t)B * l.nblk * (L > 0 ? L : 1), 256);
   l.total = o;
   return l;
 }
 
 constexpr int kLdsKeyCap = 16384;  // 128 KiB of 64-bit keys
 int next_pow2(int v) { int n = 1; while (n < v) n <<= 1; return n; }
-struct DetLayout { size_t cnt, temp, keys, mask, perm, gcls, total; int n2cap, nwords; bool lds_keys; };
+struct DetLayout { size_t cnt, temp, keys, mask, perm, gcls, gbox, total; int n2cap, nwords; bool lds_keys; };
 DetLayout det_layout(int B, int A) {
   DetLayout l;
   l.n2cap = next_pow2(A);
@@ -804,6 +1268,7 @@ DetLayout det_layout(int B, int A) {
   l.mask = o; o = dspn::align_up(o + 8 * (size_t)B * A * l.nwords, 256);
   l.perm = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
   l.gcls = o; o = dspn::align_up(o + sizeof(int) * (size_t)B * A, 256);
+  l.gbox = o; o = dspn::align_up(o + 32 * (size_t)B * A, 256);
   l.total = o;
   return l;
 }
@@ -840,9 +1305,8 @@ int dspn_multibox_prior_f32(const float *sizes, int num_sizes, const float *rati
 }
 
 size_t dspn_multibox_target_workspace_bytes(int batch, int num_anchors, int num_labels) {
-  (void)num_labels;
   if (batch <= 0 || num_anchors <= 0) return 0;
-  return target_layout(batch, num_anchors).total;
+  return target_layout(batch, num_anchors, num_labels).total;
 }
 
 int dspn_multibox_target_f32(const float *anchors_dev, const float *labels_dev,
@@ -866,7 +1330,7 @@ int dspn_multibox_target_f32(const float *anchors_dev, const float *labels_dev,
     DSPN_REQUIRE(negative_mining_thresh > 0, "negative_mining_thresh must be > 0");
   DSPN_REQUIRE(anchors_dev && labels_dev && cls_preds_dev && loc_target_dev && loc_mask_dev &&
                    cls_target_dev && workspace_dev, "MultiBoxTarget: null pointer");
-  const TargetLayout l = target_layout(batch, num_anchors);
+  const TargetLayout l = target_layout(batch, num_anchors, num_labels);
   if (workspace_bytes < l.total)
     return dspn::fail(DSPN_ERR_WORKSPACE_, "MultiBoxTarget: workspace %zu < %zu bytes",
                       workspace_bytes, l.total);
@@ -878,14 +1342,21 @@ int dspn_multibox_target_f32(const float *anchors_dev, const float *labels_dev,
   ws.row_gt = reinterpret_cast<int *>(w + l.row_gt);
   ws.bgkey = reinterpret_cast<unsigned *>(w + l.bgkey);
   ws.flag = reinterpret_cast<signed char *>(w + l.flag);
+  ws.cpart = reinterpret_cast<unsigned long long *>(w + l.cpart);
+  ws.nblk = l.nblk;
   hipStream_t s = (hipStream_t)stream;
   const float4 *an = reinterpret_cast<const float4 *>(anchors_dev);
   const dim3 grid(dspn::cdiv(num_anchors, 256), batch);
   hipLaunchKernelGGL(target_rows_kernel, grid, dim3(256), 0, s, an, labels_dev, cls_preds_dev,
                      num_anchors, num_labels, label_width, num_classes, ws);
-  hipLaunchKernelGGL(target_match_kernel, dim3(batch), dim3(kTB), 0, s, an, labels_dev,
-                     num_anchors, num_labels, label_width, overlap_threshold,
-                     negative_mining_ratio, negative_mining_thresh, ws);
+  if (num_anchors <= 8 * kTB)
+    hipLaunchKernelGGL(target_match_reg_kernel<8>, dim3(batch), dim3(kTB), 0, s, an, labels_dev,
+                       num_anchors, num_labels, label_width, overlap_threshold,
+                       negative_mining_ratio, negative_mining_thresh, ws);
+  else
+    hipLaunchKernelGGL(target_match_kernel, dim3(batch), dim3(kTB), 0, s, an, labels_dev,
+                       num_anchors, num_labels, label_width, overlap_threshold,
+                       negative_mining_ratio, negative_mining_thresh, ws);
   hipLaunchKernelGGL(target_write_kernel, grid, dim3(256), 0, s, an, labels_dev, num_anchors,
                      num_labels, label_width, ignore_label, variances[0], variances[1],
                      variances[2], variances[3], ws, loc_target_dev, loc_mask_dev, cls_target_dev);
@@ -940,31 +1411,36 @@ int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred
   ws.mask = reinterpret_cast<unsigned long long *>(w + l.mask);
   ws.perm = reinterpret_cast<int *>(w + l.perm);
   ws.gcls = reinterpret_cast<int *>(w + l.gcls);
+  ws.gbox = reinterpret_cast<float4 *>(w + l.gbox);
   hipStream_t s = (hipStream_t)stream;
   const float4 *an = reinterpret_cast<const float4 *>(anchors_dev);
   const int nms_enabled = !(nms_threshold <= 0 || nms_threshold > 1);
   if (l.lds_keys) {
-    const size_t lds = 8 * (size_t)l.n2cap;
+    // keys of the whole list + (when nms_topk cuts it to at most half) the selected keys, beside ~18 KiB of static LDS
+    constexpr size_t kDynMax = 140 * 1024;
+    int selcap = nms_topk > 0 ? next_pow2(std::min(nms_topk, num_anchors)) : 0;
+    if (!nms_enabled || 2 * selcap > l.n2cap || 8 * (size_t)(l.n2cap + selcap) > kDynMax) selcap = 0;
+    const size_t lds = 8 * (size_t)(l.n2cap + selcap);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_decode_sort_kernel<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kLdsKeyCap);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynMax);
       attr_set = true;
     }
     hipLaunchKernelGGL(det_decode_sort_kernel<true>, dim3(batch), dim3(kTB), lds, s, cls_prob_dev,
                        loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
-                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap,
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap, selcap,
                        ws, out_dev);
   } else {
     hipLaunchKernelGGL(det_decode_sort_kernel<false>, dim3(batch), dim3(kTB), 0, s, cls_prob_dev,
                        loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
-                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap,
+                       variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap, 0,
                        ws, out_dev);
   }
   if (nms_enabled) {
     const int nt = l.nwords;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, batch, (nt + kMaskChunk - 1) / kMaskChunk), dim3(64), 0, s, out_dev,
-                       num_anchors, l.nwords, nms_threshold, force_suppress != 0, ws);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nt, batch), dim3(64 * kMaskWaves), 0, s, ws.gbox, ws.gcls,
+                       ws.nms_count, ws.mask, num_anchors, l.nwords, nms_threshold, force_suppress != 0);
     // one scan per (sample, class id 0 .. num_classes - 2); a single one per sample under force_suppress
     hipLaunchKernelGGL(nms_scan_kernel, dim3(batch, (force_suppress || num_classes < 3) ? 1 : num_classes - 1), dim3(kScanThreads),
                        8 * (size_t)l.nwords, s, out_dev, num_anchors, l.nwords, force_suppress != 0, ws);

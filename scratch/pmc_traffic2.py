@@ -16,21 +16,25 @@ def load(d, counter):
     return agg
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
 steps = int(sys.argv[3])
+# forward/backward passes actually profiled: the range guard's calibration pass (two-piece math, before the first step) is one
+# more than steps + warmup -- counted from a kernel that runs once per pass
+passes = max([v[0] for k, v in fetch.items() if k.startswith('maxpool_fwd_kernel')] + [0]) or steps
+steps = passes
 rows = []
 fam_bytes = fam_launch = 0
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch[k][1] + write[k][1])):
     n = max(fetch[k][0], write[k][0])
     b = (2 * fetch[k][1] + write[k][1]) * 1024
     rows.append((k, n, fetch[k][1], write[k][1], b / max(n, 1)))
-    if k.startswith(('conv_nt_kernel', 'conv_wgrad_kernel', 'slab_reduce', 'nt_split_reduce')):
+    if k.startswith(('conv_nt', 'conv_stem', 'conv_wgrad_kernel', 'slab_reduce', 'nt_split_reduce')):   # conv_nt / conv_ntw / conv_ntv
         fam_bytes += b; fam_launch += n if k.startswith('conv_') else 0
 with open(sys.argv[4], 'w') as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py --steps %d --warmup 1 --no-cpu-baseline --no-roofline\n" % (steps - 1))
     f.write("# units: KiB as reported; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024/launches (gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md section HBM)\n")
     f.write("kernel,launches_%d_steps,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n" % steps)
-    for r in rows[:40]:
+    for r in rows[:60]:
         f.write("%s,%d,%.0f,%.0f,%.0f\n" % (r[0].replace(',', ';'), r[1], r[2], r[3], r[4]))
-j = {"family": "conv_nt + conv_wgrad (+ their slab reduces)", "launches_per_step": fam_launch / steps,
+j = {"family": "conv_nt + conv_ntw + conv_ntv + conv_stem + conv_wgrad (+ their slab reduces)", "launches_per_step": fam_launch / steps,
      "hbm_bytes_per_step": fam_bytes / steps, "hbm_bytes_per_launch": fam_bytes / max(fam_launch, 1),
      "source": sys.argv[4] + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"}
 json.dump(j, open(sys.argv[5], 'w'), indent=1)
