@@ -228,7 +228,7 @@ def roofline_ops(net, solver, dev):
     # MultiBoxTarget: reads cls_pred + labels (+ the anchor table once), writes loc_target, loc_mask, cls_target
     tb = B * (9 * A * 4 + 200 * 6 * 4 + A * 11 * 4) + A * 16
     out["MultiBoxTarget"] = row("target", tb, timed(lambda: op.MultiBoxTarget(anchors, lab, pred, negative_mining_ratio=3)),
-                                "B = %d, one workgroup per sample in the matching kernel: latency-bound by construction" % B)
+                                "B = %d; IoUs, column maxima and background keys on the whole chip, the greedy matching / mining on one workgroup per sample (registers + LDS)" % B)
     db = B * (9 * A * 4 + A * 5 * 4 + A * 7 * 4) + A * 16
     det_out = torch.empty(B, A, 7, device=dev)
     out["MultiBoxDetection"] = row("detection", db, timed(lambda: op.MultiBoxDetection(prob, loc, anchors, nms_topk=400, out=det_out)),

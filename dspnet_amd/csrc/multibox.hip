@@ -185,21 +185,24 @@ __global__ __launch_bounds__(256) void target_rows_kernel(
     if (j < A) { ws.row_iou[o] = -1.f; ws.row_gt[o] = -1; ws.bgkey[o] = 0u; }
     return;
   }
-  if (j < A) {
-    const float4 a = anchors[j];
-    float best = -1.0f; int bk = -1;
-    for (int k = 0; k < G; ++k) {
-      const float iou = target_iou(a, s_gt[4 * k], s_gt[4 * k + 1], s_gt[4 * k + 2], s_gt[4 * k + 3]);
-      if (iou > best) { best = iou; bk = k; }
-      // the wave's best for GT k: largest IoU bits (positive floats order as unsigned), lowest lane = lowest anchor among equals
-      const unsigned bits = iou > 0.f ? __float_as_uint(iou) : 0u;
-      const unsigned top = wave_max_u32(bits);
-      if (top != 0u) {
-        const int first = __ffsll((long long)__ballot(bits == top)) - 1;
-        if ((threadIdx.x & 63) == first)
-          atomicMax(&s_cmax[k], ((unsigned long long)top << 32) | (0xffffffffu - (unsigned)j));
-      }
+  // (every lane of a wave takes part in the loop -- wave_max_u32 is a butterfly over all 64 lanes --; the lanes past the last
+  // anchor work on a copy of it and contribute nothing)
+  const bool live = j < A;
+  const float4 a = anchors[live ? j : A - 1];
+  float best = -1.0f; int bk = -1;
+  for (int k = 0; k < G; ++k) {
+    const float iou = target_iou(a, s_gt[4 * k], s_gt[4 * k + 1], s_gt[4 * k + 2], s_gt[4 * k + 3]);
+    if (iou > best) { best = iou; bk = k; }
+    // the wave's best for GT k: largest IoU bits (positive floats order as unsigned), lowest lane = lowest anchor among equals
+    const unsigned bits = (live && iou > 0.f) ? __float_as_uint(iou) : 0u;
+    const unsigned top = wave_max_u32(bits);
+    if (top != 0u) {
+      const int first = __ffsll((long long)__ballot(bits == top)) - 1;
+      if ((threadIdx.x & 63) == first)
+        atomicMax(&s_cmax[k], ((unsigned long long)top << 32) | (0xffffffffu - (unsigned)j));
     }
+  }
+  if (live) {
     ws.row_iou[o] = best;
     ws.row_gt[o] = bk;
     // softmax P(background), float, sequential sum (multibox_target.cc:218-232)
@@ -463,8 +466,10 @@ __global__ __launch_bounds__(kTB) void target_match_reg_kernel(
   __shared__ Best s_best;
   __shared__ unsigned s_hist[256];
   __shared__ int s_w[kTB / 64];
-  __shared__ int s_G, s_cnt, s_bin, s_kk, s_ties;
+  __shared__ int s_G, s_cnt, s_bin, s_kk, s_ties, s_dup;
   __shared__ signed char s_flag[kPer * kTB];
+  __shared__ unsigned long long s_cmax[kMaxLabels];
+  __shared__ unsigned s_used[kPer * kTB / 32];      // anchors that are some matchable GT's column maximum
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *lab = labels + (size_t)b * L * lw;
@@ -496,19 +501,46 @@ __global__ __launch_bounds__(kTB) void target_match_reg_kernel(
     for (int u = 0; u < kPer; ++u) { const int j = u * kTB + tid; if (j < A) flag[j] = s_flag[j]; }
   };
   for (int i = tid; i < G * 4; i += kTB) s_gt[i] = lab[(i >> 2) * lw + 1 + (i & 3)];
+  // column maxima: the blocks' partials, one (GT, block) pair per thread
+  for (int k = tid; k < G; k += kTB) s_cmax[k] = 0ull;
+  for (int i = tid; i < kPer * kTB / 32; i += kTB) s_used[i] = 0u;
+  if (tid == 0) s_dup = 0;
+  __syncthreads();
+  for (int i = tid; i < G * ws.nblk; i += kTB) {
+    const int q = i / G, k = i - q * G;
+    const unsigned long long c = ws.cpart[((size_t)b * ws.nblk + q) * L + k];
+    if (c) atomicMax(&s_cmax[k], c);
+  }
+  __syncthreads();
   for (int k = tid; k < G; k += kTB) {
-    const unsigned long long *cp = ws.cpart + (size_t)b * ws.nblk * L + k;
-    unsigned long long m = 0ull;
-    for (int q = 0; q < ws.nblk; ++q) { const unsigned long long c = cp[(size_t)q * L]; m = c > m ? c : m; }
-    s_ciou[k] = m ? __uint_as_float((unsigned)(m >> 32)) : -1.0f;
-    s_ca[k] = m ? (int)(0xffffffffu - (unsigned)m) : 0x7fffffff;
-    s_gflag[k] = 0;
+    const unsigned long long m = s_cmax[k];
+    const float ciou = m ? __uint_as_float((unsigned)(m >> 32)) : -1.0f;
+    const int ca = m ? (int)(0xffffffffu - (unsigned)m) : 0x7fffffff;
+    s_ciou[k] = ciou; s_ca[k] = ca; s_gflag[k] = 0;
+    if (ciou > 1e-6f) {       // would be picked: does another such GT share its best anchor?
+      const unsigned bit = 1u << (ca & 31);
+      if (atomicOr(&s_used[ca >> 5], bit) & bit) s_dup = 1;
+    }
   }
   __syncthreads();
 
   // greedy bipartite matching (multibox_target.cc:113-149), as in the generic kernel: wave 0 runs consecutive picks, the
   // workgroup meets only when a pick consumed an anchor that is still some unmatched GT's column maximum
   int npos = 0;
+  if (!s_dup) {
+    // No two ground truths that can be matched (IoU > 1e-6) share their best anchor: every pick of the greedy loop takes a GT
+    // with its column maximum, no pick changes another GT's maximum that matters (a GT at or below the cut may lose its
+    // anchor, but whatever replaces it is no larger and never picked) -- the result is all of them at once.
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int add = 0;
+    for (int k = tid; k < G; k += kTB)
+      if (s_ciou[k] > 1e-6f) { s_flag[s_ca[k]] = 1; row_gt[s_ca[k]] = k; ++add; }
+    for (int m = 32; m >= 1; m >>= 1) add += __shfl_xor(add, m, 64);
+    if (lane == 0 && add) atomicAdd(&s_cnt, add);
+    __syncthreads();
+    npos = s_cnt;
+  } else
   for (;;) {
     if (wave == 0) {
       int consumed = -1;
@@ -1097,15 +1129,30 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4 
   auto vmin_sv = [](float sv, float vv) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(sv), "v"(vv)); return r; };
   auto vmax_sv = [](float sv, float vv) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(sv), "v"(vv)); return r; };
   auto rl = [](float v, int t) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t)); };
+  // a column tile: this lane's record and the classes of the tile's first and last row; the NEXT tile of the wave is
+  // requested before the current one is worked on (its latency, ~2 us, would otherwise stand between two 3-us loops)
+  struct Col { float4 cb, ce; int c_first, c_last; };
+  auto fetch = [&](int ct) {
+    Col c;
+    c.cb = make_float4(0.f, 0.f, 0.f, 0.f); c.ce = make_float4(0.f, -2.f, 0.f, 0.f); c.c_first = 0x7fffffff; c.c_last = 0;
+    if (ct < ntile) {
+      const int jc = ct * 64 + lane;
+      if (jc < V) { c.cb = gbox[2 * jc]; c.ce = gbox[2 * jc + 1]; }
+      c.c_first = gcls[ct * 64];
+      c.c_last = gcls[min(V, ct * 64 + 64) - 1];
+    }
+    return c;
+  };
+  Col nxt = fetch(ct0);
   for (int ct = ct0; ct < ntile; ct += kMaskWaves) {
-    if (gcls[ct * 64] > c_hi) break;      // (wave-uniform) this and every later column tile hold other classes only
-    const int jc = ct * 64 + lane;
-    const bool colv = jc < V;
-    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), ce = make_float4(0.f, -2.f, 0.f, 0.f);
-    if (colv) { cb = gbox[2 * jc]; ce = gbox[2 * jc + 1]; }
+    const Col cur = nxt;
+    if (cur.c_first > c_hi) break;        // (wave-uniform) this and every later column tile hold other classes only
+    nxt = fetch(ct + kMaskWaves);
+    const bool colv = ct * 64 + lane < V;
+    const float4 cb = cur.cb, ce = cur.ce;
     const bool diag = ct == rt;
     // every pair of the two tiles is of one class (or classes do not matter), and no pair is below the diagonal
-    const bool plain = !diag && (force || (c_lo == c_hi && gcls[min(V, ct * 64 + 64) - 1] == c_lo));
+    const bool plain = !diag && (force || (c_lo == c_hi && cur.c_last == c_lo));
     int bits_lo = 0, bits_hi = 0;
     const unsigned long long colv_m = __ballot(colv);
     if (rows_tame && __ballot(!tame4(cb)) == 0ull) {
@@ -1206,9 +1253,15 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(float *__restric
   for (int w0 = wb; w0 < nw; ++w0) {
     if (w0 + 1 < nw) { preload(w0 + 1, vn); diag_n = load_diag(w0 + 1); }   // in flight while this block is resolved
     if (wave == 0) {
-      unsigned long long cur = removed[w0];
+      // (round 5: the 64-step chain in scalar registers -- v_readlane of row t's word, not a trip through the LDS crossbar
+      // per step: 3 us -> 0.3 us per block, and a class of 766 rows is a chain of 12 blocks)
+      const unsigned long long cur0 = removed[w0];
+      unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur0 >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur0);
+      const int dlo = (int)(unsigned)diag, dhi = (int)(unsigned)(diag >> 32);
       for (int t = 0; t < 64; ++t) {
-        const unsigned long long d = __shfl(diag, t, 64);
+        const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, t) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane(dlo, t);
         if (!((cur >> t) & 1ull)) cur |= d;
       }
       const int lo = max(seg_s - w0 * 64, 0), hi = min(seg_e - w0 * 64, 64);     // this segment's rows of the block

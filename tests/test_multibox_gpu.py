@@ -113,6 +113,23 @@ def test_target_duplicate_and_overlapping_gt(gpu_device):
     run_target(anc, lab, pred, negative_mining_ratio=3)
 
 
+@pytest.mark.parametrize("num_anchors", [3382, 256 * 5 + 7, 256 * 9 + 33, 64 * 3 + 50, 6132])
+def test_target_best_anchor_in_the_last_partial_wave(gpu_device, num_anchors):
+    """round 5: the best anchor of a ground truth is found per 64-anchor wave inside target_rows_kernel (a butterfly over the
+    wave's lanes); ground truths that coincide with the LAST anchors of the table have their column maximum in a wave whose
+    upper lanes hold no anchor (the inceptionv3 1024x512 graph, 3382 anchors, met this case)"""
+    anc = mc.r50_anchors(512, 512)[:, :num_anchors].copy()
+    lab = -np.ones((2, 40, 6), np.float32)
+    for k, j in enumerate(range(num_anchors - 1, num_anchors - 12, -2)):
+        box = np.clip(anc[0, j], 0.0, 1.0)
+        lab[0, k] = [k % 8, box[0], box[1], box[2], box[3], .1 * k]
+    lab[1, 0] = [3, *np.clip(anc[0, num_anchors - 3], 0.0, 1.0), .5]
+    lab[1, 1] = [5, .1, .1, .4, .5, .5]
+    gen = np.random.default_rng(11)
+    pred = gen.standard_normal((2, 9, num_anchors)).astype(np.float32)
+    run_target(anc, lab, pred, negative_mining_ratio=3)
+
+
 def test_target_full_label_table_and_many_positives(gpu_device):
     anc = mc.small_anchors(10, 10)
     lab, pred = mc.target_inputs(anc, batch=2, num_labels=7, num_classes=3, max_gt=7, seed=8)
