@@ -56,8 +56,6 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = bias[co + e];
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
   constexpr float kInf = __builtin_huge_valf();
   float sK[HALVES][4], s1[HALVES][4], s2[HALVES][4], vmn[HALVES][4], vmx[HALVES][4], gs[HALVES][4], gss[HALVES][4];
   int scnt[HALVES];
@@ -68,70 +66,82 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sK[h][e] = 0.f; s1[h][e] = 0.f; s2[h][e] = 0.f; vmn[h][e] = kInf; vmx[h][e] = -kInf; gs[h][e] = 0.f; gss[h][e] = 0.f; }
   }
+  // The rows of a chunk (RC per thread) need their residual / BatchNorm-input rows from global memory; the requests of chunk
+  // c + 1 are issued before chunk c is worked on (two register sets; the accumulators are dead by now), and those of chunk 0
+  // above the barrier that publishes the staged tile: on the short-K layers of the residual stream the epilogue moves more
+  // bytes than the k-loop, and a chunk that waits for its own requests leaves one memory latency per chunk exposed.
+  constexpr int CPH = NPH / RC, NCH = HALVES * CPH;              // chunks per half, chunks per tile (2 or 4)
+  int offs[2][RC];
+  float4 rq[2][RC], xq[2][EPI == 2 ? RC : 1];
+  auto issue = [&](const int c, const int b) __attribute__((always_inline)) {
+    const int h = c / CPH, ch = c - h * CPH;
 #pragma unroll
-  for (int h = 0; h < HALVES; ++h) {
-#pragma unroll 1
-    for (int ch = 0; ch < NPH / RC; ++ch) {
-      int offs[RC];
-      float4 rq[RC], xq[EPI == 2 ? RC : 1];
-#pragma unroll
-      for (int p = 0; p < RC; ++p) {
-        const int m = m0 + h * SR + er0 + (ch * RC + p) * RPP;
-        if (g.dense) {
-          offs[p] = m * g.ldc + co;
-        } else {
-          const int hw = g.Hg * g.Wg;
-          const int n = m / hw, rem = m - n * hw;
-          const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
-          offs[p] = n * (int)g.obs + ((oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
-        }
-        if (m >= M || !cvalid) offs[p] = -1;
-        rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (addsrc && offs[p] >= 0) rq[p] = ld4(addsrc + offs[p]);
-        if constexpr (EPI == 2) {
-          xq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (offs[p] >= 0) xq[p] = ld4(g.bn_x + offs[p]);
-        }
+    for (int p = 0; p < RC; ++p) {
+      const int m = m0 + h * SR + er0 + (ch * RC + p) * RPP;
+      int off;
+      if (g.dense) {
+        off = m * g.ldc + co;
+      } else {
+        const int hw = g.Hg * g.Wg;
+        const int n = m / hw, rem = m - n * hw;
+        const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
+        off = n * (int)g.obs + ((oi * g.osh + g.ooh) * g.OW + (oj * g.osw + g.oow)) * g.ldc + co;
       }
+      if (m >= M || !cvalid) off = -1;
+      offs[b][p] = off;
+      rq[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (addsrc && off >= 0) rq[b][p] = ld4(addsrc + off);
+      if constexpr (EPI == 2) {
+        xq[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (off >= 0) xq[b][p] = ld4(g.bn_x + off);
+      }
+    }
+  };
+  issue(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int p = 0; p < RC; ++p) {
-        const int off = offs[p];
-        if (off < 0) continue;
-        const float4 tv = *reinterpret_cast<const float4 *>(st + (h * SR + er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
-        float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
-        v[0] += rq[p].x; v[1] += rq[p].y; v[2] += rq[p].z; v[3] += rq[p].w;
-        if (has_res && accum) {
-          const float4 q = ld4(out + off);
-          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+  for (int c = 0; c < NCH; ++c) {
+    const int h = c / CPH, ch = c % CPH, b = c & 1;              // (compile-time after unrolling)
+    if (c + 1 < NCH) issue(c + 1, b ^ 1);
+#pragma unroll
+    for (int p = 0; p < RC; ++p) {
+      const int off = offs[b][p];
+      if (off < 0) continue;
+      const float4 tv = *reinterpret_cast<const float4 *>(st + (h * SR + er0 + (ch * RC + p) * RPP) * SLD + c4 * 4);
+      float v[4] = {tv.x + bv[0], tv.y + bv[1], tv.z + bv[2], tv.w + bv[3]};
+      v[0] += rq[b][p].x; v[1] += rq[b][p].y; v[2] += rq[b][p].z; v[3] += rq[b][p].w;
+      if (has_res && accum) {
+        const float4 q = ld4(out + off);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if constexpr (kHalf) {   // what is stored (and what the statistics / sums below describe) is the bf16 value
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dspn::round_bf16(v[e]);
+      }
+      dspn::A1Ptr(out + off).vec4()[0] = make_float4(v[0], v[1], v[2], v[3]);
+      if constexpr (EPI == 2) {
+        const float xv[4] = {xq[b][p].x, xq[b][p].y, xq[b][p].z, xq[b][p].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gd = (!g.bn_relu || fmaf(xv[e], bsc[e], bsh[e]) > 0.f) ? v[e] : 0.f;
+          gs[h][e] += gd;
+          gss[h][e] += gd * ((xv[e] - bmu[e]) * brs[e]);
         }
-        if (relu) {
+        gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
+      if constexpr (EPI == 1) {
+        if (scnt[h] == 0) { sK[h][0] = v[0]; sK[h][1] = v[1]; sK[h][2] = v[2]; sK[h][3] = v[3]; }
+        ++scnt[h];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if constexpr (kHalf) {   // what is stored (and what the statistics / sums below describe) is the bf16 value
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = dspn::round_bf16(v[e]);
-        }
-        dspn::A1Ptr(out + off).vec4()[0] = make_float4(v[0], v[1], v[2], v[3]);
-        if constexpr (EPI == 2) {
-          const float xv[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float gd = (!g.bn_relu || fmaf(xv[e], bsc[e], bsh[e]) > 0.f) ? v[e] : 0.f;
-            gs[h][e] += gd;
-            gss[h][e] += gd * ((xv[e] - bmu[e]) * brs[e]);
-          }
-          gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        }
-        if constexpr (EPI == 1) {
-          if (scnt[h] == 0) { sK[h][0] = v[0]; sK[h][1] = v[1]; sK[h][2] = v[2]; sK[h][3] = v[3]; }
-          ++scnt[h];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float d = v[e] - sK[h][e];
-            s1[h][e] += d; s2[h][e] += d * d;
-            vmn[h][e] = fminf(vmn[h][e], v[e]); vmx[h][e] = fmaxf(vmx[h][e], v[e]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[e] - sK[h][e];
+          s1[h][e] += d; s2[h][e] += d * d;
+          vmn[h][e] = fminf(vmn[h][e], v[e]); vmx[h][e] = fmaxf(vmx[h][e], v[e]);
         }
       }
     }
@@ -480,6 +490,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
 // family's (statistics at no measurable cost where conv_nt_kernel's 128-register epilogue pays 15 - 30 %).
 // A thread moves `A_U` units of (row, 8 channels): two 16-byte loads, two 16-byte LDS stores (one per piece).  Two LDS stages:
 // the requests of k-step kt + 1 are issued before the MFMAs of k-step kt, the pieces are formed between its two MFMA halves.
+typedef float ntv_f32x4_t __attribute__((ext_vector_type(4)));
+// "at most NEWER requests are still outstanding", tied to the registers it guards (see wait_set in conv_ntv_kernel)
+template <int NEWER>
+__device__ __forceinline__ void ntv_wait2(ntv_f32x4_t &a, ntv_f32x4_t &b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(NEWER));
+}
+template <int NEWER>
+__device__ __forceinline__ void ntv_wait4(ntv_f32x4_t &a, ntv_f32x4_t &b, ntv_f32x4_t &c, ntv_f32x4_t &d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(NEWER));
+}
 template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
@@ -492,6 +512,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
   constexpr int B_NI = BN / (8 * NWV);                   // 1-KiB pieces of the weight image per wave and k-step
   static_assert((BM * 4) % NTHR == 0 && BN % (8 * NWV) == 0, "whole units / pieces per thread / wave");
   constexpr int STG = (BM + BN) * 128;
+  // rows in flight: with at most two units per thread the rows of k-step kt + 2 are requested while k-step kt is multiplied (a
+  // second register set) -- the 1 x 1 layers of the residual stream are HBM-bound and a workgroup with ONE 16-KiB request in
+  // flight leaves the memory latency (about one k-step) exposed: 3.4 - 3.9 TB/s before, see DESIGN.md
+#ifdef DSPN_NTV_SHALLOW
+  constexpr bool DEEP = false;
+#else
+  constexpr bool DEEP = A_U <= 2;
+#endif
+  constexpr int NSET = DEEP ? 2 : 1;
+  constexpr int NA = A_U * 2 + (INTF ? 4 : 0);           // vector loads of one request of A rows
   extern __shared__ __attribute__((aligned(1024))) char wsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,12 +531,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
   const int nk = g.TR * g.TS * CB;
   const float sc_a = operand_scale(g.a_absmax), sc_b = operand_scale(g.b_absmax);
   const float inv_a = 1.f / sc_a, inv_b = 1.f / sc_b;
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, g.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, g.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.in_scale), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.in_shift), 0, INTF ? (unsigned)g.Cin * 4u : 0u, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
   const bool in_relu = g.flags & 32;
+  // The A rows (and their affine) are requested by asm statements, not builtins: hipcc sinks a builtin load whose value is
+  // first used behind the NEXT barrier down to that use (the rows of k-step kt + 2 would be requested one k-step late, and
+  // behind the weight requests the counted waits rely on being older).  The compiler does not know these registers are
+  // pending, so every read of a set is preceded by wait_set(), an s_waitcnt that names the set's registers.
+  auto rsrc_words = [](const float *p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    return u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+  };
+  const u32x4_t rw_a = rsrc_words(in, g.in_bytes);
+  const u32x4_t rw_sc = rsrc_words(g.in_scale, INTF ? (unsigned)g.Cin * 4u : 0u), rw_sh = rsrc_words(g.in_shift, INTF ? (unsigned)g.Cin * 4u : 0u);
+  typedef ntv_f32x4_t f32x4_t;
+  auto load16 = [](const u32x4_t rw, const unsigned voff) __attribute__((always_inline)) {
+    f32x4_t r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rw));
+    return r;
+  };
 
   // ---- A units of this thread: unit u = tid + j NTHR -> row u >> 2, channel group q = tid & 3 (the same for all its units)
   const int aq = tid & 3;
@@ -523,10 +568,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     b_row[i] = 2 * line + (sl >> 3); b_cb[i] = (sl & 7) * 16;
   }
   int a_ih0[A_U], a_iw0[A_U], a_boff[A_U], b_boff[B_NI];
-  int l_tr = 0, l_ts = 0, l_cb = 0;
-  float4 ra[A_U][2];                                     // the rows requested last
-  float4 tsc[2], tsh[2];                                 // affine of this thread's 8 channels (INTF)
-  unsigned a_mask = 0;                                   // bit j: unit j of the k-step requested last lies inside the image
+  int l_tr = 0, l_ts = 0, l_cb = 0;                      // (tap row, tap column, channel block) of the next A request
+  int lb_tr = 0, lb_ts = 0, lb_cb = 0;                   // ... and of the next weight request
+  f32x4_t ra[NSET][A_U][2];                              // the rows requested last (per register set)
+  f32x4_t tsc[NSET][2], tsh[NSET][2];                    // affine of this thread's 8 channels (INTF)
+  unsigned a_mask[NSET] = {};                            // bit j: unit j of the set's k-step lies inside the image
   u32x4_t pa[A_U][2];                                    // its pieces, kept until the image being read has been released
 
   const int wm = (wave / WAVES_N) * (TM * 32), wn = (wave % WAVES_N) * (TN * 32);
@@ -559,43 +605,33 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
         b_boff[i] = k * (g.WTAPS * CB * 128) + b_cb[i];
       }
       l_tr = 0; l_ts = 0; l_cb = 0;
+      lb_tr = 0; lb_ts = 0; lb_cb = 0;
     }
-    // requests of the next k-step: the A rows into registers, the weight pieces into ring slot `slot`; past the last k-step every
-    // lane is out of range (zeros, no traffic)
-    auto request = [&](const int slot, const bool live) __attribute__((always_inline)) {
+    // requests: the A rows of a k-step into register set SET, the weight pieces of a k-step into ring slot `slot`; past the last
+    // k-step every lane is out of range (zeros, no traffic).  Each kind walks the (tap, channel block) sequence with its own counters.
+    auto request_a = [&](auto set_c, const bool live) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
       const int dh = l_tr * g.idh, dw = l_ts * g.idw;
       const int a_tap = ((dh * g.Win + dw) * g.Cin + l_cb * 32) * 4;
-      const int wtap = (g.wr0 + l_tr * g.wrs) * g.WS + g.ws0 + l_ts * g.wss;
-      const int b_soff = (wtap * CB + l_cb) * 128;
       const unsigned oob = live ? 0u : kOOB;
       if constexpr (INTF) {
         const unsigned coff = (unsigned)(l_cb * 32 + aq * 8) * 4u | oob;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const auto s4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, (int)(coff + 16u * h), 0, 0);
-          const auto h4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, (int)(coff + 16u * h), 0, 0);
-          tsc[h] = make_float4(__uint_as_float(s4[0]), __uint_as_float(s4[1]), __uint_as_float(s4[2]), __uint_as_float(s4[3]));
-          tsh[h] = make_float4(__uint_as_float(h4[0]), __uint_as_float(h4[1]), __uint_as_float(h4[2]), __uint_as_float(h4[3]));
+          tsc[SET][h] = load16(rw_sc, coff + 16u * h);
+          tsh[SET][h] = load16(rw_sh, coff + 16u * h);
         }
       }
-      a_mask = 0;
+      a_mask[SET] = 0;
 #pragma unroll
       for (int j = 0; j < A_U; ++j) {
         const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
         const bool v = live && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
-        a_mask |= v ? (1u << j) : 0u;
+        a_mask[SET] |= v ? (1u << j) : 0u;
         const unsigned off = (unsigned)(a_boff[j] + a_tap) | (v ? 0u : kOOB);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const auto q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * h), 0, 0);
-          ra[j][h] = make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
-        }
+        for (int h = 0; h < 2; ++h) ra[SET][j][h] = load16(rw_a, off + 16u * h);
       }
-      char *base = wsm + slot * STG + BM * 128;
-#pragma unroll
-      for (int i = 0; i < B_NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(base + (wave * B_NI + i) * 1024),
-                                                 16, (int)((unsigned)b_boff[i] | oob), b_soff, 0, 0);
       ++l_ts;
       const bool wrap = l_ts == g.TS;
       l_ts = wrap ? 0 : l_ts;
@@ -604,20 +640,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       l_tr = wrap2 ? 0 : l_tr;
       l_cb += wrap2 ? 1 : 0;
     };
+    auto request_b = [&](const int slot, const bool live) __attribute__((always_inline)) {
+      const int wtap = (g.wr0 + lb_tr * g.wrs) * g.WS + g.ws0 + lb_ts * g.wss;
+      const int b_soff = (wtap * CB + lb_cb) * 128;
+      const unsigned oob = live ? 0u : kOOB;
+      char *base = wsm + slot * STG + BM * 128;
+#pragma unroll
+      for (int i = 0; i < B_NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(base + (wave * B_NI + i) * 1024),
+                                                 16, (int)((unsigned)b_boff[i] | oob), b_soff, 0, 0);
+      ++lb_ts;
+      const bool wrap = lb_ts == g.TS;
+      lb_ts = wrap ? 0 : lb_ts;
+      lb_tr += wrap ? 1 : 0;
+      const bool wrap2 = lb_tr == g.TR;
+      lb_tr = wrap2 ? 0 : lb_tr;
+      lb_cb += wrap2 ? 1 : 0;
+    };
     // affine (+ ReLU, zero outside the image: the padding is applied AFTER the affine, as in the forward of the layer in front) and
     // the cut of the rows requested last
-    auto cut = [&]() __attribute__((always_inline)) {
+    // the rows (and affine) of register set SET have arrived once at most NEWER requests are outstanding (requests complete in
+    // order); the statement names the set's registers so that no read of them is scheduled above it
+    auto wait_set = [&](auto set_c, auto newer_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value, NEWER = decltype(newer_c)::value;
+      if constexpr (INTF) ntv_wait4<NEWER>(tsc[SET][0], tsc[SET][1], tsh[SET][0], tsh[SET][1]);
+#pragma unroll
+      for (int j = 0; j < A_U; ++j) ntv_wait2<NEWER>(ra[SET][j][0], ra[SET][j][1]);
+    };
+    auto cut = [&](auto set_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
 #pragma unroll
       for (int j = 0; j < A_U; ++j) {
         bf16x4 p0[2], p1[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          float4 u = ra[j][h];
+          float4 u = make_float4(ra[SET][j][h][0], ra[SET][j][h][1], ra[SET][j][h][2], ra[SET][j][h][3]);
           if constexpr (INTF) {
             // fmaf, like every other place that evaluates this affine: the ReLU mask must come out identical in forward and backward
-            u = make_float4(fmaf(u.x, tsc[h].x, tsh[h].x), fmaf(u.y, tsc[h].y, tsh[h].y), fmaf(u.z, tsc[h].z, tsh[h].z), fmaf(u.w, tsc[h].w, tsh[h].w));
+            u = make_float4(fmaf(u.x, tsc[SET][h][0], tsh[SET][h][0]), fmaf(u.y, tsc[SET][h][1], tsh[SET][h][1]),
+                            fmaf(u.z, tsc[SET][h][2], tsh[SET][h][2]), fmaf(u.w, tsc[SET][h][3], tsh[SET][h][3]));
             if (in_relu) u = make_float4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
-            const bool v = (a_mask >> j) & 1u;
+            const bool v = (a_mask[SET] >> j) & 1u;
             u = make_float4(v ? u.x : 0.f, v ? u.y : 0.f, v ? u.z : 0.f, v ? u.w : 0.f);
           }
           split2h(u, sc_a, p0[h], p1[h]);
@@ -636,10 +699,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
         *reinterpret_cast<u32x4_t *>(base + (a_lds[j] ^ 64)) = pa[j][1];
       }
     };
-    request(0, true);
-    cut();
+    typedef std::integral_constant<int, 0> set0_t;
+    typedef std::integral_constant<int, 1> set1_t;
+    request_b(0, true);
+    __builtin_amdgcn_sched_barrier(0);      // the weight requests FIRST: the counted wait below lets the NA newest requests fly
+    request_a(set0_t{}, true);
+    if constexpr (DEEP) request_a(set1_t{}, 1 < nk);
+    wait_set(set0_t{}, std::integral_constant<int, DEEP ? NA : 0>{});
+    cut(set0_t{});
     store_a(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the weight pieces of k-step 0 have landed and the A image is written; the rows of k-step 1 (DEEP) may still be on their way
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DEEP ? NA : 0) : "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -647,9 +717,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      request(cur ^ 1, kt + 1 < nk);        // (every wave has read ring slot cur ^ 1 before the barrier it has just passed)
+    // one k-step; PAR = kt & 1 picks the register sets at compile time: the rows of k-step kt + 1 are cut out of set CS, the rows
+    // of k-step kt + 2 (DEEP; kt + 1 otherwise) are requested into set RS
+    auto kstep = [&](auto par_c, const int kt) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_c)::value;
+      typedef std::integral_constant<int, DEEP ? PAR : 0> rs_t;
+      typedef std::integral_constant<int, DEEP ? (PAR ^ 1) : 0> cs_t;
+      const int cur = PAR;
+      request_b(cur ^ 1, kt + 1 < nk);      // (every wave has read ring slot cur ^ 1 before the barrier it has just passed)
+      // the weight requests are issued FIRST and stay first: the wait at the end of the k-step counts on the NA newest
+      // requests being the rows (hipcc otherwise hoists the row loads above the LDS-DMA instructions)
+      __builtin_amdgcn_sched_barrier(0);
+      request_a(rs_t{}, kt + (DEEP ? 2 : 1) < nk);
       __builtin_amdgcn_sched_barrier(0);
       const char *sa = wsm + cur * STG + wm * 128, *sb = wsm + cur * STG + BM * 128 + wn * 128;
       bf16x8 fa[4][TM], fb[4][TN];          // fragment f = 2 piece + kk: chunk 2 f + (lane >> 5) of the row's record
@@ -666,9 +745,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        if (kk == 1) {                      // the rows requested above have had the first half's MFMAs to arrive
+        if (kk == 1) {                      // the rows to cut have had (at least) the first half's MFMAs to arrive
           __builtin_amdgcn_sched_barrier(0);
-          cut();
+          wait_set(cs_t{}, std::integral_constant<int, DEEP ? B_NI + NA : 0>{});
+          cut(cs_t{});
         }
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3)
@@ -690,9 +770,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
       store_a(cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // the weight pieces requested at the top have landed (they were issued BEFORE the rows, which may stay in flight)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DEEP ? NA : 0) : "memory");
       __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      kstep(set0_t{}, kt);
+      if (kt + 1 < nk) kstep(set1_t{}, kt + 1);
     }
+    // the last requests (past the last k-step: out of range, zeros) still name their registers: nothing else may be given
+    // those registers before they have landed -- the compiler does not know they are pending
+    wait_set(set0_t{}, std::integral_constant<int, 0>{});
+    if constexpr (DEEP) wait_set(set1_t{}, std::integral_constant<int, 0>{});
     {
       constexpr int SLD = BN + 4;
       float *st = reinterpret_cast<float *>(wsm);

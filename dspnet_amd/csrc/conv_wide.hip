@@ -9,6 +9,7 @@
 #include "../../include/dspn_nn.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace dspn::pieces;
