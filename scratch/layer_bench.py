@@ -6,6 +6,10 @@ from dspnet_amd import engine as E, functional as fn, synthetic
 from dspnet_amd.symbol.multitask_symbol_factory import get_multi_symbol_train
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda", 0)
+import os
+if os.environ.get("DSPN_WIDE_TILES"):      # force one tile shape of the wide family (dspn_conv_set_wide_tiles)
+    from dspnet_amd import _lib
+    _lib.lib().dspn_conv_set_wide_tiles(int(os.environ["DSPN_WIDE_TILES"]))
 net = get_multi_symbol_train("resnet-50", 512, num_classes=8, batch_size=B, device=dev)
 gen = synthetic.rng(1)
 net.data.data.copy_(torch.from_numpy(synthetic.images(B, 512, 512, gen)))
