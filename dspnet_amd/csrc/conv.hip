@@ -1894,8 +1894,26 @@ int nt_config(long long M, int Cout) {
   if ((g_debug_bits >> 8) & 7) cfg = ((g_debug_bits >> 8) & 7) - 1;   // timing experiments only
   return cfg;
 }
+int dispatch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g_in,
+                     hipStream_t s, SplitWs ws, const st_t *residual, bool *wide_used);
+// one convolution launch; g.bn_dy_absmax without g.bn_sums = the magnitude block of the stored output (conv2d_forward_one):
+// written by the wide family's epilogue, by a pass over the output behind any other kernel
 int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g_in,
                 hipStream_t s, SplitWs ws, const st_t *residual = nullptr) {
+  bool wide = false;
+  const int rc = dispatch_nt_impl(in, w, bias, out, g_in, s, ws, residual, &wide);
+#ifndef DSPN_HALF
+  if (!rc && g_in.bn_dy_absmax && !g_in.bn_sums && !wide) {
+    if (!(g_in.dense && g_in.obs == (long long)g_in.Hg * g_in.Wg * g_in.ldc && g_in.ldc % 4 == 0))
+      return dspn::fail(DSPN_ERR_ARG_, "conv2d_forward: the output magnitude block needs a dense output with ldc %% 4 == 0");
+    return dspn_absmax_f32(out, (long long)g_in.N * g_in.Hg * g_in.Wg, g_in.ldc, nullptr, nullptr, 0,
+                           reinterpret_cast<float *>(g_in.bn_dy_absmax), s);
+  }
+#endif
+  return rc;
+}
+int dispatch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g_in,
+                     hipStream_t s, SplitWs ws, const st_t *residual, bool *wide_used) {
   ConvGeom g = g_in;
   g.dbg = g_debug_bits;
   // the 4-element-vector epilogue needs aligned rows (16 bytes float, 8 bytes bf16) in every operand it touches
@@ -1971,7 +1989,7 @@ int dispatch_nt(const st_t *in, const st_t *w, const float *bias, st_t *out, con
       // a float A operand (with or without the folded BatchNorm affine) goes through the family's register-staged member:
       // shapes 12 / 13 / 14 = 128 x 256, 128 x 128 on four waves, 256 x 64 (conv_wide.h, conv_ntv_kernel)
       if (shape && !kHalf && !g.a_planes) shape = 10 + (shape == 1 ? 3 : shape);
-      if (shape) return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual);
+      if (shape) { *wide_used = true; return dspn::conv::launch_wide(shape, in, w, bias, out, g, s, residual); }
     }
   }
   if (cfg == 0 && eight) return launch_nt<4, 2, 1, 2>(in, w, bias, out, g, s, splits, per, ws.ptr, residual);
@@ -2091,6 +2109,10 @@ static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine
   g.in_scale = tf.scale; g.in_shift = tf.shift;
   g.stats = stats;
   g.minmax = (stats && !kHalf && math == DSPN_MATH_F32_F16X2) ? minmax : nullptr;
+  // round 5: `minmax` WITHOUT `stats` = the 64-slot magnitude block of the output as stored (after bias / residual / ReLU): what the
+  // next convolution of a graph without BatchNorm (vgg16_reduced, the SSD extra layers) needs instead of a pass over this tensor.
+  // The wide family's plain epilogue takes it along (one atomic per workgroup and launch); any other kernel is followed by that pass.
+  g.bn_dy_absmax = (!stats && minmax && !kHalf && math == DSPN_MATH_F32_F16X2) ? reinterpret_cast<unsigned *>(minmax) : nullptr;
   g.bf16 = kHalf ? 1 : math;
   g.w_planes = w_planes;
   g.a_absmax = scales.a; g.b_absmax = scales.b;

@@ -124,6 +124,9 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
         for (int e = 0; e < 4; ++e) v[e] = dspn::round_bf16(v[e]);
       }
       dspn::A1Ptr(out + off).vec4()[0] = make_float4(v[0], v[1], v[2], v[3]);
+      if constexpr (EPI == 0) {      // the magnitude of the stored output, when asked for (g.bn_dy_absmax without BatchNorm sums)
+        if (g.bn_dy_absmax) gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
       if constexpr (EPI == 2) {
         const float xv[4] = {xq[b][p].x, xq[b][p].y, xq[b][p].z, xq[b][p].w};
 #pragma unroll
@@ -225,6 +228,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
     }
     gmx_all = fmaxf(gmx_all, gmx);
   }
+  if constexpr (EPI == 0) gmx_all = fmaxf(gmx_all, gmx);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();        // the staging area / the exchange has been read: the next tile's images may land
 }
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     }
     wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
   }
-  if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+  if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
 #ifndef DSPN_HALF
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     }
     wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
   }
-  if constexpr (EPI == 2) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+  if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
 template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR>

@@ -864,13 +864,14 @@ __global__ __launch_bounds__(kT) void relu_bwd_colsum_partial_kernel(const CA4Pt
                                                                    const CA4Ptr dy,
                                                                    const A4Ptr dx, long long rows, int ld4,
                                                                    int CL, float *__restrict__ partial, int C,
-                                                                   int slab_rows) {
+                                                                   int slab_rows, unsigned *__restrict__ dx_absmax) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   const int RL = kT / CL;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int c4 = blockIdx.y * CL + cl;
   const long long r0 = (long long)blockIdx.x * slab_rows, r1 = min(rows, r0 + slab_rows);
   float4 s = make_float4(0, 0, 0, 0);
+  float mx = 0.f;
   if (rl < RL && c4 < ld4) {
 #pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += RL) {
@@ -880,7 +881,13 @@ __global__ __launch_bounds__(kT) void relu_bwd_colsum_partial_kernel(const CA4Pt
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
       dx[r * ld4 + c4] = g;
       s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
     }
+  }
+  if (dx_absmax) {     // (kernel-uniform) the magnitude block of dx as stored: one atomic per wave
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(dx_absmax + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u), __float_as_uint(mx));
   }
   sm4[threadIdx.x] = s;
   __syncthreads();
@@ -1925,9 +1932,11 @@ int DSPN_FN(dspn_relu_backward)(const st_t *y, const st_t *dy, st_t *dx, long lo
   return dspn::check_launch("relu_backward");
 }
 
-/* dx = (y > 0) ? dy : 0 (dx may alias dy) and out[c] = sum over rows of dx[:, c], c < C, in one pass */
+/* dx = (y > 0) ? dy : 0 (dx may alias dy) and out[c] = sum over rows of dx[:, c], c < C, in one pass; dx_absmax (float tensors,
+ * optional): the magnitude block of dx as stored (max into a block the caller zeroed) */
 int DSPN_FN(dspn_relu_backward_colsum)(const st_t *y, const st_t *dy, st_t *dx, long long rows, int C, int ld, float *out,
-                                  void *workspace, size_t workspace_bytes, void *stream) {
+                                  float *dx_absmax, void *workspace, size_t workspace_bytes, void *stream) {
+  DSPN_REQUIRE(!dx_absmax || !dspn::kHalf, "relu_backward_colsum: dx_absmax is for float tensors");
   DSPN_REQUIRE(y && dy && dx && out && workspace && rows > 0 && C > 0 && ld >= C && ld % 4 == 0,
                "relu_backward_colsum: bad argument");
   const int sr = colsum_slab_rows(rows);
@@ -1938,7 +1947,7 @@ int DSPN_FN(dspn_relu_backward_colsum)(const st_t *y, const st_t *dy, st_t *dx, 
   float *partial = static_cast<float *>(workspace);
   hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(ns, (ld4 + CL - 1) / CL), dim3(kT), sizeof(float4) * kT,
                      S_(stream), CA4Ptr(y), CA4Ptr(dy),
-                     A4Ptr(dx), rows, ld4, CL, partial, C, sr);
+                     A4Ptr(dx), rows, ld4, CL, partial, C, sr, reinterpret_cast<unsigned *>(dx_absmax));
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), partial, ns, C, out);
   return dspn::check_launch("relu_backward_colsum");
 }

@@ -163,6 +163,7 @@ class Graph:
         self.scalars = None
         self.am_table = None       # descriptor table of the weight magnitudes (one launch per step)
         self._am_x = {}            # (id of the raw input tensor, id of its affine scale) -> slot shared by its readers
+        self._am_wanted = set()    # magnitude slots some two-piece convolution will read off its input tensor (want_magnitude)
         self._am_done = set()      # slots already computed in the current step
         self._am_bwd_slots, self._am_bwd_ran = set(), False
         self._am_table_slots = set()   # weight magnitudes taken by the one batched launch at the top of forward()
@@ -207,6 +208,14 @@ class Graph:
 
     def scalar(self, i):
         return None if (i is None or self.scalars is None) else self.scalars[i * fn.ABSMAX_SLOTS:(i + 1) * fn.ABSMAX_SLOTS]
+
+    def want_magnitude(self, t):
+        """a two-piece convolution will multiply tensor t as it is: whoever produces it (or what it was pooled from) is asked
+        to leave its magnitude block (Conv._out_magnitude) -- nobody takes one for tensors no convolution reads"""
+        while t is not None:
+            if t.am_slot is not None:
+                self._am_wanted.add(t.am_slot)
+            t = t.alias_of
 
     def magnitude(self, slot, tensor, src=None):
         """"f16x2" math: the magnitude block of `tensor` in slot `slot` (a node-owned index from new_scalar), taken by a pass
@@ -1026,6 +1035,16 @@ class BatchNorm(Node):
                        accumulate=acc, dx_absmax=am)
 
 
+# round 5: convolutions no BatchNorm reads leave the magnitude of their output (forward epilogue) and of their masked gradient
+# (the ReLU-backward / bias-gradient pass) as by-products; DSPN_CONV_MAGNITUDES=0 keeps the stand-alone passes (same-box A/B)
+FUSE_CONV_MAGNITUDES = _os.environ.get("DSPN_CONV_MAGNITUDES", "1") != "0"
+
+
+def xa_unavailable(conv):
+    """the output-magnitude epilogue needs a dense output of whole float4 rows (every Conv output of the engine is one)"""
+    return conv.out.data is None or conv.out.data.shape[-1] % 4 != 0
+
+
 class Conv(Node):
     """mx.sym.Convolution (+ bias) (+ ReLU epilogue); weight [Cout, R, S, Cin_phys]"""
 
@@ -1087,6 +1106,13 @@ class Conv(Node):
             if key not in g._am_x:
                 g._am_x[key] = g.new_scalar()
             self.am_x, self.am_dy, self.am_w = g._am_x[key], g.new_scalar(backward=True), g.new_scalar()
+        # ... and of the OUTPUT as stored, where no BatchNorm reads it (no statistics epilogue: vgg16_reduced, the SSD extra layers):
+        # the convolution's own epilogue leaves it (fn.conv2d_forward out_absmax), the next convolution needs no pass over the tensor
+        self.am_out = g.new_scalar() if (self.am_x is not None and not tap_expand) else None
+        if self.am_out is not None:
+            self.out.am_slot = self.am_out       # (pooled / aliased tensors built on it inherit the slot)
+        if self.am_x is not None and self.in_affine is None:
+            g.want_magnitude(self.x_raw)         # the producer of this input leaves its magnitude if it can
         self.x_planes_bn = None      # the deferred BatchNorm that also leaves this node's input as piece planes (Graph._plan_input_planes)
         self.guard_fb = False        # range guard (Graph._update_guard): this pass's calls run in the three-piece bf16 math
         self.wp = self.wtp = None
@@ -1174,12 +1200,25 @@ class Conv(Node):
         if self.guard_fb:
             return self._forward_fallback()
         xp = self._x_planes()
+        oa = self._out_magnitude()
         fn.conv2d_forward(self.x_raw.data if xp is None else xp, self.wop(), None if self.b is None else self.b.data, self.stride,
                           self.pad, self.dil, relu=self.relu, out=self.out.data,
                           residual=None if self.residual is None else self.residual.data,
                           in_affine=self.in_affine if xp is None else None,
                           out_stats=None if self.out_stats is None else self.out_stats[0], w_planes=self.wp,
-                          math=self.math, x_absmax=xa, w_absmax=wa, out_minmax=self.out_minmax, x_planes=xp is not None)
+                          math=self.math, x_absmax=xa, w_absmax=wa, out_minmax=self.out_minmax, x_planes=xp is not None,
+                          out_absmax=oa)
+        if oa is not None:
+            self._g._am_done.add(self.am_out)
+
+    def _out_magnitude(self):
+        """the magnitude block this call's epilogue fills (None where a BatchNorm takes statistics -- its finalize hands the
+        magnitude on -- or the math is not "f16x2")"""
+        g = self._g
+        if (not FUSE_CONV_MAGNITUDES or self.am_out is None or g.scalars is None or self.out_stats is not None
+                or self.am_out not in g._am_wanted or xa_unavailable(self)):
+            return None
+        return g.scalar(self.am_out)
 
     def _x_planes(self):
         """the input as piece planes, when the BatchNorm in front wrote them this step (cut by this node's x magnitude)"""
@@ -1205,6 +1244,10 @@ class Conv(Node):
                           w_planes=self._w3(False), math="bf16x3")
         if self.out_minmax is not None:
             fn.tile_minmax(self.out.data, self.out_stats[2], self.out_minmax)
+        oa = self._out_magnitude()
+        if oa is not None:
+            fn.absmax(self.out.data, out=oa)
+            self._g._am_done.add(self.am_out)
         self._g.guard["calls"] += 1
         self._g.guard["calls_total"] += 1
 
@@ -1214,7 +1257,14 @@ class Conv(Node):
         dy = self.out.grad
         planes = self.out.grad_planes            # fp16 piece planes from the BatchNorm behind this convolution (never with relu / bias / residual)
         if self.relu and self.b is not None:     # ReLU mask and bias gradient in one pass over dy
-            fn.relu_backward_colsum(self.out.data, dy, self.cout, dx=dy, out=self.b.grad)
+            # "f16x2" math: that pass also leaves the magnitude of the masked gradient, which both of its readers cut it by
+            dya0 = None
+            if (FUSE_CONV_MAGNITUDES and self.am_dy is not None and self._g.scalars is not None
+                    and self.am_dy not in self._g._am_done and dy.dtype == torch.float32):
+                dya0 = self._g.scalar(self.am_dy)
+            fn.relu_backward_colsum(self.out.data, dy, self.cout, dx=dy, out=self.b.grad, dx_absmax=dya0)
+            if dya0 is not None:
+                self._g._am_done.add(self.am_dy)
         elif self.relu:
             fn.relu_backward(self.out.data, dy, dx=dy)
         if self.residual is not None and self.residual.requires_grad:

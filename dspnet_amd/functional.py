@@ -66,7 +66,7 @@ _lib.register({
     "dspn_add_f32": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "dspn_relu_backward_f32": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "dspn_fill_f32": (_i, [_vp, _f, _ll, _vp]),
-    "dspn_relu_backward_colsum_f32": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
+    "dspn_relu_backward_colsum_f32": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dspn_colsum_workspace_bytes": (_sz, [_ll, _i]),
     "dspn_colsum_f32": (_i, [_vp, _ll, _i, _i, _vp, _vp, _sz, _vp]),
     "dspn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -410,18 +410,21 @@ def weight_planes_batch(table, n, total):
 
 def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, accumulate=False, residual=None,
                    in_affine=None, out_stats=None, w_planes=None, math=None, x_absmax=None, w_absmax=None,
-                   out_minmax=None, x_planes=False):
+                   out_minmax=None, x_planes=False, out_absmax=None):
     """x (N,H,W,Cin) ; w (Cout,R,S,Cin) -> (N,Ho,Wo,ldc) with ldc = out.shape[3] if out is given else pad4(Cout).
     in_affine = (scale (Cin,), shift (Cin,), relu): convolve (relu)(x * scale + shift) instead of x.
     math: "fp32" / "bf16" / "bf16x3" / "f16x2" (default: set_conv_math's).  w_planes: weight_planes(w), used in the split
     math modes when Cin % 32 == 0 (made here, one extra launch, when the caller keeps none).
-    x_planes: x holds the fp16 piece planes bn_apply_planes wrote (cut by x_absmax), "f16x2" only."""
+    x_planes: x holds the fp16 piece planes bn_apply_planes wrote (cut by x_absmax), "f16x2" only.
+    out_absmax ("f16x2", float tensors, no out_stats, dense output): a 64-float magnitude block that receives the partial
+    maxima of |out| as stored (not zeroed here) -- the x_absmax of the next convolution without a pass over out."""
     N, H, W, Cin = x.shape
     Cout, R, S, Cw = w.shape
     assert Cw == Cin, (w.shape, x.shape)
     math = _math_code(math)
     assert not x_planes or (math == 3 and x.dtype == torch.float32 and x_absmax is not None and in_affine is None)
     assert out_minmax is None or (out_stats is not None and out_minmax.numel() == out_stats.numel())
+    assert out_absmax is None or (out_stats is None and math == 3 and x.dtype == torch.float32 and out_absmax.numel() == ABSMAX_SLOTS)
     if math == 3 and x.dtype == torch.float32:     # "f16x2": operand magnitudes (made here when the caller keeps none)
         assert w_planes is None or w_absmax is not None, "f16x2 planes come with the magnitude block they were cut by"
         x_absmax = absmax(x, in_affine) if x_absmax is None else x_absmax
@@ -447,7 +450,8 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, out=None
                                          ptr(residual), ptr(out),
                                          N, H, W, Cin, Cout, R, S, stride, ph, pw, dil, Ho, Wo, 0, ldc, int(relu),
                                          int(accumulate), ptr(out_stats), 0 if out_stats is None else out_stats.numel() * 4,
-                                         ptr(out_minmax), math | (MATH_X_PLANES if x_planes else 0), ptr(x_absmax),
+                                         ptr(out_minmax if out_absmax is None else out_absmax),      # (without out_stats: the magnitude block)
+                                         math | (MATH_X_PLANES if x_planes else 0), ptr(x_absmax),
                                          ptr(w_absmax), ptr(ws), ws.numel(), stream()),
           "conv2d_forward")
     return out
@@ -779,16 +783,18 @@ def relu_backward(y, dy, dx=None, accumulate=False):
     return dx
 
 
-def relu_backward_colsum(y, dy, C, dx=None, out=None):
-    """dx = (y > 0) * dy (in place by default) and the column sums of dx over all rows, in one pass"""
+def relu_backward_colsum(y, dy, C, dx=None, out=None, dx_absmax=None):
+    """dx = (y > 0) * dy (in place by default) and the column sums of dx over all rows, in one pass; dx_absmax (float
+    tensors): a 64-float magnitude block that receives the partial maxima of |dx| (not zeroed here)"""
     dx = dy if dx is None else dx
     ld = y.shape[-1]
     rows = _rows(y)
     out = empty(C, device=y.device) if out is None else out
     ws = workspace(L().dspn_colsum_workspace_bytes(rows, C), y.device, "colsum")
     assert y.dtype == dy.dtype == dx.dtype
-    check(_f("dspn_relu_backward_colsum", y)(ptr(y), ptr(dy), ptr(dx), rows, C, ld, ptr(out), ptr(ws), ws.numel(), stream()),
-          "relu_backward_colsum")
+    assert dx_absmax is None or (y.dtype == torch.float32 and dx_absmax.numel() == ABSMAX_SLOTS)
+    check(_f("dspn_relu_backward_colsum", y)(ptr(y), ptr(dy), ptr(dx), rows, C, ld, ptr(out), ptr(dx_absmax), ptr(ws), ws.numel(),
+                                             stream()), "relu_backward_colsum")
     return dx, out
 
 

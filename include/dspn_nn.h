@@ -121,7 +121,11 @@ int dspn_conv2d_forward_bn_f32(const float *x, const float *in_scale, const floa
                                float *out_stats, size_t out_stats_bytes, float *out_minmax, int math,
                                const float *x_absmax, const float *w_absmax,
                                void *workspace, size_t workspace_bytes, void *stream);
-/* out_minmax (optional; written in DSPN_MATH_F32_F16X2 together with out_stats, SAME size and tiling -- the buffer must hold
+/* out_minmax WITHOUT out_stats (round 5, DSPN_MATH_F32_F16X2, float tensors, dense output with ldc % 4 == 0): the pointer is a
+ * DSPN_ABSMAX_SLOTS magnitude block that receives, by maximum, the partial maxima of |y| as stored -- dspn_absmax_f32(y) without its
+ * pass over y for the convolutions no BatchNorm reads (the wide family's epilogue takes it along; other kernels are followed by
+ * that pass inside the call).
+ * out_minmax (optional; written in DSPN_MATH_F32_F16X2 together with out_stats, SAME size and tiling -- the buffer must hold
  * out_stats_bytes bytes, the one size argument covers both tables): per row tile and
  * channel the smallest [(t*2 + 0)*Cout + c] and largest [(t*2 + 1)*Cout + c] stored value.  A BatchNorm(+ReLU) of y is
  * monotone per channel, so the magnitude of what the next convolution multiplies is dspn_absmax_f32 over THIS table
@@ -387,7 +391,8 @@ int dspn_relu_backward_f32(const float *y, const float *dy, float *dx, long long
  * dx = (y > 0) ? dy : 0 (dx may alias dy), out[c] = sum_rows dx[:, c] for c < C; rows of ld floats (ld % 4 == 0);
  * workspace: dspn_colsum_workspace_bytes(rows, C) */
 int dspn_relu_backward_colsum_f32(const float *y, const float *dy, float *dx, long long rows, int C, int ld,
-                                  float *out, void *workspace, size_t workspace_bytes, void *stream);
+                                  float *out, float *dx_absmax /* optional: the magnitude block of dx as stored (round 5) */,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 int dspn_fill_f32(float *p, float v, long long n, void *stream);
 /* per-column sum of a (rows, ld) matrix over its first C columns: out[c] = sum_r a[r, c] (bias grads) */
 size_t dspn_colsum_workspace_bytes(long long rows, int C);
@@ -590,7 +595,8 @@ int dspn_bn_backward_from_sums_bf16(const dspn_bf16 *x, const float *scale, cons
 int dspn_add_bf16(const dspn_bf16 *a, const dspn_bf16 *b, dspn_bf16 *out, long long n, void *stream);
 int dspn_relu_backward_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long n, int accumulate, void *stream);
 int dspn_relu_backward_colsum_bf16(const dspn_bf16 *y, const dspn_bf16 *dy, dspn_bf16 *dx, long long rows, int C, int ld,
-                                  float *out, void *workspace, size_t workspace_bytes, void *stream);
+                                  float *out, float *dx_absmax_unused /* must be NULL */, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 int dspn_colsum_bf16(const dspn_bf16 *a, long long rows, int C, int ld, float *out,
                     void *workspace, size_t workspace_bytes, void *stream);
 int dspn_nchw_to_nhwc_bf16(const float *src, dspn_bf16 *dst, int N, int C, int H, int W, int Cp, void *stream);

@@ -931,6 +931,11 @@ def test_relu_backward_colsum(gpu_device, rows, C, ld):
     assert float((out.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
     out2 = fn.colsum(ref_dx, C)
     assert float((out2.double() - ref_sum).abs().max()) <= 1e-5 * float(ref_sum.abs().max() + 1)
+    # round 5: the magnitude block of dx as a by-product of the same pass
+    block = torch.zeros(fn.ABSMAX_SLOTS, device="cuda")
+    dx3, out3 = fn.relu_backward_colsum(y, dy.clone(), C, out=torch.empty(C, device="cuda"), dx_absmax=block)
+    assert torch.equal(dx3, ref_dx) and torch.equal(out3, out)
+    assert float(block.max()) == float(ref_dx.abs().max()) == float(fn.absmax(ref_dx).max())
 
 
 # BASELINE.json's full sizes (batch 32 at 512x512): where the fp64 CPU reference of the cases above would take minutes,
@@ -1262,3 +1267,28 @@ def test_batched_weight_transposes_match_permute(gpu_device, half):
         assert torch.equal(wt, ref.to(dt))
         if half:
             assert torch.equal(wh, w.to(dt))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(4, 64, 64, 64, 128, 3, 1, 1, True),      # float A operand on the wide family (conv_ntv_kernel)
+                                  (4, 64, 64, 256, 64, 1, 1, 0, False),     # 64 output columns: the 256 x 64 tile
+                                  (2, 9, 9, 32, 24, 3, 2, 1, True),         # small: conv_nt_kernel, followed by the pass over out
+                                  (1, 5, 7, 8, 12, 3, 1, 1, False)])
+def test_conv_forward_leaves_the_magnitude_of_its_output(gpu_device, case):
+    """round 5: fn.conv2d_forward(out_absmax=block) -- a convolution no BatchNorm reads (vgg16_reduced, the SSD extra layers)
+    leaves the magnitude block of what it stored (after bias and ReLU), which is what fn.absmax(out) would give, so that the
+    next convolution of the two-piece math needs no pass over the tensor"""
+    N, H, W, Cin, Cout, k, stride, pad, relu = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case[:8]))
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    block = torch.zeros(fn.ABSMAX_SLOTS, device="cuda")
+    y = fn.conv2d_forward(x, w, b, stride=stride, pad=pad, dil=1, relu=relu, math="f16x2", out_absmax=block)
+    ref = fn.conv2d_forward(x, w, b, stride=stride, pad=pad, dil=1, relu=relu, math="f16x2")
+    assert torch.equal(y, ref)                                  # the epilogue that tracks the magnitude stores the same bits
+    assert float(block.max()) == float(y.abs().max()) > 0
+    assert float(fn.absmax(y).max()) == float(block.max())
+    # a second call accumulates by maximum (the caller zeroes the block once per step)
+    fn.conv2d_forward(0.5 * x, w, None, stride=stride, pad=pad, dil=1, relu=relu, math="f16x2", out_absmax=block)
+    assert float(block.max()) == float(y.abs().max())
