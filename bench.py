@@ -80,6 +80,9 @@ def parse():
                          "0 at N = 1; at N > 1 switched to 16 after warm-up iff the exposed all-reduce time exceeds 1 ms")
     ap.add_argument("--wide-tiles", type=int, default=0,
                     help="dspn_conv_set_wide_tiles: 0 automatic (default), 1 never (the round-4 128x128 kernels), 2 / 3 / 4 force a shape")
+    ap.add_argument("--sustained-steps", type=int, default=-1,
+                    help="further steps run AFTER the timed region for the `sustained` block of the line (0: skip; default: 200, "
+                         "or 0 for the short experiment runs that pass --no-other-configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -319,6 +322,59 @@ def math_accuracy_check(dev):
     return out
 
 
+class GpuSensors:
+    """engine clock (MHz) and board power (W) of one GPU from the amdgpu driver's sysfs files -- read directly (no child
+    process: a process that has initialised the GPU must not exec on this pool, and rocm-smi is a program).  Every field is
+    optional: a box that hides the files gives an empty summary."""
+
+    def __init__(self, index):
+        import glob
+        self.freq, self.power, self.dpm = None, None, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*"))]
+        if index >= len(cards):
+            return
+        dev = cards[index]
+        for h in sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*"))):
+            for name in ("freq1_input",):
+                if self.freq is None and os.path.exists(os.path.join(h, name)):
+                    self.freq = os.path.join(h, name)
+            for name in ("power1_average", "power1_input"):
+                if self.power is None and os.path.exists(os.path.join(h, name)):
+                    self.power = os.path.join(h, name)
+        if os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+            self.dpm = os.path.join(dev, "pp_dpm_sclk")
+
+    def read(self):
+        out = {}
+        try:
+            if self.freq:
+                out["sclk_mhz"] = int(open(self.freq).read()) / 1e6
+            elif self.dpm:
+                for l in open(self.dpm).read().splitlines():
+                    if l.rstrip().endswith("*"):
+                        out["sclk_mhz"] = float(l.split(":")[1].strip().lower().split("mhz")[0])
+        except (OSError, ValueError, IndexError):
+            pass
+        try:
+            if self.power:
+                out["power_w"] = int(open(self.power).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return out
+
+    @staticmethod
+    def summarise(samples):
+        out = {}
+        for key in ("sclk_mhz", "power_w"):
+            v = sorted(x[key] for x in samples if key in x)
+            if v:
+                out[key] = {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1), "samples": len(v)}
+        if not out:
+            out["sensors"] = "not readable from this process (sysfs clock / power files absent)"
+        return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run and
     pass their exit status on.  Runs BEFORE anything in this process touches the GPU (no torch.cuda call, no HIP
@@ -333,7 +389,37 @@ def spawn_ranks(args):
     env.setdefault("NCCL_DEBUG", "WARN")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the launcher and its ranks form a process group of their own: when a rank fails (the elastic agent then stops the
+    # others and exits non-zero) or this parent is interrupted, whatever is left of exactly THAT group is ended -- fresh
+    # children only, never a re-exec of a process that touched the GPU, never a kill by pattern
+    import signal
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait()
+    except BaseException:
+        rc = 1
+        raise
+    finally:
+        if rc != 0:
+            try:
+                os.killpg(child.pid, signal.SIGTERM)
+                time.sleep(2.0)
+                os.killpg(child.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank failed (torch.distributed.run exit status %d); no result line\n" % rc)
+    return rc if rc != 0 else 0
+
+
+def check_distinct_devices(dist, identity, rank, world):
+    """first-contact hygiene of an N > 1 run: every rank reports the device it sits on; N ranks must hold N DISTINCT devices
+    (two ranks on one GPU would still produce a plausible-looking line at half the throughput).  -> the list of identities"""
+    ids = [None] * world
+    dist.all_gather_object(ids, identity)
+    if len(set(ids)) != world:
+        sys.exit("bench.py: %d ranks but only %d distinct devices: %s" % (world, len(set(ids)), ids))
+    return ids
 
 
 def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, traffic=None, traffic_source=None):
@@ -472,6 +558,11 @@ def dry_run(args):
     line = {"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        # the distinct-device check of the real run, on pretended devices (LOCAL_RANK; DSPN_DRY_DEVICE pins every rank to one
+        # index: the failure the check exists for)
+        local = os.environ.get("DSPN_DRY_DEVICE", os.environ.get("LOCAL_RANK", str(rank)))
+        sys.stderr.write("[bench rank %d/%d] device %s (dry run), buckets n/a\n" % (rank, world, local))
+        check_distinct_devices(dist, "dry-device-" + local, rank, world)
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
         dist.barrier()
@@ -575,6 +666,17 @@ def main():
         sys.exit("bench.py: --wide-tiles %d rejected by the library (0 .. 4)" % args.wide_tiles)
     if solver.reducer is not None:
         solver.reducer.measure_exposed = True          # event records around the collective waits (and per bucket)
+    if use_dist:
+        # first contact with a multi-GPU node: who sits where, before any step (stderr; stdout carries the one JSON line)
+        props = torch.cuda.get_device_properties(local)
+        ident = "%s/%s" % (os.uname().nodename, getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or local)
+        sys.stderr.write("[bench rank %d/%d] cuda:%d %s (%s), %d gradient buckets of <= %.0f MB, reducer %s\n"
+                         % (rank, world, local, torch.cuda.get_device_name(local), ident, len(solver.buckets),
+                            max((hi - lo) * 4 / 2 ** 20 for lo, hi, _ in solver.buckets),
+                            "on" if solver.reducer is not None else "off"))
+        sys.stderr.flush()
+        assert dist.get_world_size() == world
+        check_distinct_devices(dist, ident, rank, world)
     for _ in range(args.warmup):
         solver.step()
     sync()
@@ -612,6 +714,34 @@ def main():
     exposed_ms = solver.reducer.exposed_ms() if solver.reducer is not None else None
     bucket_ms = solver.reducer.bucket_latency_ms() if solver.reducer is not None else None
     n_buckets = len(solver.buckets)
+    # OUTSIDE the timed region (never part of `value`): the same step for SUSTAINED_STEPS further steps -- the headline's K
+    # steps last under a second and say nothing about the clock the chip settles to -- with the engine clock and board power
+    # sampled from sysfs while they run, where the box lets this process read them
+    sustained = None
+    if args.sustained_steps < 0:
+        args.sustained_steps = 0 if args.no_other_configs else 200
+    if args.sustained_steps > 0:
+        if solver.reducer is not None:
+            solver.reducer.measure_exposed = False
+        sensors = GpuSensors(local)
+        samples = []
+        sync()
+        ts = time.perf_counter()
+        for i in range(args.sustained_steps):
+            solver.step()
+            if i % 25 == 24:
+                samples.append(sensors.read())
+        sync()
+        dts = time.perf_counter() - ts
+        tsus = torch.tensor([dts], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(tsus, op=dist.ReduceOp.MAX)
+        dts = float(tsus.item())
+        sustained = {"value": round(world * B * args.sustained_steps / dts, 2), "unit": "images/s", "steps": args.sustained_steps,
+                     "ms_per_step": round(dts / args.sustained_steps * 1e3, 3), "seconds": round(dts, 2),
+                     "note": "the same step, run for this many further steps after the timed region (not part of `value`)"}
+        sustained.update(GpuSensors.summarise(samples))
+    rerecorded = solver.graph_rerecorded
     range_rep = net.g.range_report()     # (one device -> host copy, after the timed region)
     dt_rank = dt
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -729,6 +859,11 @@ def main():
             line["dist_world_size"] = world_dist
             line["rccl_version"] = rccl_version
         line["reserved_cus"] = reserved
+        if sustained is not None:
+            line["sustained"] = sustained
+        if graphed:
+            line["config"]["hip_graph"] = {"replayed": True, "range_guard": "spans polled every %d replays; a changed decision "
+                                           "drops the recording (re-recorded %d times)" % (net.g.GUARD_PERIOD, rerecorded)}
         if args.math == "f16x2" and args.store == "fp32":
             # range monitor of the two-piece math (Graph.range_report): convolution inputs whose per-channel magnitudes were
             # seen by a BatchNorm finalize, how many of them span more than 2^16, and the widest span in bits

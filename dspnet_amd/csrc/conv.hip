@@ -2121,7 +2121,10 @@ static int conv2d_forward_one(int math, OpScales scales, const st_t *x, InAffine
   // the ResNet stem (7x7 / 2 on 4 physical channels -> 64, with BatchNorm statistics) has a kernel of its own (conv_stem.h)
   if (math == DSPN_MATH_F32_F16X2 && R == 7 && S == 7 && stride == 2 && pad_h == 3 && pad_w == 3 && dil == 1 && Cin == 4 &&
       Cout == 64 && !bias && !relu && !accumulate && !residual && !tf.scale && g.dense && g.ldc == Cout && scales.a && scales.b &&
-      !scales.a_planes && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      !scales.a_planes && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      // the stem kernel writes neither the magnitude block of a statistics-free call (out_absmax) nor any table but the
+      // 64-row one: both stay with the generic kernel (and its follow-up dspn_absmax_f32 pass)
+      !g.bn_dy_absmax && (!stats || kNtBm[nt_config((long long)N * Ho * Wo, Cout)] == 64)) {
     const int rc = dspn::conv::launch_stem(x, w, y, N, H, W, Cin, Cout, Ho, Wo, scales.a, scales.b, stats, g.minmax, (hipStream_t)stream);
     if (rc <= 0) return rc;
   }

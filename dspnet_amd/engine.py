@@ -266,35 +266,50 @@ class Graph:
         pass in the three-piece math.  The spans of the pass issued last are copied to pinned host memory behind it (no
         synchronisation); the decisions are taken from the copy made one pass EARLIER, which has long arrived -- the host
         runs ahead of the device and must not wait for it, and taking a fixed lag (not "whatever has arrived") keeps a run
-        reproducible.  blocking=True (MultiTaskSolver's calibration pass, tests): decide from the pass issued last."""
+        reproducible.  blocking=True (MultiTaskSolver's calibration pass, tests): decide from the pass issued last.
+        A forward() that is being RECORDED into a HIP graph cannot look at the device: it keeps the decisions it is recorded
+        with and takes the weights' minima every step; MultiTaskSolver polls guard_poll() between replays instead."""
         gd = self.guard
         gd["calls"] = 0
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            gd["wmin_now"] = True      # (the recorded launch sequence is the same every step: the minima are part of it)
+            return
         gd["count"] = gd.get("count", 0) + 1
         # the weights' per-channel minima cost a launch over every weight: taken in the pass BEFORE one whose spans are read
         gd["wmin_now"] = blocking or gd["count"] % self.GUARD_PERIOD == self.GUARD_PERIOD - 1 or not gd["have_stats"]
         if not gd["enabled"] or self.scalars is None or not gd["have_stats"]:
             return
-        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            return                     # (a recorded step cannot look at the device: it keeps the decisions it was recorded with)
         if not blocking and gd["count"] % self.GUARD_PERIOD != 0:
             return                     # spans move over many steps: looked at every GUARD_PERIOD-th pass (0.7 % of the step -> 0.2 %)
+        both = self._guard_fetch(blocking)
+        if both is not None:
+            self._guard_decide(both)
+
+    def _guard_fetch(self, blocking):
+        """the (largest, smallest) magnitudes per slot of the pass issued last: read now (blocking), or -- without waiting for
+        the device -- the copy requested one call EARLIER (None while there is none)"""
+        gd = self.guard
         if blocking:
             gd["queue"] = []
-            both = self._spans_device().cpu().numpy()
-        else:
-            pool = gd.setdefault("pinned", [torch.empty((2, self.scalars_min.numel()), dtype=torch.float32, pin_memory=True)
-                                            for _ in range(3)])       # (at most two copies are in flight)
-            host = pool[gd.get("pin_i", 0) % 3]
-            gd["pin_i"] = gd.get("pin_i", 0) + 1
-            host.copy_(self._spans_device(), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            gd.setdefault("queue", []).append((host, ev))
-            if len(gd["queue"]) < 2:
-                return
-            host, ev = gd["queue"].pop(0)
-            ev.synchronize()
-            both = host.numpy()
+            return self._spans_device().cpu().numpy()
+        pool = gd.setdefault("pinned", [torch.empty((2, self.scalars_min.numel()), dtype=torch.float32, pin_memory=True)
+                                        for _ in range(3)])       # (at most two copies are in flight)
+        host = pool[gd.get("pin_i", 0) % 3]
+        gd["pin_i"] = gd.get("pin_i", 0) + 1
+        host.copy_(self._spans_device(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        gd.setdefault("queue", []).append((host, ev))
+        if len(gd["queue"]) < 2:
+            return None
+        host, ev = gd["queue"].pop(0)
+        ev.synchronize()
+        return host.numpy()
+
+    def _guard_decide(self, both):
+        """-> True when the set of convolutions on the fallback changed"""
+        gd = self.guard
         mx, mn = both[0], both[1]
         ok = np.isfinite(mn) & (mn > 0) & (mx > 0)
         wide = np.zeros(mx.shape, bool)
@@ -306,11 +321,24 @@ class Graph:
                 if isinstance(n, Conv) and n.am_x is not None and not n.tap_expand:
                     if wide[n.am_x] or wide[n.am_w] or wide[n.am_dy]:
                         risk.add(id(n))
-        if risk != gd["risk"]:
-            gd["risk"] = frozenset(risk)
-            for n in self.nodes:
-                if isinstance(n, Conv):
-                    n.guard_fb = id(n) in risk
+        if risk == gd["risk"]:
+            return False
+        gd["risk"] = frozenset(risk)
+        for n in self.nodes:
+            if isinstance(n, Conv):
+                n.guard_fb = id(n) in risk
+        return True
+
+    def guard_poll(self, blocking=False):
+        """The guard of a RECORDED step (MultiTaskSolver.capture; advisor r5): called between two replays, on the stream they
+        run on.  Copies the spans of the replayed pass out behind it and decides from the copy of the previous poll
+        (blocking=True: from this pass).  -> True when the set of convolutions on the fallback changed: the recorded launch
+        sequence no longer is the step, the caller drops the graph and records a new one."""
+        gd = self.guard
+        if not gd["enabled"] or self.scalars is None or not gd["have_stats"]:
+            return False
+        both = self._guard_fetch(blocking)
+        return both is not None and self._guard_decide(both)
 
     def guard_report(self):
         """(convolutions on the fallback this pass, fallback kernel calls this pass, slots whose span exceeded 2^GUARD_BITS last pass)"""

@@ -138,6 +138,7 @@ class MultiTaskSolver:
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
         self._graph, self._graph_hyper = None, None
+        self._replays, self.graph_rerecorded = 0, 0     # replays of the recorded step / recordings dropped by the range guard
         g = self.g
         owner = {}
         for idx, n in enumerate(g.nodes):
@@ -208,17 +209,22 @@ class MultiTaskSolver:
         fn.sgd_momentum(g.arena, g.grad_arena, g.mom_arena, self.lr, self.momentum, self.wd,
                         1.0 / (self.batch_size * self.world_size))
 
-    def step(self):
+    def _on_step_stream(self, body):
+        """run body() on the solver's stream with ordinary stream semantics for the caller (behind the caller's current
+        stream on entry, the caller's stream behind it on exit)"""
         if self.stream is None:
-            return self._step()
+            return body()
         import torch
         cur = torch.cuda.current_stream(self.g.device)
         if cur == self.stream:
-            return self._step()
+            return body()
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            self._step()
+            body()
         cur.wait_stream(self.stream)
+
+    def step(self):
+        self._on_step_stream(self._step)
 
     def _calibrate_guard(self):
         """range guard of the "f16x2" math (engine.Graph._update_guard): the decisions of a pass come from the spans the previous
@@ -243,6 +249,13 @@ class MultiTaskSolver:
                     self.forward(); self.backward(); self.update()
                     return
             self._graph.replay()
+            # the range guard cannot act from inside a recorded step: every GUARD_PERIOD-th replay its spans are looked at from
+            # here, and a changed decision drops the recording (advisor r5)
+            self._replays += 1
+            if self._replays % self.g.GUARD_PERIOD == 0 and self.g.guard_poll():
+                self._graph = None
+                self.graph_rerecorded += 1
+                self.capture(warmup=0)
             return
         self.forward()
         self.backward()
@@ -258,8 +271,15 @@ class MultiTaskSolver:
         import torch
         if self.reducer is not None or self.g.device.type != "cuda" or self._graph is not None:
             return self._graph is not None
-        for _ in range(warmup):                   # first-use work (function attributes, workspace growth) happens eagerly
-            self.step()
+        # the recording keeps the range guard's decisions it is made with: they come from a calibration pass (a graph
+        # recorded before any step would otherwise never be calibrated) and are settled BEFORE the recording starts
+        def settle():
+            self._calibrate_guard()
+            for _ in range(warmup):               # first-use work (function attributes, workspace growth) happens eagerly
+                self._step()
+            if self.g.guard.pop("decide_now", False):
+                self.g.guard_poll(blocking=True)
+        self._on_step_stream(settle)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         det = getattr(self.net, "det", None)

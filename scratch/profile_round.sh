@@ -7,7 +7,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-COMMON="--no-cpu-baseline --no-other-configs"
+COMMON="--no-cpu-baseline --no-other-configs --sustained-steps 0"
 # f16x2 = the default math (fp32 results from two fp16 pieces, DSPN_MATH_F32_F16X2), x3 = three bf16 pieces (round 2's default),
 # fp32 = fp32 MFMA, bf16 = bf16 tensors in HBM
 for MODE in f16x2 x3 fp32 bf16; do

@@ -64,3 +64,18 @@ def test_failing_rank_fails_the_parent():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     assert r.returncode != 0
     assert _json_lines(r.stdout) == []
+
+
+def test_two_ranks_on_one_device_is_an_error():
+    """N ranks must hold N distinct devices.  Under the gloo dry run every rank reports LOCAL_RANK as its
+    device; DSPN_DRY_DEVICE=0 makes both claim device 0 -- the parent exits non-zero, no result line, the reason on stderr"""
+    r = _run("--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", env={"DSPN_DRY_DEVICE": "0"})
+    assert r.returncode != 0
+    assert _json_lines(r.stdout) == []
+    assert "distinct devices" in r.stderr and "a rank failed" in r.stderr
+
+
+def test_ranks_report_their_device_before_the_first_step():
+    r = _run("--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[bench rank 0/2] device 0" in r.stderr and "[bench rank 1/2] device 1" in r.stderr

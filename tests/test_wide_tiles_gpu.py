@@ -217,6 +217,27 @@ def test_stem_convolution_kernel_matches_the_generic_one(tiles, shape):
     assert float((st - out[1][1]).abs().max()) <= 1e-4 * float(out[1][1].abs().max())
 
 
+def test_stem_shape_without_statistics_still_fills_the_magnitude_block(tiles):
+    """Advisor r5: a 7x7 / 2, 4 -> 64 channel convolution called WITHOUT out_stats but WITH out_absmax (an engine stem with no
+    BatchNorm behind it) must not take the stem kernel's shortcut, which writes no magnitude block: the block has to hold the
+    largest |y| as stored, exactly as the generic path leaves it (a zero block makes the next convolution cut its operand with
+    scale 1)."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 128, 512, 4, generator=g).cuda() * 40
+    x[..., 3] = 0
+    w = (torch.randn(64, 7, 7, 4, generator=g) / 3).cuda()
+    w[..., 3] = 0
+    xa, wa = fn.absmax(x), fn.absmax(w)
+    blocks = {}
+    for mode in (1, 0):
+        tiles(mode)
+        am = torch.zeros(fn.ABSMAX_SLOTS, device="cuda")
+        y = fn.conv2d_forward(x, w, None, 2, 3, 1, x_absmax=xa, w_absmax=wa, out_absmax=am)
+        assert float(am.max()) == float(y.abs().max()) > 0, mode
+        blocks[mode] = (y, am)
+    assert torch.equal(blocks[0][0], blocks[1][0])
+
+
 BF_CASES = [(4, 32, 32, 64, 128, 3, 1), (8, 32, 32, 128, 256, 3, 1), (4, 33, 31, 64, 192, 3, 2), (8, 64, 64, 64, 256, 1, 1),
             (8, 64, 64, 128, 64, 3, 1), (16, 32, 32, 256, 128, 1, 1)]
 
