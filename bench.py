@@ -330,11 +330,20 @@ class GpuSensors:
     def __init__(self, index):
         import glob
         self.freq, self.power, self.dpm = None, None, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*"))]
-        if index >= len(cards):
+        # the sysfs node of THIS device: matched by PCI address (a box shows every GPU of the node under /sys/class/drm, the
+        # process sees one of them as cuda:0)
+        self.pci = None
+        try:
+            buf = ctypes.create_string_buffer(64)
+            if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                self.pci = buf.value.decode().lower()
+        except OSError:
+            pass
+        cards = [c for c in glob.glob("/sys/class/drm/card[0-9]*/device")
+                 if self.pci and os.path.basename(os.path.realpath(c)).lower() == self.pci]
+        if not cards:
             return
-        dev = cards[index]
+        dev = cards[0]
         for h in sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*"))):
             for name in ("freq1_input",):
                 if self.freq is None and os.path.exists(os.path.join(h, name)):
@@ -371,7 +380,7 @@ class GpuSensors:
             if v:
                 out[key] = {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1), "samples": len(v)}
         if not out:
-            out["sensors"] = "not readable from this process (sysfs clock / power files absent)"
+            out["sensors"] = "not readable from this process (no sysfs clock / power files for this device's PCI address)"
         return out
 
 
@@ -741,6 +750,8 @@ def main():
                      "ms_per_step": round(dts / args.sustained_steps * 1e3, 3), "seconds": round(dts, 2),
                      "note": "the same step, run for this many further steps after the timed region (not part of `value`)"}
         sustained.update(GpuSensors.summarise(samples))
+        if sensors.pci and ("sclk_mhz" in sustained or "power_w" in sustained):
+            sustained["sensor_device"] = sensors.pci
     rerecorded = solver.graph_rerecorded
     range_rep = net.g.range_report()     # (one device -> host copy, after the timed region)
     dt_rank = dt

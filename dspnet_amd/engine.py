@@ -605,7 +605,7 @@ class Graph:
         resnet-101: the decoder reads an SSD extra layer's output, symbol/multitask_symbol_builder.py `conv_feat`) cannot
         silently become a race:
         * forward: a main-stream node behind the segment that holds a tensor written inside it waits for an event recorded
-          behind the LAST in-segment node that writes (or, failing that, first holds) that tensor -- not for the whole branch;
+          behind the LAST in-segment node that writes (or, failing that, last holds) that tensor -- not for the whole branch;
         * backward: a node leaves the side set if it shares a tensor with a main-stream node that runs between the fork and
           itself (the decoder writes that tensor's gradient on the main stream while the side stream, which only waits for
           the fork event, would read or accumulate into it), repeated until nothing changes."""
@@ -629,7 +629,9 @@ class Graph:
             if not inside or not outside or tid in before:
                 continue
             writers = [i for i in inside if any(id(t) == tid for t in self._node_outputs(self.nodes[i]))]
-            src = max(writers) if writers else min(inside)
+            # no declared writer (a node type whose output attribute _node_outputs does not know): behind the LAST in-segment
+            # holder, which is safe whichever of them writes
+            src = max(writers) if writers else max(inside)
             if src not in self.side_fwd_events:
                 self.side_fwd_events[src] = torch.cuda.Event() if cuda else None
             for r in outside:

@@ -138,6 +138,8 @@ class MultiTaskSolver:
         self.world_size, self.pg = world_size, process_group
         self.batch_size = net.data.shape[0]
         self._graph, self._graph_hyper = None, None
+        self._ran_eager = False                         # has forward / backward of this solver run outside a recording?
+        self._rerecord = False
         self._replays, self.graph_rerecorded = 0, 0     # replays of the recorded step / recordings dropped by the range guard
         g = self.g
         owner = {}
@@ -253,13 +255,19 @@ class MultiTaskSolver:
             # here, and a changed decision drops the recording (advisor r5)
             self._replays += 1
             if self._replays % self.g.GUARD_PERIOD == 0 and self.g.guard_poll():
+                # the convolutions that changed sides run kernels this process may never have launched: the next step runs
+                # eagerly (first-use work outside a recording), the recording is made behind it
                 self._graph = None
                 self.graph_rerecorded += 1
-                self.capture(warmup=0)
+                self._rerecord = True
             return
         self.forward()
         self.backward()
         self.update()
+        self._ran_eager = True
+        if self._rerecord:
+            self._rerecord = False
+            self.capture(warmup=0)
 
     def capture(self, warmup=2):
         """Record one whole step (forward, backward, update: ~700 .. 1100 kernel launches issued from Python through
@@ -277,6 +285,11 @@ class MultiTaskSolver:
             self._calibrate_guard()
             for _ in range(warmup):               # first-use work (function attributes, workspace growth) happens eagerly
                 self._step()
+            if not self._ran_eager:
+                # ... and so does the first use of THIS class's backward (the per-bucket tables of the slab sums are built and
+                # uploaded on first use: inside a recording that is a host copy of a temporary): one pass without an update
+                self.forward(); self.backward()
+                self._ran_eager = True
             if self.g.guard.pop("decide_now", False):
                 self.g.guard_poll(blocking=True)
         self._on_step_stream(settle)
