@@ -1,6 +1,7 @@
 // Library-wide C ABI helpers (error string, version).
 #include "dspn_common.h"
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "../../include/dspn_multibox.h"
@@ -50,6 +51,9 @@ static std::atomic<int> g_reserved_cus{0};
 int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
 static std::atomic<int> g_wide_tiles{0};
 int wide_tiles_mode() { return g_wide_tiles.load(std::memory_order_relaxed); }
+// round 6: the tile-spanning loop of the short-K members of the wide family (conv_wide.h, XT); DSPN_XT=0 starts with it off
+static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+int tile_spanning() { return g_tile_spanning.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
 extern "C" {
@@ -78,6 +82,11 @@ int dspn_conv_set_reserved_cus(int cus) {
 int dspn_conv_set_wide_tiles(int mode) {
   if (mode < 0 || mode > 4) return dspn::fail(DSPN_ERR_ARG_, "conv_set_wide_tiles: 0 automatic, 1 never, 2 256x128, 3 128x256, 4 128x128, got %d", mode);
   dspn::g_wide_tiles.store(mode);
+  return 0;
+}
+int dspn_conv_set_tile_spanning(int on) {
+  if (on != 0 && on != 1) return dspn::fail(DSPN_ERR_ARG_, "conv_set_tile_spanning: 0 or 1, got %d", on);
+  dspn::g_tile_spanning.store(on);
   return 0;
 }
 const char *dspn_last_error(void) { return dspn::last_error_buf(); }

@@ -24,13 +24,49 @@
 // (template parameter SR): a 256-row tile writes two (four) rows of g.stats / g.minmax / g.bn_sums, so
 // dspn_conv2d_stats_layout / dspn_conv2d_dgrad_bn_tiles and every consumer are untouched by the routing.
 
+// Phase stamps (scratch/r06/xt_bench.hip builds with -DDSPN_STAMPS; compiled out of the library): wave 0 of every workgroup
+// adds the shader-clock time between consecutive DSPN_STAMP(i) points into g_wide_stamps[workgroup][i].  A stamp waits for the
+// scalar read of the clock (lgkmcnt(0): the wave's LDS operations as well), not for vector memory.
+#ifdef DSPN_STAMPS
+__device__ unsigned long long g_wide_stamps[1024 * 16];
+struct WideStamps {
+  unsigned long long last, sum[16];
+  __device__ __forceinline__ void begin() { for (int i = 0; i < 16; ++i) sum[i] = 0; last = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int i) { const unsigned long long t = __builtin_readcyclecounter(); sum[i] += t - last; last = t; }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0 && blockIdx.x < 1024) for (int i = 0; i < 16; ++i) g_wide_stamps[blockIdx.x * 16 + i] = sum[i];
+  }
+};
+#define DSPN_STAMP_DECL WideStamps stamps_; stamps_.begin()
+#define DSPN_STAMP(i) stamps_.mark(i)
+#define DSPN_STAMP_FLUSH stamps_.flush()
+#define DSPN_STAMP_ARG , stamps_
+#define DSPN_STAMP_PARAM , WideStamps &stamps_
+#else
+#define DSPN_STAMP_DECL
+#define DSPN_STAMP(i)
+#define DSPN_STAMP_FLUSH
+#define DSPN_STAMP_ARG
+#define DSPN_STAMP_PARAM
+#endif
+
+// dspn_conv_set_tile_spanning / DSPN_XT=0: the tile-spanning loop off (tests, same-box A/B runs; the results do not depend on it)
+inline bool xt_enabled() { return dspn::tile_spanning() != 0; }
+// ... whose direct epilogue addresses the output (and the tensors of its shape) as one buffer of M rows of ldc elements
+inline bool xt_output_ok(const ConvGeom &g) {
+  const long long M = (long long)g.N * g.Hg * g.Wg;
+  return g.dense && (g.flags & 16) && M % 128 == 0 && M * g.ldc * (long long)sizeof(st_t) < (1ll << 31);
+}
+
 // The tile epilogue of the wide family, from the staged fp32 tile in LDS (st[row * (BN + 4) + col], written by the caller, which
 // has NOT yet met the barrier that publishes it) to the stored outputs and BatchNorm tables; ends with the barrier after which
 // the LDS may be overwritten.  conv_nt_kernel's epilogue per 128-row half: same arithmetic, same tables.
+struct NoStage {};
 template <int BM, int BN, int NTHR, int EPI, int SR>
 __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, const int m0, const int n0, const int M, const int tid,
                                               const float *__restrict__ bias, st_t *__restrict__ out,
-                                              const st_t *__restrict__ residual, float &gmx_all) {
+                                              const st_t *__restrict__ residual, float &gmx_all, NoStage
+                                              DSPN_STAMP_PARAM) {
   constexpr int HALVES = BM / SR;          // statistics tiles (SR rows: 128, or 64 for the Cout <= 64 layers) per output tile
   static_assert(BM % SR == 0, "whole statistics tiles");
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
@@ -100,6 +136,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
   issue(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  DSPN_STAMP(4);       // staged tile published
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int h = c / CPH, ch = c % CPH, b = c & 1;              // (compile-time after unrolling)
@@ -149,6 +186,7 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
       }
     }
   }
+  DSPN_STAMP(5);       // rows read, stores issued
   if constexpr (EPI == 1) {
     // per-thread (mean, M2) of its rows of each half -> LDS -> one thread per (half, column) merges the RPP row groups with
     // Chan's update in a fixed order -> stats[128-row tile][mean | M2][column]; the extremes (g.minmax) travel with them
@@ -231,7 +269,234 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
   if constexpr (EPI == 0) gmx_all = fmaxf(gmx_all, gmx);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();        // the staging area / the exchange has been read: the next tile's images may land
+  DSPN_STAMP(6);       // tables written, closing barrier
 }
+
+#ifndef DSPN_HALF
+// ---- round 6: the DIRECT epilogue of the tile-spanning loops (XT) -- from the accumulators as they stand to memory, no staging
+// in LDS, so the ring keeps receiving the next tile's images while this runs and nothing but a 4-KiB exchange of per-column
+// partial sums is shared between the waves (one barrier per tile where the staged epilogue meets three or four).
+// C/D layout of a 32 x 32 block: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one register of a block is two
+// 128-byte row segments per wave instruction -- the shape MI355X_MICROARCH.md measures at the full store rate.  Dense outputs
+// only (row m at m ldc) and whole row tiles (M % 128 == 0: the host routes nothing else here); columns past Cout are
+// out-of-range buffer offsets: the hardware drops their stores and returns zeros for their loads, so every wave issues the same
+// instructions (the counted waits of the k-loops rely on that).
+// Arithmetic per element as wide_epilogue's (same order of the bias / residual / accumulate additions: the stored values are
+// the same bits); the per-column reductions run over a lane's 32 rows, then over the four (wave row, half-wave) partials in a
+// fixed order -- another summation order than the staged epilogue's, i.e. tables equal within rounding, deterministic.
+template <int WAVES_M, int WAVES_N, int EPI, int RB = 16>       // RB: rows of a 32 x 32 block whose operand rows are in flight together
+__device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f32x16 (&acc)[2][2], const float inv_a, const float inv_b, const int m0,
+                                                const int n0, const int M, const int tid, const int wave,
+                                                const float *__restrict__ bias, float *__restrict__ out,
+                                                const float *__restrict__ residual, float &gmx_all) {
+  constexpr int TM = 2, TN = 2, BN = WAVES_N * 64, NTHR = WAVES_M * WAVES_N * 64, PARTS = WAVES_M * 2;
+  const int lane = tid & 63, half = lane >> 5, lc = lane & 31;
+  const int wr = wave / WAVES_N, wm = wr * 64, wn = (wave % WAVES_N) * 64;
+  const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
+  const float *addsrc = has_res ? residual : (accum ? out : nullptr);
+  const unsigned obytes = (unsigned)M * (unsigned)g.ldc * 4u;       // (the host checks M ldc 4 < 2^31)
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(addsrc ? addsrc : out), 0, addsrc ? obytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(EPI == 2 ? g.bn_x : out), 0, EPI == 2 ? obytes : 0u, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  constexpr float kInf = __builtin_huge_valf();
+  int col[TN];
+  unsigned cbyte[TN];
+  bool cv[TN];
+  float bv[TN], bsc[TN], bsh[TN], bmu[TN], brs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    col[j] = n0 + wn + j * 32 + lc;
+    cv[j] = col[j] < g.Cout;
+    cbyte[j] = cv[j] ? (unsigned)col[j] * 4u : kOOB;
+    bv[j] = (has_bias && cv[j]) ? bias[col[j]] : 0.f;
+    bsc[j] = bsh[j] = bmu[j] = brs[j] = 0.f;
+    if (EPI == 2 && cv[j]) {
+      bmu[j] = g.bn_mean[col[j]]; brs[j] = g.bn_rstd[col[j]];
+      if (g.bn_relu) { bsc[j] = g.bn_scale[col[j]]; bsh[j] = g.bn_shift[col[j]]; }
+    }
+  }
+  const int row0 = m0 + wm + 4 * half;                       // row of (i, r): row0 + 32 i + (r & 3) + 8 (r >> 2)
+  const unsigned pitch = (unsigned)g.ldc * 4u;
+  // per-column partials of this lane
+  float sK[TN], s1[TN], s2[TN], vmn[TN], vmx[TN], gs[TN], gss[TN];
+  int scnt = 0;
+  float gmx = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { sK[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; vmn[j] = kInf; vmx[j] = -kInf; gs[j] = 0.f; gss[j] = 0.f; }
+  const bool both = has_res && accum;
+  if constexpr (EPI == 2) {
+    // (one row at a time: the packed form below needs register pairs for the BatchNorm-input rows as well, which 256 registers
+    // do not hold beside the accumulators and the next tile's rows)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += RB) {
+        float rq[RB][TN], xq[RB][TN], oq[RB][TN];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+          const int r = r0 + rr;
+          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const unsigned off = rb + cbyte[j];
+            rq[rr][j] = addsrc ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)) : 0.f;
+            xq[rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+            oq[rr][j] = both ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)) : 0.f;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+          const int r = r0 + rr;
+          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][r] * inv_a * inv_b + bv[j];
+            v += rq[rr][j];
+            if (both) v += oq[rr][j];
+            if (relu) v = v > 0.f ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, (int)(rb + cbyte[j]), 0, 0);
+            const float xv = xq[rr][j];
+            const float gd = (!g.bn_relu || fmaf(xv, bsc[j], bsh[j]) > 0.f) ? v : 0.f;
+            gs[j] += gd;
+            gss[j] += gd * ((xv - bmu[j]) * brs[j]);
+            gmx = fmaxf(gmx, fabsf(v));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = cv[j] ? gs[j] : 0.f; gss[j] = cv[j] ? gss[j] : 0.f; }
+  } else {
+    // every row of the tile exists (the host routes M % 128 == 0 here): no row tests, and the element arithmetic on PAIRS of rows
+    // (r, r + 1: neighbouring accumulator registers) so that the scaling, the additions and the running sums are packed fp32
+    // instructions -- the epilogue's vector arithmetic is of the order of its store time on the short-K layers
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s1p[TN], s2p[TN], gsp[TN], gssp[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { s1p[j] = f32x2{0.f, 0.f}; s2p[j] = f32x2{0.f, 0.f}; gsp[j] = f32x2{0.f, 0.f}; gssp[j] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += RB) {
+        f32x2 rq[RB / 2][TN], xq[EPI == 2 ? RB / 2 : 1][TN], oq[RB / 2][TN];
+#pragma unroll
+        for (int rr = 0; rr < RB; rr += 2) {
+          const int r = r0 + rr;
+          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const unsigned off = rb + cbyte[j];
+            rq[rr / 2][j] = f32x2{0.f, 0.f}; oq[rr / 2][j] = f32x2{0.f, 0.f};
+            if (addsrc) rq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)),
+                                             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(off + pitch), 0, 0))};
+            if constexpr (EPI == 2) xq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0)),
+                                                           __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(off + pitch), 0, 0))};
+            if (both) oq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)(off + pitch), 0, 0))};
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; rr += 2) {
+          const int r = r0 + rr;
+          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            f32x2 t = f32x2{acc[i][j][r], acc[i][j][r + 1]} * inv_a * inv_b + bv[j];
+            t += rq[rr / 2][j];
+            // (the two conditional steps element by element: hipcc 7.2 drops the second element of a select on a two-float vector)
+            float v0 = t[0], v1 = t[1];
+            if (both) { v0 += oq[rr / 2][j][0]; v1 += oq[rr / 2][j][1]; }
+            if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_o, (int)(rb + cbyte[j]), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_o, (int)(rb + pitch + cbyte[j]), 0, 0);
+            const f32x2 v = f32x2{v0, v1};
+            if constexpr (EPI == 0) {
+              if (g.bn_dy_absmax) gmx = fmaxf(fmaxf(gmx, fabsf(v.x)), fabsf(v.y));
+            }
+            if constexpr (EPI == 2) {
+              const f32x2 xv = xq[rr / 2][j];
+              f32x2 gd = v;
+              if (g.bn_relu) gd = f32x2{fmaf(xv.x, bsc[j], bsh[j]) > 0.f ? v.x : 0.f, fmaf(xv.y, bsc[j], bsh[j]) > 0.f ? v.y : 0.f};
+              gsp[j] += gd;
+              gssp[j] += gd * ((xv - bmu[j]) * brs[j]);
+              gmx = fmaxf(fmaxf(gmx, fabsf(v.x)), fabsf(v.y));
+            }
+            if constexpr (EPI == 1) {
+              if (i == 0 && r == 0) sK[j] = v.x;
+              const f32x2 d = v - sK[j];
+              s1p[j] += d; s2p[j] += d * d;
+              vmn[j] = fminf(fminf(vmn[j], v.x), v.y); vmx[j] = fmaxf(fmaxf(vmx[j], v.x), v.y);
+            }
+          }
+        }
+      }
+    }
+    scnt = 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] = s1p[j].x + s1p[j].y; s2[j] = s2p[j].x + s2p[j].y;
+      gs[j] = cv[j] ? gsp[j].x + gsp[j].y : 0.f; gss[j] = cv[j] ? gssp[j].x + gssp[j].y : 0.f;
+    }
+  }
+  if constexpr (EPI == 0) gmx_all = fmaxf(gmx_all, gmx);
+  if constexpr (EPI == 2) gmx_all = fmaxf(gmx_all, gmx);
+  if constexpr (EPI != 0) {
+    // partial p = 2 (wave row) + half-wave of column c at red[(p * BN + c) * 4 ..]: EPI 1 (count, mean, M2) and, at red2, (min, max);
+    // EPI 2 (sum, sum x-hat).  The previous tile's exchange was read before the k-loop barriers every wave has passed since.
+    float *red = reinterpret_cast<float *>(exch);
+    float *red2 = red + PARTS * BN * 4;
+    const bool mmx = EPI == 1 && g.minmax != nullptr;
+    const int p = wr * 2 + half;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float *q = red + (p * BN + wn + j * 32 + lc) * 4;
+      if constexpr (EPI == 1) {
+        const float inv_n = scnt > 0 ? 1.f / (float)scnt : 0.f;
+        q[0] = (float)scnt; q[1] = sK[j] + s1[j] * inv_n; q[2] = s2[j] - s1[j] * s1[j] * inv_n;
+        if (mmx) { float *q2 = red2 + (p * BN + wn + j * 32 + lc) * 2; q2[0] = vmn[j]; q2[1] = vmx[j]; }
+      } else {
+        q[0] = gs[j]; q[1] = gss[j];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = tid; c < BN; c += NTHR) {
+      if (n0 + c >= g.Cout || m0 >= M) continue;
+      const long long mt_ = m0 / 128;
+      if constexpr (EPI == 1) {
+        // Chan's update over the partials in a fixed order (empty partials -- rows past M -- skipped)
+        float n = 0.f, mean = 0.f, m2 = 0.f, mn = kInf, mx = -kInf;
+#pragma unroll
+        for (int pp = 0; pp < PARTS; ++pp) {
+          const float *q = red + (pp * BN + c) * 4;
+          const float nb = q[0];
+          if (nb > 0.f) {
+            const float d = q[1] - mean, nn = n + nb;
+            mean += d * (nb / nn);
+            m2 += q[2] + d * d * (n * nb / nn);
+            n = nn;
+            if (mmx) { mn = fminf(mn, red2[(pp * BN + c) * 2]); mx = fmaxf(mx, red2[(pp * BN + c) * 2 + 1]); }
+          }
+        }
+        g.stats[(mt_ * 2 + 0) * g.Cout + n0 + c] = mean;
+        g.stats[(mt_ * 2 + 1) * g.Cout + n0 + c] = fmaxf(m2, 0.f);
+        if (mmx) {
+          g.minmax[(mt_ * 2 + 0) * g.Cout + n0 + c] = mn;
+          g.minmax[(mt_ * 2 + 1) * g.Cout + n0 + c] = mx;
+        }
+      } else {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < PARTS; ++pp) { a += red[(pp * BN + c) * 4]; b += red[(pp * BN + c) * 4 + 1]; }
+        const long long t_ = g.bn_tile_base + mt_;
+        g.bn_sums[(t_ * 2 + 0) * g.Cout + n0 + c] = a;
+        g.bn_sums[(t_ * 2 + 1) * g.Cout + n0 + c] = b;
+      }
+    }
+  }
+}
+#endif   // !DSPN_HALF
 
 // g.bn_dy_absmax: the largest |dx| this workgroup stored, over ALL its tiles -- one atomic per workgroup and launch
 template <int NWV>
@@ -252,7 +517,13 @@ __device__ __forceinline__ void wide_publish_absmax(const ConvGeom &g, char *wsm
     }
 }
 
-template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR = 128>
+// XT (round 6): the TILE-SPANNING loop for the short-K layers (1 x 1 convolutions of 2 .. 16 k-steps, where the epilogue is most
+// of the kernel and the first images of a tile used to be requested only after the previous tile's last store): two ring slots,
+// an even number of k-steps, so a tile's last k-step sits in slot 1; the request that the plain loop issues "past the last
+// k-step" (out of range, zeros) is here the LIVE request of the next tile's first k-step into slot 0, and the epilogue stages
+// its tile chunk by chunk in an area behind slot 0 (wide_epilogue) -- the next tile's rows are on their way while the current
+// tile is written out.  Same K order, same epilogue arithmetic: the bits of the plain loop.
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR = 128, bool XT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
     st_t *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -270,6 +541,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   constexpr int D = STAGES - 1;                          // k-steps in flight ahead of the one being multiplied
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   static_assert(BM % SR == 0, "BatchNorm tables are per SR rows");
+  static_assert(!XT || (STAGES == 2 && !kHalf), "the tile-spanning loop: two slots, float build");
   extern __shared__ __attribute__((aligned(1024))) char wsm[];
 
 #ifdef DSPN_ABLATE
@@ -446,12 +718,50 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
 
   float gmx_all = 0.f;       // EPI == 2: largest |dx| stored by this thread over all its tiles (g.bn_dy_absmax)
 
+  if constexpr (XT) {
+    // (the host routes an even nk >= 2 here)
+    int t = blockIdx.x;
+    if (t < ntiles) { setup_tile(t); issue(0, true); }
+    DSPN_STAMP_DECL;
+    for (; t < ntiles; t += gridDim.x) {
+      const int m0 = ld_m0, n0 = ld_n0;
+      const int tn = t + (int)gridDim.x;
+      zero_acc();
+      for (int kt = 0; kt < nk; ++kt) {
+        // slot kt & 1 has landed (this wave's pieces: the wait; the other waves': the barrier).  The images of a tile's FIRST
+        // k-step were requested before the previous tile's epilogue, whose 64 stores per wave (always issued: out-of-range
+        // lanes are dropped by the hardware) are younger: the counted wait does not ask for those to be acknowledged -- they
+        // have the whole k-step for that
+        if (kt == 0 && t != (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 == nk) {              // (wave-uniform) the next request is the NEXT tile's first k-step, into slot 0
+          const bool more = tn < ntiles;
+          if (more) setup_tile(tn);
+          issue_begin(0, more);
+        } else {
+          issue_begin((kt + 1) & 1, true);
+        }
+        mma_step(kt & 1);
+      }
+      DSPN_STAMP(2);
+      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 8 : 16)>(g, wsm + STAGES * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+      DSPN_STAMP(5);
+    }
+    DSPN_STAMP_FLUSH;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last, out-of-range request)
+    if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+    return;
+  }
+
+  DSPN_STAMP_DECL;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     setup_tile(t);
     const int m0 = ld_m0, n0 = ld_n0;
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(j, j < nk);
     zero_acc();
+    DSPN_STAMP(1);
     int slot = 0, islot = D % STAGES;
     for (int kt = 0; kt < nk; ++kt) {
       // the images of k-step kt have landed (this wave's pieces: the counted wait -- D - 1 k-steps stay in flight; the other
@@ -466,6 +776,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the out-of-range requests past K: nothing may land in the staging area)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // every wave has read its last fragments (nothing is in flight): the LDS becomes the staging area
+    DSPN_STAMP(2);
     if (dbg & 16) { if (acc[0][0][0] == 1.2345e33f) out[0] = (st_t)acc[TM - 1][TN - 1][5]; continue; }
 
     // ---- epilogue.  C/D layout: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -480,8 +791,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
           for (int r = 0; r < 16; ++r)
             st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
     }
-    wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
+    DSPN_STAMP(3);
+    wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all, NoStage() DSPN_STAMP_ARG);
   }
+  DSPN_STAMP_FLUSH;
   if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
@@ -504,7 +817,9 @@ template <int NEWER>
 __device__ __forceinline__ void ntv_wait4(ntv_f32x4_t &a, ntv_f32x4_t &b, ntv_f32x4_t &c, ntv_f32x4_t &d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(NEWER));
 }
-template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128>
+// XT: the tile-spanning loop (see conv_ntw_kernel): the weight pieces and the A rows of the NEXT tile's first two k-steps are
+// requested before the epilogue of the current one, which stages chunk by chunk behind ring slot 0.
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128, bool XT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -586,15 +901,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
   f32x16 acc[TM][TN];
   float gmx_all = 0.f;
 
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  int m0 = 0, n0 = 0;                                    // the tile being multiplied / written
+  int nm0 = 0, nn0 = 0;                                  // the tile the loaders are set up for
+  auto setup_tile = [&](const int t) __attribute__((always_inline)) {
     const int tile = xcd_remap(t, ntiles);
     const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    nm0 = mt * BM; nn0 = nt * BN;
     {
       const int hw = g.Hg * g.Wg;
 #pragma unroll
       for (int j = 0; j < A_U; ++j) {
-        const int m = m0 + ((tid + j * NTHR) >> 2);
+        const int m = nm0 + ((tid + j * NTHR) >> 2);
         const int n = m / hw, rem = m - n * hw;
         const int oi = rem / g.Wg, oj = rem - oi * g.Wg;
         const int ih0 = oi * g.ish + g.ioh, iw0 = oj * g.isw + g.iow;
@@ -605,12 +922,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       }
 #pragma unroll
       for (int i = 0; i < B_NI; ++i) {
-        const int k = min(n0 + b_row[i], g.Cout - 1);
+        const int k = min(nn0 + b_row[i], g.Cout - 1);
         b_boff[i] = k * (g.WTAPS * CB * 128) + b_cb[i];
       }
       l_tr = 0; l_ts = 0; l_cb = 0;
       lb_tr = 0; lb_ts = 0; lb_cb = 0;
     }
+  };
+  {
     // requests: the A rows of a k-step into register set SET, the weight pieces of a k-step into ring slot `slot`; past the last
     // k-step every lane is out of range (zeros, no traffic).  Each kind walks the (tap, channel block) sequence with its own counters.
     auto request_a = [&](auto set_c, const bool live) __attribute__((always_inline)) {
@@ -705,22 +1024,37 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     };
     typedef std::integral_constant<int, 0> set0_t;
     typedef std::integral_constant<int, 1> set1_t;
-    request_b(0, true);
-    __builtin_amdgcn_sched_barrier(0);      // the weight requests FIRST: the counted wait below lets the NA newest requests fly
-    request_a(set0_t{}, true);
-    if constexpr (DEEP) request_a(set1_t{}, 1 < nk);
-    wait_set(set0_t{}, std::integral_constant<int, DEEP ? NA : 0>{});
-    cut(set0_t{});
-    store_a(0);
-    // the weight pieces of k-step 0 have landed and the A image is written; the rows of k-step 1 (DEEP) may still be on their way
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DEEP ? NA : 0) : "memory");
-    __builtin_amdgcn_s_barrier();
+    // the first requests of a tile (setup_tile has run): the weight pieces of k-step 0, the rows of k-steps 0 and 1
+    auto tile_requests_a = [&](const bool live) __attribute__((always_inline)) {
+      request_a(set0_t{}, live);
+      if constexpr (DEEP) request_a(set1_t{}, live && 1 < nk);
+    };
+    // ... and what turns them into the images of k-step 0 (weights, rows 0, rows 1 are requested in this order)
+    auto tile_first_requests = [&](const bool live) __attribute__((always_inline)) {
+      request_b(0, live);
+      __builtin_amdgcn_sched_barrier(0);      // the weight requests FIRST: the counted waits let the NA newest requests fly
+      tile_requests_a(live);
+    };
+    // pre (XT, every tile but a workgroup's first): the requests were issued before the previous tile's epilogue, whose 64 stores
+    // per wave (always issued) are younger than all of them: "at most 63 younger operations outstanding" says the rows of k-step
+    // 0 -- and the weight pieces, which are older -- have landed without asking for those stores to be acknowledged
+    auto tile_head = [&](const bool pre) __attribute__((always_inline)) {
+      if (!pre) tile_first_requests(true);
+      if (pre) wait_set(set0_t{}, std::integral_constant<int, 63>{});
+      else wait_set(set0_t{}, std::integral_constant<int, DEEP ? NA : 0>{});
+      cut(set0_t{});
+      store_a(0);
+      // the weight pieces of k-step 0 have landed and the A image is written; the rows of k-step 1 (DEEP) may still be on their way
+      if (pre) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DEEP ? NA : 0) : "memory");
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
     // one k-step; PAR = kt & 1 picks the register sets at compile time: the rows of k-step kt + 1 are cut out of set CS, the rows
     // of k-step kt + 2 (DEEP; kt + 1 otherwise) are requested into set RS
     auto kstep = [&](auto par_c, const int kt) __attribute__((always_inline)) {
@@ -778,15 +1112,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DEEP ? NA : 0) : "memory");
       __builtin_amdgcn_s_barrier();
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-      kstep(set0_t{}, kt);
-      if (kt + 1 < nk) kstep(set1_t{}, kt + 1);
-    }
-    // the last requests (past the last k-step: out of range, zeros) still name their registers: nothing else may be given
-    // those registers before they have landed -- the compiler does not know they are pending
-    wait_set(set0_t{}, std::integral_constant<int, 0>{});
-    if constexpr (DEEP) wait_set(set1_t{}, std::integral_constant<int, 0>{});
-    {
+    auto kloop = [&]() __attribute__((always_inline)) {
+      for (int kt = 0; kt < nk; kt += 2) {
+        kstep(set0_t{}, kt);
+        if (kt + 1 < nk) kstep(set1_t{}, kt + 1);
+      }
+      // the last requests (past the last k-step: out of range, zeros) still name their registers: nothing else may be given
+      // those registers before they have landed -- the compiler does not know they are pending
+      wait_set(set0_t{}, std::integral_constant<int, 0>{});
+      if constexpr (DEEP) wait_set(set1_t{}, std::integral_constant<int, 0>{});
+    };
+    // the whole tile staged in LDS (the ring is done with: every k-step ends with a barrier behind its last fragment read)
+    auto stage_tile = [&]() __attribute__((always_inline)) {
       constexpr int SLD = BN + 4;
       float *st = reinterpret_cast<float *>(wsm);
 #pragma unroll
@@ -796,20 +1133,63 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
+    };
+    if constexpr (XT) {
+      // the weight pieces of the NEXT tile's first k-step and the A rows of its first two are requested before the epilogue of
+      // the current tile, which works from the accumulators (direct_epilogue: nothing of it touches the ring).  (DEEP: two
+      // register sets; the host routes an even nk >= 2 and a dense output here.)
+      static_assert(DEEP, "two register sets");
+      int t = blockIdx.x;
+      if (t < ntiles) setup_tile(t);
+      bool pre = false;
+      DSPN_STAMP_DECL;
+      for (; t < ntiles; t += gridDim.x) {
+        m0 = nm0; n0 = nn0;
+        tile_head(pre);
+        DSPN_STAMP(1);
+        kloop();
+        DSPN_STAMP(2);
+        const int tn = t + (int)gridDim.x;
+        if (tn < ntiles) setup_tile(tn);
+        tile_first_requests(tn < ntiles);
+        __builtin_amdgcn_sched_barrier(0);
+        DSPN_STAMP(3);
+        direct_epilogue<WAVES_M, WAVES_N, EPI, ((EPI == 2 || INTF) ? 4 : 8)>(g, wsm + 2 * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+        DSPN_STAMP(5);
+        pre = true;
+      }
+      DSPN_STAMP_FLUSH;
+      wait_set(set0_t{}, std::integral_constant<int, 0>{});
+      wait_set(set1_t{}, std::integral_constant<int, 0>{});
+    } else {
+      DSPN_STAMP_DECL;
+      for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        setup_tile(t);
+        m0 = nm0; n0 = nn0;
+        tile_head(false);
+        DSPN_STAMP(1);
+        kloop();
+        DSPN_STAMP(2);
+        stage_tile();
+        DSPN_STAMP(3);
+        wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all, NoStage() DSPN_STAMP_ARG);
+      }
+      DSPN_STAMP_FLUSH;
     }
-    wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all);
+    if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
   }
-  if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
 }
 
-template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR>
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR, bool XT = false>
 int launch_ntv_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
                     const float *residual) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
-  const size_t lds = std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
-  auto kern = conv_ntv_kernel<WAVES_M, WAVES_N, INTF, EPI, SR>;
+  // XT: the ring and, behind it, the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats)
+  const size_t lds = XT ? (size_t)2 * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
+                        : std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  auto kern = conv_ntv_kernel<WAVES_M, WAVES_N, INTF, EPI, SR, XT>;
   static int slots = 0, slots_per_cu = 0, slots_cus = 0;
   if (!slots) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -820,8 +1200,8 @@ int launch_ntv_impl(const float *in, const float *w, const float *bias, float *o
     slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
     slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
     if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_ntv<%d,%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
-              (int)INTF, EPI, lds, per_cu, cus, slots);
+      fprintf(stderr, "[dspn] conv_ntv<%d,%d,intf=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+              (int)INTF, EPI, (int)XT, lds, per_cu, cus, slots);
   }
   const int reserved = dspn::reserved_cus();
   const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
@@ -834,24 +1214,34 @@ int launch_ntv_impl(const float *in, const float *w, const float *bias, float *o
 }
 template <int WAVES_M, int WAVES_N, int SR = 128>
 int launch_ntv(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s, const float *residual) {
-#define DSPN_NTV_(T) \
-  (g.bn_sums ? launch_ntv_impl<WAVES_M, WAVES_N, T, 2, SR>(in, w, bias, out, g, s, residual) \
-   : g.stats ? launch_ntv_impl<WAVES_M, WAVES_N, T, 1, SR>(in, w, bias, out, g, s, residual) \
-             : launch_ntv_impl<WAVES_M, WAVES_N, T, 0, SR>(in, w, bias, out, g, s, residual))
-  return g.in_scale ? DSPN_NTV_(true) : DSPN_NTV_(false);
+#define DSPN_NTV_(T, X) \
+  (g.bn_sums ? launch_ntv_impl<WAVES_M, WAVES_N, T, 2, SR, X>(in, w, bias, out, g, s, residual) \
+   : g.stats ? launch_ntv_impl<WAVES_M, WAVES_N, T, 1, SR, X>(in, w, bias, out, g, s, residual) \
+             : launch_ntv_impl<WAVES_M, WAVES_N, T, 0, SR, X>(in, w, bias, out, g, s, residual))
+  if constexpr (WAVES_M == 2 && WAVES_N == 2 && SR == 128) {
+    const int nk = g.TR * g.TS * (g.Cin / 32);
+    // measured (scratch/r06/xt_bench.hip): the float-operand member gains where the epilogue is a large share of the tile (K <= 256)
+    // and a workgroup walks several tiles; with 16 k-steps or two tiles per workgroup the staged loop is faster
+    const long long tiles = (((long long)g.N * g.Hg * g.Wg + 127) / 128) * ((g.Cout + 127) / 128);
+    if (xt_enabled() && nk >= 2 && nk <= 8 && nk % 2 == 0 && tiles >= 2048 && xt_output_ok(g))
+      return g.in_scale ? DSPN_NTV_(true, true) : DSPN_NTV_(false, true);
+  }
+  return g.in_scale ? DSPN_NTV_(true, false) : DSPN_NTV_(false, false);
 #undef DSPN_NTV_
 }
 #endif   // !DSPN_HALF
 
 // host side: one launch of the wide family.  Persistent grid as conv_nt_kernel's (occupancy x CUs, a multiple of 8).
-template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR>
+template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR, bool XT = false>
 int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s,
                     const st_t *residual) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
-  const size_t lds = std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
-  auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR>;
+  // XT: the ring and, behind it, the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats)
+  const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
+                        : std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR, XT>;
   static int slots = 0, slots_per_cu = 0, slots_cus = 0;
   if (!slots) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -862,8 +1252,8 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
     slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
     slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
     if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_ntw<%d,%d,stages=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
-              STAGES, EPI, lds, per_cu, cus, slots);
+      fprintf(stderr, "[dspn] conv_ntw<%d,%d,stages=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+              STAGES, EPI, (int)XT, lds, per_cu, cus, slots);
   }
   const int reserved = dspn::reserved_cus();
   const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
@@ -877,6 +1267,16 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
 
 template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
 int launch_ntw(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s, const st_t *residual) {
+#ifndef DSPN_HALF
+  if constexpr (WAVES_M == 2 && WAVES_N == 2 && STAGES == 2 && SR == 128) {
+    const int nk = g.TR * g.TS * (g.Cin / 32);
+    if (xt_enabled() && nk >= 2 && nk % 2 == 0 && xt_output_ok(g)) {
+      if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR, true>(in, w, bias, out, g, s, residual);
+      if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR, true>(in, w, bias, out, g, s, residual);
+      return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR, true>(in, w, bias, out, g, s, residual);
+    }
+  }
+#endif
   if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR>(in, w, bias, out, g, s, residual);
   if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR>(in, w, bias, out, g, s, residual);
   return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR>(in, w, bias, out, g, s, residual);

@@ -41,6 +41,8 @@ struct ProfScope {
 int reserved_cus();
 // tile family of the plane-fed two-piece convolutions (dspn_conv_set_wide_tiles; a launch setting as well)
 int wide_tiles_mode();
+// the tile-spanning loop of the short-K members of that family (dspn_conv_set_tile_spanning; round 6)
+int tile_spanning();
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

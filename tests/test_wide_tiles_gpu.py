@@ -366,3 +366,89 @@ def test_float_gradient_data_gradient_on_every_tile_is_bit_identical(tiles, case
                 assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (MODES[mode], "BatchNorm-backward sums")
             else:
                 assert torch.equal(a, b), (MODES[mode], i)
+
+
+# ---- round 6: the tile-spanning loop (conv_wide.h, XT) of the 128 x 128 four-wave members, against their round-5 loop
+# (N, H, W, Cin, Cout, k, stride): even k-step counts 2 .. 18, one to four tiles per workgroup (512 workgroups fill the chip),
+# ragged last row tile / column tile
+XT_CASES = [(16, 64, 64, 64, 256, 1, 1), (32, 64, 64, 256, 128, 1, 1), (13, 61, 67, 64, 192, 1, 1), (16, 64, 64, 128, 256, 1, 2),
+            (8, 48, 48, 64, 128, 3, 1), (32, 32, 32, 512, 256, 1, 1), (3, 17, 19, 128, 256, 1, 1)]
+
+
+@pytest.fixture()
+def spanning(tiles):
+    L = _lib.lib()
+    tiles(4)
+    yield lambda on: _lib.check(L.dspn_conv_set_tile_spanning(on), "set_tile_spanning")
+    L.dspn_conv_set_tile_spanning(1)
+
+
+def test_tile_spanning_setter(gpu_device):
+    L = _lib.lib()
+    assert L.dspn_conv_set_tile_spanning(2) != 0 and b"conv_set_tile_spanning" in L.dspn_last_error()
+    assert L.dspn_conv_set_tile_spanning(1) == 0
+
+
+@pytest.mark.parametrize("case", XT_CASES)
+def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
+    """VERDICT r05 item 1.  Every kind of call the two kernels serve -- A operand as piece planes (conv_ntw_kernel) or as a
+    float tensor with / without the folded BatchNorm affine (conv_ntv_kernel); forward plain, + bias + residual + ReLU,
+    accumulating, with statistics and extremes; data gradient plain, accumulating, with the BatchNorm-backward sums and the
+    magnitude block -- with the loop that requests the next tile's operands before the current tile's epilogue and with the
+    round-5 loop: every stored tensor, the per-tile extremes and the magnitude block bit for bit (same K order, same epilogue
+    arithmetic per element); the per-tile BatchNorm tables within rounding (the direct epilogue sums a column in another order)."""
+    N, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(H + Cin + Cout + k + 11)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / np.sqrt(Cin * k * k)).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    base = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    aff = ((torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda(), True)
+    xpos = x.abs()
+    xp, xpa = planes_of(xpos)
+    xa, xaa = fn.absmax(x), fn.absmax(x, aff)
+    wa = fn.absmax(w); wp = fn.weight_planes(w, math="f16x2", w_absmax=wa)
+    t2, _ = fn.conv_stats_layout(N * Ho * Wo, Cout)
+    assert t2 > 0
+    # the data gradient of a (Cout -> Cin) convolution with the same geometry: dy has the shape of the forward output
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    dyp, dya = planes_of(dy)
+    wt = fn.weight_transpose(w)
+    wtp = fn.weight_planes(w, transposed=True, cols=Cout, math="f16x2", w_absmax=wa)
+    gamma = torch.rand(Cin, device="cuda") + 0.5; beta = torch.randn(Cin, device="cuda")
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    ntile = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    out = {}
+    for on in (0, 1):
+        spanning(on)
+        got = []
+        for src, kw in ((xp, dict(x_absmax=xpa, x_planes=True)), (x, dict(x_absmax=xa)), (x, dict(x_absmax=xaa, in_affine=aff))):
+            kw = dict(kw, w_planes=wp, w_absmax=wa)
+            got.append(fn.conv2d_forward(src, w, None, stride, pad, 1, **kw))
+            got.append(fn.conv2d_forward(src, w, bias, stride, pad, 1, residual=res, relu=True, **kw))
+            acc = base.clone()
+            fn.conv2d_forward(src, w, None, stride, pad, 1, out=acc, accumulate=True, **kw)
+            st = torch.zeros(t2, 2, Cout, device="cuda"); mm = torch.zeros(t2, 2, Cout, device="cuda")
+            got += [acc, fn.conv2d_forward(src, w, None, stride, pad, 1, out_stats=st, out_minmax=mm, **kw), st, mm]
+        for src, kw in ((dyp, dict(dy_absmax=dya, dy_planes=True)), (dy, dict(dy_absmax=dya))):
+            kw = dict(kw, wt_planes=wtp, w_absmax=wa)
+            sums = torch.zeros(ntile, 2, Cin, device="cuda"); bam = torch.zeros(64, device="cuda")
+            dx = torch.empty_like(x); dx2 = torch.empty_like(x); dx3 = x.clone()
+            fn.conv2d_dgrad(src, wt, tuple(x.shape), stride, pad, 1, out=dx, bn_bwd=(x, scale, shift, mean, rstd, True, sums),
+                            bn_dy_absmax=bam, **kw)
+            fn.conv2d_dgrad(src, wt, tuple(x.shape), stride, pad, 1, out=dx2, **kw)
+            fn.conv2d_dgrad(src, wt, tuple(x.shape), stride, pad, 1, out=dx3, accumulate=True, **kw)
+            got += [dx, dx2, dx3, sums, bam.clone()]
+        out[on] = got
+    ref32 = fn.conv2d_forward(x, w, None, stride, pad, 1, math="fp32")
+    assert float((out[1][6] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    for i, (a, b) in enumerate(zip(out[1], out[0])):
+        if i in (4, 10, 16):        # per-tile (mean, M2): the direct epilogue sums a column's rows in another order -- fp32 rounding only
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (i, "statistics")
+        elif i in (21, 26):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (i, "BatchNorm-backward sums")
+        else:                       # every stored tensor, the extremes and the magnitude block: the same bits
+            assert torch.equal(a, b), i
