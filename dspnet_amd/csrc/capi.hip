@@ -52,7 +52,7 @@ int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
 static std::atomic<int> g_wide_tiles{0};
 int wide_tiles_mode() { return g_wide_tiles.load(std::memory_order_relaxed); }
 // round 6: the tile-spanning loop of the short-K members of the wide family (conv_wide.h, XT); DSPN_XT=0 starts with it off
-static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 2 ? 2 : v); }()};
 int tile_spanning() { return g_tile_spanning.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
@@ -85,7 +85,7 @@ int dspn_conv_set_wide_tiles(int mode) {
   return 0;
 }
 int dspn_conv_set_tile_spanning(int on) {
-  if (on != 0 && on != 1) return dspn::fail(DSPN_ERR_ARG_, "conv_set_tile_spanning: 0 or 1, got %d", on);
+  if (on < 0 || on > 2) return dspn::fail(DSPN_ERR_ARG_, "conv_set_tile_spanning: 0 off, 1 plane-fed kernels (default), 2 also the float-operand kernel, got %d", on);
   dspn::g_tile_spanning.store(on);
   return 0;
 }

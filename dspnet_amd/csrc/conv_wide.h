@@ -325,43 +325,52 @@ __device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f
 #pragma unroll
   for (int j = 0; j < TN; ++j) { sK[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; vmn[j] = kInf; vmx[j] = -kInf; gs[j] = 0.f; gss[j] = 0.f; }
   const bool both = has_res && accum;
+  // The rows a block adds to (residual / accumulate) and the BatchNorm-input rows come from memory in batches of RB rows; the
+  // batch after the one being worked on is requested first (two register sets, as the staged epilogue does with its chunks): a
+  // batch that waited for its own requests would leave one memory latency per batch exposed.  Batch b = rows r0 .. r0 + RB - 1
+  // of block i, b = i (16 / RB) + r0 / RB.
+  constexpr int NB = TM * 16 / RB;
+  const bool need_rows = addsrc != nullptr || EPI == 2;      // (kernel-uniform)
   if constexpr (EPI == 2) {
     // (one row at a time: the packed form below needs register pairs for the BatchNorm-input rows as well, which 256 registers
     // do not hold beside the accumulators and the next tile's rows)
+    float rq[2][RB][TN], xq[2][RB][TN], oq[2][RB][TN];
+    auto request = [&](const int bb, const int s_) __attribute__((always_inline)) {
+      const int i = bb / (16 / RB), r0 = (bb % (16 / RB)) * RB;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = r0 + rr;
+        const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += RB) {
-        float rq[RB][TN], xq[RB][TN], oq[RB][TN];
-#pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-          const int r = r0 + rr;
-          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const unsigned off = rb + cbyte[j];
-            rq[rr][j] = addsrc ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)) : 0.f;
-            xq[rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
-            oq[rr][j] = both ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)) : 0.f;
-          }
+        for (int j = 0; j < TN; ++j) {
+          const unsigned off = rb + cbyte[j];
+          rq[s_][rr][j] = addsrc ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)) : 0.f;
+          xq[s_][rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+          oq[s_][rr][j] = both ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)) : 0.f;
         }
+      }
+    };
+    request(0, 0);
 #pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-          const int r = r0 + rr;
-          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+    for (int bb = 0; bb < NB; ++bb) {
+      const int i = bb / (16 / RB), r0 = (bb % (16 / RB)) * RB, s_ = bb & 1;
+      if (bb + 1 < NB) request(bb + 1, s_ ^ 1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            float v = acc[i][j][r] * inv_a * inv_b + bv[j];
-            v += rq[rr][j];
-            if (both) v += oq[rr][j];
-            if (relu) v = v > 0.f ? v : 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, (int)(rb + cbyte[j]), 0, 0);
-            const float xv = xq[rr][j];
-            const float gd = (!g.bn_relu || fmaf(xv, bsc[j], bsh[j]) > 0.f) ? v : 0.f;
-            gs[j] += gd;
-            gss[j] += gd * ((xv - bmu[j]) * brs[j]);
-            gmx = fmaxf(gmx, fabsf(v));
-          }
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = r0 + rr;
+        const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v = acc[i][j][r] * inv_a * inv_b + bv[j];
+          v += rq[s_][rr][j];
+          if (both) v += oq[s_][rr][j];
+          if (relu) v = v > 0.f ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, (int)(rb + cbyte[j]), 0, 0);
+          const float xv = xq[s_][rr][j];
+          const float gd = (!g.bn_relu || fmaf(xv, bsc[j], bsh[j]) > 0.f) ? v : 0.f;
+          gs[j] += gd;
+          gss[j] += gd * ((xv - bmu[j]) * brs[j]);
+          gmx = fmaxf(gmx, fabsf(v));
         }
       }
     }
@@ -372,72 +381,63 @@ __device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f
     // (r, r + 1: neighbouring accumulator registers) so that the scaling, the additions and the running sums are packed fp32
     // instructions -- the epilogue's vector arithmetic is of the order of its store time on the short-K layers
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 s1p[TN], s2p[TN], gsp[TN], gssp[TN];
+    f32x2 s1p[TN], s2p[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { s1p[j] = f32x2{0.f, 0.f}; s2p[j] = f32x2{0.f, 0.f}; gsp[j] = f32x2{0.f, 0.f}; gssp[j] = f32x2{0.f, 0.f}; }
+    for (int j = 0; j < TN; ++j) { s1p[j] = f32x2{0.f, 0.f}; s2p[j] = f32x2{0.f, 0.f}; }
+    f32x2 rq[2][RB / 2][TN], oq[2][RB / 2][TN];
+    auto request = [&](const int bb, const int s_) __attribute__((always_inline)) {
+      const int i = bb / (16 / RB), r0 = (bb % (16 / RB)) * RB;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int rr = 0; rr < RB; rr += 2) {
+        const int r = r0 + rr;
+        const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += RB) {
-        f32x2 rq[RB / 2][TN], xq[EPI == 2 ? RB / 2 : 1][TN], oq[RB / 2][TN];
-#pragma unroll
-        for (int rr = 0; rr < RB; rr += 2) {
-          const int r = r0 + rr;
-          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const unsigned off = rb + cbyte[j];
-            rq[rr / 2][j] = f32x2{0.f, 0.f}; oq[rr / 2][j] = f32x2{0.f, 0.f};
-            if (addsrc) rq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)),
-                                             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(off + pitch), 0, 0))};
-            if constexpr (EPI == 2) xq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0)),
-                                                           __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(off + pitch), 0, 0))};
-            if (both) oq[rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)),
-                                           __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)(off + pitch), 0, 0))};
-          }
+        for (int j = 0; j < TN; ++j) {
+          const unsigned off = rb + cbyte[j];
+          rq[s_][rr / 2][j] = f32x2{0.f, 0.f}; oq[s_][rr / 2][j] = f32x2{0.f, 0.f};
+          if (addsrc) rq[s_][rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)off, 0, 0)),
+                                               __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(off + pitch), 0, 0))};
+          if (both) oq[s_][rr / 2][j] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)off, 0, 0)),
+                                             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, (int)(off + pitch), 0, 0))};
         }
+      }
+    };
+    if (need_rows) request(0, 0);
 #pragma unroll
-        for (int rr = 0; rr < RB; rr += 2) {
-          const int r = r0 + rr;
-          const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+    for (int bb = 0; bb < NB; ++bb) {
+      const int i = bb / (16 / RB), r0 = (bb % (16 / RB)) * RB, s_ = bb & 1;
+      if (need_rows && bb + 1 < NB) request(bb + 1, s_ ^ 1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            f32x2 t = f32x2{acc[i][j][r], acc[i][j][r + 1]} * inv_a * inv_b + bv[j];
-            t += rq[rr / 2][j];
-            // (the two conditional steps element by element: hipcc 7.2 drops the second element of a select on a two-float vector)
-            float v0 = t[0], v1 = t[1];
-            if (both) { v0 += oq[rr / 2][j][0]; v1 += oq[rr / 2][j][1]; }
-            if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_o, (int)(rb + cbyte[j]), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_o, (int)(rb + pitch + cbyte[j]), 0, 0);
-            const f32x2 v = f32x2{v0, v1};
-            if constexpr (EPI == 0) {
-              if (g.bn_dy_absmax) gmx = fmaxf(fmaxf(gmx, fabsf(v.x)), fabsf(v.y));
-            }
-            if constexpr (EPI == 2) {
-              const f32x2 xv = xq[rr / 2][j];
-              f32x2 gd = v;
-              if (g.bn_relu) gd = f32x2{fmaf(xv.x, bsc[j], bsh[j]) > 0.f ? v.x : 0.f, fmaf(xv.y, bsc[j], bsh[j]) > 0.f ? v.y : 0.f};
-              gsp[j] += gd;
-              gssp[j] += gd * ((xv - bmu[j]) * brs[j]);
-              gmx = fmaxf(fmaxf(gmx, fabsf(v.x)), fabsf(v.y));
-            }
-            if constexpr (EPI == 1) {
-              if (i == 0 && r == 0) sK[j] = v.x;
-              const f32x2 d = v - sK[j];
-              s1p[j] += d; s2p[j] += d * d;
-              vmn[j] = fminf(fminf(vmn[j], v.x), v.y); vmx[j] = fmaxf(fmaxf(vmx[j], v.x), v.y);
-            }
+      for (int rr = 0; rr < RB; rr += 2) {
+        const int r = r0 + rr;
+        const unsigned rb = (unsigned)(row0 + 32 * i + (r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x2 t = f32x2{acc[i][j][r], acc[i][j][r + 1]} * inv_a * inv_b + bv[j];
+          if (need_rows) t += rq[s_][rr / 2][j];
+          else t += f32x2{0.f, 0.f};
+          // (the two conditional steps element by element: hipcc 7.2 drops the second element of a select on a two-float vector)
+          float v0 = t[0], v1 = t[1];
+          if (both) { v0 += oq[s_][rr / 2][j][0]; v1 += oq[s_][rr / 2][j][1]; }
+          if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_o, (int)(rb + cbyte[j]), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_o, (int)(rb + pitch + cbyte[j]), 0, 0);
+          const f32x2 v = f32x2{v0, v1};
+          if constexpr (EPI == 0) {
+            if (g.bn_dy_absmax) gmx = fmaxf(fmaxf(gmx, fabsf(v0)), fabsf(v1));
+          }
+          if constexpr (EPI == 1) {
+            if (bb == 0 && rr == 0) sK[j] = v0;
+            const f32x2 d = v - sK[j];
+            s1p[j] += d; s2p[j] += d * d;
+            vmn[j] = fminf(fminf(vmn[j], v0), v1); vmx[j] = fmaxf(fmaxf(vmx[j], v0), v1);
           }
         }
       }
     }
     scnt = 32;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      s1[j] = s1p[j].x + s1p[j].y; s2[j] = s2p[j].x + s2p[j].y;
-      gs[j] = cv[j] ? gsp[j].x + gsp[j].y : 0.f; gss[j] = cv[j] ? gssp[j].x + gssp[j].y : 0.f;
-    }
+    for (int j = 0; j < TN; ++j) { s1[j] = s1p[j].x + s1p[j].y; s2[j] = s2p[j].x + s2p[j].y; }
   }
   if constexpr (EPI == 0) gmx_all = fmaxf(gmx_all, gmx);
   if constexpr (EPI == 2) gmx_all = fmaxf(gmx_all, gmx);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
         mma_step(kt & 1);
       }
       DSPN_STAMP(2);
-      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 8 : 16)>(g, wsm + STAGES * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, wsm + STAGES * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
       DSPN_STAMP(5);
     }
     DSPN_STAMP_FLUSH;
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
         tile_first_requests(tn < ntiles);
         __builtin_amdgcn_sched_barrier(0);
         DSPN_STAMP(3);
-        direct_epilogue<WAVES_M, WAVES_N, EPI, ((EPI == 2 || INTF) ? 4 : 8)>(g, wsm + 2 * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+        direct_epilogue<WAVES_M, WAVES_N, EPI, ((EPI == 2 || INTF) ? 2 : 4)>(g, wsm + 2 * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
         DSPN_STAMP(5);
         pre = true;
       }
@@ -1220,10 +1220,13 @@ int launch_ntv(const float *in, const float *w, const float *bias, float *out, c
              : launch_ntv_impl<WAVES_M, WAVES_N, T, 0, SR, X>(in, w, bias, out, g, s, residual))
   if constexpr (WAVES_M == 2 && WAVES_N == 2 && SR == 128) {
     const int nk = g.TR * g.TS * (g.Cin / 32);
-    // measured (scratch/r06/xt_bench.hip): the float-operand member gains where the epilogue is a large share of the tile (K <= 256)
-    // and a workgroup walks several tiles; with 16 k-steps or two tiles per workgroup the staged loop is faster
+    // Measured (scratch/r06/xt_bench.hip, profiles/r06_xt_*): the float-operand member gains 5 - 15 % in isolation where the
+    // epilogue is a large share of the tile (K <= 256) and a workgroup walks several tiles, and LOSES inside the training step:
+    // its hot calls add a residual (the conv3 of every unit), and with the next tile's rows held in registers across the
+    // epilogue there is room for 2 - 4 residual rows in flight per lane where the staged epilogue keeps 16 (281 -> 305 us on
+    // the stage-1 conv3 layers).  Setting 2 of dspn_conv_set_tile_spanning routes it (experiments); the default does not.
     const long long tiles = (((long long)g.N * g.Hg * g.Wg + 127) / 128) * ((g.Cout + 127) / 128);
-    if (xt_enabled() && nk >= 2 && nk <= 8 && nk % 2 == 0 && tiles >= 2048 && xt_output_ok(g))
+    if (dspn::tile_spanning() >= 2 && nk >= 2 && nk <= 8 && nk % 2 == 0 && tiles >= 2048 && xt_output_ok(g))
       return g.in_scale ? DSPN_NTV_(true, true) : DSPN_NTV_(false, true);
   }
   return g.in_scale ? DSPN_NTV_(true, false) : DSPN_NTV_(false, false);

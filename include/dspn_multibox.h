@@ -58,10 +58,12 @@ int dspn_conv_set_reserved_cus(int cus);
  * schedule), 2 / 3 / 4 = always 256 x 128 / 128 x 256 / 128 x 128-on-four-waves where legal (tests and experiments).  The K
  * order and the per-output accumulation order are the same on every tile. */
 int dspn_conv_set_wide_tiles(int mode);
-/* Launch setting (round 6; not compute state): 1 (default; the environment variable DSPN_XT=0 starts the process with 0) = the
- * 128 x 128 four-wave members of the wide family run their TILE-SPANNING loop on layers with an even number of k-steps -- the
- * next tile's first operand images are requested while the current tile is in its epilogue.  Same K order, same epilogue
- * arithmetic, same bits; 0 = the round-5 loop (tests, same-box A/B runs). */
+/* Launch setting (round 6; not compute state): the TILE-SPANNING loop of the 128 x 128 four-wave members of the wide family on
+ * layers with an even number of k-steps and a dense output of whole 128-row tiles -- the next tile's first operand images are
+ * requested while the current tile is written out, straight from the accumulators.  0 = the round-5 loop; 1 (default; the
+ * environment variable DSPN_XT sets the process's initial value) = the plane-fed kernel; 2 = also the float-operand kernel
+ * (measured slower inside the training step: experiments only).  Stored tensors, per-tile extremes and magnitude blocks are
+ * the same bits under every value; the per-tile BatchNorm tables agree within fp32 rounding (another summation order). */
 int dspn_conv_set_tile_spanning(int on);
 
 /* Replaces MultiBoxPriorOp::Forward (operator/multibox_prior-inl.h:97-129) +

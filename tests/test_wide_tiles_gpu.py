@@ -385,7 +385,7 @@ def spanning(tiles):
 
 def test_tile_spanning_setter(gpu_device):
     L = _lib.lib()
-    assert L.dspn_conv_set_tile_spanning(2) != 0 and b"conv_set_tile_spanning" in L.dspn_last_error()
+    assert L.dspn_conv_set_tile_spanning(3) != 0 and b"conv_set_tile_spanning" in L.dspn_last_error()
     assert L.dspn_conv_set_tile_spanning(1) == 0
 
 
@@ -422,7 +422,7 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
     mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
     ntile = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
     out = {}
-    for on in (0, 1):
+    for on in (0, 2):          # 2: the plane-fed AND the float-operand kernel on the tile-spanning loop
         spanning(on)
         got = []
         for src, kw in ((xp, dict(x_absmax=xpa, x_planes=True)), (x, dict(x_absmax=xa)), (x, dict(x_absmax=xaa, in_affine=aff))):
@@ -444,8 +444,8 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
             got += [dx, dx2, dx3, sums, bam.clone()]
         out[on] = got
     ref32 = fn.conv2d_forward(x, w, None, stride, pad, 1, math="fp32")
-    assert float((out[1][6] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
-    for i, (a, b) in enumerate(zip(out[1], out[0])):
+    assert float((out[2][6] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    for i, (a, b) in enumerate(zip(out[2], out[0])):
         if i in (4, 10, 16):        # per-tile (mean, M2): the direct epilogue sums a column's rows in another order -- fp32 rounding only
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (i, "statistics")
         elif i in (21, 26):
