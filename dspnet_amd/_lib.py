@@ -23,6 +23,7 @@ SIGNATURES = {
     "dspn_conv_set_reserved_cus": (_c.c_int, [_c.c_int]),
     "dspn_conv_set_wide_tiles": (_c.c_int, [_c.c_int]),
     "dspn_conv_set_tile_spanning": (_c.c_int, [_c.c_int]),
+    "dspn_affine_sampler_set_batched": (_c.c_int, [_c.c_int]),
     "dspn_profile_collect": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
     "dspn_multibox_prior_f32": (_c.c_int, [_f32p, _c.c_int, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_float, _c.c_float, _c.c_float, _c.c_float,

@@ -54,6 +54,8 @@ int wide_tiles_mode() { return g_wide_tiles.load(std::memory_order_relaxed); }
 // round 6: the tile-spanning loop of the short-K members of the wide family (conv_wide.h, XT); DSPN_XT=0 starts with it off
 static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 2 ? 2 : v); }()};
 int tile_spanning() { return g_tile_spanning.load(std::memory_order_relaxed); }
+static std::atomic<int> g_sampler_batched{1};
+int sampler_batched() { return g_sampler_batched.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
 extern "C" {
@@ -87,6 +89,11 @@ int dspn_conv_set_wide_tiles(int mode) {
 int dspn_conv_set_tile_spanning(int on) {
   if (on < 0 || on > 2) return dspn::fail(DSPN_ERR_ARG_, "conv_set_tile_spanning: 0 off, 1 plane-fed kernels (default), 2 also the float-operand kernel, got %d", on);
   dspn::g_tile_spanning.store(on);
+  return 0;
+}
+int dspn_affine_sampler_set_batched(int on) {
+  if (on != 0 && on != 1) return dspn::fail(DSPN_ERR_ARG_, "affine_sampler_set_batched: 0 or 1, got %d", on);
+  dspn::g_sampler_batched.store(on);
   return 0;
 }
 const char *dspn_last_error(void) { return dspn::last_error_buf(); }

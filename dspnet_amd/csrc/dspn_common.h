@@ -43,6 +43,8 @@ int reserved_cus();
 int wide_tiles_mode();
 // the tile-spanning loop of the short-K members of that family (dspn_conv_set_tile_spanning; round 6)
 int tile_spanning();
+// the batched form of the affine sampler's data gradient (dspn_affine_sampler_set_batched; round 6; same bits either way)
+int sampler_batched();
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

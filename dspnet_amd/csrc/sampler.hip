@@ -232,6 +232,184 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
   }
 }
 
+// Round 6: the same sums with the GEOMETRY taken once per source position instead of once per source pixel of every image.
+// The pre-image of a source pixel under the (batch-shared) grid does not depend on the image: one workgroup per position (h, w)
+// lists the target pixels that touch it -- wave 0, one lane per candidate of the bounding box, compacted in the order the
+// kernel above visits them: slice by slice (rows ho_lo + s, + SLE, ...), rows ascending, columns ascending -- with their
+// bilinear weights and theta factors, in LDS; then every wave walks its share of the batch with lanes over channels: the
+// rows of a group of four matches are requested together (the kernel above waits for each match's row before it asks for
+// the next: a 64 x 64 map took 0.32 ms for 90 MB), the sums run in the listed order -- per slice, then the slices in order --
+// so dx, the largest stored |dx| and the theta rows are the bits of sampler_bwd_data_kernel<SLE, TH>.  A box with more
+// matches than the list holds (a strongly minifying theta) is walked as before.  At most 64 float4 columns (the host routes).
+constexpr int kSbCap = 768;        // matches per source position kept in LDS
+template <int SLE, bool TH>
+__global__ __launch_bounds__(256) void sampler_bwd_data_batched_kernel(const st_t *__restrict__ dy, const float *__restrict__ theta,
+                                                                       const A4Ptr dx, int N, int Hin, int Win, int C4, int Ho, int Wo,
+                                                                       int ldo, int coff, int accumulate, const st_t *__restrict__ xfwd,
+                                                                       double *__restrict__ tpart, unsigned *__restrict__ absmax) {
+  __shared__ int s_off[kSbCap];                       // (ho * Wo + wo) * ldo: element offset of the target pixel's row inside an image
+  __shared__ float s_w[kSbCap], s_cx[kSbCap], s_cy[kSbCap], s_xt[kSbCap], s_yt[kSbCap];
+  __shared__ int s_cnt[SLE + 1];                      // [s]: matches of slices 0 .. s - 1; [SLE]: all, or -1 when the list overflowed
+  const float khw = (float)(Win - 1) * 0.5f, khh = (float)(Hin - 1) * 0.5f;
+  const Theta th = load_theta(theta);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = (int)(blockIdx.x % Win), h = (int)(blockIdx.x / Win);
+  // (the bounding box: the statements of sampler_bwd_data_kernel)
+  const float kx = Wo > 1 ? 2.f / (float)(Wo - 1) : 0.f, ky = Ho > 1 ? 2.f / (float)(Ho - 1) : 0.f;
+  const float hw = (float)(Win - 1) / 2.f, hh = (float)(Hin - 1) / 2.f;
+  const float x0t = Wo > 1 ? -1.f : 0.f, y0t = Ho > 1 ? -1.f : 0.f;
+  const float axw = th.t[0] * kx * hw, axh = th.t[1] * ky * hw, ax0 = (th.t[0] * x0t + th.t[1] * y0t + th.t[2] + 1.f) * hw;
+  const float ayw = th.t[3] * kx * hh, ayh = th.t[4] * ky * hh, ay0 = (th.t[3] * x0t + th.t[4] * y0t + th.t[5] + 1.f) * hh;
+  const float det = axw * ayh - axh * ayw;
+  int wo_lo = 0, wo_hi = Wo - 1, ho_lo = 0, ho_hi = Ho - 1;
+  if (fabsf(det) > 1e-20f && isfinite(det)) {
+    float fw_lo = 3e38f, fw_hi = -3e38f, fh_lo = 3e38f, fh_hi = -3e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sx = (float)w + ((k & 1) ? 1.f : -1.f) - ax0, sy = (float)h + ((k & 2) ? 1.f : -1.f) - ay0;
+      const float fw = (ayh * sx - axh * sy) / det, fh = (axw * sy - ayw * sx) / det;
+      fw_lo = fminf(fw_lo, fw); fw_hi = fmaxf(fw_hi, fw); fh_lo = fminf(fh_lo, fh); fh_hi = fmaxf(fh_hi, fh);
+    }
+    if (isfinite(fw_lo) && isfinite(fw_hi) && isfinite(fh_lo) && isfinite(fh_hi)) {
+      wo_lo = (int)fmaxf(floorf(fw_lo) - 1.f, 0.f); wo_hi = (int)fminf(ceilf(fw_hi) + 1.f, (float)(Wo - 1));
+      ho_lo = (int)fmaxf(floorf(fh_lo) - 1.f, 0.f); ho_hi = (int)fminf(ceilf(fh_hi) + 1.f, (float)(Ho - 1));
+    }
+  }
+  // one candidate of the box: does it touch (h, w), and with which weights (the statements of sampler_bwd_data_kernel)
+  auto probe = [&](const int ho, const int wo, float &wgt, float &cxk, float &cyk, float &xt, float &yt) __attribute__((always_inline)) {
+    yt = tgt_coord(ho, Ho);
+    xt = tgt_coord(wo, Wo);
+    float xs, ys;
+    src_xy(th, xt, yt, Hin, Win, xs, ys);
+    const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+    float wy, wx, sy, sx;
+    if (y0 == h) { wy = 1.f - (ys - (float)y0); sy = -1.f; }
+    else if (y0 + 1 == h) { wy = 1.f - (1.f - (ys - (float)y0)); sy = 1.f; }
+    else return false;
+    if (x0 == w) { wx = 1.f - (xs - (float)x0); sx = -1.f; }
+    else if (x0 + 1 == w) { wx = 1.f - (1.f - (xs - (float)x0)); sx = 1.f; }
+    else return false;
+    wgt = wy * wx;
+    cxk = (wy * sx) * khw; cyk = (wx * sy) * khh;
+    return true;
+  };
+  const int bw = wo_hi - wo_lo + 1;
+  if (wv == 0) {
+    int cnt = 0;
+    bool over = false;
+#pragma unroll 1
+    for (int sidx = 0; sidx < SLE; ++sidx) {
+      if (lane == 0) s_cnt[sidx] = cnt;
+      const int nrows = ho_hi >= ho_lo + sidx ? (ho_hi - (ho_lo + sidx)) / SLE + 1 : 0;
+      const int ncand = nrows * bw;
+#pragma unroll 1
+      for (int c0 = 0; c0 < ncand && !over; c0 += 64) {
+        const int c = c0 + lane;
+        bool hit = false;
+        float wgt = 0.f, cxk = 0.f, cyk = 0.f, xt = 0.f, yt = 0.f;
+        int ho = 0, wo = 0;
+        if (c < ncand) {
+          ho = ho_lo + sidx + (c / bw) * SLE; wo = wo_lo + c % bw;
+          hit = probe(ho, wo, wgt, cxk, cyk, xt, yt);
+        }
+        const unsigned long long m = __ballot(hit);
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        const int tot = cnt + __popcll(m);
+        if (tot > kSbCap) { over = true; }
+        else {
+          if (hit) { s_off[pos] = (ho * Wo + wo) * ldo; s_w[pos] = wgt; s_cx[pos] = cxk; s_cy[pos] = cyk; s_xt[pos] = xt; s_yt[pos] = yt; }
+          cnt = tot;
+        }
+      }
+    }
+    if (lane == 0) s_cnt[SLE] = over ? -1 : cnt;
+  }
+  __syncthreads();
+  const bool listed = s_cnt[SLE] >= 0;
+  float mx = 0.f;
+  const long long img = (long long)Ho * Wo * ldo;
+  const int c4 = lane;
+  const bool cval = c4 < C4;
+  for (int n = (int)blockIdx.y * 4 + wv; n < N; n += (int)gridDim.y * 4) {
+    const long long pix = ((long long)n * Hin + h) * Win + w;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TH && cval) xv = ld4(xfwd + (pix * C4 + c4) * 4);
+    const st_t *base = dy + n * img + coff + (cval ? c4 : 0) * 4;
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+    double tv[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll 1
+    for (int sidx = 0; sidx < SLE; ++sidx) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float ta[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (listed) {
+        const int m0 = s_cnt[sidx], m1 = sidx + 1 < SLE ? s_cnt[sidx + 1] : s_cnt[SLE];
+#pragma unroll 1
+        for (int m = m0; m < m1; m += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (m + q < m1 && cval) ? ld4(base + s_off[m + q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (m + q < m1 && cval) {
+              const float wgt = s_w[m + q];
+              acc.x += wgt * v[q].x; acc.y += wgt * v[q].y; acc.z += wgt * v[q].z; acc.w += wgt * v[q].w;
+              if (TH) {
+                const float dot = v[q].x * xv.x + v[q].y * xv.y + v[q].z * xv.z + v[q].w * xv.w;
+                const float cx = dot * s_cx[m + q], cy = dot * s_cy[m + q];
+                const float xt = s_xt[m + q], yt = s_yt[m + q];
+                ta[0] += cx * xt; ta[1] += cx * yt; ta[2] += cx;
+                ta[3] += cy * xt; ta[4] += cy * yt; ta[5] += cy;
+              }
+            }
+          }
+        }
+      } else {
+        for (int ho = ho_lo + sidx; ho <= ho_hi; ho += SLE)
+          for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            float wgt, cxk, cyk, xt, yt;
+            if (!probe(ho, wo, wgt, cxk, cyk, xt, yt) || !cval) continue;
+            const float4 v = ld4(base + (ho * Wo + wo) * ldo);
+            acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+            if (TH) {
+              const float dot = v.x * xv.x + v.y * xv.y + v.z * xv.z + v.w * xv.w;
+              const float cx = dot * cxk, cy = dot * cyk;
+              ta[0] += cx * xt; ta[1] += cx * yt; ta[2] += cx;
+              ta[3] += cy * xt; ta[4] += cy * yt; ta[5] += cy;
+            }
+          }
+      }
+      if (sidx == 0) total = acc;
+      else { total.x += acc.x; total.y += acc.y; total.z += acc.z; total.w += acc.w; }
+      if (TH) {       // the slice's theta sums: lanes by the fixed butterfly in double, then the slices in order
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double v = (double)ta[k];
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+          tv[k] = sidx == 0 ? v : tv[k] + v;
+        }
+      }
+    }
+    if (cval) {
+      if (accumulate) { const float4 p = dx[pix * C4 + c4]; total.x += p.x; total.y += p.y; total.z += p.z; total.w += p.w; }
+      dx[pix * C4 + c4] = total;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(total.x), fabsf(total.y)), fmaxf(fabsf(total.z), fabsf(total.w))));
+    }
+    if (TH && lane < 6) {
+      double v = tv[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) v = lane == k ? tv[k] : v;
+      tpart[pix * 6 + lane] = v;
+    }
+  }
+  if (absmax) {       // (kernel-uniform pointer) one atomic per wave: the magnitude is a maximum over 64 slots, any slot serves
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    unsigned *o = absmax + ((blockIdx.x + (unsigned)wv) & 63u);
+    if (lane == 0 && mx > 0.f) atomicMax(o, __float_as_uint(mx));
+  }
+}
+
 // dx[pixel][C4] (+)= sum over the chunks of part[chunk][pixel][C4], in chunk order; optional magnitude block of the stored dx
 __global__ __launch_bounds__(256) void sampler_bwd_reduce_kernel(const float4 *__restrict__ part, const A4Ptr dx, long long n4,
                                                                  int chunks, int accumulate, unsigned *__restrict__ absmax) {
@@ -400,6 +578,7 @@ int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *thet
 }
 
 // chunks of the pre-image rows per source pixel (1: one workgroup per pixel does it all)
+static int sampler_batched() { return dspn::sampler_batched(); }
 static int sampler_chunks(int N, int Hin, int Win, int Ho) {
   const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
   return (rows >= 32 && (long long)N * Hin * Win <= 4096) ? 8 : 1;
@@ -444,6 +623,19 @@ int DSPN_FN(dspn_affine_sampler_backward_data_theta)(const st_t *dy, const float
 #define DSPN_SBD_(SL) hipLaunchKernelGGL((sampler_bwd_data_kernel<SL, true>), dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
                                          A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, x, theta_partial, \
                                          dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax), nullptr)
+  // round 6: one workgroup per source POSITION for the whole batch (the geometry once, the rows of four matches in flight):
+  // same bits; dspn_affine_sampler_set_batched(0) keeps the kernel above (tests)
+  if (sampler_batched() && rows < 32 && C / 4 <= 64) {
+    const long long pos = (long long)Hin * Win;
+    const int gy = (int)std::max<long long>(1, std::min<long long>((N + 3) / 4, (2048 + pos - 1) / pos));
+#define DSPN_SBB_(SL) hipLaunchKernelGGL((sampler_bwd_data_batched_kernel<SL, true>), dim3((unsigned)pos, gy), dim3(256), 0, s, dy, theta, \
+                                         A4Ptr(dx), N, Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, x, theta_partial, \
+                                         dspn::kHalf ? nullptr : reinterpret_cast<unsigned *>(dx_absmax))
+    if (rows >= 10) DSPN_SBB_(4);
+    else DSPN_SBB_(1);
+#undef DSPN_SBB_
+    return dspn::check_launch("affine_sampler_backward_data_theta");
+  }
   if (rows >= 32) DSPN_SBD_(16);
   else if (rows >= 10) DSPN_SBD_(4);
   else DSPN_SBD_(1);

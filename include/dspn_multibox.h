@@ -65,6 +65,11 @@ int dspn_conv_set_wide_tiles(int mode);
  * (measured slower inside the training step: experiments only).  Stored tensors, per-tile extremes and magnitude blocks are
  * the same bits under every value; the per-tile BatchNorm tables agree within fp32 rounding (another summation order). */
 int dspn_conv_set_tile_spanning(int on);
+/* Launch setting (round 6; not compute state): 1 (default) = the data gradient of the affine sampler
+ * (dspn_affine_sampler_backward_data_theta_*) takes the geometry of a source position once for the whole batch (one workgroup
+ * per position, the matching target rows of four matches requested together); 0 = one workgroup per source pixel of every
+ * image (the round-4 kernel).  The same bits either way (tests). */
+int dspn_affine_sampler_set_batched(int on);
 
 /* Replaces MultiBoxPriorOp::Forward (operator/multibox_prior-inl.h:97-129) +
  * MultiBoxPriorForward (operator/multibox_prior.cc:30-71; GPU twin

@@ -57,20 +57,36 @@ for n in net.g.nodes:
     else:
         tw = timeit(lambda: fn.conv2d_wgrad(n.x_raw.data, dy, n.w.shape, n.stride, n.pad, n.dil, out=n.w.grad, in_affine=n.in_affine, math=n.math, x_absmax=xa, dy_absmax=dya, dy_planes=dyp))
     td = None
+    fused_d = 0
     if n.x.requires_grad:
         dx = n.x.own_grad()
-        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa, wt_shape=n.wt_shape, dy_planes=dyp))
+        # round 6: the data gradient as the GRAPH calls it -- with the BatchNorm-backward sums of the layer in front in its
+        # epilogue (that epilogue also reads the BatchNorm's input rows: counted in the bytes below)
+        bn = getattr(n, "bn_bwd_node", None)
+        bn_bwd = bn_dya = None
+        if bn is not None and bn.bwd_sums is not None and n.math == "f16x2":
+            bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
+            bn_dya = net.g.scalar(bn.am_dyin) if getattr(bn, "dx_planes", False) else None
+            fused_d = 1
+        td = timeit(lambda: fn.conv2d_dgrad(dy, n.wt, n.x.shape, n.stride, n.pad, n.dil, out=dx, wt_planes=n.wtp, math=n.math, dy_absmax=dya, w_absmax=wa, wt_shape=n.wt_shape, dy_planes=dyp, bn_bwd=bn_bwd, bn_dy_absmax=bn_dya))
     tot[0] += tf; tot[2] += tw; totf[0] += fl; totf[2] += fl
     if td: tot[1] += td; totf[1] += fl
-    cnt[key] = cnt.get(key, 0) + 1
     xin = N_ * H * W * Cin * 4 // (n.stride * n.stride if R * S == 1 else 1)          # (a strided 1x1 reads every stride-th pixel)
     byt = xin + M * Cout * 4 + Cout * R * S * Cin * 4
-    rows.setdefault(key, (n.w.name[:-7] + ("*" if dyp else "") + ("+" if xp is not None else ""), M, Cout, R * S * Cin, tf, fl, td, tw, byt))
-print("(* dy as piece planes in dgrad / wgrad, + x as piece planes in forward / wgrad; TB/s = algorithmic bytes of the pass / time, of 8)")
-for key, (name, M, Cout, K, tf, fl, td, tw, byt) in rows.items():
+    # the bytes the FUSED calls move on top: forward + residual (the shortcut rows the epilogue adds), data gradient + the rows
+    # of the BatchNorm input its epilogue reads for the backward sums
+    byt_f = byt + (M * Cout * 4 if n.residual is not None else 0)
+    byt_d = byt + (xin if fused_d else 0)
+    key = key + (n.residual is not None, fused_d)
+    cnt[key] = cnt.get(key, 0) + 1
+    rows.setdefault(key, (n.w.name[:-7] + ("*" if dyp else "") + ("+" if xp is not None else "") + ("r" if n.residual is not None else "") + ("^" if fused_d else ""),
+                          M, Cout, R * S * Cin, tf, fl, td, tw, byt, byt_f, byt_d))
+print("(* dy as piece planes in dgrad / wgrad, + x as piece planes in forward / wgrad, r forward adds a residual in its epilogue, ^ data gradient with the")
+print(" BatchNorm-backward sums in its epilogue; TB/s = bytes the call moves / time, of 8: operand + output + weights, + the residual rows (r), + the BatchNorm input rows (^))")
+for key, (name, M, Cout, K, tf, fl, td, tw, byt, byt_f, byt_d) in rows.items():
     print("%-32s x%-2d %8d %5d %6d | %7.3f %6.1f %4.2f %4.1f | %7s %6s %4s %4s | %7.3f %6.1f %4.2f %4.1f" % (
-        name, cnt[key], M, Cout, K, tf, fl / tf / 1e9, fl / tf / 1e9 / PEAK, byt / tf / 1e9,
+        name, cnt[key], M, Cout, K, tf, fl / tf / 1e9, fl / tf / 1e9 / PEAK, byt_f / tf / 1e9,
         ("%.3f" % td) if td else "-", ("%.1f" % (fl / td / 1e9)) if td else "-", ("%.2f" % (fl / td / 1e9 / PEAK)) if td else "-",
-        ("%.1f" % (byt / td / 1e9)) if td else "-", tw, fl / tw / 1e9, fl / tw / 1e9 / PEAK, byt / tw / 1e9))
+        ("%.1f" % (byt_d / td / 1e9)) if td else "-", tw, fl / tw / 1e9, fl / tw / 1e9 / PEAK, byt / tw / 1e9))
 print("TOTAL fwd %.2f ms (%.1f TF)  dgrad %.2f ms (%.1f TF)  wgrad %.2f ms (%.1f TF)" % (
     tot[0], totf[0] / tot[0] / 1e9, tot[1], totf[1] / tot[1] / 1e9, tot[2], totf[2] / tot[2] / 1e9))

@@ -418,6 +418,46 @@ def test_affine_sampler_small_source_maps_split_over_workgroups(gpu_device, hw):
     assert torch.equal(again, dx)
 
 
+@pytest.mark.parametrize("theta", [(1, 0, 0, 0, 1, 0), (0.97, 0.04, -0.03, -0.05, 1.04, 0.02), (0.7, -0.5, 0.1, 0.45, 0.8, -0.2),
+                                   (0.03, 0.01, 0.2, -0.02, 0.04, -0.1), (3.0, 0.0, 0.0, 0.0, 2.5, 0.0)])
+@pytest.mark.parametrize("hw", [(64, 64), (32, 32), (16, 16), (33, 20)])
+def test_affine_sampler_batched_data_gradient_gives_the_same_bits(gpu_device, theta, hw):
+    """Round 6: the data gradient + theta rows with the geometry of a source position taken ONCE for the whole batch
+    (sampler_bwd_data_batched_kernel: a workgroup per position lists the matching target pixels in the order the per-pixel
+    kernel visits them, every wave walks its share of the batch) against the per-pixel kernel it replaces
+    (dspn_affine_sampler_set_batched(0)): dx overwritten / in place / accumulating, the magnitude block and the float64 theta
+    rows bit for bit -- near-identity grids (a handful of matches per position), a rotation, a strongly MINIFYING theta
+    (thousands of matches per position: the list overflows and the position is walked as before) and a magnifying one (most
+    positions get no match), sources of the target's size and smaller (the four-slice order of the 16 x 16 level), a
+    workgroup count that does not divide the batch."""
+    from dspnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(hw[0] * 7 + hw[1])
+    B, C, Ho, Wo = 5, 172, 64, 64
+    th = torch.tensor(theta, dtype=torch.float32, device="cuda")
+    x = torch.randn(B, hw[0], hw[1], C, generator=g).cuda()
+    dy = torch.randn(B, Ho, Wo, C + 4, generator=g).cuda()
+    rows = fn.affine_sampler_theta_rows(x.shape, Ho)
+    out = {}
+    try:
+        for on in (0, 1):
+            _lib.check(L.dspn_affine_sampler_set_batched(on), "set_batched")
+            part = torch.full((rows, 6), float("nan"), dtype=torch.float64, device="cuda")
+            am = torch.zeros(64, device="cuda")
+            dx = fn.affine_sampler_backward_data_theta(dy, th, x, 4, part, dx_absmax=am)
+            buf = x.clone()
+            part2 = torch.full((rows, 6), float("nan"), dtype=torch.float64, device="cuda")
+            inplace = fn.affine_sampler_backward_data_theta(dy, th, buf, 4, part2, dx=buf)
+            acc = fn.affine_sampler_backward_data_theta(dy, th, x, 4, part2.clone(), dx=dx.clone(), accumulate=True)
+            out[on] = [dx, inplace, acc, part, part2, am.max().reshape(1)]
+    finally:
+        L.dspn_affine_sampler_set_batched(1)
+    assert float(out[1][5]) == float(out[1][0].abs().max())
+    for i, (a, b) in enumerate(zip(out[1], out[0])):
+        assert torch.equal(a, b), i
+    assert L.dspn_affine_sampler_set_batched(2) != 0
+
+
 @pytest.mark.parametrize("hin,win", [(4, 4), (16, 16), (64, 64), (5, 9)])
 def test_affine_sampler_identity_equals_plain_resize(gpu_device, hin, win):
     """with affine_matrix = (1,0,0,0,1,0) the general sampler reproduces dspn_bilinear_forward_f32 bit for bit"""
