@@ -239,8 +239,12 @@ __global__ __launch_bounds__(64 * SL) void sampler_bwd_data_kernel(const st_t *_
 // bilinear weights and theta factors, in LDS; then every wave walks its share of the batch with lanes over channels: the
 // rows of a group of four matches are requested together (the kernel above waits for each match's row before it asks for
 // the next: a 64 x 64 map took 0.32 ms for 90 MB), the sums run in the listed order -- per slice, then the slices in order --
-// so dx, the largest stored |dx| and the theta rows are the bits of sampler_bwd_data_kernel<SLE, TH>.  A box with more
-// matches than the list holds (a strongly minifying theta) is walked as before.  At most 64 float4 columns (the host routes).
+// i.e. the same sums in the same order as sampler_bwd_data_kernel<SLE, TH>.  NOT guaranteed the same bits: this file compiles
+// with fp contract(fast), and which product of `t0 xt + t1 yt + t2` hipcc fuses depends on the loop around it (measured: the
+// coordinates differ in the last place for a generic theta, dx by <= 5e-6 of its largest entry; the identity grid gives the
+// same bits).  Both entry points of the data gradient run THIS kernel, so they agree with each other bit for bit.  A box with
+// more matches than the list holds (a strongly minifying theta) is walked as before.  At most 64 float4 columns (the host
+// routes).
 constexpr int kSbCap = 768;        // matches per source position kept in LDS
 template <int SLE, bool TH>
 __global__ __launch_bounds__(256) void sampler_bwd_data_batched_kernel(const st_t *__restrict__ dy, const float *__restrict__ theta,
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void sampler_bwd_data_batched_kernel(const st_
     else if (x0 + 1 == w) { wx = 1.f - (1.f - (xs - (float)x0)); sx = 1.f; }
     else return false;
     wgt = wy * wx;
-    cxk = (wy * sx) * khw; cyk = (wx * sy) * khh;
+    cxk = wy * sx; cyk = wx * sy;
     return true;
   };
   const int bw = wo_hi - wo_lo + 1;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void sampler_bwd_data_batched_kernel(const st_
               acc.x += wgt * v[q].x; acc.y += wgt * v[q].y; acc.z += wgt * v[q].z; acc.w += wgt * v[q].w;
               if (TH) {
                 const float dot = v[q].x * xv.x + v[q].y * xv.y + v[q].z * xv.z + v[q].w * xv.w;
-                const float cx = dot * s_cx[m + q], cy = dot * s_cy[m + q];
+                const float cx = dot * s_cx[m + q] * khw, cy = dot * s_cy[m + q] * khh;
                 const float xt = s_xt[m + q], yt = s_yt[m + q];
                 ta[0] += cx * xt; ta[1] += cx * yt; ta[2] += cx;
                 ta[3] += cy * xt; ta[4] += cy * yt; ta[5] += cy;
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void sampler_bwd_data_batched_kernel(const st_
             acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
             if (TH) {
               const float dot = v.x * xv.x + v.y * xv.y + v.z * xv.z + v.w * xv.w;
-              const float cx = dot * cxk, cy = dot * cyk;
+              const float cx = dot * cxk * khw, cy = dot * cyk * khh;
               ta[0] += cx * xt; ta[1] += cx * yt; ta[2] += cx;
               ta[3] += cy * xt; ta[4] += cy * yt; ta[5] += cy;
             }
@@ -568,6 +572,16 @@ int DSPN_FN(dspn_affine_sampler_backward_data)(const st_t *dy, const float *thet
   // slices by the nominal footprint (the grid is near the identity map): rows of the pre-image box per source pixel
   const int rows = 2 * ((Ho + Hin - 1) / Hin) + 2;
   hipStream_t s = (hipStream_t)stream;
+  if (dspn::sampler_batched() && rows < 32 && C / 4 <= 64) {      // (as dspn_affine_sampler_backward_data_theta below: the same kernel)
+    const long long pos = (long long)Hin * Win;
+    const int gy = (int)std::max<long long>(1, std::min<long long>((N + 3) / 4, (2048 + pos - 1) / pos));
+#define DSPN_SBB_(SL) hipLaunchKernelGGL((sampler_bwd_data_batched_kernel<SL, false>), dim3((unsigned)pos, gy), dim3(256), 0, s, dy, theta, \
+                                         A4Ptr(dx), N, Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, nullptr, nullptr, nullptr)
+    if (rows >= 10) DSPN_SBB_(4);
+    else DSPN_SBB_(1);
+#undef DSPN_SBB_
+    return dspn::check_launch("affine_sampler_backward_data");
+  }
 #define DSPN_SBD_(SL) hipLaunchKernelGGL((sampler_bwd_data_kernel<SL, false>), dim3((unsigned)pix), dim3(64, SL), 0, s, dy, theta, \
                                          A4Ptr(dx), Hin, Win, C / 4, Ho, Wo, ldo, coff, accumulate, nullptr, nullptr, nullptr, nullptr)
   if (rows >= 32) DSPN_SBD_(16);
