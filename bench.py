@@ -48,9 +48,9 @@ MATH_LABEL = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (operands rounded to bf16)
               "bf16x3": "fp32 on the bf16 MFMA (3-piece split, 6 products)",
               "f16x2": "fp32 on the fp16 MFMA (2-piece split after a per-tensor power-of-two scale, 3 products)"}
 # committed rocprofv3 --pmc passes of the headline workload per math mode, newest first (roofline.traffic is read from these)
-TRAFFIC_PROFILES = {"f16x2": ["r05_f16x2_pmc_conv_family.json", "r04_f16x2_pmc_conv_family.json", "r03_f16x2_pmc_conv_family.json"],
-                    "bf16x3": ["r05_x3_pmc_conv_family.json", "r04_x3_pmc_conv_family.json", "r03_x3_pmc_conv_family.json", "r02_x3_pmc_conv_family.json"],
-                    "fp32": ["r05_fp32_pmc_conv_family.json", "r04_fp32_pmc_conv_family.json", "r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json",
+TRAFFIC_PROFILES = {"f16x2": ["r06_f16x2_pmc_conv_family.json", "r05_f16x2_pmc_conv_family.json", "r04_f16x2_pmc_conv_family.json", "r03_f16x2_pmc_conv_family.json"],
+                    "bf16x3": ["r06_x3_pmc_conv_family.json", "r05_x3_pmc_conv_family.json", "r04_x3_pmc_conv_family.json", "r03_x3_pmc_conv_family.json", "r02_x3_pmc_conv_family.json"],
+                    "fp32": ["r06_fp32_pmc_conv_family.json", "r05_fp32_pmc_conv_family.json", "r04_fp32_pmc_conv_family.json", "r02_fp32_pmc_conv_family.json", "r02_pmc_conv_family.json",
                              "r01_j_pmc_conv_family.json"]}
 PROF_STEPS = 2   # steps of the timed region whose convolution launches are bracketed by HIP events (roofline.achieved)
 
