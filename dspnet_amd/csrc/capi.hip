@@ -54,7 +54,7 @@ int wide_tiles_mode() { return g_wide_tiles.load(std::memory_order_relaxed); }
 // round 6: the tile-spanning loop of the short-K members of the wide family (conv_wide.h, XT); DSPN_XT=0 starts with it off
 static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 2 ? 2 : v); }()};
 int tile_spanning() { return g_tile_spanning.load(std::memory_order_relaxed); }
-static std::atomic<int> g_sampler_batched{1};
+static std::atomic<int> g_sampler_batched{[] { const char *e = getenv("DSPN_SAMPLER_BATCHED"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 int sampler_batched() { return g_sampler_batched.load(std::memory_order_relaxed); }
 }  // namespace dspn
 
