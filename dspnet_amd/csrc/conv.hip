@@ -1809,20 +1809,14 @@ int launch_nt_impl(const st_t *in, const st_t *w, const float *bias, st_t *out, 
   auto kern = conv_nt_kernel<WAVES_M, WAVES_N, TM, TN, UNIFORM_TAP, MATH, INTF, EPI>;
   // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs, a multiple of 8 so that
   // a workgroup's tiles t, t + grid, ... stay on its XCD's run of the tile order); each walks its tiles
-  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
-  if (!slots) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
-    slots = std::max(8, std::max(1, per_cu) * std::max(1, cus) / 8 * 8);
-    if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
-              WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, per_cu, cus, slots);
-  }
+  static dspn::KernelDeviceState st;
+  const bool first = !st.slots[0] && !st.slots[1];
+  const int dev = dspn::ensure_persistent_grid(reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds, st, "conv_nt");
+  if (dev < 0) return dev;
+  const int slots = st.slots[dev], slots_per_cu = st.slots_per_cu[dev], slots_cus = st.cus[dev];
+  if (first && getenv("DSPN_DEBUG_PRINT"))
+    fprintf(stderr, "[dspn] conv_nt<%d,%d,%d,%d,uni=%d,bf16=%d,intf=%d,epi=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n",
+            WAVES_M, WAVES_N, TM, TN, (int)UNIFORM_TAP, MATH, (int)INTF, EPI, lds, slots_per_cu, slots_cus, slots);
   // dspn_conv_set_reserved_cus(k): the persistent grid leaves k CUs' worth of workgroup slots free, so that the kernels of
   // another queue (RCCL's all-reduce of the gradient buckets) find room beside a convolution instead of only between two
   const int reserved = dspn::reserved_cus();
@@ -2527,12 +2521,8 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
 #define DSPN_WGRAD_LAUNCH_(WM, WN, TM_, TN_, BF, TF)                                                     \
   {                                                                                                      \
     auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF, TF>;                                             \
-    static bool attr = false;                                                                            \
-    if (!attr) {                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-      attr = true;                                                                                       \
-    }                                                                                                    \
+    static dspn::KernelDeviceState st;                                                                   \
+    if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, st, "conv_wgrad"); dev < 0) return dev; \
     hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128

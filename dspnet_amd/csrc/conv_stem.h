@@ -169,11 +169,8 @@ int launch_conv_stem(const float *x, const float *w, float *y, int N, int H, int
   if (dspn::wide_tiles_mode() == 1) return 1;
   if (Cin != 4 || Cout != 64 || Wo % kStemSeg != 0 || Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return 1;
   const int lds = kStemWBytes + kStemRing * 2 * kStemRowBytes + 8 * 64 * 4 * (int)sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
-  }
+  static dspn::KernelDeviceState st;
+  if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(conv_stem_f16x2_kernel), (size_t)lds, st, "conv_stem"); dev < 0) return dev;
   // strips: enough workgroups for two rounds of the chip, at least 8 output rows each (the first row of a strip loads 7 input rows)
   int rows = 16;
   while (rows > 8 && (long long)N * ((Ho + rows - 1) / rows) * (Wo / kStemSeg) < 512) rows -= 4;

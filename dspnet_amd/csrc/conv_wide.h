@@ -1190,19 +1190,14 @@ int launch_ntv_impl(const float *in, const float *w, const float *bias, float *o
   const size_t lds = XT ? (size_t)2 * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
                         : std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
   auto kern = conv_ntv_kernel<WAVES_M, WAVES_N, INTF, EPI, SR, XT>;
-  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
-  if (!slots) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
-    slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
-    if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_ntv<%d,%d,intf=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
-              (int)INTF, EPI, (int)XT, lds, per_cu, cus, slots);
-  }
+  static dspn::KernelDeviceState st;
+  const bool first = !st.slots[0] && !st.slots[1];
+  const int dev = dspn::ensure_persistent_grid(reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds, st, "conv_ntv");
+  if (dev < 0) return dev;
+  const int slots = st.slots[dev], slots_per_cu = st.slots_per_cu[dev], slots_cus = st.cus[dev];
+  if (first && getenv("DSPN_DEBUG_PRINT"))
+    fprintf(stderr, "[dspn] conv_ntv<%d,%d,intf=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+            (int)INTF, EPI, (int)XT, lds, slots_per_cu, slots_cus, slots);
   const int reserved = dspn::reserved_cus();
   const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
   const int grid_x = (int)std::min<long long>((long long)mt * nt, avail);
@@ -1245,19 +1240,14 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
   const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
                         : std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
   auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR, XT>;
-  static int slots = 0, slots_per_cu = 0, slots_cus = 0;
-  if (!slots) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds);
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots_per_cu = std::max(1, per_cu); slots_cus = std::max(1, cus);
-    slots = std::max(8, slots_per_cu * slots_cus / 8 * 8);
-    if (getenv("DSPN_DEBUG_PRINT"))
-      fprintf(stderr, "[dspn] conv_ntw<%d,%d,stages=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
-              STAGES, EPI, (int)XT, lds, per_cu, cus, slots);
-  }
+  static dspn::KernelDeviceState st;
+  const bool first = !st.slots[0] && !st.slots[1];
+  const int dev = dspn::ensure_persistent_grid(reinterpret_cast<const void *>(kern), WAVES_M * WAVES_N * 64, lds, st, "conv_ntw");
+  if (dev < 0) return dev;
+  const int slots = st.slots[dev], slots_per_cu = st.slots_per_cu[dev], slots_cus = st.cus[dev];
+  if (first && getenv("DSPN_DEBUG_PRINT"))
+    fprintf(stderr, "[dspn] conv_ntw<%d,%d,stages=%d,epi=%d,xt=%d>: %zu B LDS, occupancy %d/CU x %d CUs -> grid %d\n", WAVES_M, WAVES_N,
+            STAGES, EPI, (int)XT, lds, slots_per_cu, slots_cus, slots);
   const int reserved = dspn::reserved_cus();
   const int avail = reserved > 0 ? std::max(8, slots_per_cu * std::max(8, slots_cus - reserved) / 8 * 8) : slots;
   const int grid_x = (int)std::min<long long>((long long)mt * nt, avail);

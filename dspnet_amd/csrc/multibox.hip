@@ -1474,12 +1474,10 @@ int dspn_multibox_detection_f32(const float *cls_prob_dev, const float *loc_pred
     int selcap = nms_topk > 0 ? next_pow2(std::min(nms_topk, num_anchors)) : 0;
     if (!nms_enabled || 2 * selcap > l.n2cap || 8 * (size_t)(l.n2cap + selcap) > kDynMax) selcap = 0;
     const size_t lds = 8 * (size_t)(l.n2cap + selcap);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_decode_sort_kernel<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynMax);
-      attr_set = true;
-    }
+    // (kDynMax + the kernel's ~18.5 KiB of static LDS is ~158 of gfx950's 160 KiB: a part with less, or one more static array,
+    // fails in ensure_dynamic_lds with a message instead of at the launch)
+    static dspn::KernelDeviceState st;
+    if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(det_decode_sort_kernel<true>), kDynMax, st, "multibox_detection"); dev < 0) return dev;
     hipLaunchKernelGGL(det_decode_sort_kernel<true>, dim3(batch), dim3(kTB), lds, s, cls_prob_dev,
                        loc_pred_dev, an, num_anchors, num_classes, threshold, clip, variances[0],
                        variances[1], variances[2], variances[3], nms_enabled, nms_topk, force_suppress != 0, l.n2cap, selcap,

@@ -183,12 +183,8 @@ int dspn_nms_pixel_f32(const float *dets_dev, int n, float thresh, int suppress_
   float *sorted = reinterpret_cast<float *>(w + dspn::align_up(sizeof(int) * n, 16));
   unsigned long long *mask = reinterpret_cast<unsigned long long *>(
       w + dspn::align_up(sizeof(int) * n, 16) + dspn::align_up(sizeof(float) * 4 * n, 16));
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kMaxN * 8);
-    attr = true;
-  }
+  static dspn::KernelDeviceState st;
+  if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(nms_sort_kernel), (size_t)kMaxN * 8, st, "nms_pixel"); dev < 0) return dev;
   hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), (size_t)np2 * 8, s, dets_dev, n, np2, order, sorted);
   hipLaunchKernelGGL(nms_mask_kernel_px, dim3(cb, cb), dim3(64), 0, s, sorted, n, thresh, suppress_ge, mask, cb);
   hipLaunchKernelGGL(nms_scan_kernel_px, dim3(1), dim3(64), 0, s, mask, order, n, cb, keep_dev, num_keep_dev);
