@@ -424,7 +424,7 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
     out = {}
     for on in (0, 2):          # 2: the plane-fed AND the float-operand kernel on the tile-spanning loop
         spanning(on)
-        got = []
+        got, extra = [], []
         for src, kw in ((xp, dict(x_absmax=xpa, x_planes=True)), (x, dict(x_absmax=xa)), (x, dict(x_absmax=xaa, in_affine=aff))):
             kw = dict(kw, w_planes=wp, w_absmax=wa)
             got.append(fn.conv2d_forward(src, w, None, stride, pad, 1, **kw))
@@ -433,6 +433,11 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
             fn.conv2d_forward(src, w, None, stride, pad, 1, out=acc, accumulate=True, **kw)
             st = torch.zeros(t2, 2, Cout, device="cuda"); mm = torch.zeros(t2, 2, Cout, device="cuda")
             got += [acc, fn.conv2d_forward(src, w, None, stride, pad, 1, out_stats=st, out_minmax=mm, **kw), st, mm]
+            both = base.clone()          # residual AND accumulate in one call, with bias + ReLU and the magnitude block
+            am = torch.zeros(fn.ABSMAX_SLOTS, device="cuda")
+            fn.conv2d_forward(src, w, bias, stride, pad, 1, residual=res, relu=True, out=both, accumulate=True, **kw)
+            plain_am = fn.conv2d_forward(src, w, None, stride, pad, 1, out_absmax=am, **kw)
+            extra.append([both, plain_am, am.max().reshape(1)])
         for src, kw in ((dyp, dict(dy_absmax=dya, dy_planes=True)), (dy, dict(dy_absmax=dya))):
             kw = dict(kw, wt_planes=wtp, w_absmax=wa)
             sums = torch.zeros(ntile, 2, Cin, device="cuda"); bam = torch.zeros(64, device="cuda")
@@ -443,6 +448,7 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
             fn.conv2d_dgrad(src, wt, tuple(x.shape), stride, pad, 1, out=dx3, accumulate=True, **kw)
             got += [dx, dx2, dx3, sums, bam.clone()]
         out[on] = got
+        out[(on, "extra")] = [t for e in extra for t in e]
     ref32 = fn.conv2d_forward(x, w, None, stride, pad, 1, math="fp32")
     assert float((out[2][6] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
     for i, (a, b) in enumerate(zip(out[2], out[0])):
@@ -452,3 +458,6 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (i, "BatchNorm-backward sums")
         else:                       # every stored tensor, the extremes and the magnitude block: the same bits
             assert torch.equal(a, b), i
+    for i, (a, b) in enumerate(zip(out[(2, "extra")], out[(0, "extra")])):
+        assert torch.equal(a, b), ("extra", i)
+    assert float(out[(2, "extra")][2]) == float(out[(2, "extra")][1].abs().max())
