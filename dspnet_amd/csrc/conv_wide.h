@@ -52,6 +52,14 @@ struct WideStamps {
 
 // dspn_conv_set_tile_spanning / DSPN_XT=0: the tile-spanning loop off (tests, same-box A/B runs; the results do not depend on it)
 inline bool xt_enabled() { return dspn::tile_spanning() != 0; }
+// DSPN_XT8=1: the eight-wave 128 x 256 member on the tile-spanning loop too.  Built, bit-identical (tests/test_wide_tiles_gpu.py runs
+// it under the forced tile shape) and NEUTRAL on the step -- 954.5 vs 956.8 images/s over three alternating runs on one box, conv
+// family 26.66 vs 26.79 ms: its layers have 36+ k-steps and one to four tiles per workgroup, the epilogue is a tenth of a tile --
+// so the default leaves it on the round-5 loop; setting 2 of dspn_conv_set_tile_spanning routes it as well.
+inline bool xt_wide8_enabled() {
+  static const bool on = [] { const char *e = getenv("DSPN_XT8"); return e && atoi(e) != 0; }();
+  return on || dspn::tile_spanning() >= 2;
+}
 // ... whose direct epilogue addresses the output (and the tensors of its shape) as one buffer of M rows of ldc elements
 inline bool xt_output_ok(const ConvGeom &g) {
   const long long M = (long long)g.N * g.Hg * g.Wg;
@@ -517,12 +525,12 @@ __device__ __forceinline__ void wide_publish_absmax(const ConvGeom &g, char *wsm
     }
 }
 
-// XT (round 6): the TILE-SPANNING loop for the short-K layers (1 x 1 convolutions of 2 .. 16 k-steps, where the epilogue is most
-// of the kernel and the first images of a tile used to be requested only after the previous tile's last store): two ring slots,
-// an even number of k-steps, so a tile's last k-step sits in slot 1; the request that the plain loop issues "past the last
-// k-step" (out of range, zeros) is here the LIVE request of the next tile's first k-step into slot 0, and the epilogue stages
-// its tile chunk by chunk in an area behind slot 0 (wide_epilogue) -- the next tile's rows are on their way while the current
-// tile is written out.  Same K order, same epilogue arithmetic: the bits of the plain loop.
+// XT (round 6): the TILE-SPANNING loop (first for the short-K layers -- 1 x 1 convolutions of 2 .. 16 k-steps, where the epilogue
+// is most of the kernel and the first images of a tile used to be requested only after the previous tile's last store -- then
+// for every member with 128-row tiles): the ring runs on across tile boundaries -- the requests the plain loop issues "past
+// the last k-step" (out of range, zeros) are here the LIVE requests of the next tile's first k-steps -- and the epilogue works
+// from the accumulators (direct_epilogue), so the next tile's images are on their way while the current tile is written out.
+// Same K order, same epilogue arithmetic per element: the bits of the plain loop.
 template <int WAVES_M, int WAVES_N, int STAGES, int EPI, int SR = 128, bool XT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     const st_t *__restrict__ in, const st_t *__restrict__ wgt, const float *__restrict__ bias,
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   constexpr int D = STAGES - 1;                          // k-steps in flight ahead of the one being multiplied
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   static_assert(BM % SR == 0, "BatchNorm tables are per SR rows");
-  static_assert(!XT || (STAGES == 2 && !kHalf), "the tile-spanning loop: two slots, float build");
+  static_assert(!XT || (!kHalf && WAVES_M == 2), "the tile-spanning loop: float build, one 128-row statistics tile per output tile");
   extern __shared__ __attribute__((aligned(1024))) char wsm[];
 
 #ifdef DSPN_ABLATE
@@ -719,38 +727,62 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   float gmx_all = 0.f;       // EPI == 2: largest |dx| stored by this thread over all its tiles (g.bn_dy_absmax)
 
   if constexpr (XT) {
-    // (the host routes an even nk >= 2 here)
+    // One ring for the whole walk: k-step s of the flattened (tile, k-step) sequence sits in slot s % STAGES and is requested D
+    // k-steps ahead, across tile boundaries (the host routes nk >= STAGES: a tile's first D requests all belong to one tile).
+    // The exchange of the direct epilogue's per-column partials lives behind the ring where that fits beside a second
+    // workgroup (four waves), and IN the slot of the tile's last k-step -- the one slot no request is aimed at while the
+    // epilogue runs -- where one workgroup owns the CU (eight waves, 144 KiB of ring): that costs one barrier per tile.
+    constexpr bool EXCH_IN_RING = NWV == 8;
     int t = blockIdx.x;
-    if (t < ntiles) { setup_tile(t); issue(0, true); }
+    if (t < ntiles) {
+      setup_tile(t);
+#pragma unroll
+      for (int j = 0; j < D; ++j) issue(j, true);
+    }
+    int slot = 0, islot = D % STAGES;
+    bool more = false;
     DSPN_STAMP_DECL;
     for (; t < ntiles; t += gridDim.x) {
-      const int m0 = ld_m0, n0 = ld_n0;
+      const int m0 = ld_m0, n0 = ld_n0;            // (the loaders moved on to this tile during the previous tile's last D k-steps)
       const int tn = t + (int)gridDim.x;
+      const bool first = t == (int)blockIdx.x;
       zero_acc();
+      int last_slot = 0;
       for (int kt = 0; kt < nk; ++kt) {
-        // slot kt & 1 has landed (this wave's pieces: the wait; the other waves': the barrier).  The images of a tile's FIRST
-        // k-step were requested before the previous tile's epilogue, whose 64 stores per wave (always issued: out-of-range
-        // lanes are dropped by the hardware) are younger: the counted wait does not ask for those to be acknowledged -- they
-        // have the whole k-step for that
-        if (kt == 0 && t != (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the images of this k-step have landed (this wave's pieces: the wait; the other waves': the barrier).  A tile's first D
+        // k-steps were requested BEFORE the previous tile's epilogue, whose 64 stores per wave (always issued: out-of-range
+        // lanes are dropped by the hardware) are younger, as are the D - 1 requests behind them: "at most 63 younger
+        // operations outstanding" says they have landed without asking for those stores to be acknowledged
+        if (!first && kt < D) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 == nk) {              // (wave-uniform) the next request is the NEXT tile's first k-step, into slot 0
-          const bool more = tn < ntiles;
-          if (more) setup_tile(tn);
-          issue_begin(0, more);
-        } else {
-          issue_begin((kt + 1) & 1, true);
+        if (kt + D < nk) {
+          issue_begin(islot, true);
+        } else {                         // (wave-uniform) the request belongs to the NEXT tile: k-step kt + D - nk of it
+          if (kt + D == nk) { more = tn < ntiles; if (more) setup_tile(tn); }
+          issue_begin(islot, more);
         }
-        mma_step(kt & 1);
+        mma_step(slot);
+        last_slot = slot;
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        islot = islot + 1 == STAGES ? 0 : islot + 1;
       }
       DSPN_STAMP(2);
-      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, wsm + STAGES * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+      char *exch = wsm + STAGES * STG;
+      if constexpr (EXCH_IN_RING) {
+        exch = wsm + last_slot * STG;
+        if constexpr (EPI != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // every wave has read its last fragments
+      }
+      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, exch, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
       DSPN_STAMP(5);
     }
     DSPN_STAMP_FLUSH;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last, out-of-range request)
-    if constexpr (EPI != 1) wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last, out-of-range requests)
+    if constexpr (EPI != 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // (the exchange of the last tile has been read)
+      wide_publish_absmax<NWV>(g, wsm, gmx_all, tid);
+    }
     return;
   }
 
@@ -1236,8 +1268,9 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
-  // XT: the ring and, behind it, the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats)
-  const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
+  // XT: the ring and -- four waves -- behind it the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats;
+  // eight waves keep it in the ring slot of the tile's last k-step)
+  const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + (WAVES_M * WAVES_N == 8 ? 0 : sizeof(float) * 4 * BN * 6)
                         : std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
   auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR, XT>;
   static dspn::KernelDeviceState st;
@@ -1261,9 +1294,11 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
 template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
 int launch_ntw(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s, const st_t *residual) {
 #ifndef DSPN_HALF
-  if constexpr (WAVES_M == 2 && WAVES_N == 2 && STAGES == 2 && SR == 128) {
+  if constexpr (WAVES_M == 2 && SR == 128) {
+    // the four-wave 128 x 128 tile (setting >= 1) and the eight-wave 128 x 256 tile (setting 2 / DSPN_XT8=1: neutral on the step,
+    // see xt_wide8_enabled) on layers of at least STAGES k-steps
     const int nk = g.TR * g.TS * (g.Cin / 32);
-    if (xt_enabled() && nk >= 2 && nk % 2 == 0 && xt_output_ok(g)) {
+    if (xt_enabled() && nk >= STAGES && xt_output_ok(g) && (WAVES_N == 2 || xt_wide8_enabled())) {
       if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR, true>(in, w, bias, out, g, s, residual);
       if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR, true>(in, w, bias, out, g, s, residual);
       return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR, true>(in, w, bias, out, g, s, residual);

@@ -61,8 +61,8 @@ int dspn_conv_set_wide_tiles(int mode);
 /* Launch setting (round 6; not compute state): the TILE-SPANNING loop of the 128 x 128 four-wave members of the wide family on
  * layers with an even number of k-steps and a dense output of whole 128-row tiles -- the next tile's first operand images are
  * requested while the current tile is written out, straight from the accumulators.  0 = the round-5 loop; 1 (default; the
- * environment variable DSPN_XT sets the process's initial value) = the plane-fed kernel; 2 = also the float-operand kernel
- * (measured slower inside the training step: experiments only).  Stored tensors, per-tile extremes and magnitude blocks are
+ * environment variable DSPN_XT sets the process's initial value) = the plane-fed 128 x 128 kernel; 2 = also the eight-wave
+ * 128 x 256 kernel (measured neutral) and the float-operand kernel (measured slower inside the training step): experiments.  Stored tensors, per-tile extremes and magnitude blocks are
  * the same bits under every value; the per-tile BatchNorm tables agree within fp32 rounding (another summation order). */
 int dspn_conv_set_tile_spanning(int on);
 /* Launch setting (round 6; not compute state): 1 (default) = the data gradient of the affine sampler

@@ -368,17 +368,18 @@ def test_float_gradient_data_gradient_on_every_tile_is_bit_identical(tiles, case
                 assert torch.equal(a, b), (MODES[mode], i)
 
 
-# ---- round 6: the tile-spanning loop (conv_wide.h, XT) of the 128 x 128 four-wave members, against their round-5 loop
+# ---- round 6: the tile-spanning loop (conv_wide.h, XT) of the 128-row members (128 x 128 on four waves, two ring slots, exchange
+# behind the ring; 128 x 256 on eight waves, three slots, exchange inside the ring), against their round-5 loop
 # (N, H, W, Cin, Cout, k, stride): even k-step counts 2 .. 18, one to four tiles per workgroup (512 workgroups fill the chip),
 # ragged last row tile / column tile
 XT_CASES = [(16, 64, 64, 64, 256, 1, 1), (32, 64, 64, 256, 128, 1, 1), (13, 61, 67, 64, 192, 1, 1), (16, 64, 64, 128, 256, 1, 2),
             (8, 48, 48, 64, 128, 3, 1), (32, 32, 32, 512, 256, 1, 1), (3, 17, 19, 128, 256, 1, 1)]
 
 
-@pytest.fixture()
-def spanning(tiles):
+@pytest.fixture(params=[4, 3], ids=["128x128 on four waves", "128x256 on eight waves"])
+def spanning(tiles, request):
     L = _lib.lib()
-    tiles(4)
+    tiles(request.param)
     yield lambda on: _lib.check(L.dspn_conv_set_tile_spanning(on), "set_tile_spanning")
     L.dspn_conv_set_tile_spanning(1)
 
