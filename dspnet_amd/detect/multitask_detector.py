@@ -34,7 +34,13 @@ class Detector:
         """data: (B,3,H,W) float32 device tensor, RGB, mean already subtracted (dataset/iterator.py:570-571)"""
         if data is not None:
             self.net.data.data.copy_(data)
-        self.net.g.forward()
+        g = self.net.g
+        if g.scalars is not None and g.guard["enabled"] and not g.guard["have_stats"]:
+            # range guard of the default math (advisor r5): the very first batch of a freshly loaded net has no spans to decide
+            # from -- one extra forward measures them (inputs, weights), the next decides from that pass before it runs
+            g.forward()
+            g.guard["decide_now"] = True
+        g.forward()
         self.net.det.join()        # MultiBoxDetection runs on a side stream beside the seg decoder
         return self.net.det.out.data, self.net.seg_out.prob.data
 
