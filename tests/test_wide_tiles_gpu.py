@@ -370,10 +370,12 @@ def test_float_gradient_data_gradient_on_every_tile_is_bit_identical(tiles, case
 
 # ---- round 6: the tile-spanning loop (conv_wide.h, XT) of the 128-row members (128 x 128 on four waves, two ring slots, exchange
 # behind the ring; 128 x 256 on eight waves, three slots, exchange inside the ring), against their round-5 loop
-# (N, H, W, Cin, Cout, k, stride): even k-step counts 2 .. 18, one to four tiles per workgroup (512 workgroups fill the chip),
+# (N, H, W, Cin, Cout, k, stride): k-step counts 2 .. 18, one to four tiles per workgroup (512 workgroups fill the chip),
 # ragged last row tile / column tile
 XT_CASES = [(16, 64, 64, 64, 256, 1, 1), (32, 64, 64, 256, 128, 1, 1), (13, 61, 67, 64, 192, 1, 1), (16, 64, 64, 128, 256, 1, 2),
-            (8, 48, 48, 64, 128, 3, 1), (32, 32, 32, 512, 256, 1, 1), (3, 17, 19, 128, 256, 1, 1)]
+            (8, 48, 48, 64, 128, 3, 1), (32, 32, 32, 512, 256, 1, 1), (3, 17, 19, 128, 256, 1, 1),
+            # odd k-step counts (3 and 9): the ring's slot runs on across tiles, no parity condition
+            (16, 64, 64, 96, 256, 1, 1), (8, 64, 64, 32, 128, 3, 1)]
 
 
 @pytest.fixture(params=[4, 3], ids=["128x128 on four waves", "128x256 on eight waves"])
