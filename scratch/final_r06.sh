@@ -14,7 +14,7 @@ python bench.py --mode infer --no-cpu-baseline > gpurun_out/profiles_r06/r06_inf
 bash scratch/r05/mgpu_r05.sh > gpurun_out/profiles_r06/r06_reserved_cus_world1.txt 2>&1
 bash scratch/r05/ops_prof.sh > gpurun_out/final_r06/ops_prof.txt 2>&1; python scratch/r05/ops_split.py >> gpurun_out/final_r06/ops_prof.txt 2>&1
 cp gpurun_out/final_r06/ops_prof.txt gpurun_out/profiles_r06/r06_multibox_ops_alone.txt
-( echo "# same box, alternating: the tile-spanning loop off (DSPN_XT=0) / on (default) and the batched sampler gradient off / on"; echo "# columns: images/s, ms per step, conv family TFLOP/s, conv family ms per step"
+( echo "# same box, alternating: the tile-spanning loop off (DSPN_XT=0) / on (default)"; echo "# columns: images/s, ms per step, conv family TFLOP/s, conv family ms per step"
 for R in 1 2 3; do for X in 0 1; do
 DSPN_XT=$X python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
 import json,sys
