@@ -483,6 +483,43 @@ def test_range_guard_acts_on_a_recorded_step(gpu_device):
     assert bool(torch.isfinite(net.g.grad_arena).all())
 
 
+@pytest.mark.parametrize("setting", [1, 2])
+def test_tile_spanning_training_is_reproducible_at_the_bench_shape(gpu_device, setting):
+    """Round 6: the tile-spanning loops rely on counted waits (`s_waitcnt vmcnt(63)` past an epilogue's 64 unconditional stores)
+    and on ring slots reused across tile boundaries; a hazard there would show as run-to-run differences or non-finite values
+    at the BENCH shape, where every qualifying layer walks 2 - 16 tiles per workgroup (the small graphs of the other tests give
+    a workgroup one tile).  Eight training steps at 32 x 512 x 512, twice from the same state, per setting of
+    dspn_conv_set_tile_spanning: the parameter arenas bit-identical, finite (40 steps: profiles/r06_tile_spanning_determinism_soak.txt)."""
+    from dspnet_amd import _lib, functional as fn
+    if fn.get_conv_math() != "f16x2":
+        pytest.skip("the tile-spanning loop belongs to the two-piece math")
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+
+    def run():
+        net = get_multi_symbol_train("resnet-50", (3, 512, 512), num_classes=8, batch_size=32, device=dev, seed=0)
+        gen = synthetic.rng(233)
+        solver = MultiTaskSolver(net)
+        solver.set_batch(torch.from_numpy(synthetic.images(32, 512, 512, gen)).to(dev),
+                         torch.from_numpy(synthetic.det_labels(32, gen=gen, height=512, width=512)).to(dev),
+                         torch.from_numpy(synthetic.seg_labels(32, 512, 512, gen=gen)).to(dev))
+        for _ in range(8):
+            solver.step()
+        torch.cuda.synchronize()
+        a = net.g.arena.detach().clone()
+        del solver, net
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        return a
+
+    try:
+        _lib.check(L.dspn_conv_set_tile_spanning(setting), "set_tile_spanning")
+        a, b = run(), run()
+    finally:
+        L.dspn_conv_set_tile_spanning(1)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 def test_second_step_with_moved_affine_matrix_matches_cpu_restatement(gpu_device):
     """`affine_matrix` is an ordinary argument of the reference's graph (multitask_symbol_builder.py:574, initialised by
     multi_init.py:72, updated by multi_solver.py:291-293).  After one SGD step (large learning rate, so that the grid
