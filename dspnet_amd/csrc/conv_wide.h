@@ -851,7 +851,7 @@ __device__ __forceinline__ void ntv_wait4(ntv_f32x4_t &a, ntv_f32x4_t &b, ntv_f3
 }
 // XT: the tile-spanning loop (see conv_ntw_kernel): the weight pieces and the A rows of the NEXT tile's first two k-steps are
 // requested before the epilogue of the current one, which stages chunk by chunk behind ring slot 0.
-template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128, bool XT = false>
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR = 128, int XT = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
     const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
     float *__restrict__ out, const ConvGeom g, const int m_tiles, const int n_tiles,
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
           for (int r = 0; r < 16; ++r)
             st[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + wn + j * 32 + (lane & 31)] = acc[i][j][r] * inv_a * inv_b;
     };
-    if constexpr (XT) {
+    if constexpr (XT == 1) {
       // the weight pieces of the NEXT tile's first k-step and the A rows of its first two are requested before the epilogue of
       // the current tile, which works from the accumulators (direct_epilogue: nothing of it touches the ring).  (DEEP: two
       // register sets; the host routes an even nk >= 2 and a dense output here.)
@@ -1194,6 +1194,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
       wait_set(set0_t{}, std::integral_constant<int, 0>{});
       wait_set(set1_t{}, std::integral_constant<int, 0>{});
     } else {
+      // XT == 2 (round 6): the round-5 loop with the DIRECT epilogue -- no staging, no publishing barrier, the table partials in the
+      // lanes -- and nothing held in registers across it, so its operand rows run 8 deep like the plane-fed kernel's
       DSPN_STAMP_DECL;
       for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         setup_tile(t);
@@ -1202,9 +1204,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
         DSPN_STAMP(1);
         kloop();
         DSPN_STAMP(2);
-        stage_tile();
-        DSPN_STAMP(3);
-        wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all, NoStage() DSPN_STAMP_ARG);
+        if constexpr (XT == 2) {
+          direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, wsm + 2 * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+          DSPN_STAMP(5);
+        } else {
+          stage_tile();
+          DSPN_STAMP(3);
+          wide_epilogue<BM, BN, NTHR, EPI, SR>(g, wsm, m0, n0, M, tid, bias, out, residual, gmx_all, NoStage() DSPN_STAMP_ARG);
+        }
       }
       DSPN_STAMP_FLUSH;
     }
@@ -1212,7 +1219,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
   }
 }
 
-template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR, bool XT = false>
+template <int WAVES_M, int WAVES_N, bool INTF, int EPI, int SR, int XT = 0>
 int launch_ntv_impl(const float *in, const float *w, const float *bias, float *out, const ConvGeom &g, hipStream_t s,
                     const float *residual) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -1254,9 +1261,23 @@ int launch_ntv(const float *in, const float *w, const float *bias, float *out, c
     // the stage-1 conv3 layers).  Setting 2 of dspn_conv_set_tile_spanning routes it (experiments); the default does not.
     const long long tiles = (((long long)g.N * g.Hg * g.Wg + 127) / 128) * ((g.Cout + 127) / 128);
     if (dspn::tile_spanning() >= 2 && nk >= 2 && nk <= 8 && nk % 2 == 0 && tiles >= 2048 && xt_output_ok(g))
-      return g.in_scale ? DSPN_NTV_(true, true) : DSPN_NTV_(false, true);
+      return g.in_scale ? DSPN_NTV_(true, 1) : DSPN_NTV_(false, 1);
+    // The direct epilogue ALONE (XT = 2: the round-5 loop, nothing held across the epilogue): measured on the step, three
+    // alternating runs on one box: 948.4 -> 953.9 images/s, conv family 27.04 -> 26.66 ms.  Default at setting >= 1;
+    // DSPN_NTV_DIRECT=0 keeps the staged epilogue (A/B runs).
+    static const bool direct_only = [] { const char *e = getenv("DSPN_NTV_DIRECT"); return !e || atoi(e) != 0; }();
+    if (direct_only && xt_enabled() && nk >= 2 && xt_output_ok(g))
+      return g.in_scale ? DSPN_NTV_(true, 2) : DSPN_NTV_(false, 2);
   }
-  return g.in_scale ? DSPN_NTV_(true, false) : DSPN_NTV_(false, false);
+  if constexpr (WAVES_M == 2 && WAVES_N == 4 && SR == 128) {
+    // ... and on the eight-wave 128 x 256 member: 953.9 -> 955.6 images/s (+0.1 ... +0.3 % in each of three alternating pairs);
+    // DSPN_NTV_DIRECT8=0 keeps the staged epilogue
+    static const bool direct8 = [] { const char *e = getenv("DSPN_NTV_DIRECT8"); return !e || atoi(e) != 0; }();
+    const int nk = g.TR * g.TS * (g.Cin / 32);
+    if (direct8 && xt_enabled() && nk >= 2 && xt_output_ok(g))
+      return g.in_scale ? DSPN_NTV_(true, 2) : DSPN_NTV_(false, 2);
+  }
+  return g.in_scale ? DSPN_NTV_(true, 0) : DSPN_NTV_(false, 0);
 #undef DSPN_NTV_
 }
 #endif   // !DSPN_HALF
