@@ -52,13 +52,13 @@ struct WideStamps {
 
 // dspn_conv_set_tile_spanning / DSPN_XT=0: the tile-spanning loop off (tests, same-box A/B runs; the results do not depend on it)
 inline bool xt_enabled() { return dspn::tile_spanning() != 0; }
-// DSPN_XT8=1: the eight-wave 128 x 256 member on the tile-spanning loop too.  Built, bit-identical (tests/test_wide_tiles_gpu.py runs
-// it under the forced tile shape) and NEUTRAL on the step -- 954.5 vs 956.8 images/s over three alternating runs on one box, conv
-// family 26.66 vs 26.79 ms: its layers have 36+ k-steps and one to four tiles per workgroup, the epilogue is a tenth of a tile --
-// so the default leaves it on the round-5 loop; setting 2 of dspn_conv_set_tile_spanning routes it as well.
+// The eight-wave 128 x 256 member on the tile-spanning loop too: bit-identical (tests/test_wide_tiles_gpu.py) and small on the step --
+// its layers have 36+ k-steps and one to four tiles per workgroup, the epilogue is a tenth of a tile: 954.6 -> 958.8 images/s
+// (+0.2 ... +0.5 % in each of four alternating pairs on one box, beside the float-operand kernels' direct epilogue).  Default;
+// DSPN_XT8=0 keeps it on the round-5 loop (A/B runs).
 inline bool xt_wide8_enabled() {
-  static const bool on = [] { const char *e = getenv("DSPN_XT8"); return e && atoi(e) != 0; }();
-  return on || dspn::tile_spanning() >= 2;
+  static const bool on = [] { const char *e = getenv("DSPN_XT8"); return !e || atoi(e) != 0; }();
+  return on;
 }
 // ... whose direct epilogue addresses the output (and the tensors of its shape) as one buffer of M rows of ldc elements
 inline bool xt_output_ok(const ConvGeom &g) {
@@ -1316,8 +1316,7 @@ template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
 int launch_ntw(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s, const st_t *residual) {
 #ifndef DSPN_HALF
   if constexpr (WAVES_M == 2 && SR == 128) {
-    // the four-wave 128 x 128 tile (setting >= 1) and the eight-wave 128 x 256 tile (setting 2 / DSPN_XT8=1: neutral on the step,
-    // see xt_wide8_enabled) on layers of at least STAGES k-steps
+    // the four-wave 128 x 128 tile and the eight-wave 128 x 256 tile (xt_wide8_enabled) on layers of at least STAGES k-steps
     const int nk = g.TR * g.TS * (g.Cin / 32);
     if (xt_enabled() && nk >= STAGES && xt_output_ok(g) && (WAVES_N == 2 || xt_wide8_enabled())) {
       if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR, true>(in, w, bias, out, g, s, residual);

@@ -58,12 +58,14 @@ int dspn_conv_set_reserved_cus(int cus);
  * schedule), 2 / 3 / 4 = always 256 x 128 / 128 x 256 / 128 x 128-on-four-waves where legal (tests and experiments).  The K
  * order and the per-output accumulation order are the same on every tile. */
 int dspn_conv_set_wide_tiles(int mode);
-/* Launch setting (round 6; not compute state): the TILE-SPANNING loop of the 128 x 128 four-wave members of the wide family on
- * layers with an even number of k-steps and a dense output of whole 128-row tiles -- the next tile's first operand images are
- * requested while the current tile is written out, straight from the accumulators.  0 = the round-5 loop; 1 (default; the
- * environment variable DSPN_XT sets the process's initial value) = the plane-fed 128 x 128 kernel; 2 = also the eight-wave
- * 128 x 256 kernel (measured neutral) and the float-operand kernel (measured slower inside the training step): experiments.  Stored tensors, per-tile extremes and magnitude blocks are
- * the same bits under every value; the per-tile BatchNorm tables agree within fp32 rounding (another summation order). */
+/* Launch setting (round 6; not compute state): the round-6 loops of the 128-row members of the wide convolution family on layers
+ * with a dense output of whole 128-row tiles.  1 (default; the environment variable DSPN_XT sets the process's initial value):
+ * the plane-fed kernels (128 x 128 on four waves, 128 x 256 on eight) run their TILE-SPANNING loop -- the next tile's first
+ * operand images are requested while the current tile is written out -- with the epilogue straight from the accumulators, and
+ * the float-operand kernels run that direct epilogue on their round-5 loop.  0 = the round-5 kernels as they were; 2 = also the
+ * float-operand kernel's tile-spanning loop (measured slower inside the training step: experiments).  Stored tensors, per-tile
+ * extremes and magnitude blocks are the same bits under every value; the per-tile BatchNorm tables agree within fp32 rounding
+ * (another summation order). */
 int dspn_conv_set_tile_spanning(int on);
 /* Launch setting (round 6; not compute state): 1 (default) = the data gradient of the affine sampler
  * (dspn_affine_sampler_backward_data_theta_*) takes the geometry of a source position once for the whole batch (one workgroup
