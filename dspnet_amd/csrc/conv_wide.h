@@ -60,10 +60,17 @@ inline bool xt_wide8_enabled() {
   static const bool on = [] { const char *e = getenv("DSPN_XT8"); return !e || atoi(e) != 0; }();
   return on;
 }
+// The 256 x 64 members (<= 64 output columns, 64-row statistics tiles: stage 1 of the ResNets) on the round-6 loops too: bit-identical
+// stored tensors (tests), +0.2 ... +0.5 % on the step in each of three alternating pairs on one box.  Default; DSPN_XT64=0 keeps
+// them on the round-5 loops (A/B runs).
+inline bool xt_c64_enabled() {
+  static const bool on = [] { const char *e = getenv("DSPN_XT64"); return !e || atoi(e) != 0; }();
+  return on;
+}
 // ... whose direct epilogue addresses the output (and the tensors of its shape) as one buffer of M rows of ldc elements
-inline bool xt_output_ok(const ConvGeom &g) {
+inline bool xt_output_ok(const ConvGeom &g, const int bm = 128) {
   const long long M = (long long)g.N * g.Hg * g.Wg;
-  return g.dense && (g.flags & 16) && M % 128 == 0 && M * g.ldc * (long long)sizeof(st_t) < (1ll << 31);
+  return g.dense && (g.flags & 16) && M % bm == 0 && M * g.ldc * (long long)sizeof(st_t) < (1ll << 31);
 }
 
 // The tile epilogue of the wide family, from the staged fp32 tile in LDS (st[row * (BN + 4) + col], written by the caller, which
@@ -292,12 +299,17 @@ __device__ __forceinline__ void wide_epilogue(const ConvGeom &g, char *wsm, cons
 // Arithmetic per element as wide_epilogue's (same order of the bias / residual / accumulate additions: the stored values are
 // the same bits); the per-column reductions run over a lane's 32 rows, then over the four (wave row, half-wave) partials in a
 // fixed order -- another summation order than the staged epilogue's, i.e. tables equal within rounding, deterministic.
-template <int WAVES_M, int WAVES_N, int EPI, int RB = 16>       // RB: rows of a 32 x 32 block whose operand rows are in flight together
+// SR: rows of a statistics tile (128, or 64 on the <= 64-column layers: one wave row each); CLOSE: end with a barrier (the exchange
+// lies in a ring slot the next tile's first requests are aimed at)
+template <int WAVES_M, int WAVES_N, int EPI, int RB = 16, int SR = 128, bool CLOSE = false>       // RB: rows of a 32 x 32 block whose operand rows are in flight together
 __device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f32x16 (&acc)[2][2], const float inv_a, const float inv_b, const int m0,
                                                 const int n0, const int M, const int tid, const int wave,
                                                 const float *__restrict__ bias, float *__restrict__ out,
                                                 const float *__restrict__ residual, float &gmx_all) {
   constexpr int TM = 2, TN = 2, BN = WAVES_N * 64, NTHR = WAVES_M * WAVES_N * 64, PARTS = WAVES_M * 2;
+  constexpr int WRT = SR / 64, TILES = WAVES_M / WRT, PPT = WRT * 2;       // wave rows per statistics tile, tiles per output tile, partials per tile
+  static_assert(SR == 64 || SR == 128, "statistics tiles of 64 or 128 rows");
+  static_assert(WAVES_M % WRT == 0, "whole statistics tiles per output tile");
   const int lane = tid & 63, half = lane >> 5, lc = lane & 31;
   const int wr = wave / WAVES_N, wm = wr * 64, wn = (wave % WAVES_N) * 64;
   const bool has_bias = g.flags & 1, relu = g.flags & 2, accum = g.flags & 4, has_res = g.flags & 8;
@@ -469,14 +481,16 @@ __device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int c = tid; c < BN; c += NTHR) {
-      if (n0 + c >= g.Cout || m0 >= M) continue;
-      const long long mt_ = m0 / 128;
+    for (int hc = tid; hc < TILES * BN; hc += NTHR) {
+      const int h = hc / BN, c = hc - h * BN;                 // statistics tile h of this output tile: partials h PPT .. h PPT + PPT - 1
+      if (n0 + c >= g.Cout || m0 + h * SR >= M) continue;
+      const long long mt_ = m0 / SR + h;
       if constexpr (EPI == 1) {
         // Chan's update over the partials in a fixed order (empty partials -- rows past M -- skipped)
         float n = 0.f, mean = 0.f, m2 = 0.f, mn = kInf, mx = -kInf;
 #pragma unroll
-        for (int pp = 0; pp < PARTS; ++pp) {
+        for (int pq = 0; pq < PPT; ++pq) {
+          const int pp = h * PPT + pq;
           const float *q = red + (pp * BN + c) * 4;
           const float nb = q[0];
           if (nb > 0.f) {
@@ -496,11 +510,15 @@ __device__ __forceinline__ void direct_epilogue(const ConvGeom &g, char *exch, f
       } else {
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int pp = 0; pp < PARTS; ++pp) { a += red[(pp * BN + c) * 4]; b += red[(pp * BN + c) * 4 + 1]; }
+        for (int pq = 0; pq < PPT; ++pq) { a += red[((h * PPT + pq) * BN + c) * 4]; b += red[((h * PPT + pq) * BN + c) * 4 + 1]; }
         const long long t_ = g.bn_tile_base + mt_;
         g.bn_sums[(t_ * 2 + 0) * g.Cout + n0 + c] = a;
         g.bn_sums[(t_ * 2 + 1) * g.Cout + n0 + c] = b;
       }
+    }
+    if constexpr (CLOSE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // the exchange has been read: the ring slot it lies in may be requested into
     }
   }
 }
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
   constexpr int D = STAGES - 1;                          // k-steps in flight ahead of the one being multiplied
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   static_assert(BM % SR == 0, "BatchNorm tables are per SR rows");
-  static_assert(!XT || (!kHalf && WAVES_M == 2), "the tile-spanning loop: float build, one 128-row statistics tile per output tile");
+  static_assert(!XT || !kHalf, "the tile-spanning loop: float build");
   extern __shared__ __attribute__((aligned(1024))) char wsm[];
 
 #ifdef DSPN_ABLATE
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
     // The exchange of the direct epilogue's per-column partials lives behind the ring where that fits beside a second
     // workgroup (four waves), and IN the slot of the tile's last k-step -- the one slot no request is aimed at while the
     // epilogue runs -- where one workgroup owns the CU (eight waves, 144 KiB of ring): that costs one barrier per tile.
-    constexpr bool EXCH_IN_RING = NWV == 8;
+    constexpr bool EXCH_IN_RING = NWV == 8 || BM == 256;      // (256 x 64 on four waves: two workgroups of exactly 80 KiB)
     int t = blockIdx.x;
     if (t < ntiles) {
       setup_tile(t);
@@ -773,7 +791,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntw_kernel(
         exch = wsm + last_slot * STG;
         if constexpr (EPI != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // every wave has read its last fragments
       }
-      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, exch, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+      if constexpr (!kHalf) direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8), SR>(g, exch, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
       DSPN_STAMP(5);
     }
     DSPN_STAMP_FLUSH;
@@ -1205,7 +1223,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_ntv_kernel(
         kloop();
         DSPN_STAMP(2);
         if constexpr (XT == 2) {
-          direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8)>(g, wsm + 2 * STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
+          // the exchange of the per-column partials lies in ring slot 1: nothing is in flight after the k-loop, and the next writes
+          // into that slot (k-step 0's weight request, its closing A store) sit behind the barrier of the next tile's head, which
+          // a wave passes only after its part of the merge
+          direct_epilogue<WAVES_M, WAVES_N, EPI, (EPI == 2 ? 4 : 8), SR>(g, wsm + STG, acc, inv_a, inv_b, m0, n0, M, tid, wave, bias, out, residual, gmx_all);
           DSPN_STAMP(5);
         } else {
           stage_tile();
@@ -1226,8 +1247,10 @@ int launch_ntv_impl(const float *in, const float *w, const float *bias, float *o
   const long long M = (long long)g.N * g.Hg * g.Wg;
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // XT: the ring and, behind it, the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats)
-  const size_t lds = XT ? (size_t)2 * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
-                        : std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  const size_t lds = XT == 1 ? (size_t)2 * (BM + BN) * 128 + sizeof(float) * 4 * BN * 6
+                     : XT == 2 ? (size_t)2 * (BM + BN) * 128         // (the exchange lies inside ring slot 1)
+                               : std::max<size_t>((size_t)2 * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
+  static_assert(XT != 2 || (size_t)(BM + BN) * 128 >= sizeof(float) * 2 * WAVES_M * BN * 6, "the exchange fits a ring slot");
   auto kern = conv_ntv_kernel<WAVES_M, WAVES_N, INTF, EPI, SR, XT>;
   static dspn::KernelDeviceState st;
   const bool first = !st.slots[0] && !st.slots[1];
@@ -1277,6 +1300,11 @@ int launch_ntv(const float *in, const float *w, const float *bias, float *out, c
     if (direct8 && xt_enabled() && nk >= 2 && xt_output_ok(g))
       return g.in_scale ? DSPN_NTV_(true, 2) : DSPN_NTV_(false, 2);
   }
+  if constexpr (WAVES_M == 4 && WAVES_N == 1 && SR == 64) {      // the 256 x 64 member (xt_c64_enabled)
+    const int nk = g.TR * g.TS * (g.Cin / 32);
+    if (xt_c64_enabled() && xt_enabled() && nk >= 2 && xt_output_ok(g, 256))
+      return g.in_scale ? DSPN_NTV_(true, 2) : DSPN_NTV_(false, 2);
+  }
   return g.in_scale ? DSPN_NTV_(true, 0) : DSPN_NTV_(false, 0);
 #undef DSPN_NTV_
 }
@@ -1291,7 +1319,7 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
   const int mt = (int)((M + BM - 1) / BM), nt = (g.Cout + BN - 1) / BN;
   // XT: the ring and -- four waves -- behind it the exchange of the direct epilogue's per-column partials (4 x BN x 6 floats;
   // eight waves keep it in the ring slot of the tile's last k-step)
-  const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + (WAVES_M * WAVES_N == 8 ? 0 : sizeof(float) * 4 * BN * 6)
+  const size_t lds = XT ? (size_t)STAGES * (BM + BN) * 128 + ((WAVES_M * WAVES_N == 8 || BM == 256) ? 0 : sizeof(float) * 4 * BN * 6)
                         : std::max<size_t>((size_t)STAGES * (BM + BN) * 128, sizeof(float) * BM * (BN + 4));
   auto kern = conv_ntw_kernel<WAVES_M, WAVES_N, STAGES, EPI, SR, XT>;
   static dspn::KernelDeviceState st;
@@ -1315,10 +1343,12 @@ int launch_ntw_impl(const st_t *in, const st_t *w, const float *bias, st_t *out,
 template <int WAVES_M, int WAVES_N, int STAGES, int SR = 128>
 int launch_ntw(const st_t *in, const st_t *w, const float *bias, st_t *out, const ConvGeom &g, hipStream_t s, const st_t *residual) {
 #ifndef DSPN_HALF
-  if constexpr (WAVES_M == 2 && SR == 128) {
-    // the four-wave 128 x 128 tile and the eight-wave 128 x 256 tile (xt_wide8_enabled) on layers of at least STAGES k-steps
+  if constexpr ((WAVES_M == 2 && SR == 128) || (WAVES_M == 4 && WAVES_N == 1 && SR == 64)) {
+    // the four-wave 128 x 128 tile, the eight-wave 128 x 256 tile (xt_wide8_enabled) and the 256 x 64 tile of the <= 64-column
+    // layers (xt_c64_enabled) on layers of at least STAGES k-steps
     const int nk = g.TR * g.TS * (g.Cin / 32);
-    if (xt_enabled() && nk >= STAGES && xt_output_ok(g) && (WAVES_N == 2 || xt_wide8_enabled())) {
+    if (xt_enabled() && nk >= STAGES && xt_output_ok(g, WAVES_M * 64) &&
+        (WAVES_M == 4 ? xt_c64_enabled() : (WAVES_N == 2 || xt_wide8_enabled()))) {
       if (g.bn_sums) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 2, SR, true>(in, w, bias, out, g, s, residual);
       if (g.stats) return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 1, SR, true>(in, w, bias, out, g, s, residual);
       return launch_ntw_impl<WAVES_M, WAVES_N, STAGES, 0, SR, true>(in, w, bias, out, g, s, residual);

@@ -60,7 +60,7 @@ int dspn_conv_set_reserved_cus(int cus);
 int dspn_conv_set_wide_tiles(int mode);
 /* Launch setting (round 6; not compute state): the round-6 loops of the 128-row members of the wide convolution family on layers
  * with a dense output of whole 128-row tiles.  1 (default; the environment variable DSPN_XT sets the process's initial value):
- * the plane-fed kernels (128 x 128 on four waves, 128 x 256 on eight) run their TILE-SPANNING loop -- the next tile's first
+ * the plane-fed kernels (128 x 128 and 256 x 64 on four waves, 128 x 256 on eight) run their TILE-SPANNING loop -- the next tile's first
  * operand images are requested while the current tile is written out -- with the epilogue straight from the accumulators, and
  * the float-operand kernels run that direct epilogue on their round-5 loop.  0 = the round-5 kernels as they were; 2 = also the
  * float-operand kernel's tile-spanning loop (measured slower inside the training step: experiments).  Stored tensors, per-tile

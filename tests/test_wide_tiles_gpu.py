@@ -375,7 +375,9 @@ def test_float_gradient_data_gradient_on_every_tile_is_bit_identical(tiles, case
 XT_CASES = [(16, 64, 64, 64, 256, 1, 1), (32, 64, 64, 256, 128, 1, 1), (13, 61, 67, 64, 192, 1, 1), (16, 64, 64, 128, 256, 1, 2),
             (8, 48, 48, 64, 128, 3, 1), (32, 32, 32, 512, 256, 1, 1), (3, 17, 19, 128, 256, 1, 1),
             # odd k-step counts (3 and 9): the ring's slot runs on across tiles, no parity condition
-            (16, 64, 64, 96, 256, 1, 1), (8, 64, 64, 32, 128, 3, 1)]
+            (16, 64, 64, 96, 256, 1, 1), (8, 64, 64, 32, 128, 3, 1),
+            # at most 64 output columns: the 256 x 64 members with 64-row statistics tiles (stage 1 of the ResNets)
+            (16, 64, 64, 64, 64, 3, 1), (32, 64, 64, 256, 64, 1, 1), (16, 64, 64, 64, 64, 1, 1)]
 
 
 @pytest.fixture(params=[4, 3], ids=["128x128 on four waves", "128x256 on eight waves"])
