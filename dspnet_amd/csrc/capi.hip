@@ -1,8 +1,10 @@
 // Library-wide C ABI helpers (error string, version).
 #include "dspn_common.h"
+#include "bn_final_job.h"
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <vector>
 #include "../../include/dspn_multibox.h"
 
@@ -56,6 +58,24 @@ static std::atomic<int> g_tile_spanning{[] { const char *e = getenv("DSPN_XT"); 
 int tile_spanning() { return g_tile_spanning.load(std::memory_order_relaxed); }
 static std::atomic<int> g_sampler_batched{[] { const char *e = getenv("DSPN_SAMPLER_BATCHED"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 int sampler_batched() { return g_sampler_batched.load(std::memory_order_relaxed); }
+// round 6: a BatchNorm-backward finalize parked for the next weight-gradient launch on its stream (bn_final_job.h).  One job
+// per stream (a second one for the same stream replaces nothing: the first is handed to whoever asks first, then the second)
+static std::mutex g_job_mu;
+static std::vector<std::pair<hipStream_t, BnFinalJob>> g_jobs;
+void bn_job_defer(hipStream_t s, const BnFinalJob &job) {
+  std::lock_guard<std::mutex> lk(g_job_mu);
+  g_jobs.emplace_back(s, job);
+}
+bool bn_job_take(hipStream_t s, BnFinalJob *job) {
+  std::lock_guard<std::mutex> lk(g_job_mu);
+  for (size_t i = 0; i < g_jobs.size(); ++i)
+    if (g_jobs[i].first == s) {
+      *job = g_jobs[i].second;
+      g_jobs.erase(g_jobs.begin() + (long)i);
+      return true;
+    }
+  return false;
+}
 }  // namespace dspn
 
 extern "C" {

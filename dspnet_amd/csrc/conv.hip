@@ -24,6 +24,7 @@
 //
 // fp32 MFMA is an exact fmaf chain (no reduced precision); peak 157 TFLOP/s.
 #include "dspn_common.h"
+#include "bn_final_job.h"
 #include "dspn_store.h"
 #include "dspn_pieces.h"
 #include "conv_geom.h"
@@ -1066,7 +1067,19 @@ struct WgradGeom {
   int bf16;                           // host side only: math mode of this call
   const float *dy_absmax, *x_absmax;  // DSPN_MATH_F32_F16X2: device scalars, largest magnitude of dy / of x after its affine (ConvGeom)
   int dy_planes, x_planes;            // host side only: dy / x are fp16 piece planes (MATHX = 4 / 5 / 6)
+  // round 6: a BatchNorm-backward finalize riding in this launch (bn_final_job.h): the first job_rows rows of the grid
+  // (blockIdx.y < job_rows: dispatched first) run it, sixteen channels per workgroup, and leave; the splits follow
+  int job_rows;
+  dspn::BnFinalJob job;
 };
+// -> (row, rows) of the weight gradient's own grid, or row < 0 for a workgroup that has run its share of the job
+#define DSPN_WGRAD_JOB_ROWS(g, smem_)                                                                              \
+  if (g.job_rows > 0 && (int)blockIdx.y < g.job_rows) {                                                           \
+    const int jb_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;                                            \
+    if (jb_ < g.job.blocks) dspn::bn_final_job_run(g.job, jb_, smem_);                                             \
+    return;                                                                                                        \
+  }                                                                                                                \
+  const int grid_y = (int)gridDim.y - g.job_rows, block_y = (int)blockIdx.y - g.job_rows;
 
 // bf16 mode of the weight gradient: LDS images stay [pixel][channel] (as loaded), rows padded so that the
 // four pixel rows of a transposed block fall on disjoint banks; ds_read_b64_tr_b16 hands every lane the 4
@@ -1097,12 +1110,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   float *sA = smem;                      // [2][kPK][BM]
   float *sB = smem + 2 * kPK * BM;       // [2][kPK][BN]
 
+  DSPN_WGRAD_JOB_ROWS(g, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (tile, split) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest): taken as
   // is, the tiles of one split -- which all stream the SAME pixel range of dy and x -- land on all eight L2s and every L2
   // fetches that range for its four or five tiles.  xcd_remap gives each XCD a contiguous run of (split, tile) pairs
   // instead: a pixel range is then read through ONE L2 and shared there by all the tiles of its split
-  const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int lin = xcd_remap(block_y * gridDim.x + blockIdx.x, gridDim.x * grid_y);
   const int split = lin / (int)gridDim.x, tile = lin - split * (int)gridDim.x;
   const int kt_i = tile / j_tiles, jt_i = tile - kt_i * j_tiles;
   const int k0 = kt_i * BM, j0 = jt_i * BN;
@@ -1447,6 +1461,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   }
 }
 
+
+#ifndef DSPN_HALF
+#include "conv_wgrad_wide.h"
+#endif
 
 // ---------------------------------------------------------------------------
 // g[c] = sum over all input pixels of the data gradient, WITHOUT forming it:
@@ -2484,6 +2502,9 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     return dspn::fail(DSPN_ERR_WORKSPACE_, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   float *slab = static_cast<float *>(workspace);
+  // round 6: a parked BatchNorm-backward finalize of this stream rides in front of the grid (bn_final_job.h)
+  g.job = dspn::BnFinalJob{};
+  g.job_rows = dspn::bn_job_take(s, &g.job) ? (g.job.blocks + kt * jt - 1) / (kt * jt) : 0;
   // mainloop buffers | staged output tile
   // (the float build sizes for its largest mode: float images 2 * kPK * (BM + BN) * 4 B; the three-piece bf16 image of the
   // split mode, single-buffered, 3 * kPK * row bytes, is smaller than the staged output tile for every tile shape but 32 x 128)
@@ -2523,8 +2544,22 @@ static int conv2d_wgrad_one(int math, OpScales scales, const st_t *x, InAffine t
     auto kern = conv_wgrad_kernel<WM, WN, TM_, TN_, BF, TF>;                                             \
     static dspn::KernelDeviceState st;                                                                   \
     if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, st, "conv_wgrad"); dev < 0) return dev; \
-    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits + g.job_rows), dim3(WM * WN * 64), lds, s, x, dy, slab, g, kt, jt); \
   }
+#ifndef DSPN_HALF
+  // round 6: both operands as piece planes on a 128 x 128 tile -- global -> LDS directly, 64 x 64 per wave (conv_wgrad_wide.h);
+  // same split plan, same slabs, same bits.  dspn_conv_set_wide_tiles(1) / DSPN_WGW=0: conv_wgrad_kernel (tests, same-box A/B)
+  static const bool wgw_env = [] { const char *e = getenv("DSPN_WGW"); return !(e && atoi(e) == 0); }();
+  // (eight waves on 128 x 256 with a three-slot ring measured no faster where the plan fills the chip -- stages 3 and 4: 0.37 - 0.39
+  // of 833.3 either way -- and 1.5 x slower where it does not; profiles/r06_wgrad_wide_tile.txt)
+  if (g.bf16 == 3 && g.x_planes && g.dy_planes && BM == 128 && BN == 128 && wgw_env && dspn::wide_tiles_mode() != 1) {
+    auto kern = conv_wgw_kernel<2, 2, 2>;
+    const size_t lds_w = std::max<size_t>(2 * (size_t)kPK * (128 + 128) * 4, sizeof(float) * 128 * (128 + 4));
+    static dspn::KernelDeviceState st;
+    if (const int dev = dspn::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_w, st, "conv_wgrad (wide)"); dev < 0) return dev;
+    hipLaunchKernelGGL(kern, dim3(kt * jt, (int)splits + g.job_rows), dim3(256), lds_w, s, x, dy, slab, g, kt, jt);
+  } else
+#endif
   if (BM == 32) DSPN_WGRAD_LAUNCH(1, 4, 1, 1)                     // 32 x 128
   else if (BM == 64) DSPN_WGRAD_LAUNCH(2, 2, 1, 2)                // 64 x 128
   else if (BN == 64) DSPN_WGRAD_LAUNCH(2, 2, 2, 1)                // 128 x 64

@@ -8,6 +8,7 @@
 // in a caller workspace, then a fixed-order finalize in double), never float
 // atomics, so every result is bitwise reproducible run to run.
 #include "dspn_common.h"
+#include "bn_final_job.h"
 #include "dspn_store.h"
 #include "dspn_pieces.h"
 #include "../../include/dspn_nn.h"
@@ -503,30 +504,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(
   __syncthreads();
   if (sl == 0 && c < C) {
     for (int k = 1; k < 16; ++k) { S += s_S[k][cl]; SS += s_SS[k][cl]; }
-    if (dbeta) dbeta[c] = (float)S;
-    if (dgamma) dgamma[c] = (float)SS;
-    const double rs = rstd[c], mu = mean[c];
-    const double a = (gamma ? (double)gamma[c] : 1.0) * rs;
-    const double c1 = -a * rs * (SS * inv_rows);
-    coef[c] = (float)a;
-    coef[C + c] = (float)c1;
-    const double c0 = -a * (S * inv_rows) - c1 * mu;
-    coef[2 * C + c] = (float)c0;
-    if (dx_bound) {
-      // |dx| = |a dy' + c1 x + c0| <= |a| D + max(|c1 lo + c0|, |c1 hi + c0|) over the channel's x in [lo, hi] (the affine
-      // part is monotone in x): the magnitude block of the dx the apply kernel is ABOUT to write as piece planes -- a bound,
-      // a few times the true maximum at most (the two-piece math tolerates 2^17)
-      const double lo = x_minmax[c], hi = x_minmax[C + c];
-      double b = fabs(a) * (double)s_D + fmax(fabs(c1 * lo + c0), fabs(c1 * hi + c0));
-      b *= 1.0 + 1e-6;
-      float bf = (float)b;
-      if (!(bf == bf)) bf = INFINITY;
-      if (bf > 0.f) atomicMax(dx_bound + (c & 63), __float_as_uint(bf));
-      // round 5 (range guard): the SMALLEST non-zero per-channel bound -- the ratio to the block above is the span of channel
-      // magnitudes the planes are cut over (one word, the caller presets it to +inf; min of positive floats = min of their bits)
-      if (dx_bound_min && bf > 0.f && bf < INFINITY) atomicMin(dx_bound_min, __float_as_uint(bf));
-    }
+    dspn::bn_final_channel(c, C, S, SS, inv_rows, mean, rstd, gamma, coef, dgamma, dbeta, x_minmax, dx_bound, dx_bound_min,
+                           dx_bound ? s_D : 0.f);      // (bn_final_job.h: the same arithmetic as the job form)
   }
+}
+
+// a parked finalize job (bn_final_job.h) that no weight-gradient launch took: on its own
+__global__ __launch_bounds__(256) void bn_final_job_kernel(const dspn::BnFinalJob j) {
+  __shared__ double sm[2 * 16 * dspn::kBnJobChannels + 1];
+  dspn::bn_final_job_run(j, blockIdx.x, sm);
 }
 
 // the apply pass of the BatchNorm backward with dx written as fp16 PIECE PLANES for the two-piece math (round 4):
@@ -1856,7 +1842,15 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
                                    const float *mean, const float *rstd, const float *gamma, const float *tile_sums,
                                    int tiles, st_t *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
                                    int accumulate, float *dx_absmax, float *dx_absmin, const float *dy_absmax, const float *x_chan_minmax,
-                                   int dx_planes, void *workspace, size_t workspace_bytes, void *stream) {
+                                   int dx_planes_phase, void *workspace, size_t workspace_bytes, void *stream) {
+  // round 6: bits 1 / 2 of the flag word split the call in two -- 2 = the finalize alone (the per-channel coefficients into the
+  // workspace, dgamma / dbeta, the bound of dx), 4 = the apply pass alone from the coefficients an earlier call with bit 2 left
+  // in the SAME workspace -- so that a caller can run the latency-bound finalize on a second stream beside a weight gradient
+  // | 8 (with | 2): the finalize is PARKED as a job for the next weight-gradient launch on this stream (bn_final_job.h); the
+  // apply-only call runs it stand-alone if no weight gradient took it
+  const int dx_planes = dx_planes_phase & 1, phase = (dx_planes_phase >> 1) & 3, defer = (dx_planes_phase >> 3) & 1;
+  DSPN_REQUIRE(dx_planes_phase >= 0 && dx_planes_phase < 16 && phase <= 2 && (!defer || phase == 1),
+               "bn_backward_from_sums: flag word = dx_planes | 2 (finalize only, | 8: parked for the next weight gradient) | 4 (apply only)");
   DSPN_REQUIRE(x && dy && mean && rstd && dx && workspace && tile_sums && tiles > 0, "bn_backward_from_sums: null pointer");
   DSPN_REQUIRE(!dx_planes || (!dspn::kHalf && !accumulate && C % 32 == 0 && dx_absmax && dy_absmax && x_chan_minmax &&
                               static_cast<const void *>(dx) != static_cast<const void *>(dy) && static_cast<const void *>(dx) != static_cast<const void *>(x)),
@@ -1868,7 +1862,30 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
     return dspn::fail(DSPN_ERR_WORKSPACE_, "bn_backward_from_sums: workspace too small (3*C floats)");
   const int C4 = C / 4;
   float *coef = static_cast<float *>(workspace);
-  if (tiles >= tile_group_min() && workspace_bytes >= sizeof(float) * 3 * (size_t)C + bn_tiles_workspace_bytes(tiles, C)) {
+  const bool group_first = tiles >= tile_group_min() && workspace_bytes >= sizeof(float) * 3 * (size_t)C + bn_tiles_workspace_bytes(tiles, C);
+  if (defer) {
+    if (group_first) {      // (the group level needs hundreds of workgroups: a launch of its own, now)
+      const int groups = (tiles + kTileGroup - 1) / kTileGroup;
+      float *grouped = coef + 3 * (size_t)C;
+      hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
+                         (long long)tiles, C, grouped, static_cast<const float *>(nullptr), static_cast<float *>(nullptr));
+      tile_sums = grouped; tiles = groups;
+    }
+    dspn::BnFinalJob j;
+    j.tile_sums = tile_sums; j.tiles = tiles; j.C = C;
+    j.blocks = (C + dspn::kBnJobChannels - 1) / dspn::kBnJobChannels;
+    j.inv_rows = 1.0 / (double)rows; j.mean = mean; j.rstd = rstd; j.gamma = gamma; j.coef = coef; j.dgamma = dgamma; j.dbeta = dbeta;
+    j.dy_absmax = dx_planes ? dy_absmax : nullptr; j.x_minmax = dx_planes ? x_chan_minmax : nullptr;
+    j.dx_bound = dx_planes ? reinterpret_cast<unsigned *>(dx_absmax) : nullptr;
+    j.dx_bound_min = dx_planes ? reinterpret_cast<unsigned *>(dx_absmin) : nullptr;
+    dspn::bn_job_defer(S_(stream), j);
+    return dspn::check_launch("bn_backward_from_sums (parked)");
+  }
+  if (phase == 2)      // (jobs of this stream no weight gradient took: here, before the apply pass)
+    for (dspn::BnFinalJob parked; dspn::bn_job_take(S_(stream), &parked);)
+      hipLaunchKernelGGL(bn_final_job_kernel, dim3(parked.blocks), dim3(256), 0, S_(stream), parked);
+  if (phase != 2) {
+  if (group_first) {
     const int groups = (tiles + kTileGroup - 1) / kTileGroup;
     float *grouped = coef + 3 * (size_t)C;
     hipLaunchKernelGGL(tile_group_kernel<1>, dim3(groups, (C + 63) / 64), dim3(256), 0, S_(stream), tile_sums, tiles, 1,
@@ -1879,6 +1896,8 @@ int DSPN_FN(dspn_bn_backward_from_sums)(const st_t *x, const float *scale, const
                      1.0 / (double)rows, mean, rstd, gamma, coef, dgamma, dbeta, dx_planes ? dy_absmax : nullptr,
                      dx_planes ? x_chan_minmax : nullptr, dx_planes ? reinterpret_cast<unsigned *>(dx_absmax) : nullptr,
                      dx_planes ? reinterpret_cast<unsigned *>(dx_absmin) : nullptr);
+  }
+  if (phase == 1) return dspn::check_launch("bn_backward_from_sums (finalize)");
   const long long n4 = rows * C4;
 #ifndef DSPN_HALF
   if (dx_planes) {

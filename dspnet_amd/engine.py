@@ -977,6 +977,9 @@ class BatchNorm(Node):
         # True when this node's backward is the LAST writer of x's gradient (set by Graph.finalize): only then is the dx it
         # stores the complete gradient whose magnitude the producing convolution may use
         self.completes_x_grad = False
+        # round 6: the finalize half of this node's backward is parked for / rode in the weight gradient of the convolution
+        # whose data gradient gathered the sums: (args, kwargs) of the apply half, or None
+        self._pending = None
 
     def forward(self):
         if self.tile_stats is not None:
@@ -1013,7 +1016,32 @@ class BatchNorm(Node):
         slot = g._am_x.get((id(self.x), id(self.scale)))
         return slot is not None and slot in g._am_done
 
-    def backward(self):
+    def finalize_beside(self):
+        """Round 6: called by the convolution whose data gradient has just gathered this node's backward
+        sums in its epilogue, BEFORE it launches its weight gradient.  The finalize half of dspn_bn_backward_from_sums (one or
+        two launches on 1 - 64 workgroups, 6 - 15 us of an otherwise idle chip) is PARKED in the library and rides in front of
+        that weight gradient's grid (csrc/bn_final_job.h); backward() later launches the apply half.  (On a second stream
+        instead -- two events per node -- the step LOST 1.5 %: profiles/r06_finalize_beside_ab.txt.)  -> True if it did."""
+        g = self._g
+        if (not FINALIZE_BESIDE or g.device.type != "cuda" or not self.bwd_sums_ready or self.pool_grad is not None
+                or not self.out._gw or self._pending is not None):
+            return False
+        self.backward(beside=True)
+        return self._pending is not None
+
+    def _from_sums(self, beside, args, kw):
+        if not beside:
+            fn.bn_backward_from_sums(*args, **kw)
+            return
+        fn.bn_backward_from_sums(*args, phase=1, park=True, **kw)
+        self._pending = (args, kw)
+
+    def backward(self, beside=False):
+        if self._pending is not None:
+            args, kw = self._pending
+            self._pending = None
+            fn.bn_backward_from_sums(*args, phase=2, **kw)
+            return
         if not self.out._gw:
             return
         am = None
@@ -1044,26 +1072,31 @@ class BatchNorm(Node):
                 and not getattr(prod, "guard_fb", False)):      # (a convolution on the guard's fallback reads a FLOAT gradient)
             # the gradient leaves as fp16 piece planes (same buffer): `am` receives the BOUND it is cut by
             self.bwd_sums_ready = False
-            fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
-                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
-                                     relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
-                                     dbeta=self.beta.grad, accumulate=False, dx_absmax=am,
-                                     dy_absmax=self._g.scalar(self.am_dyin), x_chan_minmax=self.x_ext, dx_planes=True,
-                                     dx_absmin=g.scalars_min[prod.am_dy:prod.am_dy + 1] if g.guard["enabled"] else None)
+            self._from_sums(beside, (self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
+                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1]),
+                            dict(relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
+                                 dbeta=self.beta.grad, accumulate=False, dx_absmax=am,
+                                 dy_absmax=self._g.scalar(self.am_dyin), x_chan_minmax=self.x_ext, dx_planes=True,
+                                 dx_absmin=g.scalars_min[prod.am_dy:prod.am_dy + 1] if g.guard["enabled"] else None))
             self.x.grad_planes = True
             return
         if self.bwd_sums_ready:      # the two reductions came out of the data-gradient kernel's epilogue
             self.bwd_sums_ready = False
-            fn.bn_backward_from_sums(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
-                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1],
-                                     relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
-                                     dbeta=self.beta.grad, accumulate=acc, dx_absmax=am)
+            self._from_sums(beside, (self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
+                                     None if self.gamma is None else self.gamma.data, self.bwd_sums[0], self.bwd_sums[1]),
+                            dict(relu=self.relu, dx=dx, dgamma=None if self.gamma is None else self.gamma.grad,
+                                 dbeta=self.beta.grad, accumulate=acc, dx_absmax=am))
             return
+        assert not beside, "finalize_beside() without the data gradient's sums"
         fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
                        accumulate=acc, dx_absmax=am)
 
+
+# round 6: the finalize half of a BatchNorm backward rides in the weight-gradient launch of the layer behind it
+# (DSPN_FINALIZE_BESIDE=0: launches of its own, as round 5 -- same-box A/B; the results do not depend on it)
+FINALIZE_BESIDE = _os.environ.get("DSPN_FINALIZE_BESIDE", "1") != "0"
 
 # round 5: convolutions no BatchNorm reads leave the magnitude of their output (forward epilogue) and of their masked gradient
 # (the ReLU-backward / bias-gradient pass) as by-products; DSPN_CONV_MAGNITUDES=0 keeps the stand-alone passes (same-box A/B)
@@ -1306,6 +1339,22 @@ class Conv(Node):
         if dya is not None and self.am_dy not in self._g._am_done:       # (else: the BatchNorm backward that completed dy took it)
             fn.absmax(dy, out=dya)
             self._g._am_done.add(self.am_dy)      # (a projection shortcut that shares this slot reads the same gradient)
+        # round 6: when this data gradient gathers the backward sums of the BatchNorm in front (bn_bwd_node), it goes FIRST and
+        # that node's finalize rides in front of the weight gradient's grid (BatchNorm.finalize_beside)
+        bn = getattr(self, "bn_bwd_node", None) if self.x.requires_grad else None
+        early = (bn is not None and FINALIZE_BESIDE and not self.guard_fb and self._g.device.type == "cuda"
+                 and bn.pool_grad is None)
+        if early:
+            self._data_gradient(dy, planes, dya, wa)
+            bn.finalize_beside()
+        self._weight_gradient(dy, planes, xa, dya)
+        if self.input_sum_grad is not None:
+            fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
+                                     out=self.input_sum_grad.grad)
+        if self.x.requires_grad and not early:
+            self._data_gradient(dy, planes, dya, wa)
+
+    def _weight_gradient(self, dy, planes, xa, dya):
         if self.tap_expand:
             cout, kh, kw, cin = self.w.shape
             fn.tap_spread(dy, cout, kh, kw, self.pad, out=self.z)
@@ -1337,35 +1386,33 @@ class Conv(Node):
                             out=self.w.grad, in_affine=self.in_affine if xp is None else None, math=self.math, x_absmax=xa,
                             dy_absmax=dya, dy_planes=planes, x_planes=xp is not None)
         self.slabs_fresh = self.slabs is not None
-        if self.input_sum_grad is not None:
-            fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
-                                     out=self.input_sum_grad.grad)
-        if self.x.requires_grad:
-            if self.wtp is not None and self._g.wp_table is None:
-                fn.weight_planes(self.w.data, transposed=True, cols=self.wtp.shape[2] * 32, out=self.wtp, math=self.math,
-                                 w_absmax=wa)
-            elif self.wtp is None and not self._g.wt_batched:
-                fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
-            dx, acc = self.x.grad_target()
-            bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
-            bn_bwd, bn_dya = None, None
-            if bn is not None:
-                bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
-                bn.bwd_sums_ready = True
-                if bn.dx_planes:         # that BatchNorm's backward bounds its dx from the largest gradient stored here
-                    bn_dya = self._g.scalar(bn.am_dyin)
-            if self.guard_fb:
-                w3 = self._w3(True)
-                fn.conv2d_dgrad(dy, self.wt if w3 is None else None, self.x.shape, self.stride, self.pad, self.dil, out=dx,
-                                accumulate=acc, bn_bwd=bn_bwd, wt_planes=w3, math="bf16x3", wt_shape=self.wt_shape)
-                if bn_dya is not None:       # (the two-piece data gradient leaves this by-product in its epilogue)
-                    fn.absmax(dx, out=bn_dya)
-                self._g.guard["calls"] += 1
-                self._g.guard["calls_total"] += 1
-                return
-            fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
-                            bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa,
-                            bn_dy_absmax=bn_dya, dy_planes=planes, wt_shape=self.wt_shape)
+
+    def _data_gradient(self, dy, planes, dya, wa):
+        if self.wtp is not None and self._g.wp_table is None:
+            fn.weight_planes(self.w.data, transposed=True, cols=self.wtp.shape[2] * 32, out=self.wtp, math=self.math,
+                             w_absmax=wa)
+        elif self.wtp is None and not self._g.wt_batched:
+            fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
+        dx, acc = self.x.grad_target()
+        bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
+        bn_bwd, bn_dya = None, None
+        if bn is not None:
+            bn_bwd = (bn.x.data, bn.scale, bn.shift, bn.mean, bn.rstd, bn.relu, bn.bwd_sums[0])
+            bn.bwd_sums_ready = True
+            if bn.dx_planes:         # that BatchNorm's backward bounds its dx from the largest gradient stored here
+                bn_dya = self._g.scalar(bn.am_dyin)
+        if self.guard_fb:
+            w3 = self._w3(True)
+            fn.conv2d_dgrad(dy, self.wt if w3 is None else None, self.x.shape, self.stride, self.pad, self.dil, out=dx,
+                            accumulate=acc, bn_bwd=bn_bwd, wt_planes=w3, math="bf16x3", wt_shape=self.wt_shape)
+            if bn_dya is not None:       # (the two-piece data gradient leaves this by-product in its epilogue)
+                fn.absmax(dx, out=bn_dya)
+            self._g.guard["calls"] += 1
+            self._g.guard["calls_total"] += 1
+            return
+        fn.conv2d_dgrad(dy, self.wt, self.x.shape, self.stride, self.pad, self.dil, out=dx, accumulate=acc,
+                        bn_bwd=bn_bwd, wt_planes=self.wtp, math=self.math, dy_absmax=dya, w_absmax=wa,
+                        bn_dy_absmax=bn_dya, dy_planes=planes, wt_shape=self.wt_shape)
 
 
 class BilinearConcatConv(Node):

@@ -746,11 +746,16 @@ def bn_backward_maxpool(x, scale, shift, dy_pool, argmax, k, stride, pad, mean, 
 
 def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, relu=False, dx=None, dgamma=None,
                           dbeta=None, accumulate=False, dx_absmax=None, dy_absmax=None, x_chan_minmax=None, dx_planes=False,
-                          dx_absmin=None):
+                          dx_absmin=None, phase=0, park=False):
     """bn_backward with the two reductions already gathered per row tile (conv2d_dgrad(bn_bwd=...)).
     dx_planes ("f16x2" math): dx is written as fp16 piece planes (same bytes, same buffer shape) cut by the power of two of a
     BOUND of |dx| that is formed from dy_absmax (the magnitude block of dy, conv2d_dgrad's bn_dy_absmax) and x_chan_minmax
-    (2 x C per-channel extremes of x, bn_stats_from_tiles' out_chan_minmax) and left in dx_absmax"""
+    (2 x C per-channel extremes of x, bn_stats_from_tiles' out_chan_minmax) and left in dx_absmax.
+    phase (round 6): 1 = the finalize alone (coefficients into the "bn" workspace of the current lane), 2 = the apply pass alone
+    from what a phase-1 call with the same arguments left there; 0 = both.  park (with phase 1): the finalize is not launched but
+    parked for the NEXT weight-gradient launch on this stream, in front of whose grid it rides (csrc/bn_final_job.h); the
+    phase-2 call runs it on its own if no weight gradient came by"""
+    assert phase in (0, 1, 2) and (not park or phase == 1)
     C = x.shape[-1]
     rows = _rows(x)
     dx = torch.empty_like(x) if dx is None else dx
@@ -762,7 +767,7 @@ def bn_backward_from_sums(x, scale, shift, dy, mean, rstd, gamma, sums, tiles, r
     check(_f("dspn_bn_backward_from_sums", x)(ptr(x), ptr(scale), ptr(shift), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma),
                                              ptr(sums), tiles, ptr(dx), ptr(dgamma), ptr(dbeta), rows, C, int(relu),
                                              int(accumulate), ptr(dx_absmax), ptr(dx_absmin), ptr(dy_absmax), ptr(x_chan_minmax),
-                                             int(bool(dx_planes)), ptr(ws), ws.numel(), stream()),
+                                             int(bool(dx_planes)) | (phase << 1) | (8 if park else 0), ptr(ws), ws.numel(), stream()),
           "bn_backward_from_sums")
     return dx, dgamma, dbeta
 

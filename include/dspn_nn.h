@@ -370,6 +370,11 @@ int dspn_bn_backward_from_sums_f32(const float *x, const float *scale, const flo
                                    int tiles, float *dx, float *dgamma, float *dbeta, long long rows, int C, int relu,
                                    int accumulate, float *dx_absmax, float *dx_absmin, const float *dy_absmax, const float *x_chan_minmax,
                                    int dx_planes, void *workspace, size_t workspace_bytes, void *stream);
+/* dx_planes is a flag word (round 6): bit 0 = dx as piece planes (below); | 2 = the FINALIZE alone (per-channel coefficients
+ * into the first 3 * C floats of the workspace, dgamma / dbeta, the bound of dx); | 4 = the APPLY pass alone, from the
+ * coefficients an earlier call with | 2 (same arguments, same workspace) left there.  The finalize is a chain of one or two
+ * latency-bound launches on 1 - 64 workgroups: a caller runs it on a second stream beside the layer's weight gradient
+ * (dspnet_amd/engine.py, Conv.backward) and the apply behind both.  0 / 1: both, as before. */
 /* dx_absmin (optional, with dx_planes; round 5): ONE float, preset to +inf by the caller, that receives the smallest non-zero
  * per-channel bound of |dx| -- with dx_absmax, the span of channel magnitudes the planes are cut over (the range guard of
  * DSPN_MATH_F32_F16X2 reads it; elements more than 2^17 below the tensor's largest magnitude lose relative accuracy). */

@@ -816,6 +816,74 @@ def test_dgrad_epilogue_batchnorm_backward_sums(gpu_device, conv_math, case, acc
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), (float((a - r).abs().max()), float(r.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 24, 24, 96, 1), (2, 16, 16, 48, 1), (8, 128, 128, 64, 1), (4, 128, 128, 256, 1), (3, 25, 23, 64, 2)])
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("rider", ["wgrad", "wide wgrad", "nobody"])
+def test_parked_finalize_rides_in_the_weight_gradient_with_the_same_bits(gpu_device, case, planes, rider):
+    """Round 6: dspn_bn_backward_from_sums split in two -- the finalize PARKED (flag | 2 | 8) and run by extra workgroups in
+    front of the next weight-gradient launch on the stream (csrc/bn_final_job.h), or by the apply-only call (flag | 4) itself
+    when no weight gradient came by -- against the one-call form: dx, dgamma, dbeta, the bound of dx and its per-channel minimum
+    bit for bit (grouped and plain tile tables, float dx and piece planes), and the weight gradient that carried the job unchanged."""
+    N, H, W, C, stride = case
+    if planes and (fn.get_conv_math() != "f16x2" or C % 32):
+        pytest.skip("piece planes: the two-piece math, C % 32 == 0")
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dyb = torch.randn(N, Ho, Wo, 32, generator=g).cuda()
+    wb = (torch.randn(32, 1, 1, C, generator=g) / np.sqrt(C)).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda(); beta = torch.randn(C, generator=g).cuda()
+    mean, rstd, scale, shift = fn.bn_stats(x, 2e-5, gamma, beta)
+    xr = x.view(-1, C)
+    x_ext = torch.stack([xr.min(0).values, xr.max(0).values]).contiguous()
+    tiles = fn.conv_dgrad_bn_tiles(tuple(x.shape), stride)
+    sums = torch.zeros(tiles, 2, C, device="cuda"); am_in = torch.zeros(64, device="cuda")
+    d = fn.conv2d_dgrad(dyb, fn.weight_transpose(wb), tuple(x.shape), stride, 0, 1, bn_bwd=(x, scale, shift, mean, rstd, True, sums),
+                        bn_dy_absmax=am_in)
+    # a weight gradient to ride in (any: the job does not touch its operands): both operands as planes for the wide kernel
+    xw = torch.randn(2, 20, 20, 128, generator=g).cuda().abs_(); dyw = torch.randn(2, 20, 20, 128, generator=g).cuda()
+    one, zero = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+    xa, dya = fn.absmax(xw), fn.absmax(dyw)
+    xp, dyp = fn.bn_apply_planes(xw, one, zero, xa), fn.bn_apply_planes(dyw, one, zero, dya)
+    wide = rider == "wide wgrad"
+    if wide and fn.get_conv_math() != "f16x2":
+        pytest.skip("the two-piece math is not this process's default")
+    def wgrad():
+        if wide:
+            return fn.conv2d_wgrad(xp, dyp, (128, 3, 3, 128), 1, 1, 1, x_absmax=xa, dy_absmax=dya, x_planes=True, dy_planes=True)
+        return fn.conv2d_wgrad(xw, dyw, (128, 3, 3, 128), 1, 1, 1, x_absmax=xa, dy_absmax=dya)
+    dw_alone = wgrad()
+
+    def run(split):
+        kw = dict(relu=True, dx=torch.empty_like(x), dgamma=torch.zeros(C, device="cuda"), dbeta=torch.zeros(C, device="cuda"))
+        bound, bmin = torch.zeros(64, device="cuda"), torch.full((1,), float("inf"), device="cuda")
+        if planes:
+            kw.update(dx_absmax=bound, dy_absmax=am_in, x_chan_minmax=x_ext, dx_planes=True, dx_absmin=bmin)
+        args = (x, scale, shift, d, mean, rstd, gamma, sums, tiles)
+        dw = None
+        if not split:
+            out = fn.bn_backward_from_sums(*args, **kw)
+        else:
+            fn.bn_backward_from_sums(*args, phase=1, park=True, **kw)
+            if rider != "nobody":
+                dw = wgrad()
+            out = fn.bn_backward_from_sums(*args, phase=2, **kw)
+        return out + (bound, bmin), dw
+
+    ref, _ = run(False)
+    got, dw = run(True)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(got[1]).all()) and float(got[1].abs().max()) > 0
+    if dw is not None:
+        assert torch.equal(dw, dw_alone)
+    # nothing stays parked: the next weight gradient is a plain one, the next one-call backward unchanged
+    assert torch.equal(wgrad(), dw_alone)
+    again, _ = run(False)
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+
+
 def _decode_planes(planes, shape, block):
     """fp16 piece planes [rows][C / 32][2][32] (stored in a float32 buffer of `shape`) -> float64 values (h0 + h1) / s with the
     power of two s the kernels derive from the magnitude block (csrc/dspn_pieces.h operand_scale)"""

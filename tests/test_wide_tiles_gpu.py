@@ -466,3 +466,45 @@ def test_tile_spanning_loop_gives_the_bits_of_the_plain_loop(spanning, case):
     for i, (a, b) in enumerate(zip(out[(2, "extra")], out[(0, "extra")])):
         assert torch.equal(a, b), ("extra", i)
     assert float(out[(2, "extra")][2]) == float(out[(2, "extra")][1].abs().max())
+
+
+# ---- round 6: the weight gradient of the plane-fed layers on the same footing (csrc/conv_wgrad_wide.h) ------------------------
+# (N, H, W, Cin, Cout, k, stride, pad, dil): Cout not a multiple of the tile (blocks past Cout are not fetched), J = taps x Cin with
+# a ragged last column tile, pixels not a multiple of the k-step, maps smaller than one k-step, stride 2, dilation, many splits
+WG_CASES = [(2, 24, 24, 64, 128, 3, 1, 1, 1), (3, 25, 23, 96, 160, 3, 2, 1, 1), (1, 17, 19, 128, 256, 1, 1, 0, 1),
+            (5, 5, 5, 256, 192, 3, 1, 1, 1), (2, 20, 20, 32, 96, 5, 1, 2, 1), (1, 33, 31, 64, 128, 3, 1, 6, 6),
+            (8, 64, 64, 64, 128, 3, 1, 1, 1), (4, 32, 32, 256, 256, 3, 1, 1, 1), (2, 16, 16, 512, 512, 3, 2, 1, 1),
+            (1, 17, 17, 128, 192, (1, 7), 1, (0, 3), 1)]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_plane_fed_weight_gradient_on_the_wide_tile_is_bit_identical(tiles, case):
+    """dW from dy and x as piece planes: conv_wgw_kernel (64 x 64 per wave, global -> LDS directly, source-side XOR instead of
+    row padding under the transposed reads) against conv_wgrad_kernel (dspn_conv_set_wide_tiles(1)) -- same split plan, same
+    pixel blocks and piece products per accumulator: the same bits, in the summed gradient and slab by slab; and both against
+    the fp32-MFMA weight gradient of the decoded operands."""
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    kh, kw = fn._hw(k); ph, pw = fn._hw(pad)
+    g = torch.Generator().manual_seed(H + Cin + Cout + kh + 5)
+    Ho, Wo = (H + 2 * ph - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pw - dil * (kw - 1) - 1) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).cuda().abs_()
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    xp, xa = planes_of(x)
+    dyp, dya = planes_of(dy)
+    wshape = (Cout, kh, kw, Cin)
+    kw_ = dict(x_absmax=xa, dy_absmax=dya, x_planes=True, dy_planes=True)
+    got = {}
+    for mode in (1, 0):
+        tiles(mode)
+        got[mode] = fn.conv2d_wgrad(xp, dyp, wshape, stride, pad, dil, **kw_)
+    assert torch.equal(got[0], got[1])
+    splits = fn.conv2d_wgrad_splits(tuple(x.shape), tuple(dy.shape), wshape, stride)
+    if splits > 0:
+        slabs = {}
+        for mode in (1, 0):
+            tiles(mode)
+            slabs[mode] = torch.full((splits, Cout * kh * kw * Cin), float("nan"), device="cuda")
+            fn.conv2d_wgrad_slabs(xp, dyp, wshape, slabs[mode], stride, pad, dil, **kw_)
+        assert torch.equal(slabs[0], slabs[1]) and bool(torch.isfinite(slabs[0]).all())
+    ref = fn.conv2d_wgrad(x, dy, wshape, stride, pad, dil, math="fp32")
+    assert float((got[0] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
