@@ -556,6 +556,7 @@ class Graph:
         nodes, table = self.slab_tables[key]
         if not nodes:
             return
+        self.wgrad_beside_join()
         if all(n.slabs_fresh for n in nodes):
             fn.slab_reduce_batch(*table)
         else:   # some convolution had no output gradient in this pass: reduce only the ones that ran
@@ -751,7 +752,45 @@ class Graph:
         if idx == sb["fork_after"]:
             sb["fork_ev"].record(torch.cuda.current_stream(self.device))
 
+    # -- experiment (DSPN_WGRAD_SIDE=1): every weight gradient of the main stream on the second stream, off the data-gradient chain
+    def wgrad_beside(self, conv, dy, planes, xa, dya):
+        main, side = torch.cuda.current_stream(self.device), shared_stream(self.device, "branch", -1)
+        if main == side or conv.tap_expand:
+            return False
+        st = self.__dict__.setdefault("_wg", dict(events=[], used=0, reads={}, last=None))
+        def ev():
+            if st["used"] == len(st["events"]):
+                st["events"].append(torch.cuda.Event())
+            st["used"] += 1
+            return st["events"][st["used"] - 1]
+        ready, done = ev(), ev()
+        ready.record(main)
+        side.wait_event(ready)
+        with torch.cuda.stream(side), fn.workspace_lane(1):
+            conv._weight_gradient(dy, planes, xa, dya)
+            done.record(side)
+        st["reads"][dy.data_ptr()] = done
+        st["last"] = done
+        return True
+
+    def wgrad_beside_before_write(self, buf):
+        st = self.__dict__.get("_wg")
+        if st and buf is not None:
+            ev = st["reads"].pop(buf.data_ptr(), None)
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def wgrad_beside_join(self, final=False):
+        st = self.__dict__.get("_wg")
+        if st and st["last"] is not None:
+            torch.cuda.current_stream(self.device).wait_event(st["last"])
+            st["last"] = None
+        if st and final:
+            st["used"] = 0
+            st["reads"].clear()
+
     def join_side_backward(self):
+        self.wgrad_beside_join(final=True)
         sb = self.side_bwd
         if sb is not None and sb["dirty"]:
             torch.cuda.current_stream(self.device).wait_event(sb["prog_ev"])
@@ -1030,6 +1069,8 @@ class BatchNorm(Node):
         return self._pending is not None
 
     def _from_sums(self, beside, args, kw):
+        if WGRAD_SIDE and kw.get("accumulate"):
+            self._g.wgrad_beside_before_write(kw.get("dx"))
         if not beside:
             fn.bn_backward_from_sums(*args, **kw)
             return
@@ -1088,11 +1129,16 @@ class BatchNorm(Node):
                                  dbeta=self.beta.grad, accumulate=acc, dx_absmax=am))
             return
         assert not beside, "finalize_beside() without the data gradient's sums"
+        if WGRAD_SIDE and acc:
+            self._g.wgrad_beside_before_write(dx)
         fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
                        accumulate=acc, dx_absmax=am)
 
+
+# experiment: all weight gradients of the main stream on the second stream (DSPN_WGRAD_SIDE=1)
+WGRAD_SIDE = _os.environ.get("DSPN_WGRAD_SIDE", "0") == "1"
 
 # round 6: the finalize half of a BatchNorm backward rides in the weight-gradient launch of the layer behind it
 # (DSPN_FINALIZE_BESIDE=0: launches of its own, as round 5 -- same-box A/B; the results do not depend on it)
@@ -1344,6 +1390,14 @@ class Conv(Node):
         bn = getattr(self, "bn_bwd_node", None) if self.x.requires_grad else None
         early = (bn is not None and FINALIZE_BESIDE and not self.guard_fb and self._g.device.type == "cuda"
                  and bn.pool_grad is None)
+        if WGRAD_SIDE and self._g.device.type == "cuda" and self._g.wgrad_beside(self, dy, planes, xa, dya):
+            early = False          # (experiment: the weight gradient went to the second stream; nothing to ride in)
+            if self.input_sum_grad is not None:
+                fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
+                                         out=self.input_sum_grad.grad)
+            if self.x.requires_grad:
+                self._data_gradient(dy, planes, dya, wa)
+            return
         if early:
             self._data_gradient(dy, planes, dya, wa)
             bn.finalize_beside()
@@ -1394,6 +1448,8 @@ class Conv(Node):
         elif self.wtp is None and not self._g.wt_batched:
             fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
         dx, acc = self.x.grad_target()
+        if WGRAD_SIDE and acc:
+            self._g.wgrad_beside_before_write(dx)
         bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
         bn_bwd, bn_dya = None, None
         if bn is not None:

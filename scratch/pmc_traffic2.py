@@ -26,7 +26,7 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch[k][1] + write
     n = max(fetch[k][0], write[k][0])
     b = (2 * fetch[k][1] + write[k][1]) * 1024
     rows.append((k, n, fetch[k][1], write[k][1], b / max(n, 1)))
-    if k.startswith(('conv_nt', 'conv_stem', 'conv_wgrad_kernel', 'slab_reduce', 'nt_split_reduce')):   # conv_nt / conv_ntw / conv_ntv
+    if k.startswith(('conv_nt', 'conv_stem', 'conv_wgrad_kernel', 'conv_wgw_kernel', 'slab_reduce', 'nt_split_reduce')):   # conv_nt / conv_ntw / conv_ntv
         fam_bytes += b; fam_launch += n if k.startswith('conv_') else 0
 with open(sys.argv[4], 'w') as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py --steps %d --warmup 1 --no-cpu-baseline --no-roofline\n" % (steps - 1))
