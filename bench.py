@@ -431,6 +431,22 @@ def check_distinct_devices(dist, identity, rank, world):
     return ids
 
 
+_WGRAD_SIDE_DEFAULT = None
+
+
+def instrument_step(lib, on):
+    """HIP events around every convolution launch (dspn_profile_enable) for the steps that feed `roofline`.  Round 6: the
+    engine runs the weight gradients on a stream of their own, beside the data-gradient chain (dspnet_amd/engine.py:
+    WGRAD_SIDE) -- a kernel timed while another one shares the chip measures the pair, so the instrumented steps run
+    everything on the step's stream, as `rocprofv3 --kernel-trace` of a DSPN_WGRAD_SIDE=0 run sees the kernels."""
+    global _WGRAD_SIDE_DEFAULT
+    from dspnet_amd import engine as E
+    if _WGRAD_SIDE_DEFAULT is None:
+        _WGRAD_SIDE_DEFAULT = E.WGRAD_SIDE
+    E.WGRAD_SIDE = 0 if on else _WGRAD_SIDE_DEFAULT
+    lib.dspn_profile_enable(1 if on else 0)
+
+
 def conv_family_roofline(lib, steps, flops_step, flops_3x_step, math, step_s, traffic=None, traffic_source=None):
     """roofline block of the implicit-GEMM convolution family from the HIP events the library recorded on the launch
     stream around every conv launch since dspn_profile_enable(1).  `frac` = executed multiply-adds / conv kernel time /
@@ -499,11 +515,11 @@ def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
         ps = min(PROF_STEPS, steps)
         t0 = time.perf_counter()
         for i in range(steps):
-            lib.dspn_profile_enable(1 if i < ps else 0)
+            instrument_step(lib, i < ps)
             solver.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        lib.dspn_profile_enable(0)
+        instrument_step(lib, False)
         return {"workload": "%s multitask (det+depth+seg) %dx%d (HxW), bs %d, %s, forward+backward+SGD, N=%d anchors"
                             % (network, H, W, B, MATH_LABEL[math] if math != "bf16" else ("bf16 MFMA convs" + (
                                 ", bf16 tensors in HBM" if store == "bf16" else ", fp32 tensors in HBM")), net.anchors.shape[1]),
@@ -713,13 +729,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == 0 and prof_steps:
-            lib.dspn_profile_enable(1)
+            instrument_step(lib, True)
         if i == prof_steps:
-            lib.dspn_profile_enable(0)
+            instrument_step(lib, False)
         solver.step()
     sync()
     dt = time.perf_counter() - t0
-    lib.dspn_profile_enable(0)
+    instrument_step(lib, False)
     exposed_ms = solver.reducer.exposed_ms() if solver.reducer is not None else None
     bucket_ms = solver.reducer.bucket_latency_ms() if solver.reducer is not None else None
     n_buckets = len(solver.buckets)
@@ -790,6 +806,11 @@ def main():
         roofline = conv_family_roofline(lib, prof_steps, flops_step, flops_3x, args.math, dt / args.steps, traffic, tsrc)
         if roofline is not None:
             roofline["instrumented_steps"] = "%d of the %d timed steps" % (prof_steps, args.steps)
+            if _WGRAD_SIDE_DEFAULT:
+                roofline["instrumented_schedule"] = ("serial: in the instrumented steps every kernel runs alone on the step's stream "
+                                                     "(DSPN_WGRAD_SIDE=0); the other timed steps run the weight gradients on a second "
+                                                     "stream beside the data-gradient chain, where a per-launch duration would measure "
+                                                     "the pair of kernels sharing the chip")
 
     ops_roofline = None
     if rank == 0 and world == 1 and not args.no_roofline and args.store == "fp32":
@@ -895,7 +916,9 @@ def main():
             "detection_branch_forward": gsched.side_segment is not None,
             "detection_branch_backward_part": bool(gsched.side_bwd is not None and gsched.side_bwd.get("active", False)),
             "nodes_on_side_stream": (0 if gsched.side_segment is None else gsched.side_segment[1] - gsched.side_segment[0] + 1,
-                                     0 if gsched.side_bwd is None else len(gsched.side_bwd["side"]))}
+                                     0 if gsched.side_bwd is None else len(gsched.side_bwd["side"])),
+            # round 6: the weight gradients (and their slab sums) on a stream of their own beside the data-gradient chain
+            "weight_gradients_beside": bool(__import__("dspnet_amd.engine", fromlist=["WGRAD_SIDE"]).WGRAD_SIDE)}
         if other is not None:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

@@ -55,6 +55,21 @@ def shared_stream(device, kind, priority=0):
     return ent[0]
 
 
+# Round 6: weight gradients on a stream of their own (WGRAD_SIDE below).  A weight gradient READS its layer's output gradient;
+# the only writers of that buffer later in the same backward pass are ACCUMULATIONS through an alias (the residual stream:
+# conv3's output gradient is handed to the unit's input, whose first BatchNorm adds its own gradient in place).  Every
+# accumulating writer gets its target from Tensor.grad_target() / give_grad(): they make the current stream wait for the
+# weight gradient that still reads the buffer.
+_WG_READS = {}      # data_ptr of an output-gradient buffer -> (event recorded behind the weight gradient that reads it, device)
+
+
+def _wg_before_write(buf):
+    if _WG_READS and buf is not None:
+        ent = _WG_READS.pop(buf.data_ptr(), None)
+        if ent is not None:
+            torch.cuda.current_stream(ent[1]).wait_event(ent[0])
+
+
 class Tensor:
     """An activation: NHWC (or any) device buffer + its gradient slot.  dtype: the graph's activation storage type
     (functional.ACT_DTYPE: float32, or bfloat16 for the `*_bf16` kernels) unless given -- graph inputs, loss inputs
@@ -94,6 +109,7 @@ class Tensor:
             self.grad = self.own_grad()
             self._gw = True
             return self.grad, False
+        _wg_before_write(self.grad)
         return self.grad, True
 
     def give_grad(self, buf):
@@ -102,6 +118,7 @@ class Tensor:
             self.grad = buf
             self._gw = True
         else:
+            _wg_before_write(self.grad)
             fn.add(self.grad, buf, out=self.grad)
 
 
@@ -547,22 +564,38 @@ class Graph:
                     n.alloc_slabs()
         return self
 
-    def flush_slabs(self, key="all", convs=None):
-        """sum the pending split-K slabs of `convs` (default: every Conv) into their weight gradients, one launch"""
+    def flush_slabs(self, key="all", convs=None, beside=False):
+        """sum the pending split-K slabs of `convs` (default: every Conv) into their weight gradients, one launch.
+        beside (the weight gradients run on a stream of their own, WGRAD_SIDE): the sum goes to THAT stream, behind the weight
+        gradients it reads and behind what the current stream has issued; the current stream does not wait (join_side_backward
+        does, at the end of the pass)"""
         if key not in self.slab_tables:
             nodes = [n for n in (convs if convs is not None else self.nodes) if isinstance(n, Conv) and n.slabs is not None]
             table = fn.slab_reduce_table([(n.slabs, n.w.grad, False) for n in nodes], self.device) if nodes else None
             self.slab_tables[key] = (nodes, table)
         nodes, table = self.slab_tables[key]
+        st = self.__dict__.get("_wg")
+        beside = beside and st is not None and st["last"] is not None
+        if not beside:
+            self.wgrad_beside_join()      # (before a bucket's gradients leave: its weight gradients on the second stream have finished)
         if not nodes:
             return
-        self.wgrad_beside_join()
-        if all(n.slabs_fresh for n in nodes):
-            fn.slab_reduce_batch(*table)
-        else:   # some convolution had no output gradient in this pass: reduce only the ones that ran
-            ran = [n for n in nodes if n.slabs_fresh]
-            if ran:
-                fn.slab_reduce_batch(*fn.slab_reduce_table([(n.slabs, n.w.grad, False) for n in ran], self.device))
+        ran = nodes if all(n.slabs_fresh for n in nodes) else [n for n in nodes if n.slabs_fresh]
+        if ran:
+            # (some convolution had no output gradient in this pass: reduce only the ones that ran)
+            args = table if ran is nodes else fn.slab_reduce_table([(n.slabs, n.w.grad, False) for n in ran], self.device)
+            if beside:
+                main, side = torch.cuda.current_stream(self.device), st["stream"]
+                ev = self._wg_event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    fn.slab_reduce_batch(*args)
+                    done = self._wg_event()
+                    done.record(side)
+                st["last"] = done
+            else:
+                fn.slab_reduce_batch(*args)
         for n in nodes:
             n.slabs_fresh = False
 
@@ -752,33 +785,32 @@ class Graph:
         if idx == sb["fork_after"]:
             sb["fork_ev"].record(torch.cuda.current_stream(self.device))
 
-    # -- experiment (DSPN_WGRAD_SIDE=1): every weight gradient of the main stream on the second stream, off the data-gradient chain
+    # -- round 6 (WGRAD_SIDE): every weight gradient of the step's stream on a second stream, off the data-gradient chain
+    def _wg_event(self):
+        st = self._wg
+        if st["used"] == len(st["events"]):
+            st["events"].append(torch.cuda.Event())
+        st["used"] += 1
+        return st["events"][st["used"] - 1]
+
     def wgrad_beside(self, conv, dy, planes, xa, dya):
-        main, side = torch.cuda.current_stream(self.device), shared_stream(self.device, "branch", -1)
-        if main == side or conv.tap_expand:
+        main = torch.cuda.current_stream(self.device)
+        if main == shared_stream(self.device, "branch", -1) or conv.tap_expand:
             return False
-        st = self.__dict__.setdefault("_wg", dict(events=[], used=0, reads={}, last=None))
-        def ev():
-            if st["used"] == len(st["events"]):
-                st["events"].append(torch.cuda.Event())
-            st["used"] += 1
-            return st["events"][st["used"] - 1]
-        ready, done = ev(), ev()
+        # the stream MultiBoxTarget uses in the forward pass (normal priority, idle during backward): the data-gradient chain on
+        # the step's high-priority stream gets the compute units first, the weight gradients fill in.  (On the detection
+        # branch's high-priority stream +0.9 % instead of +1.9 %; a fifth stream of its own: the same +1.9 %.)
+        side = shared_stream(self.device, "target")
+        st = self.__dict__.setdefault("_wg", dict(events=[], used=0, last=None, stream=side))
+        ready, done = self._wg_event(), self._wg_event()
         ready.record(main)
         side.wait_event(ready)
-        with torch.cuda.stream(side), fn.workspace_lane(1):
+        with torch.cuda.stream(side), fn.workspace_lane(2):
             conv._weight_gradient(dy, planes, xa, dya)
             done.record(side)
-        st["reads"][dy.data_ptr()] = done
+        _WG_READS[dy.data_ptr()] = (done, self.device)
         st["last"] = done
         return True
-
-    def wgrad_beside_before_write(self, buf):
-        st = self.__dict__.get("_wg")
-        if st and buf is not None:
-            ev = st["reads"].pop(buf.data_ptr(), None)
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
 
     def wgrad_beside_join(self, final=False):
         st = self.__dict__.get("_wg")
@@ -787,7 +819,8 @@ class Graph:
             st["last"] = None
         if st and final:
             st["used"] = 0
-            st["reads"].clear()
+            for k in [k for k, v in _WG_READS.items() if v[1] == self.device]:
+                del _WG_READS[k]
 
     def join_side_backward(self):
         self.wgrad_beside_join(final=True)
@@ -1069,8 +1102,6 @@ class BatchNorm(Node):
         return self._pending is not None
 
     def _from_sums(self, beside, args, kw):
-        if WGRAD_SIDE and kw.get("accumulate"):
-            self._g.wgrad_beside_before_write(kw.get("dx"))
         if not beside:
             fn.bn_backward_from_sums(*args, **kw)
             return
@@ -1129,16 +1160,20 @@ class BatchNorm(Node):
                                  dbeta=self.beta.grad, accumulate=acc, dx_absmax=am))
             return
         assert not beside, "finalize_beside() without the data gradient's sums"
-        if WGRAD_SIDE and acc:
-            self._g.wgrad_beside_before_write(dx)
         fn.bn_backward(self.x.data, self.scale, self.shift, self.out.grad, self.mean, self.rstd,
                        None if self.gamma is None else self.gamma.data, relu=self.relu, dx=dx,
                        dgamma=None if self.gamma is None else self.gamma.grad, dbeta=self.beta.grad,
                        accumulate=acc, dx_absmax=am)
 
 
-# experiment: all weight gradients of the main stream on the second stream (DSPN_WGRAD_SIDE=1)
-WGRAD_SIDE = _os.environ.get("DSPN_WGRAD_SIDE", "0") == "1"
+# round 6: the weight gradients of the step's stream on a stream of their own (Graph.wgrad_beside): nothing on the critical
+# chain data gradient -> BatchNorm finalize -> apply -> next data gradient reads them, so they run BESIDE it -- in the gaps of
+# the latency-bound finalize launches and under the HBM-bound apply passes -- and the bucket's slab sums follow them there;
+# the step's stream waits for that stream once, at the end of the pass (and before an accumulation into a buffer one of
+# them still reads: _wg_before_write).  Same kernels, same bits; +1.9 % on the step (profiles/r06_wgrad_beside_ab.txt).
+# DSPN_WGRAD_SIDE=0: on the step's stream, with the BatchNorm finalize riding in their launches (below).  bench.py switches
+# it off for its instrumented steps: a kernel timed beside another one measures the pair, not the kernel.
+WGRAD_SIDE = int(_os.environ.get("DSPN_WGRAD_SIDE", "1"))
 
 # round 6: the finalize half of a BatchNorm backward rides in the weight-gradient launch of the layer behind it
 # (DSPN_FINALIZE_BESIDE=0: launches of its own, as round 5 -- same-box A/B; the results do not depend on it)
@@ -1391,7 +1426,7 @@ class Conv(Node):
         early = (bn is not None and FINALIZE_BESIDE and not self.guard_fb and self._g.device.type == "cuda"
                  and bn.pool_grad is None)
         if WGRAD_SIDE and self._g.device.type == "cuda" and self._g.wgrad_beside(self, dy, planes, xa, dya):
-            early = False          # (experiment: the weight gradient went to the second stream; nothing to ride in)
+            early = False          # (the weight gradient went to its own stream: nothing to ride in, and the finalize's gap is filled)
             if self.input_sum_grad is not None:
                 fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
                                          out=self.input_sum_grad.grad)
@@ -1448,8 +1483,6 @@ class Conv(Node):
         elif self.wtp is None and not self._g.wt_batched:
             fn.weight_transpose(self.w.data, out=self.wt, copy=self.wh)
         dx, acc = self.x.grad_target()
-        if WGRAD_SIDE and acc:
-            self._g.wgrad_beside_before_write(dx)
         bn = getattr(self, "bn_bwd_node", None)   # set by Graph.finalize on the LAST writer of a deferred BN's gradient
         bn_bwd, bn_dya = None, None
         if bn is not None:

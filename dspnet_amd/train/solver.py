@@ -186,7 +186,7 @@ class MultiTaskSolver:
                 g.backward_node(idx)
                 while pending and self.bucket_convs[pending[0]][0] >= idx and not g.side_backward_busy(idx):
                     b = pending.pop(0)
-                    g.flush_slabs(("bucket", b), self.bucket_convs[b][1])
+                    g.flush_slabs(("bucket", b), self.bucket_convs[b][1], beside=True)
             g.join_side_backward()
             for b in pending:
                 g.flush_slabs(("bucket", b), self.bucket_convs[b][1])

@@ -22,7 +22,8 @@ l=json.loads(sys.stdin.read()); r=l['roofline']
 print('xt$X', l['value'], l['ms_per_step'], r['achieved'], r['conv_ms_per_step'])"
 done; done ) > gpurun_out/profiles_r06/r06_tile_spanning_step_ab.txt 2>&1
 ( echo "# the closing run's box, alternating: DSPN_WGW=0 (conv_wgrad_kernel for the plane x plane weight gradients) / 1 (conv_wgw_kernel, default)"; bash scratch/r06/ab_env.sh DSPN_WGW 3 ) > gpurun_out/profiles_r06/r06_wgrad_wide_step_ab.txt 2>&1
-( echo "# the closing run's box, alternating: DSPN_FINALIZE_BESIDE=0 (the BatchNorm-backward finalize as launches of its own) / 1 (riding in front of the weight-gradient grid, default)"; bash scratch/r06/ab_env.sh DSPN_FINALIZE_BESIDE 3 ) > gpurun_out/profiles_r06/r06_finalize_rides_step_ab.txt 2>&1
+( echo "# the closing run's box, alternating, with DSPN_WGRAD_SIDE=0 (everything on the step's stream): DSPN_FINALIZE_BESIDE=0 (the BatchNorm-backward finalize as launches of its own) / 1 (riding in front of the weight-gradient grid)"; DSPN_WGRAD_SIDE=0 bash scratch/r06/ab_env.sh DSPN_FINALIZE_BESIDE 3 ) > gpurun_out/profiles_r06/r06_finalize_rides_step_ab.txt 2>&1
+( echo "# the closing run's box, alternating: DSPN_WGRAD_SIDE=0 (weight gradients on the step's stream, the BatchNorm finalize riding in them) / 1 (on a stream of their own beside the data-gradient chain, default)"; bash scratch/r06/ab_env.sh DSPN_WGRAD_SIDE 3 ) > gpurun_out/profiles_r06/r06_wgrad_beside_ab.txt 2>&1
 fi
 timeout 900 python bench.py > gpurun_out/final_r06/bench_default.log 2>&1; echo "bench rc $?"; tail -1 gpurun_out/final_r06/bench_default.log | cut -c1-600
 tail -1 gpurun_out/final_r06/bench_default.log > gpurun_out/profiles_r06/r06_default_bench_line.json

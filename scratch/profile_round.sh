@@ -8,6 +8,14 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 COMMON="--no-cpu-baseline --no-other-configs --sustained-steps 0"
+# round 6: the engine runs the weight gradients on a second stream beside the data-gradient chain; a kernel listed while
+# another one shares the chip shows the pair's time.  One trace of the schedule AS IT RUNS first (wall against kernel sum),
+# then every per-kernel pass with DSPN_WGRAD_SIDE=0: the kernels alone, as bench.py's instrumented steps time them
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_beside -o kt -- python3 bench.py --steps 6 --warmup 2 $COMMON > $OUT/bench_beside.log 2>&1
+grep '^{"metric"' $OUT/bench_beside.log > profiles/${TAG}_f16x2_beside_bench_line.json
+T=$(ls $OUT/kt_beside/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$T" ] && python3 scratch/step_profile_csv.py "$T" 40 > profiles/${TAG}_f16x2_beside_last_step_by_kernel.txt
+export DSPN_WGRAD_SIDE=0
 # f16x2 = the default math (fp32 results from two fp16 pieces, DSPN_MATH_F32_F16X2), x3 = three bf16 pieces (round 2's default),
 # fp32 = fp32 MFMA, bf16 = bf16 tensors in HBM
 for MODE in f16x2 x3 fp32 bf16; do

@@ -520,6 +520,43 @@ def test_tile_spanning_training_is_reproducible_at_the_bench_shape(gpu_device, s
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", [("resnet-50", 512, 32, 6), ("resnet-50", 512, 3, 4), ("vgg16_reduced", 512, 2, 4), ("inceptionv3", 512, 2, 3)])
+def test_weight_gradients_on_their_own_stream_give_the_same_bits(gpu_device, case):
+    """Round 6: the weight gradients of the step's stream run on a second stream beside the data-gradient chain, their slab
+    sums behind them (engine.WGRAD_SIDE); the step's stream waits for them at the end of the pass and before an accumulation
+    into a buffer one of them still reads (the residual stream's gradient).  Same kernels, same operands: after several
+    training steps the parameter arena is bit for bit what the one-stream schedule (with the BatchNorm finalize riding in the
+    weight-gradient launches) gives -- at the bench shape, where the weight gradients overlap whole units of the chain, and on
+    the small graphs of the other backbones, where a missed ordering would race at once."""
+    from dspnet_amd import engine as E
+    network, size, B, steps = case
+    dev = torch.device("cuda", 0)
+
+    def run(side):
+        prev, E.WGRAD_SIDE = E.WGRAD_SIDE, side
+        try:
+            net = get_multi_symbol_train(network, (3, size, size), num_classes=8, batch_size=B, device=dev, seed=0)
+            gen = synthetic.rng(233)
+            solver = MultiTaskSolver(net)
+            solver.set_batch(torch.from_numpy(synthetic.images(B, size, size, gen)).to(dev),
+                             torch.from_numpy(synthetic.det_labels(B, gen=gen, height=size, width=size)).to(dev),
+                             torch.from_numpy(synthetic.seg_labels(B, size, size, gen=gen)).to(dev))
+            for _ in range(steps):
+                solver.step()
+            torch.cuda.synchronize()
+            a = net.g.arena.detach().clone()
+            del solver, net
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            return a
+        finally:
+            E.WGRAD_SIDE = prev
+
+    a, b, c = run(1), run(0), run(1)
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_second_step_with_moved_affine_matrix_matches_cpu_restatement(gpu_device):
     """`affine_matrix` is an ordinary argument of the reference's graph (multitask_symbol_builder.py:574, initialised by
     multi_init.py:72, updated by multi_solver.py:291-293).  After one SGD step (large learning rate, so that the grid
