@@ -786,6 +786,16 @@ class Graph:
             sb["fork_ev"].record(torch.cuda.current_stream(self.device))
 
     # -- round 6 (WGRAD_SIDE): every weight gradient of the step's stream on a second stream, off the data-gradient chain
+    def batchnorm_chain(self):
+        """True for a graph whose backward pass is mostly the chain data gradient -> BatchNorm finalize -> apply (more than half
+        of its convolutions gather a BatchNorm's backward sums): there a weight gradient beside the chain fills gaps (resnet-50);
+        without BatchNorm the chain is as MFMA-bound as the weight gradients and sharing the chip costs (vgg16_reduced)"""
+        v = self.__dict__.get("_bn_chain")
+        if v is None:
+            convs = [n for n in self.nodes if isinstance(n, Conv)]
+            v = self._bn_chain = 2 * sum(1 for n in convs if getattr(n, "bn_bwd_node", None) is not None) > len(convs)
+        return v
+
     def _wg_event(self):
         st = self._wg
         if st["used"] == len(st["events"]):
@@ -1174,6 +1184,7 @@ class BatchNorm(Node):
 # DSPN_WGRAD_SIDE=0: on the step's stream, with the BatchNorm finalize riding in their launches (below).  bench.py switches
 # it off for its instrumented steps: a kernel timed beside another one measures the pair, not the kernel.
 WGRAD_SIDE = int(_os.environ.get("DSPN_WGRAD_SIDE", "1"))
+WGRAD_SIDE_MIN_US = float(_os.environ.get("DSPN_WGRAD_SIDE_MIN_US", "30"))      # (Conv._wgrad_worth_a_stream)
 
 # round 6: the finalize half of a BatchNorm backward rides in the weight-gradient launch of the layer behind it
 # (DSPN_FINALIZE_BESIDE=0: launches of its own, as round 5 -- same-box A/B; the results do not depend on it)
@@ -1425,7 +1436,8 @@ class Conv(Node):
         bn = getattr(self, "bn_bwd_node", None) if self.x.requires_grad else None
         early = (bn is not None and FINALIZE_BESIDE and not self.guard_fb and self._g.device.type == "cuda"
                  and bn.pool_grad is None)
-        if WGRAD_SIDE and self._g.device.type == "cuda" and self._g.wgrad_beside(self, dy, planes, xa, dya):
+        if (WGRAD_SIDE and self._g.device.type == "cuda" and (bn is not None or self._g.batchnorm_chain()) and self._wgrad_worth_a_stream()
+                and self._g.wgrad_beside(self, dy, planes, xa, dya)):
             early = False          # (the weight gradient went to its own stream: nothing to ride in, and the finalize's gap is filled)
             if self.input_sum_grad is not None:
                 fn.conv2d_input_sum_grad(dy, self.w.data, self.x.shape, self.stride, self.pad, self.dil,
@@ -1442,6 +1454,22 @@ class Conv(Node):
                                      out=self.input_sum_grad.grad)
         if self.x.requires_grad and not early:
             self._data_gradient(dy, planes, dya, wa)
+
+    def _wgrad_worth_a_stream(self):
+        """The weight gradient goes beside the chain only where that pays: behind a data gradient that feeds a BatchNorm
+        backward (its finalize launches leave gaps, its apply pass is HBM-bound; the caller checks that) and where the kernel is
+        long enough to carry the two events it costs.  Measured with every weight gradient beside: resnet-50 +1.9 %,
+        vgg16_reduced (no BatchNorm: the chain is MFMA-bound like the weight gradients) -3.4 %, inceptionv3 1024 x 512 bs 8
+        (launches of ~15 us) -7 % (profiles/r06_wgrad_beside_other_configs.txt).  Estimate: the larger of multiply-adds at
+        250 TFLOP/s and operand bytes at 4 TB/s, at least WGRAD_SIDE_MIN_US."""
+        w = getattr(self, "_wg_worth", None)
+        if w is None:
+            P = float(np.prod(self.out.shape[:-1]))
+            cout, kh, kw, cin = self.w.shape
+            esz = 4.0 if self.out.dtype == torch.float32 else 2.0
+            est = max(2.0 * P * cout * kh * kw * cin / 2.5e14, esz * (P * cout + float(np.prod(self.x.shape))) / 4e12)
+            w = self._wg_worth = est * 1e6 >= WGRAD_SIDE_MIN_US
+        return w
 
     def _weight_gradient(self, dy, planes, xa, dya):
         if self.tap_expand:

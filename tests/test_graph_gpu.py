@@ -533,7 +533,10 @@ def test_weight_gradients_on_their_own_stream_give_the_same_bits(gpu_device, cas
     dev = torch.device("cuda", 0)
 
     def run(side):
-        prev, E.WGRAD_SIDE = E.WGRAD_SIDE, side
+        # (side: EVERY weight gradient of the step's stream beside the chain -- the engine's own rule keeps the short ones and the
+        # graphs without a BatchNorm chain on one stream)
+        prev, E.WGRAD_SIDE = (E.WGRAD_SIDE, E.WGRAD_SIDE_MIN_US, E.Graph.batchnorm_chain), side
+        E.WGRAD_SIDE_MIN_US, E.Graph.batchnorm_chain = 0.0, (lambda self: True)
         try:
             net = get_multi_symbol_train(network, (3, size, size), num_classes=8, batch_size=B, device=dev, seed=0)
             gen = synthetic.rng(233)
@@ -550,7 +553,7 @@ def test_weight_gradients_on_their_own_stream_give_the_same_bits(gpu_device, cas
             gc.collect(); torch.cuda.empty_cache()
             return a
         finally:
-            E.WGRAD_SIDE = prev
+            E.WGRAD_SIDE, E.WGRAD_SIDE_MIN_US, E.Graph.batchnorm_chain = prev
 
     a, b, c = run(1), run(0), run(1)
     assert bool(torch.isfinite(a).all())
