@@ -434,16 +434,21 @@ def check_distinct_devices(dist, identity, rank, world):
 _WGRAD_SIDE_DEFAULT = None
 
 
-def instrument_step(lib, on):
-    """HIP events around every convolution launch (dspn_profile_enable) for the steps that feed `roofline`.  Round 6: the
-    engine runs the weight gradients on a stream of their own, beside the data-gradient chain (dspnet_amd/engine.py:
-    WGRAD_SIDE) -- a kernel timed while another one shares the chip measures the pair, so the instrumented steps run
-    everything on the step's stream, as `rocprofv3 --kernel-trace` of a DSPN_WGRAD_SIDE=0 run sees the kernels."""
+def serial_schedule(on):
+    """everything on the step's stream (engine.WGRAD_SIDE = 0) while `on`, the engine's own schedule otherwise"""
     global _WGRAD_SIDE_DEFAULT
     from dspnet_amd import engine as E
     if _WGRAD_SIDE_DEFAULT is None:
         _WGRAD_SIDE_DEFAULT = E.WGRAD_SIDE
     E.WGRAD_SIDE = 0 if on else _WGRAD_SIDE_DEFAULT
+
+
+def instrument_step(lib, on):
+    """HIP events around every convolution launch (dspn_profile_enable) for the steps that feed `roofline`.  Round 6: the
+    engine runs the weight gradients on a stream of their own, beside the data-gradient chain (dspnet_amd/engine.py:
+    WGRAD_SIDE) -- a kernel timed while another one shares the chip measures the pair, so the instrumented steps run
+    everything on the step's stream, as `rocprofv3 --kernel-trace` of a DSPN_WGRAD_SIDE=0 run sees the kernels."""
+    serial_schedule(on)
     lib.dspn_profile_enable(1 if on else 0)
 
 
@@ -509,8 +514,10 @@ def side_train(network, H, W, B, math, steps, warmup, dev, store="fp32"):
         convs = conv_nodes(net)
         flops_step = sum(n.flops_fwd + n.flops_bwd for n in convs)
         flops_3x = 3.0 * sum(getattr(n, "flops_direct", n.flops_fwd) for n in convs)
-        for _ in range(warmup):
+        for w in range(warmup):
+            serial_schedule(w == warmup - 1)
             solver.step()
+        serial_schedule(False)
         torch.cuda.synchronize()
         ps = min(PROF_STEPS, steps)
         t0 = time.perf_counter()
@@ -702,8 +709,12 @@ def main():
         sys.stderr.flush()
         assert dist.get_world_size() == world
         check_distinct_devices(dist, ident, rank, world)
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        # (the last warm-up step runs the schedule of the instrumented steps -- everything on the step's stream -- so that
+        # nothing of that path runs for the first time inside the timed region)
+        serial_schedule(w == args.warmup - 1 and not args.no_roofline)
         solver.step()
+    serial_schedule(False)
     sync()
     warm_exposed = solver.reducer.exposed_ms() if solver.reducer is not None else None
     if solver.reducer is not None:

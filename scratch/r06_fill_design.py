@@ -9,7 +9,7 @@ if "sclk_mhz" in s:
     sens = " at %.0f MHz / %.0f W (median of %d sysfs samples)" % (s["sclk_mhz"]["median"], s.get("power_w", {}).get("median", float("nan")), s["sclk_mhz"]["samples"])
 head = ("Headline of the closing run (`profiles/r06_default_bench_line.json`): **%.1f images/s** (%.2f ms per step over the K = %d timed steps; "
         "`sustained` over 200 further steps: %.1f images/s%s), conv family %.2f ms (forward + data gradient %.2f, weight gradient %.2f) = %.1f TFLOP/s "
-        "executed = **%.3f of 833.3** by HIP events, `frac_end_to_end_3x` %.3f; boxes of this round ranged 913 - 980 images/s on the same library "
+        "executed = **%.3f of 833.3** by HIP events, `frac_end_to_end_3x` %.3f; boxes of this round ranged 913 - 985 images/s on the same library "
         "(±2.5 %%; every comparison in this file is same-box)."
         % (d["value"], d["ms_per_step"], d["steps"], s["value"], sens, r["conv_ms_per_step"], r["nt_ms_per_step"], r["wgrad_ms_per_step"],
            r["achieved"], r["frac"], r["frac_end_to_end_3x"]))
