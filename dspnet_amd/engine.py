@@ -807,9 +807,9 @@ class Graph:
         main = torch.cuda.current_stream(self.device)
         if main == shared_stream(self.device, "branch", -1) or conv.tap_expand:
             return False
-        # the stream MultiBoxTarget uses in the forward pass (normal priority, idle during backward): the data-gradient chain on
-        # the step's high-priority stream gets the compute units first, the weight gradients fill in.  (On the detection
-        # branch's high-priority stream +0.9 % instead of +1.9 %; a fifth stream of its own: the same +1.9 %.)
+        # the stream MultiBoxTarget uses in the forward pass, idle during backward.  (On the detection branch's stream, behind that
+        # branch's own backward: +0.9 % instead of +1.9 %; a fifth stream of its own: the same +1.9 %; stream priorities make no
+        # measurable difference: profiles/r06_stream_priority_ab.txt.)
         side = shared_stream(self.device, "target")
         st = self.__dict__.setdefault("_wg", dict(events=[], used=0, last=None, stream=side))
         ready, done = self._wg_event(), self._wg_event()
