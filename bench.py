@@ -929,7 +929,8 @@ def main():
             "nodes_on_side_stream": (0 if gsched.side_segment is None else gsched.side_segment[1] - gsched.side_segment[0] + 1,
                                      0 if gsched.side_bwd is None else len(gsched.side_bwd["side"])),
             # round 6: the weight gradients (and their slab sums) on a stream of their own beside the data-gradient chain
-            "weight_gradients_beside": bool(__import__("dspnet_amd.engine", fromlist=["WGRAD_SIDE"]).WGRAD_SIDE)}
+            "weight_gradients_beside": bool(__import__("dspnet_amd.engine", fromlist=["WGRAD_SIDE"]).WGRAD_SIDE
+                                            and gsched.wgrad_side_allowed and gsched.batchnorm_chain())}
         if other is not None:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

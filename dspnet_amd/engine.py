@@ -155,6 +155,9 @@ class Graph:
         self.tensors = {}
         self.all_tensors = []
         self.pre_forward = []      # callables run at the top of forward() (joins of side-stream work)
+        # round 6: weight gradients may run on a stream of their own (WGRAD_SIDE).  A solver with a gradient all-reduce clears it:
+        # every bucket release would make the step's stream wait for that stream, and no N > 1 run has measured the mix
+        self.wgrad_side_allowed = True
         # round 4: nodes [first, last] whose FORWARD runs on a second stream beside the nodes behind them (the detection
         # branch -- small SSD layers, heads, packing, target matching: tens of launches of 1 - 32 workgroups -- beside the
         # segmentation decoder); the first reader of their results calls join_side().  (first, last, stream, ready, done)
@@ -1436,7 +1439,7 @@ class Conv(Node):
         bn = getattr(self, "bn_bwd_node", None) if self.x.requires_grad else None
         early = (bn is not None and FINALIZE_BESIDE and not self.guard_fb and self._g.device.type == "cuda"
                  and bn.pool_grad is None)
-        if (WGRAD_SIDE and self._g.device.type == "cuda" and (bn is not None or self._g.batchnorm_chain()) and self._wgrad_worth_a_stream()
+        if (WGRAD_SIDE and self._g.wgrad_side_allowed and self._g.device.type == "cuda" and (bn is not None or self._g.batchnorm_chain()) and self._wgrad_worth_a_stream()
                 and self._g.wgrad_beside(self, dy, planes, xa, dya)):
             early = False          # (the weight gradient went to its own stream: nothing to ride in, and the finalize's gap is filled)
             if self.input_sum_grad is not None:

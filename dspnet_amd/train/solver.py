@@ -152,6 +152,9 @@ class MultiTaskSolver:
         self.buckets = plan_buckets(params, owner, g.arena.numel(), int(bucket_mb * (1 << 20) / 4))
         self.reducer = (GradBucketReducer(g.grad_arena, self.buckets, process_group)
                         if (world_size > 1 or force_reducer) else None)
+        # round 6: with an all-reduce to feed, the weight gradients stay on the step's stream (engine.WGRAD_SIDE): a bucket's
+        # release would make that stream wait for theirs eight times per pass, and no N > 1 run has measured the mix
+        g.wgrad_side_allowed = self.reducer is None
         # convolutions whose weight gradient lies in each bucket: their split-K slabs are summed in one launch
         # right before the bucket is released to the all-reduce
         self.bucket_convs = []
